@@ -1,0 +1,23 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu through gpurun)")
+
+
+@pytest.fixture(scope="session")
+def oracle_factory():
+    """kktsolver factory backed by the CPU oracle (test infrastructure)."""
+    from oracle.kkt_oracle import OracleKKTSolver
+
+    def fac(P, A, cones, m, n, settings, ordering="mmd"):
+        return OracleKKTSolver(P, A, cones, m, n, settings, ordering=ordering)
+
+    return fac

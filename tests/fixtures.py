@@ -1,0 +1,109 @@
+"""Problem fixtures taken from the reference's own tests (data only, /root/reference/test/OptTests).
+Each returns (P, q, A, b, cone_specs) in scipy/numpy form."""
+import numpy as np
+import scipy.sparse as sp
+
+import clarabel_jl_amd as cl
+
+
+def basic_qp():  # basic_qp.jl:6-19
+    P = sp.csc_matrix(np.array([[4.0, 1.0], [1.0, 2.0]]))
+    c = np.array([1.0, 1.0])
+    A0 = np.array([[1.0, 1.0], [1.0, 0.0], [0.0, 1.0]])
+    A = sp.csc_matrix(np.vstack([-A0, A0]))
+    b = np.array([-1.0, 0.0, 0.0, 1.0, 0.7, 0.7])
+    return P, c, A, b, [cl.NonnegativeConeT(3), cl.NonnegativeConeT(3)]
+
+
+def basic_qp_dualinf():  # basic_qp.jl:20-30
+    P = sp.csc_matrix(np.array([[1.0, 1.0], [1.0, 1.0]]))
+    c = np.array([1.0, -1.0])
+    A = sp.csc_matrix(np.array([[1.0, 1.0], [1.0, 0.0]]))
+    b = np.array([1.0, 1.0])
+    return P, c, A, b, [cl.NonnegativeConeT(2)]
+
+
+def univariate_qp():  # basic_qp.jl:44-60
+    return (sp.identity(1, format="csc"), np.zeros(1), sp.identity(1, format="csc"), np.ones(1),
+            [cl.NonnegativeConeT(1)])
+
+
+def basic_lp():  # basic_lp.jl:6-16
+    P = sp.csc_matrix((3, 3))
+    A = sp.vstack([sp.identity(3), -sp.identity(3)]).tocsc() * 2.0
+    c = np.array([3.0, -2.0, 1.0])
+    b = np.ones(6)
+    return P, c, A, b, [cl.NonnegativeConeT(3), cl.NonnegativeConeT(3)]
+
+
+def eq_constrained(variant=1):  # basic_eq_constrained.jl:16-42
+    P = sp.identity(3, format="csc")
+    if variant == 1:
+        c = np.zeros(3)
+        A = sp.csc_matrix(np.array([[0.0, 1.0, 1.0], [0.0, 1.0, -1.0]]))
+    else:
+        c = np.array([1.0, 2.0, 3.0])
+        A = sp.csc_matrix(np.array([[1.0, 1.0, 1.0], [0.0, 1.0, -1.0]]))
+    b = np.array([2.0, 0.0])
+    return P, c, A, b, [cl.ZeroConeT(2)]
+
+
+def unconstrained():  # basic_unconstrained.jl:16-26
+    return sp.identity(3, format="csc"), np.array([1.0, 2.0, -3.0]), sp.csc_matrix((0, 3)), np.zeros(0), []
+
+
+def basic_socp():  # basic_socp.jl:6-30
+    P = np.array([[1.4652521089139698, 0.6137176286085666, -1.1527861771130112],
+                  [0.6137176286085666, 2.219109946678485, -1.4400420548730628],
+                  [-1.1527861771130112, -1.4400420548730628, 1.6014483534926371]])
+    I3 = sp.identity(3)
+    A = sp.vstack([I3 * 2.0, -I3 * 2.0, I3]).tocsc()
+    c = np.array([0.1, -2.0, 1.0])
+    b = np.concatenate([np.ones(6), np.zeros(3)])
+    return sp.csc_matrix(P), c, A, b, [cl.NonnegativeConeT(3), cl.NonnegativeConeT(3), cl.SecondOrderConeT(3)]
+
+
+def basic_sdp():  # basic_sdp.jl:6-20
+    P = sp.identity(6, format="csc")
+    c = np.zeros(6)
+    A = sp.identity(6, format="csc")
+    b = np.array([-3.0, 1.0, 4.0, 1.0, 2.0, 5.0])
+    return P, c, A, b, [cl.PSDTriangleConeT(3)]
+
+
+def updating_data():  # data_updating.jl:6-21
+    P = sp.csc_matrix(np.array([[4.0, 1.0], [1.0, 2.0]]))
+    q = np.array([1.0, 1.0])
+    I2 = sp.identity(2)
+    A = sp.vstack([-I2, I2]).tocsc()
+    b = np.ones(4)
+    return P, q, A, b, [cl.NonnegativeConeT(2), cl.NonnegativeConeT(2)]
+
+
+def lasso_socp(seed=12345, n=8):
+    """Shape of socp-lasso.jl:6-54 (SOC of dim 50n+2 -> sparse expansion path).  The Julia
+    MersenneTwister stream is not reproducible here, so the random data are numpy-seeded."""
+    rng = np.random.default_rng(seed)
+    m = 50 * n
+    F = rng.random((m, n))
+    vtrue = np.where(rng.random(n) < 0.3, rng.random(n), 0.0)
+    bb = F @ vtrue + 0.1 * rng.random(m)
+    mu = 0.1 * np.max(np.abs(F.T @ bb))
+    Z = np.zeros
+    I = np.eye
+    A1 = -np.block([[np.ones((1, 1)), Z((1, 2 * n + 1)), np.ones((1, 1)), Z((1, m))],
+                    [-np.ones((1, 1)), Z((1, 2 * n)), np.ones((1, 1)), Z((1, m + 1))],
+                    [Z((m, 1)), -2 * F, Z((m, n + 2)), I(m)]])
+    A2 = -np.block([[Z((n, 1)), I(n), -I(n), Z((n, m + 2))],
+                    [Z((n, 1)), -I(n), -I(n), Z((n, m + 2))]])
+    A3 = -np.block([[Z((1, 2 * n + 1)), -np.ones((1, 1)), Z((1, m + 1))],
+                    [Z((1, 2 * n + 2)), -np.ones((1, 1)), Z((1, m))],
+                    [Z((m, 2 * n + 3)), -I(m)]])
+    b1 = np.concatenate([[1.0, 1.0], -2 * bb])
+    b2 = np.zeros(2 * n)
+    b3 = np.zeros(m + 2)
+    c = np.concatenate([[1.0], np.zeros(n), mu * np.ones(n), np.zeros(m + 2)])
+    P = sp.identity(len(c), format="csc")
+    A = sp.csc_matrix(np.vstack([A1, A2, A3]))
+    b = np.concatenate([b1, b2, b3])
+    return P, c, A, b, [cl.NonnegativeConeT(len(b1)), cl.NonnegativeConeT(len(b2)), cl.SecondOrderConeT(len(b3))]
