@@ -1,0 +1,250 @@
+#!/usr/bin/env python
+"""bench.py — IPM-iterations/s of the MI355X-native KKT path (BASELINE.json metric).
+
+A *step* = one KKT iteration unit of the hot path = what `kkt_update!` + 2x `kkt_solve!` do per IPM
+iteration (reference src/solver.jl:278-323): 1 Hs value update + static regularisation + 1 numeric
+LDL^T + 3 solves, each with iterative refinement, replayed from the (Hs, rhs) trace recorded while
+the problem is solved end-to-end once.  In the timed region every input is already resident in HBM
+(torch tensors -> device pointers through the `_dev` entry points of the C ABI).
+
+Workload at N=1: BASELINE.json configs[1] = random sparse QP n=10000 m=20000, NN cone ("2a",
+uniform random pattern: SURVEY.md §8d).  N>1: one independent problem per GPU (different seed),
+no data-path collective; RCCL only for the start/stop barrier + max-over-ranks time.
+
+One JSON line on rank 0 (see DESIGN.md §6 for the roofline / cpu_baseline definitions).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+F64_MFMA_PEAK_TFLOPS = 78.6   # MI355X datasheet FP64 matrix (not in the local guides)
+
+
+def make_problem(cfg, seed_shift=0):
+    from clarabel_jl_amd import problems
+
+    if cfg == "2a":
+        return problems.random_sparse_qp(10000, 20000, 2 + seed_shift, 3, 1), "random sparse QP n=10000 m=20000 NN cone, uniform pattern (cfg 2a)"
+    if cfg == "2b":
+        return problems.random_sparse_qp(10000, 20000, 2 + seed_shift, 4, 2, window=50), "random sparse QP n=10000 m=20000 NN cone, banded +-50 (cfg 2b)"
+    if cfg == "1":
+        return problems.random_sparse_qp(1000, 2000, 1 + seed_shift, 4, 2), "random sparse QP n=1000 m=2000 NN cone (cfg 1)"
+    if cfg == "3":
+        return problems.portfolio_socp(seed=3 + seed_shift), "portfolio QP + 50 SOC(101), n=5000 (cfg 3)"
+    if cfg == "5":
+        return problems.sdp_blocks(seed=5 + seed_shift), "SDP 20 x PSDTriangle(50), n=1000 (cfg 5)"
+    raise SystemExit(f"unknown config {cfg}")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="2a")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--update-policy", type=int, default=None)
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the KKT path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+
+        dist = dist_
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    import clarabel_jl_amd as cl
+    from clarabel_jl_amd.kktsolver import HipKKTSolver
+
+    (P, q, A, b, cones), workload = make_problem(args.config, seed_shift=rank)
+
+    # ---- 1. solve once end-to-end on the HIP path, recording the KKT inputs of every iteration
+    trace = []
+
+    class Recorder(HipKKTSolver):
+        def kktsolver_update(self, cones_):
+            ok = super().kktsolver_update(cones_)
+            trace.append(dict(hs=self.Hsblocks.copy(), u=self._u.copy(), v=self._v.copy(), eta2=self._eta2.copy(), rhs=[]))
+            return ok
+
+        def kktsolver_setrhs(self, rhsx, rhsz):
+            self._last_rhs = np.concatenate([rhsx, rhsz])
+            super().kktsolver_setrhs(rhsx, rhsz)
+
+        def kktsolver_solve(self, lhsx, lhsz):
+            if trace:
+                trace[-1]["rhs"].append(self._last_rhs)
+            return super().kktsolver_solve(lhsx, lhsz)
+
+    optkw = {}
+    if args.update_policy is not None:
+        optkw["update_policy"] = args.update_policy
+    st = cl.Settings(device_id=local)
+    t0 = time.perf_counter()
+    solver = cl.Solver(P, q, A, b, cones, st, kktsolver_factory=lambda *a: Recorder(*a, **optkw))
+    t_setup = time.perf_counter() - t0
+    sol = solver.solve()
+    ks = solver.kktsystem.kktsolver
+    h = ks.h
+    e2e_iters = sol.iterations
+    e2e_time = solver.info.timers["IP iteration"]
+    tm = h.timing()
+    # keep iterations that carry the regular 3 solves (the initial factorisation has 2 or 3)
+    units = [t for t in trace if len(t["rhs"]) == 3]
+    if not units:
+        raise SystemExit("no complete KKT iteration units recorded")
+
+    # ---- 2. stage the trace in HBM
+    dev = torch.device("cuda", local)
+    for t in units:
+        t["hs_d"] = torch.from_numpy(t["hs"]).to(dev)
+        t["rhs_d"] = [torch.from_numpy(r).to(dev) for r in t["rhs"]]
+    out_d = torch.zeros(h.n + h.m, dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    ir = dict(ir_enable=st.iterative_refinement_enable, reltol=st.iterative_refinement_reltol,
+              abstol=st.iterative_refinement_abstol, max_iter=st.iterative_refinement_max_iter,
+              stop_ratio=st.iterative_refinement_stop_ratio)
+    has_soc = ks._soc_total > 0
+    ir_steps_total = [0]
+
+    def step(i):
+        t = units[i % len(units)]
+        h.set_hs_dev(t["hs_d"].data_ptr(), h.nHs)
+        if has_soc:
+            h.set_soc_batch(t["eta2"], t["u"], t["v"])
+        ok, _, _ = h.refactor(st.static_regularization_enable, st.static_regularization_constant,
+                              st.static_regularization_proportional)
+        for r in t["rhs_d"]:
+            h.setrhs_dev(r.data_ptr())
+            ok2, steps = h.solve_dev(out_d.data_ptr(), **ir)
+            ir_steps_total[0] += steps
+            ok = ok and ok2
+        if not ok:
+            raise SystemExit("numerical failure inside the timed region")
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    h.reset_timing()
+    ir_steps_total[0] = 0
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    tm = h.timing()
+    factor_ms = tm["acc_factor_ms"] / max(1, tm["n_factor"])
+    solve_ms = tm["acc_solve_ms"] / max(1, tm["n_solve_calls"])
+    ldl_per_unit = tm["n_ldl_solves"] / max(1, args.steps)
+
+    # ---- 3. roofline of the dominant kernel (k_update_stage, FP64 MFMA): live HIP-event timing of
+    #         every update launch on the handle's stream, in a profiling pass over the same inputs
+    cm = h.cost_model()
+    h.set_profiling(True)
+    upd_ms = []
+    for i in range(3):
+        t = units[i % len(units)]
+        h.set_hs_dev(t["hs_d"].data_ptr(), h.nHs)
+        h.refactor(st.static_regularization_enable, st.static_regularization_constant,
+                   st.static_regularization_proportional)
+        upd_ms.append(h.timing()["last_update_ms"])
+    h.set_profiling(False)
+    upd = float(np.median(upd_ms))
+    achieved = cm["flops_update"] / (upd * 1e-3) / 1e12 if upd > 0 else 0.0
+    roofline = dict(bound="mfma", achieved=round(achieved, 3), peak=F64_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
+                    frac=round(achieved / F64_MFMA_PEAK_TFLOPS, 4), traffic=None,
+                    kernel="k_update_stage", flops_per_refactor=cm["flops_update"],
+                    launches_per_refactor=h.nlevels - 1, ms_per_refactor=round(upd, 4))
+
+    result = {
+        "metric": "IPM iterations/sec + KKT factor+solve ms, 10k-var sparse QP, 1/2/4/8 GPU",
+        "value": round(world * args.steps / elapsed, 4),
+        "unit": "IPM-iterations/s (KKT iteration units: 1 update + 1 factor + 3 refined solves, inputs in HBM)",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": workload, "N": h.N, "nnzK": h.nnzK, "nnzL": h.nnzL, "supernodes": h.nsuper,
+                   "levels": h.nlevels, "parallelism": f"{world} independent problem(s), one per GPU"},
+        "kkt_factor_ms": round(factor_ms, 4), "kkt_solve_ms_per_call": round(solve_ms, 4),
+        "kkt_factor_plus_3solves_ms": round(factor_ms + 3 * solve_ms, 4),
+        "ldl_solves_per_step": round(ldl_per_unit, 2),
+        "end_to_end": {"ipm_iterations": e2e_iters, "status": sol.status, "iterations_per_s": round(e2e_iters / e2e_time, 4),
+                       "note": "full IPM loop incl. host cone algebra (numpy) and PCIe of Hs/rhs per call",
+                       "setup_s": round(t_setup, 3)},
+        "roofline": roofline,
+    }
+
+    # ---- 4. CPU baseline: the oracle (C restatement of the reference's :qdldl path), 1 thread,
+    #         same permutation, one KKT iteration unit of the same trace
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle.kkt_oracle import OracleKKTSolver
+
+        perm = h.perm()
+        data = solver.data
+        cpu = OracleKKTSolver(data.P, data.A, solver.cones, data.m, data.n, st, ordering=perm)
+        t = units[min(len(units) - 1, len(units) // 2)]
+        L = cpu.k.L
+        tc0 = time.perf_counter()
+        L.oracle_kkt_update_Hs(cpu.k.h, t["hs"])
+        if has_soc:
+            off = 0
+            for si, c in enumerate(ks._soc):
+                L.oracle_kkt_update_soc(cpu.k.h, si, t["eta2"][si], np.ascontiguousarray(t["u"][off:off + c.dim]),
+                                        np.ascontiguousarray(t["v"][off:off + c.dim]))
+                off += c.dim
+        import ctypes as C
+
+        eps = C.c_double(0)
+        okc = L.oracle_kkt_regularize_and_refactor(cpu.k.h, int(st.static_regularization_enable),
+                                                   st.static_regularization_constant,
+                                                   st.static_regularization_proportional, C.byref(eps))
+        t_fac = time.perf_counter() - tc0
+        lx, lz = np.zeros(data.n), np.zeros(data.m)
+        for r in t["rhs"]:
+            cpu.kktsolver_setrhs(np.ascontiguousarray(r[:data.n]), np.ascontiguousarray(r[data.n:]))
+            okc = cpu.kktsolver_solve(lx, lz) and okc
+        t_unit = time.perf_counter() - tc0
+        result["cpu_baseline"] = {
+            "value": round(1.0 / t_unit, 5), "unit": "IPM-iterations/s", "cores": 1, "kind": "port",
+            "sample": "1 KKT iteration unit (1 update + 1 QDLDL refactor + 3 refined solves) of the same trace, "
+                      "same permutation, oracle/ C restatement of the reference's :qdldl path, gcc -O3",
+            "factor_s": round(t_fac, 3), "unit_s": round(t_unit, 3), "host_cores_available": os.cpu_count(),
+            "ok": bool(okc)}
+        result["speedup_vs_cpu_baseline"] = round(result["value"] / result["cpu_baseline"]["value"], 1)
+
+    if rank == 0:
+        print(json.dumps(result))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

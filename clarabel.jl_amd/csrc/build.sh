@@ -1,0 +1,17 @@
+#!/bin/bash
+# Builds libclarabel_hipkkt.so for gfx950 in-tree (clarabel.jl_amd/).  hipcc cross-compiles without a GPU.
+set -e
+cd "$(dirname "$0")"
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+OUT=../libclarabel_hipkkt.so
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-result"
+mkdir -p ../../build/obj
+OBJ=../../build/obj
+pids=()
+for f in hipkkt.cpp symbolic.cpp ordering.cpp assemble.cpp; do
+  $HIPCC $FLAGS -x c++ -I/opt/rocm/include -D__HIP_PLATFORM_AMD__ -c $f -o $OBJ/${f%.cpp}.o & pids+=($!)
+done
+$HIPCC $FLAGS -c kernels.hip -o $OBJ/kernels.o & pids+=($!)
+for p in "${pids[@]}"; do wait $p; done
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT $OBJ/hipkkt.o $OBJ/symbolic.o $OBJ/ordering.o $OBJ/assemble.o $OBJ/kernels.o
+echo "built $(readlink -f $OUT)"

@@ -1,0 +1,48 @@
+// Device-resident image of the symbolic plan + numeric state; passed BY VALUE to the kernels.
+#pragma once
+#include <stdint.h>
+
+#include "symbolic.h"
+
+namespace hipkkt {
+
+enum { SC_MAXDIAG = 0, SC_NORMB = 1, SC_NORME = 2, SC_COUNT = 8 };  // 64-bit scalar slots
+enum { FL_NONFINITE = 0, FL_NREG = 1, FL_COUNT = 4 };                // int flags
+
+struct DevPlan {
+    // structure (read-only after setup)
+    const int *sn_first;
+    const int64_t *sn_rowptr;
+    const int *sn_rows;
+    const int64_t *sn_panel;
+    const int64_t *sn_diag;
+    const int64_t *u_off;
+    const int64_t *p_off;
+    const int *lvl_sn;
+    const int *perm;
+    const signed char *sgn_perm;
+    const FacItem *fac_items;
+    const FacItem *slv_items;
+    const int *rel;
+    const UpdTask *upd_tasks;
+    const UpdGroup *upd_groups;
+    const int64_t *g_ptr;
+    const int *g_idx;
+    const int64_t *kmap;
+    const signed char *kdiag_sign;
+    const int64_t *sym_rowptr;
+    const int *sym_col;
+    const int64_t *sym_q;
+    // numeric state
+    double *kval;    // resident, UNREGULARISED triu KKT values (original nz order)
+    double *Lx;      // supernodal panels
+    double *Ldiag;   // factored unit-lower diagonal blocks
+    double *D;
+    double *Dinv;
+    double *ubuf;    // forward-solve update vectors
+    double *pbuf;    // backward-solve partial dot products
+    double *scal;    // SC_* slots (raw 64-bit)
+    int *flags;      // FL_* slots
+};
+
+}  // namespace hipkkt

@@ -1,0 +1,919 @@
+// C ABI of libclarabel_hipkkt.so (see include/hipkkt.h for the contract and the reference
+// interfaces each entry point replaces).  Host orchestration only: symbolic analysis, device
+// residency, stream / hipGraph management and the control flow of iterative refinement.  All
+// numeric work is in kernels.hip.
+#include "../../include/hipkkt.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "assemble.h"
+#include "device_plan.h"
+#include "kernels.h"
+#include "symbolic.h"
+
+using namespace hipkkt;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct DeviceError {
+    std::string msg;
+};
+
+#define HK_CHECK(expr)                                                                            \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            throw DeviceError{std::string(#expr) + ": " + hipGetErrorString(e_)};                 \
+    } while (0)
+
+struct GraphSlot {
+    hipGraphExec_t exec = nullptr;
+    bool valid = false;
+    // parameters baked into the captured kernel arguments
+    int static_enable = -1;
+    double eps_const = 0, eps_prop = 0;
+};
+
+}  // namespace
+
+struct hipkkt_solver {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipkkt_opts opts{};
+    bool l1 = false;
+    KKTImage img;      // L1: assembled image; L0: colptr/rowval/nzval/dsigns copied in
+    HostPlan plan;
+    DevPlan dp{};
+    std::vector<void *> allocs;
+    std::string err;
+
+    int N = 0;
+    int64_t nnzK = 0;
+    // solve item lists (256-row blocks) per level
+    std::vector<FacItem> slv_items;
+    std::vector<int> slv_lvl_ptr;
+    std::vector<int64_t> p_off;
+
+    // device index arrays for value updates
+    int64_t *d_mapHs = nullptr, *d_mapP = nullptr, *d_mapA = nullptr, *d_diag_full = nullptr;
+    // all sparse SOC cones concatenated
+    int64_t soc_total = 0;
+    int nsoc = 0;
+    std::vector<int64_t> soc_off;  // per sparse map (SOC only) offset into the concatenated arrays
+    std::vector<int> soc_of_sparse; // sparse-map index -> soc ordinal or -1
+    int64_t *d_soc_uidx = nullptr, *d_soc_vidx = nullptr, *d_soc_didx = nullptr;
+    int *d_soc_cone = nullptr;
+    double *d_soc_u = nullptr, *d_soc_v = nullptr, *d_soc_eta2 = nullptr;
+
+    // vectors
+    double *d_b = nullptr, *d_x = nullptr, *d_dx = nullptr, *d_e = nullptr;
+    double *d_sin = nullptr, *d_sout = nullptr, *d_y = nullptr, *d_z = nullptr, *d_xp = nullptr;
+    double *d_stage = nullptr;   // staging for host-supplied values
+    int64_t *d_stage_idx = nullptr;
+    int64_t stage_cap = 0;
+    double *h_scal = nullptr;    // pinned read-back area
+    int *h_flags = nullptr;
+
+    GraphSlot g_factor, g_solve;
+    bool use_graph = true;
+    bool profiling = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
+    double t_last_factor = 0, t_last_solve = 0, t_acc_factor = 0, t_acc_solve = 0, t_last_update = 0;
+    int64_t n_factor = 0, n_solvecalls = 0, n_ldlsolves = 0;
+    double last_eps = 0;
+    int64_t last_nreg = 0;
+
+    template <class T>
+    T *dalloc(size_t n) {
+        void *p = nullptr;
+        if (n == 0) n = 1;
+        hipError_t e = hipMalloc(&p, n * sizeof(T));
+        if (e != hipSuccess) throw std::bad_alloc();
+        allocs.push_back(p);
+        return (T *)p;
+    }
+    template <class T>
+    T *upload(const std::vector<T> &v) {
+        T *p = dalloc<T>(v.size());
+        if (!v.empty()) HK_CHECK(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+        return p;
+    }
+    void ensure_stage(int64_t n) {
+        if (n <= stage_cap) return;
+        int64_t cap = std::max<int64_t>(n, 2 * stage_cap);
+        d_stage = dalloc<double>(cap);
+        d_stage_idx = dalloc<int64_t>(cap);
+        stage_cap = cap;
+    }
+    ~hipkkt_solver() {
+        hipSetDevice(device);
+        if (g_factor.exec) hipGraphExecDestroy(g_factor.exec);
+        if (g_solve.exec) hipGraphExecDestroy(g_solve.exec);
+        for (void *p : allocs) hipFree(p);
+        if (h_scal) hipHostFree(h_scal);
+        if (h_flags) hipHostFree(h_flags);
+        for (hipEvent_t e : {ev0, ev1, ev2, ev3})
+            if (e) hipEventDestroy(e);
+        if (stream) hipStreamDestroy(stream);
+    }
+};
+
+namespace {
+
+void setup_device(hipkkt_solver *S) {
+    HK_CHECK(hipSetDevice(S->device));
+    HK_CHECK(hipStreamCreateWithFlags(&S->stream, hipStreamNonBlocking));
+    for (hipEvent_t *e : {&S->ev0, &S->ev1, &S->ev2, &S->ev3}) HK_CHECK(hipEventCreate(e));
+    HK_CHECK(hipHostMalloc((void **)&S->h_scal, SC_COUNT * sizeof(double), hipHostMallocDefault));
+    HK_CHECK(hipHostMalloc((void **)&S->h_flags, FL_COUNT * sizeof(int), hipHostMallocDefault));
+    const char *ng = getenv("HIPKKT_NO_GRAPH");
+    if (ng && ng[0] == '1') S->use_graph = false;
+
+    HostPlan &P = S->plan;
+    const int N = P.N;
+    S->N = N;
+    S->nnzK = P.nnzK;
+    // solve items: 256-row blocks
+    S->slv_lvl_ptr.assign(P.nlevels + 1, 0);
+    S->p_off.assign(P.nsuper + 1, 0);
+    for (int s = 0; s < P.nsuper; s++) {
+        int w = P.sn_first[s + 1] - P.sn_first[s];
+        int64_t r = P.sn_rowptr[s + 1] - P.sn_rowptr[s];
+        int64_t nb = std::max<int64_t>(1, (r - w + 255) / 256);
+        S->p_off[s + 1] = S->p_off[s] + nb * w;
+    }
+    for (int l = 0; l < P.nlevels; l++) {
+        for (int q = P.lvl_ptr[l]; q < P.lvl_ptr[l + 1]; q++) {
+            int s = P.lvl_sn[q];
+            int w = P.sn_first[s + 1] - P.sn_first[s];
+            int64_t r = P.sn_rowptr[s + 1] - P.sn_rowptr[s];
+            int nb = (int)std::max<int64_t>(1, (r - w + 255) / 256);
+            for (int b = 0; b < nb; b++) S->slv_items.push_back({s, b});
+        }
+        S->slv_lvl_ptr[l + 1] = (int)S->slv_items.size();
+    }
+    std::vector<signed char> sgn_perm(N), kdiag(S->nnzK, 0);
+    for (int k = 0; k < N; k++) sgn_perm[k] = (signed char)(S->img.dsigns[P.perm[k]] >= 0 ? 1 : -1);
+    for (int j = 0; j < N; j++)
+        for (int64_t q = S->img.colptr[j]; q < S->img.colptr[j + 1]; q++)
+            if (S->img.rowval[q] == j) kdiag[q] = (signed char)(S->img.dsigns[j] >= 0 ? 1 : -1);
+
+    DevPlan &D = S->dp;
+    D.sn_first = S->upload(P.sn_first);
+    D.sn_rowptr = S->upload(P.sn_rowptr);
+    D.sn_rows = S->upload(P.sn_rows);
+    D.sn_panel = S->upload(P.sn_panel);
+    D.sn_diag = S->upload(P.sn_diag);
+    D.u_off = S->upload(P.u_off);
+    D.p_off = S->upload(S->p_off);
+    D.lvl_sn = S->upload(P.lvl_sn);
+    D.perm = S->upload(P.perm);
+    D.sgn_perm = S->upload(sgn_perm);
+    D.fac_items = S->upload(P.fac_items);
+    D.slv_items = S->upload(S->slv_items);
+    D.rel = S->upload(P.rel);
+    D.upd_tasks = S->upload(P.upd_tasks);
+    D.upd_groups = S->upload(P.upd_groups);
+    D.g_ptr = S->upload(P.g_ptr);
+    D.g_idx = S->upload(P.g_idx);
+    D.kmap = S->upload(P.kmap);
+    D.kdiag_sign = S->upload(kdiag);
+    D.sym_rowptr = S->upload(P.sym_rowptr);
+    D.sym_col = S->upload(P.sym_col);
+    D.sym_q = S->upload(P.sym_q);
+    D.kval = S->upload(S->img.nzval);
+    D.Lx = S->dalloc<double>(P.panel_doubles);
+    D.Ldiag = S->dalloc<double>(P.diag_doubles);
+    D.D = S->dalloc<double>(N);
+    D.Dinv = S->dalloc<double>(N);
+    D.ubuf = S->dalloc<double>(P.ubuf_len);
+    D.pbuf = S->dalloc<double>(S->p_off[P.nsuper]);
+    D.scal = S->dalloc<double>(SC_COUNT);
+    D.flags = S->dalloc<int>(FL_COUNT);
+    HK_CHECK(hipMemset(D.scal, 0, SC_COUNT * sizeof(double)));
+    HK_CHECK(hipMemset(D.flags, 0, FL_COUNT * sizeof(int)));
+    HK_CHECK(hipMemset(D.Dinv, 0, (size_t)std::max(N, 1) * sizeof(double)));
+    HK_CHECK(hipMemset(D.Ldiag, 0, (size_t)std::max<int64_t>(P.diag_doubles, 1) * sizeof(double)));
+
+    S->d_diag_full = S->upload(S->img.diag_full);
+    if (S->l1) {
+        S->d_mapHs = S->upload(S->img.mapHs);
+        S->d_mapP = S->upload(S->img.mapP);
+        S->d_mapA = S->upload(S->img.mapA);
+        // concatenated SOC expansion maps
+        std::vector<int64_t> uidx, vidx, didx;
+        std::vector<int> coneof;
+        S->soc_of_sparse.assign(S->img.smaps.size(), -1);
+        for (size_t i = 0; i < S->img.smaps.size(); i++) {
+            const SparseMap &sm = S->img.smaps[i];
+            if (sm.kind != 1) continue;
+            S->soc_of_sparse[i] = S->nsoc;
+            S->soc_off.push_back((int64_t)uidx.size());
+            for (size_t q = 0; q < sm.vec[0].size(); q++) {
+                uidx.push_back(sm.vec[0][q]);
+                vidx.push_back(sm.vec[1][q]);
+                coneof.push_back(S->nsoc);
+            }
+            didx.push_back(sm.D[0]);
+            didx.push_back(sm.D[1]);
+            S->nsoc++;
+        }
+        S->soc_off.push_back((int64_t)uidx.size());
+        S->soc_total = (int64_t)uidx.size();
+        S->d_soc_uidx = S->upload(uidx);
+        S->d_soc_vidx = S->upload(vidx);
+        S->d_soc_didx = S->upload(didx);
+        S->d_soc_cone = S->upload(coneof);
+        S->d_soc_u = S->dalloc<double>(S->soc_total);
+        S->d_soc_v = S->dalloc<double>(S->soc_total);
+        S->d_soc_eta2 = S->dalloc<double>(S->nsoc);
+    }
+    for (double **v : {&S->d_b, &S->d_x, &S->d_dx, &S->d_e, &S->d_sin, &S->d_sout, &S->d_y, &S->d_z, &S->d_xp}) {
+        *v = S->dalloc<double>(N);
+        HK_CHECK(hipMemset(*v, 0, (size_t)std::max(N, 1) * sizeof(double)));
+    }
+    S->ensure_stage(std::max<int64_t>(1024, std::max<int64_t>(S->img.nHs, N)));
+    HK_CHECK(hipDeviceSynchronize());
+}
+
+// ---- enqueue helpers (no synchronisation inside; capturable) ---------------------------------
+
+void enqueue_factor(hipkkt_solver *S, int static_enable, double eps_const, double eps_prop) {
+    const HostPlan &P = S->plan;
+    hipStream_t st = S->stream;
+    HK_CHECK(hipMemsetAsync(S->dp.scal, 0, sizeof(double), st));  // SC_MAXDIAG
+    HK_CHECK(hipMemsetAsync(S->dp.flags, 0, FL_COUNT * sizeof(int), st));
+    launch_maxabs_gather(st, S->dp.kval, S->d_diag_full, S->N, (unsigned long long *)S->dp.scal + SC_MAXDIAG);
+    HK_CHECK(hipMemsetAsync(S->dp.Lx, 0, (size_t)P.panel_doubles * sizeof(double), st));
+    launch_init_panels(st, S->dp, S->nnzK, static_enable, eps_const, eps_prop);
+    for (int l = 0; l < P.nlevels; l++) {
+        launch_factor_level(st, S->dp, P.fac_lvl_ptr[l], P.fac_lvl_ptr[l + 1] - P.fac_lvl_ptr[l], P.fac_lvl_maxw[l],
+                            S->opts.dynamic_reg_eps, S->opts.dynamic_reg_delta);
+        launch_update_stage(st, S->dp, P.upd_stage_ptr[l], P.upd_stage_ptr[l + 1] - P.upd_stage_ptr[l]);
+    }
+}
+
+// d_sin -> d_sout (original ordering on both sides)
+void enqueue_ldl_solve(hipkkt_solver *S) {
+    const HostPlan &P = S->plan;
+    hipStream_t st = S->stream;
+    launch_permute_in(st, S->d_sin, S->dp.perm, S->d_y, S->N);
+    for (int l = 0; l < P.nlevels; l++)
+        launch_fwd_level(st, S->dp, S->slv_lvl_ptr[l], S->slv_lvl_ptr[l + 1] - S->slv_lvl_ptr[l], S->d_y, S->d_z);
+    for (int l = P.nlevels - 1; l >= 0; l--) {
+        launch_bwd_partial(st, S->dp, S->slv_lvl_ptr[l], S->slv_lvl_ptr[l + 1] - S->slv_lvl_ptr[l], S->d_xp);
+        launch_bwd_final(st, S->dp, P.lvl_ptr[l], P.lvl_ptr[l + 1] - P.lvl_ptr[l], S->d_z, S->d_xp, S->d_sout);
+    }
+}
+
+template <class F>
+void run_graphed(hipkkt_solver *S, GraphSlot &slot, bool reusable, F &&enqueue) {
+    if (!S->use_graph) { enqueue(); return; }
+    if (!(slot.valid && reusable)) {
+        if (slot.exec) { hipGraphExecDestroy(slot.exec); slot.exec = nullptr; slot.valid = false; }
+        hipGraph_t graph = nullptr;
+        HK_CHECK(hipStreamBeginCapture(S->stream, hipStreamCaptureModeThreadLocal));
+        try {
+            enqueue();
+        } catch (...) {
+            hipStreamEndCapture(S->stream, &graph);
+            if (graph) hipGraphDestroy(graph);
+            throw;
+        }
+        HK_CHECK(hipStreamEndCapture(S->stream, &graph));
+        hipError_t e = hipGraphInstantiate(&slot.exec, graph, nullptr, nullptr, 0);
+        hipGraphDestroy(graph);
+        if (e != hipSuccess) { slot.exec = nullptr; S->use_graph = false; enqueue(); return; }
+        slot.valid = true;
+    }
+    HK_CHECK(hipGraphLaunch(slot.exec, S->stream));
+}
+
+void ldl_solve_dev(hipkkt_solver *S, const double *in, double *out) {
+    size_t nb = (size_t)S->N * sizeof(double);
+    if (in != S->d_sin) HK_CHECK(hipMemcpyAsync(S->d_sin, in, nb, hipMemcpyDeviceToDevice, S->stream));
+    run_graphed(S, S->g_solve, true, [&] { enqueue_ldl_solve(S); });
+    if (out != S->d_sout) HK_CHECK(hipMemcpyAsync(out, S->d_sout, nb, hipMemcpyDeviceToDevice, S->stream));
+    S->n_ldlsolves++;
+}
+
+double slot_value(const hipkkt_solver *S, int slot) {
+    double v;
+    memcpy(&v, (const char *)S->h_scal + slot * sizeof(double), sizeof(double));
+    return v;  // the slot holds the raw bit pattern of a non-negative double (or NaN)
+}
+
+void read_scalars(hipkkt_solver *S) {
+    HK_CHECK(hipMemcpyAsync(S->h_scal, S->dp.scal, SC_COUNT * sizeof(double), hipMemcpyDeviceToHost, S->stream));
+    HK_CHECK(hipStreamSynchronize(S->stream));
+}
+
+// e = b - K*xi, returns ||e||_inf (ref: _get_refine_error!, kktsolver_directldl.jl:455-466)
+double refine_error(hipkkt_solver *S, const double *xi, bool also_normb, double *normb) {
+    hipStream_t st = S->stream;
+    HK_CHECK(hipMemsetAsync((char *)S->dp.scal + SC_NORMB * sizeof(double), 0, 2 * sizeof(double), st));
+    if (also_normb) launch_norm_inf(st, S->d_b, S->N, (unsigned long long *)S->dp.scal + SC_NORMB);
+    launch_spmv_residual(st, S->dp, S->d_b, xi, S->d_e, S->N, (unsigned long long *)S->dp.scal + SC_NORME);
+    read_scalars(S);
+    if (also_normb && normb) *normb = slot_value(S, SC_NORMB);
+    return slot_value(S, SC_NORME);
+}
+
+// ref: kktsolver_solve! + _iterative_refinement (kktsolver_directldl.jl:346-449); d_b holds b
+int32_t solve_core(hipkkt_solver *S, int ir_enable, double reltol, double abstol, int64_t max_iter,
+                   double stop_ratio, int64_t *ir_steps) {
+    HK_CHECK(hipEventRecord(S->ev2, S->stream));
+    int64_t steps = 0;
+    bool ok = true;
+    double *x = S->d_x, *dx = S->d_dx;
+    ldl_solve_dev(S, S->d_b, x);
+    if (ir_enable) {
+        double normb = 0;
+        double norme = refine_error(S, x, true, &normb);
+        if (!std::isfinite(norme)) ok = false;
+        for (int64_t i = 0; ok && i < max_iter; i++) {
+            if (norme <= abstol + reltol * normb) break;
+            const double lastnorme = norme;
+            ldl_solve_dev(S, S->d_e, dx);
+            steps++;
+            launch_add(S->stream, dx, x, S->N);
+            norme = refine_error(S, dx, false, nullptr);
+            if (!std::isfinite(norme)) { ok = false; break; }
+            const double improved = lastnorme / norme;
+            if (improved < stop_ratio) {
+                if (improved > 1.0) std::swap(x, dx);
+                break;
+            }
+            std::swap(x, dx);
+        }
+    } else {
+        HK_CHECK(hipMemsetAsync(S->dp.flags, 0, sizeof(int), S->stream));
+        launch_check_finite(S->stream, x, S->N, S->dp.flags);
+        HK_CHECK(hipMemcpyAsync(S->h_flags, S->dp.flags, FL_COUNT * sizeof(int), hipMemcpyDeviceToHost, S->stream));
+        HK_CHECK(hipStreamSynchronize(S->stream));
+        ok = S->h_flags[FL_NONFINITE] == 0;
+    }
+    S->d_x = x;
+    S->d_dx = dx;
+    HK_CHECK(hipEventRecord(S->ev3, S->stream));
+    HK_CHECK(hipStreamSynchronize(S->stream));
+    float ms = 0;
+    HK_CHECK(hipEventElapsedTime(&ms, S->ev2, S->ev3));
+    S->t_last_solve = ms;
+    S->t_acc_solve += ms;
+    S->n_solvecalls++;
+    if (ir_steps) *ir_steps = steps;
+    return ok ? HIPKKT_OK : HIPKKT_NUMERICAL_FAILURE;
+}
+
+int32_t finish_create(hipkkt_solver *S, const hipkkt_opts *opts, hipkkt_handle *out) {
+    PlanOptions po;
+    po.max_width = opts->supernode_max_width > 0 ? opts->supernode_max_width : kMaxSnWidth;
+    po.relax = opts->relax_supernodes != 0;
+    po.update_policy = opts->update_policy;
+    po.amd_dense_scale = opts->amd_dense_scale > 0 ? opts->amd_dense_scale : 1.5;
+    std::vector<int64_t> up;
+    const int64_t *uperm = nullptr;
+    if (opts->user_perm) {
+        up.resize(S->img.N);
+        for (int64_t k = 0; k < S->img.N; k++) up[k] = opts->user_perm[k] - opts->index_base;
+        uperm = up.data();
+    }
+    if (S->img.N >= ((int64_t)1 << 31)) { g_create_error = "N exceeds int32"; delete S; return HIPKKT_ERR_ARGUMENT; }
+    std::string err = build_plan((int)S->img.N, S->img.colptr.data(), S->img.rowval.data(), uperm, po, S->plan);
+    if (!err.empty()) { g_create_error = err; delete S; return HIPKKT_ERR_ARGUMENT; }
+    try {
+        setup_device(S);
+    } catch (const DeviceError &e) {
+        g_create_error = e.msg; delete S; return HIPKKT_ERR_DEVICE;
+    } catch (const std::bad_alloc &) {
+        g_create_error = "out of (device) memory"; delete S; return HIPKKT_ERR_ALLOC;
+    }
+    *out = S;
+    return HIPKKT_OK;
+}
+
+}  // namespace
+
+#define HK_ENTER(h)                                                      \
+    if (!(h)) return HIPKKT_ERR_ARGUMENT;                                \
+    hipkkt_solver *S = (h);                                              \
+    try {                                                                \
+        if (hipSetDevice(S->device) != hipSuccess) { S->err = "hipSetDevice failed"; return HIPKKT_ERR_DEVICE; }
+
+#define HK_LEAVE                                                         \
+    }                                                                    \
+    catch (const DeviceError &e) { S->err = e.msg; return HIPKKT_ERR_DEVICE; } \
+    catch (const std::bad_alloc &) { S->err = "out of memory"; return HIPKKT_ERR_ALLOC; } \
+    catch (...) { S->err = "internal error"; return HIPKKT_ERR_INTERNAL; }
+
+extern "C" {
+
+void hipkkt_default_opts(hipkkt_opts *o) {
+    if (!o) return;
+    memset(o, 0, sizeof(*o));
+    o->index_base = 0;
+    o->supernode_max_width = kMaxSnWidth;
+    o->relax_supernodes = 1;
+    o->update_policy = 0;
+    o->dynamic_reg_eps = 1e-13;
+    o->dynamic_reg_delta = 2e-7;
+    o->amd_dense_scale = 1.5;
+    o->user_perm = nullptr;
+}
+
+int32_t hipkkt_is_available(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n > 0 ? n : 0;
+}
+
+int32_t hipkkt_create(int32_t device_id, int64_t N, const int64_t *colptr, const int64_t *rowval,
+                      const double *nzval, const int64_t *dsigns, const hipkkt_opts *opts, hipkkt_handle *out) {
+    if (!out || N < 0 || !colptr || (!rowval && N) || !opts) { g_create_error = "null argument"; return HIPKKT_ERR_ARGUMENT; }
+    *out = nullptr;
+    hipkkt_solver *S = nullptr;
+    try {
+        S = new hipkkt_solver();
+        S->device = device_id;
+        S->opts = *opts;
+        S->l1 = false;
+        const int64_t base = opts->index_base;
+        KKTImage &K = S->img;
+        K.N = N;
+        K.colptr.resize(N + 1);
+        for (int64_t j = 0; j <= N; j++) K.colptr[j] = colptr[j] - base;
+        const int64_t nnz = K.colptr[N];
+        K.rowval.resize(nnz);
+        K.nzval.resize(nnz);
+        for (int64_t q = 0; q < nnz; q++) { K.rowval[q] = rowval[q] - base; K.nzval[q] = nzval ? nzval[q] : 0.0; }
+        K.dsigns.resize(N);
+        for (int64_t j = 0; j < N; j++) K.dsigns[j] = dsigns ? dsigns[j] : 1;
+        K.diag_full.resize(N);
+        for (int64_t j = 0; j < N; j++) {
+            if (K.colptr[j + 1] <= K.colptr[j] || K.rowval[K.colptr[j + 1] - 1] != j) {
+                g_create_error = "KKT must be :triu with the diagonal stored last in every column";
+                delete S;
+                return HIPKKT_ERR_ARGUMENT;
+            }
+            K.diag_full[j] = K.colptr[j + 1] - 1;
+        }
+    } catch (const std::bad_alloc &) {
+        delete S;
+        g_create_error = "out of memory";
+        return HIPKKT_ERR_ALLOC;
+    }
+    return finish_create(S, opts, out);
+}
+
+int32_t hipkkt_create_from_parts(int32_t device_id, int64_t n, int64_t m, const int64_t *Pcolptr,
+                                 const int64_t *Prowval, const double *Pnzval, const int64_t *Acolptr,
+                                 const int64_t *Arowval, const double *Anzval, int64_t ncones,
+                                 const int64_t *cone_numel, const int32_t *cone_hs_dense,
+                                 const int32_t *cone_sparse_kind, const int64_t *cone_dim1, const hipkkt_opts *opts,
+                                 hipkkt_handle *out) {
+    if (!out || !opts || n < 0 || m < 0 || !Pcolptr || !Acolptr) { g_create_error = "null argument"; return HIPKKT_ERR_ARGUMENT; }
+    *out = nullptr;
+    hipkkt_solver *S = nullptr;
+    try {
+        S = new hipkkt_solver();
+        S->device = device_id;
+        S->opts = *opts;
+        S->l1 = true;
+        const int64_t base = opts->index_base;
+        std::vector<int64_t> Pp(n + 1), Ap(n + 1);
+        for (int64_t j = 0; j <= n; j++) { Pp[j] = Pcolptr[j] - base; Ap[j] = Acolptr[j] - base; }
+        std::vector<int64_t> Pi(Pp[n]), Ai(Ap[n]);
+        for (int64_t q = 0; q < Pp[n]; q++) Pi[q] = Prowval[q] - base;
+        for (int64_t q = 0; q < Ap[n]; q++) Ai[q] = Arowval[q] - base;
+        std::vector<int64_t> dim1(ncones, 0);
+        if (cone_dim1) for (int64_t c = 0; c < ncones; c++) dim1[c] = cone_dim1[c];
+        std::string err = assemble_kkt(n, m, Pp.data(), Pi.data(), Pnzval, Ap.data(), Ai.data(), Anzval, ncones,
+                                       cone_numel, cone_hs_dense, cone_sparse_kind, dim1.data(), S->img);
+        if (!err.empty()) { g_create_error = err; delete S; return HIPKKT_ERR_ARGUMENT; }
+    } catch (const std::bad_alloc &) {
+        delete S;
+        g_create_error = "out of memory";
+        return HIPKKT_ERR_ALLOC;
+    }
+    return finish_create(S, opts, out);
+}
+
+void hipkkt_destroy(hipkkt_handle h) { delete h; }
+
+int32_t hipkkt_get_dims(hipkkt_handle h, int64_t *o) {
+    if (!h || !o) return HIPKKT_ERR_ARGUMENT;
+    const KKTImage &K = h->img;
+    const HostPlan &P = h->plan;
+    o[0] = K.N; o[1] = K.n; o[2] = K.m; o[3] = K.p; o[4] = h->nnzK; o[5] = K.nHs; o[6] = (int64_t)K.smaps.size();
+    o[7] = K.nnzP; o[8] = K.nnzA; o[9] = P.nnzL; o[10] = P.nsuper; o[11] = P.nlevels; o[12] = P.panel_doubles;
+    o[13] = (int64_t)P.upd_tasks.size(); o[14] = P.etree_height; o[15] = 0;
+    return HIPKKT_OK;
+}
+
+int32_t hipkkt_info(hipkkt_handle h, int64_t *nnzA, int64_t *nnzL) {
+    if (!h) return HIPKKT_ERR_ARGUMENT;
+    if (nnzA) *nnzA = h->nnzK;
+    if (nnzL) *nnzL = h->plan.nnzL;
+    return HIPKKT_OK;
+}
+
+int32_t hipkkt_get_cost_model(hipkkt_handle h, double *o) {
+    if (!h || !o) return HIPKKT_ERR_ARGUMENT;
+    const HostPlan &P = h->plan;
+    const double N = P.N, nnzK = (double)P.nnzK, nnzL = (double)P.nnzL;
+    o[0] = P.flops_colcount;
+    o[1] = P.flops_exec;
+    o[2] = 4.0 * nnzL + N;
+    o[3] = 8.0 * (nnzK + nnzL + N);
+    o[4] = 2.0 * (8.0 + 4.0) * nnzL + 8.0 * 5.0 * N;
+    o[5] = (8.0 + 4.0) * nnzK + 8.0 * 3.0 * N;
+    o[6] = P.flops_update;
+    o[7] = 0;
+    return HIPKKT_OK;
+}
+
+int32_t hipkkt_get_kkt(hipkkt_handle h, int64_t *colptr, int64_t *rowval, double *nzval) {
+    HK_ENTER(h)
+    const KKTImage &K = S->img;
+    const int64_t base = S->opts.index_base;
+    if (colptr) for (int64_t j = 0; j <= K.N; j++) colptr[j] = K.colptr[j] + base;
+    if (rowval) for (int64_t q = 0; q < S->nnzK; q++) rowval[q] = K.rowval[q] + base;
+    if (nzval) HK_CHECK(hipMemcpy(nzval, S->dp.kval, (size_t)S->nnzK * sizeof(double), hipMemcpyDeviceToHost));
+    return HIPKKT_OK;
+    HK_LEAVE
+}
+
+int32_t hipkkt_get_perm(hipkkt_handle h, int64_t *perm) {
+    if (!h || !perm) return HIPKKT_ERR_ARGUMENT;
+    for (int k = 0; k < h->N; k++) perm[k] = h->plan.perm[k] + h->opts.index_base;
+    return HIPKKT_OK;
+}
+
+int32_t hipkkt_get_dsigns(hipkkt_handle h, int64_t *dsigns) {
+    if (!h || !dsigns) return HIPKKT_ERR_ARGUMENT;
+    for (int k = 0; k < h->N; k++) dsigns[k] = h->img.dsigns[k];
+    return HIPKKT_OK;
+}
+
+int32_t hipkkt_get_map(hipkkt_handle h, int32_t which, int64_t *out) {
+    if (!h || !out) return HIPKKT_ERR_ARGUMENT;
+    const KKTImage &K = h->img;
+    const std::vector<int64_t> *v = nullptr;
+    switch (which) {
+        case 0: v = &K.mapP; break;
+        case 1: v = &K.mapA; break;
+        case 2: v = &K.mapHs; break;
+        case 3: v = &K.diagP; break;
+        case 4: v = &K.diag_full; break;
+        default: return HIPKKT_ERR_ARGUMENT;
+    }
+    for (size_t i = 0; i < v->size(); i++) out[i] = (*v)[i] + h->opts.index_base;
+    return HIPKKT_OK;
+}
+
+int32_t hipkkt_get_sparse_map(hipkkt_handle h, int64_t i, int32_t which, int64_t *out, int64_t *len) {
+    if (!h || i < 0 || i >= (int64_t)h->img.smaps.size() || which < 0 || which > 3) return HIPKKT_ERR_ARGUMENT;
+    const SparseMap &sm = h->img.smaps[i];
+    if (which == 3) {
+        if (len) *len = sm.pdim;
+        if (out) for (int t = 0; t < sm.pdim; t++) out[t] = sm.D[t] + h->opts.index_base;
+    } else {
+        if (len) *len = (int64_t)sm.vec[which].size();
+        if (out) for (size_t q = 0; q < sm.vec[which].size(); q++) out[q] = sm.vec[which][q] + h->opts.index_base;
+    }
+    return HIPKKT_OK;
+}
+
+// ---- value updates ----------------------------------------------------------------------------
+
+int32_t hipkkt_update_values(hipkkt_handle h, const int64_t *index, const double *values, int64_t k) {
+    HK_ENTER(h)
+    if (k < 0 || (k && (!index || !values))) return HIPKKT_ERR_ARGUMENT;
+    if (k == 0) return HIPKKT_OK;
+    S->ensure_stage(k);
+    std::vector<int64_t> idx(k);
+    for (int64_t i = 0; i < k; i++) {
+        idx[i] = index[i] - S->opts.index_base;
+        if (idx[i] < 0 || idx[i] >= S->nnzK) { S->err = "index out of range"; return HIPKKT_ERR_ARGUMENT; }
+    }
+    HK_CHECK(hipMemcpyAsync(S->d_stage_idx, idx.data(), k * sizeof(int64_t), hipMemcpyHostToDevice, S->stream));
+    HK_CHECK(hipMemcpyAsync(S->d_stage, values, k * sizeof(double), hipMemcpyHostToDevice, S->stream));
+    launch_scatter_values(S->stream, S->dp.kval, S->d_stage_idx, S->d_stage, k, 1.0);
+    HK_CHECK(hipStreamSynchronize(S->stream));
+    return HIPKKT_OK;
+    HK_LEAVE
+}
+
+int32_t hipkkt_scale_values(hipkkt_handle h, const int64_t *index, int64_t k, double scale) {
+    HK_ENTER(h)
+    if (k < 0 || (k && !index)) return HIPKKT_ERR_ARGUMENT;
+    if (k == 0) return HIPKKT_OK;
+    S->ensure_stage(k);
+    std::vector<int64_t> idx(k);
+    for (int64_t i = 0; i < k; i++) {
+        idx[i] = index[i] - S->opts.index_base;
+        if (idx[i] < 0 || idx[i] >= S->nnzK) { S->err = "index out of range"; return HIPKKT_ERR_ARGUMENT; }
+    }
+    HK_CHECK(hipMemcpyAsync(S->d_stage_idx, idx.data(), k * sizeof(int64_t), hipMemcpyHostToDevice, S->stream));
+    launch_scale_values(S->stream, S->dp.kval, S->d_stage_idx, k, scale);
+    HK_CHECK(hipStreamSynchronize(S->stream));
+    return HIPKKT_OK;
+    HK_LEAVE
+}
+
+int32_t hipkkt_set_hs_dev(hipkkt_handle h, const double *hs_dev, int64_t nHs) {
+    HK_ENTER(h)
+    if (!S->l1 || nHs != S->img.nHs || (nHs && !hs_dev)) { S->err = "set_hs: wrong length / not an L1 handle"; return HIPKKT_ERR_ARGUMENT; }
+    launch_scatter_values(S->stream, S->dp.kval, S->d_mapHs, hs_dev, nHs, -1.0);
+    HK_CHECK(hipStreamSynchronize(S->stream));
+    return HIPKKT_OK;
+    HK_LEAVE
+}
+
+int32_t hipkkt_set_hs(hipkkt_handle h, const double *hs, int64_t nHs) {
+    HK_ENTER(h)
+    if (!S->l1 || nHs != S->img.nHs || (nHs && !hs)) { S->err = "set_hs: wrong length / not an L1 handle"; return HIPKKT_ERR_ARGUMENT; }
+    S->ensure_stage(nHs);
+    HK_CHECK(hipMemcpyAsync(S->d_stage, hs, nHs * sizeof(double), hipMemcpyHostToDevice, S->stream));
+    launch_scatter_values(S->stream, S->dp.kval, S->d_mapHs, S->d_stage, nHs, -1.0);
+    HK_CHECK(hipStreamSynchronize(S->stream));
+    return HIPKKT_OK;
+    HK_LEAVE
+}
+
+int32_t hipkkt_set_soc_batch(hipkkt_handle h, int64_t nsoc, const double *eta2, const double *u_all, const double *v_all,
+                             int64_t total) {
+    HK_ENTER(h)
+    if (!S->l1 || nsoc != S->nsoc || total != S->soc_total) { S->err = "set_soc_batch: size mismatch"; return HIPKKT_ERR_ARGUMENT; }
+    if (nsoc == 0) return HIPKKT_OK;
+    HK_CHECK(hipMemcpyAsync(S->d_soc_u, u_all, total * sizeof(double), hipMemcpyHostToDevice, S->stream));
+    HK_CHECK(hipMemcpyAsync(S->d_soc_v, v_all, total * sizeof(double), hipMemcpyHostToDevice, S->stream));
+    HK_CHECK(hipMemcpyAsync(S->d_soc_eta2, eta2, nsoc * sizeof(double), hipMemcpyHostToDevice, S->stream));
+    launch_soc_batch(S->stream, S->dp.kval, S->d_soc_uidx, S->d_soc_vidx, S->d_soc_cone, S->d_soc_u, S->d_soc_v,
+                     S->d_soc_eta2, total, S->d_soc_didx, (int)nsoc);
+    HK_CHECK(hipStreamSynchronize(S->stream));
+    return HIPKKT_OK;
+    HK_LEAVE
+}
+
+int32_t hipkkt_set_soc(hipkkt_handle h, int64_t sparse_idx, double eta2, const double *u, const double *v, int64_t dim) {
+    HK_ENTER(h)
+    if (!S->l1 || sparse_idx < 0 || sparse_idx >= (int64_t)S->img.smaps.size()) return HIPKKT_ERR_ARGUMENT;
+    const int o = S->soc_of_sparse[sparse_idx];
+    if (o < 0 || S->soc_off[o + 1] - S->soc_off[o] != dim) { S->err = "set_soc: not a SOC map / wrong dim"; return HIPKKT_ERR_ARGUMENT; }
+    const int64_t off = S->soc_off[o];
+    HK_CHECK(hipMemcpyAsync(S->d_soc_u + off, u, dim * sizeof(double), hipMemcpyHostToDevice, S->stream));
+    HK_CHECK(hipMemcpyAsync(S->d_soc_v + off, v, dim * sizeof(double), hipMemcpyHostToDevice, S->stream));
+    launch_scatter_values(S->stream, S->dp.kval, S->d_soc_uidx + off, S->d_soc_u + off, dim, -eta2);
+    launch_scatter_values(S->stream, S->dp.kval, S->d_soc_vidx + off, S->d_soc_v + off, dim, -eta2);
+    const double dv[2] = {-eta2, eta2};
+    HK_CHECK(hipMemcpyAsync(S->d_stage, dv, 2 * sizeof(double), hipMemcpyHostToDevice, S->stream));
+    launch_scatter_values(S->stream, S->dp.kval, S->d_soc_didx + 2 * o, S->d_stage, 2, 1.0);
+    HK_CHECK(hipStreamSynchronize(S->stream));
+    return HIPKKT_OK;
+    HK_LEAVE
+}
+
+int32_t hipkkt_set_genpow(hipkkt_handle h, int64_t sparse_idx, double sqrtmu, const double *p, const double *q,
+                          const double *r) {
+    HK_ENTER(h)
+    if (!S->l1 || sparse_idx < 0 || sparse_idx >= (int64_t)S->img.smaps.size()) return HIPKKT_ERR_ARGUMENT;
+    const SparseMap &sm = S->img.smaps[sparse_idx];
+    if (sm.kind != 2) { S->err = "set_genpow: not a GenPow map"; return HIPKKT_ERR_ARGUMENT; }
+    const double *src[3] = {q, r, p};
+    for (int t = 0; t < 3; t++) {
+        const int64_t k = (int64_t)sm.vec[t].size();
+        if (!k) continue;
+        S->ensure_stage(k);
+        HK_CHECK(hipMemcpyAsync(S->d_stage_idx, sm.vec[t].data(), k * sizeof(int64_t), hipMemcpyHostToDevice, S->stream));
+        HK_CHECK(hipMemcpyAsync(S->d_stage, src[t], k * sizeof(double), hipMemcpyHostToDevice, S->stream));
+        launch_scatter_values(S->stream, S->dp.kval, S->d_stage_idx, S->d_stage, k, -sqrtmu);
+        HK_CHECK(hipStreamSynchronize(S->stream));
+    }
+    const double dv[3] = {-1.0, -1.0, 1.0};
+    HK_CHECK(hipMemcpyAsync(S->d_stage_idx, sm.D, 3 * sizeof(int64_t), hipMemcpyHostToDevice, S->stream));
+    HK_CHECK(hipMemcpyAsync(S->d_stage, dv, 3 * sizeof(double), hipMemcpyHostToDevice, S->stream));
+    launch_scatter_values(S->stream, S->dp.kval, S->d_stage_idx, S->d_stage, 3, 1.0);
+    HK_CHECK(hipStreamSynchronize(S->stream));
+    return HIPKKT_OK;
+    HK_LEAVE
+}
+
+int32_t hipkkt_update_P(hipkkt_handle h, const double *Pnzval, int64_t nnzP) {
+    HK_ENTER(h)
+    if (!S->l1 || nnzP != S->img.nnzP) { S->err = "update_P: wrong length"; return HIPKKT_ERR_ARGUMENT; }
+    if (!nnzP) return HIPKKT_OK;
+    S->ensure_stage(nnzP);
+    HK_CHECK(hipMemcpyAsync(S->d_stage, Pnzval, nnzP * sizeof(double), hipMemcpyHostToDevice, S->stream));
+    launch_scatter_values(S->stream, S->dp.kval, S->d_mapP, S->d_stage, nnzP, 1.0);
+    HK_CHECK(hipStreamSynchronize(S->stream));
+    return HIPKKT_OK;
+    HK_LEAVE
+}
+
+int32_t hipkkt_update_A(hipkkt_handle h, const double *Anzval, int64_t nnzA) {
+    HK_ENTER(h)
+    if (!S->l1 || nnzA != S->img.nnzA) { S->err = "update_A: wrong length"; return HIPKKT_ERR_ARGUMENT; }
+    if (!nnzA) return HIPKKT_OK;
+    S->ensure_stage(nnzA);
+    HK_CHECK(hipMemcpyAsync(S->d_stage, Anzval, nnzA * sizeof(double), hipMemcpyHostToDevice, S->stream));
+    launch_scatter_values(S->stream, S->dp.kval, S->d_mapA, S->d_stage, nnzA, 1.0);
+    HK_CHECK(hipStreamSynchronize(S->stream));
+    return HIPKKT_OK;
+    HK_LEAVE
+}
+
+// ---- factor ------------------------------------------------------------------------------------
+
+int32_t hipkkt_refactor(hipkkt_handle h, int32_t static_reg_enable, double eps_const, double eps_prop,
+                        double *eps_used, int64_t *n_dynamic_reg) {
+    HK_ENTER(h)
+    HK_CHECK(hipEventRecord(S->ev0, S->stream));
+    if (S->profiling) {
+        // eager, with the dense-update launches timed separately (adds event overhead)
+        const HostPlan &P = S->plan;
+        hipStream_t st = S->stream;
+        HK_CHECK(hipMemsetAsync(S->dp.scal, 0, sizeof(double), st));
+        HK_CHECK(hipMemsetAsync(S->dp.flags, 0, FL_COUNT * sizeof(int), st));
+        launch_maxabs_gather(st, S->dp.kval, S->d_diag_full, S->N, (unsigned long long *)S->dp.scal + SC_MAXDIAG);
+        HK_CHECK(hipMemsetAsync(S->dp.Lx, 0, (size_t)P.panel_doubles * sizeof(double), st));
+        launch_init_panels(st, S->dp, S->nnzK, static_reg_enable, eps_const, eps_prop);
+        std::vector<hipEvent_t> evs;
+        for (int l = 0; l < P.nlevels; l++) {
+            launch_factor_level(st, S->dp, P.fac_lvl_ptr[l], P.fac_lvl_ptr[l + 1] - P.fac_lvl_ptr[l], P.fac_lvl_maxw[l],
+                                S->opts.dynamic_reg_eps, S->opts.dynamic_reg_delta);
+            if (P.upd_stage_ptr[l + 1] > P.upd_stage_ptr[l]) {
+                hipEvent_t a, b;
+                HK_CHECK(hipEventCreate(&a));
+                HK_CHECK(hipEventCreate(&b));
+                HK_CHECK(hipEventRecord(a, st));
+                launch_update_stage(st, S->dp, P.upd_stage_ptr[l], P.upd_stage_ptr[l + 1] - P.upd_stage_ptr[l]);
+                HK_CHECK(hipEventRecord(b, st));
+                evs.push_back(a);
+                evs.push_back(b);
+            }
+        }
+        HK_CHECK(hipStreamSynchronize(st));
+        double tot = 0;
+        for (size_t i = 0; i + 1 < evs.size(); i += 2) {
+            float ms = 0;
+            hipEventElapsedTime(&ms, evs[i], evs[i + 1]);
+            tot += ms;
+        }
+        for (hipEvent_t e : evs) hipEventDestroy(e);
+        S->t_last_update = tot;
+    } else {
+        GraphSlot &g = S->g_factor;
+        const bool same = g.static_enable == static_reg_enable && g.eps_const == eps_const && g.eps_prop == eps_prop;
+        run_graphed(S, g, same, [&] { enqueue_factor(S, static_reg_enable, eps_const, eps_prop); });
+        g.static_enable = static_reg_enable; g.eps_const = eps_const; g.eps_prop = eps_prop;
+    }
+    HK_CHECK(hipEventRecord(S->ev1, S->stream));
+    HK_CHECK(hipMemcpyAsync(S->h_flags, S->dp.flags, FL_COUNT * sizeof(int), hipMemcpyDeviceToHost, S->stream));
+    read_scalars(S);
+    float ms = 0;
+    HK_CHECK(hipEventElapsedTime(&ms, S->ev0, S->ev1));
+    S->t_last_factor = ms;
+    S->t_acc_factor += ms;
+    S->n_factor++;
+    const double maxdiag = slot_value(S, SC_MAXDIAG);
+    S->last_eps = static_reg_enable ? eps_const + eps_prop * maxdiag : 0.0;
+    S->last_nreg = S->h_flags[FL_NREG];
+    if (eps_used) *eps_used = S->last_eps;
+    if (n_dynamic_reg) *n_dynamic_reg = S->last_nreg;
+    return S->h_flags[FL_NONFINITE] ? HIPKKT_NUMERICAL_FAILURE : HIPKKT_OK;
+    HK_LEAVE
+}
+
+// ---- solve -------------------------------------------------------------------------------------
+
+int32_t hipkkt_setrhs(hipkkt_handle h, const double *rhsx, const double *rhsz) {
+    HK_ENTER(h)
+    const int64_t n = S->img.n, m = S->img.m;
+    if (!S->l1 || (n && !rhsx) || (m && !rhsz)) return HIPKKT_ERR_ARGUMENT;
+    if (n) HK_CHECK(hipMemcpyAsync(S->d_b, rhsx, n * sizeof(double), hipMemcpyHostToDevice, S->stream));
+    if (m) HK_CHECK(hipMemcpyAsync(S->d_b + n, rhsz, m * sizeof(double), hipMemcpyHostToDevice, S->stream));
+    if (S->img.p) HK_CHECK(hipMemsetAsync(S->d_b + n + m, 0, S->img.p * sizeof(double), S->stream));
+    HK_CHECK(hipStreamSynchronize(S->stream));
+    return HIPKKT_OK;
+    HK_LEAVE
+}
+
+int32_t hipkkt_setrhs_dev(hipkkt_handle h, const double *rhs_dev) {
+    HK_ENTER(h)
+    if (!S->l1 || !rhs_dev) return HIPKKT_ERR_ARGUMENT;
+    launch_set_rhs(S->stream, S->d_b, rhs_dev, (int)(S->img.n + S->img.m), S->N);
+    HK_CHECK(hipStreamSynchronize(S->stream));
+    return HIPKKT_OK;
+    HK_LEAVE
+}
+
+int32_t hipkkt_solve(hipkkt_handle h, double *lhsx, double *lhsz, int32_t ir_enable, double reltol, double abstol,
+                     int64_t max_iter, double stop_ratio, int64_t *ir_steps) {
+    HK_ENTER(h)
+    if (!S->l1) return HIPKKT_ERR_ARGUMENT;
+    int32_t rc = solve_core(S, ir_enable, reltol, abstol, max_iter, stop_ratio, ir_steps);
+    if (rc == HIPKKT_OK) {  // ref: kktsolver_getlhs! only on success
+        const int64_t n = S->img.n, m = S->img.m;
+        if (lhsx && n) HK_CHECK(hipMemcpy(lhsx, S->d_x, n * sizeof(double), hipMemcpyDeviceToHost));
+        if (lhsz && m) HK_CHECK(hipMemcpy(lhsz, S->d_x + n, m * sizeof(double), hipMemcpyDeviceToHost));
+    }
+    return rc;
+    HK_LEAVE
+}
+
+int32_t hipkkt_solve_dev(hipkkt_handle h, double *lhs_dev, int32_t ir_enable, double reltol, double abstol,
+                         int64_t max_iter, double stop_ratio, int64_t *ir_steps) {
+    HK_ENTER(h)
+    if (!S->l1) return HIPKKT_ERR_ARGUMENT;
+    int32_t rc = solve_core(S, ir_enable, reltol, abstol, max_iter, stop_ratio, ir_steps);
+    if (rc == HIPKKT_OK && lhs_dev) {
+        HK_CHECK(hipMemcpyAsync(lhs_dev, S->d_x, (S->img.n + S->img.m) * sizeof(double), hipMemcpyDeviceToDevice, S->stream));
+        HK_CHECK(hipStreamSynchronize(S->stream));
+    }
+    return rc;
+    HK_LEAVE
+}
+
+int32_t hipkkt_ldl_solve(hipkkt_handle h, double *x, const double *b) {
+    HK_ENTER(h)
+    if (!x || !b) return HIPKKT_ERR_ARGUMENT;
+    HK_CHECK(hipEventRecord(S->ev2, S->stream));
+    HK_CHECK(hipMemcpyAsync(S->d_sin, b, (size_t)S->N * sizeof(double), hipMemcpyHostToDevice, S->stream));
+    ldl_solve_dev(S, S->d_sin, S->d_sout);
+    HK_CHECK(hipEventRecord(S->ev3, S->stream));
+    HK_CHECK(hipMemcpyAsync(x, S->d_sout, (size_t)S->N * sizeof(double), hipMemcpyDeviceToHost, S->stream));
+    HK_CHECK(hipStreamSynchronize(S->stream));
+    float ms = 0;
+    HK_CHECK(hipEventElapsedTime(&ms, S->ev2, S->ev3));
+    S->t_last_solve = ms;
+    S->t_acc_solve += ms;
+    S->n_solvecalls++;
+    return HIPKKT_OK;
+    HK_LEAVE
+}
+
+int32_t hipkkt_get_timing(hipkkt_handle h, double *o) {
+    if (!h || !o) return HIPKKT_ERR_ARGUMENT;
+    o[0] = h->t_last_factor; o[1] = h->t_last_solve; o[2] = h->t_acc_factor; o[3] = h->t_acc_solve;
+    o[4] = (double)h->n_factor; o[5] = (double)h->n_solvecalls; o[6] = (double)h->n_ldlsolves; o[7] = h->t_last_update;
+    return HIPKKT_OK;
+}
+
+int32_t hipkkt_reset_timing(hipkkt_handle h) {
+    if (!h) return HIPKKT_ERR_ARGUMENT;
+    h->t_acc_factor = h->t_acc_solve = 0;
+    h->n_factor = h->n_solvecalls = h->n_ldlsolves = 0;
+    return HIPKKT_OK;
+}
+
+int32_t hipkkt_set_profiling(hipkkt_handle h, int32_t enable) {
+    if (!h) return HIPKKT_ERR_ARGUMENT;
+    h->profiling = enable != 0;
+    return HIPKKT_OK;
+}
+
+// D = A(16x4) * B(4x16) through the matrix-core path used by the update kernel; returns the max
+// abs deviation from the host product (layout self-test), or a negative status
+int32_t hipkkt_selftest_mfma(int32_t device_id, double *max_err) {
+    if (hipSetDevice(device_id) != hipSuccess) return HIPKKT_ERR_DEVICE;
+    double A[64], B[64], Dh[256], Dd[256];
+    for (int i = 0; i < 16; i++)
+        for (int k = 0; k < 4; k++) A[i * 4 + k] = 1.0 + i * 0.37 - k * 1.13 + (i * k) * 0.05;
+    for (int k = 0; k < 4; k++)
+        for (int j = 0; j < 16; j++) B[k * 16 + j] = -0.5 + j * 0.21 + k * 0.77 - (j * j) * 0.013;  // asymmetric
+    for (int i = 0; i < 16; i++)
+        for (int j = 0; j < 16; j++) {
+            double s = 0;
+            for (int k = 0; k < 4; k++) s += A[i * 4 + k] * B[k * 16 + j];
+            Dh[i * 16 + j] = s;
+        }
+    double *dA = nullptr, *dB = nullptr, *dD = nullptr;
+    if (hipMalloc((void **)&dA, sizeof(A)) != hipSuccess || hipMalloc((void **)&dB, sizeof(B)) != hipSuccess ||
+        hipMalloc((void **)&dD, sizeof(Dd)) != hipSuccess)
+        return HIPKKT_ERR_ALLOC;
+    hipMemcpy(dA, A, sizeof(A), hipMemcpyHostToDevice);
+    hipMemcpy(dB, B, sizeof(B), hipMemcpyHostToDevice);
+    launch_mfma_probe(nullptr, dA, dB, dD);
+    hipError_t e = hipMemcpy(Dd, dD, sizeof(Dd), hipMemcpyDeviceToHost);
+    hipFree(dA); hipFree(dB); hipFree(dD);
+    if (e != hipSuccess) return HIPKKT_ERR_DEVICE;
+    double me = 0;
+    for (int i = 0; i < 256; i++) me = std::max(me, std::fabs(Dd[i] - Dh[i]));
+    if (max_err) *max_err = me;
+    return me < 1e-12 ? HIPKKT_OK : HIPKKT_NUMERICAL_FAILURE;
+}
+
+const char *hipkkt_last_error(hipkkt_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+}  // extern "C"

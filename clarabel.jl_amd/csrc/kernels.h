@@ -1,0 +1,27 @@
+// launchers implemented in kernels.hip (all work is enqueued on the given stream)
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "device_plan.h"
+
+namespace hipkkt {
+void launch_scatter_values(hipStream_t st, double *kval, const int64_t *idx, const double *vals, int64_t n, double scale);
+void launch_scale_values(hipStream_t st, double *kval, const int64_t *idx, int64_t n, double scale);
+void launch_soc_batch(hipStream_t st, double *kval, const int64_t *uidx, const int64_t *vidx, const int *cone_of,
+                      const double *u, const double *v, const double *eta2, int64_t n, const int64_t *didx, int nsoc);
+void launch_maxabs_gather(hipStream_t st, const double *v, const int64_t *idx, int64_t n, unsigned long long *slot);
+void launch_init_panels(hipStream_t st, const DevPlan &P, int64_t nnz, int static_enable, double eps_const, double eps_prop);
+void launch_factor_level(hipStream_t st, const DevPlan &P, int item_begin, int nitems, int wmax, double dyn_eps, double dyn_delta);
+void launch_update_stage(hipStream_t st, const DevPlan &P, int group_begin, int ngroups);
+void launch_mfma_probe(hipStream_t st, const double *A, const double *B, double *out);
+void launch_permute_in(hipStream_t st, const double *b, const int *perm, double *y, int n);
+void launch_fwd_level(hipStream_t st, const DevPlan &P, int item_begin, int nitems, double *y, double *z);
+void launch_bwd_partial(hipStream_t st, const DevPlan &P, int item_begin, int nitems, const double *x);
+void launch_bwd_final(hipStream_t st, const DevPlan &P, int sn_begin, int nsn, const double *z, double *x, double *xout);
+void launch_spmv_residual(hipStream_t st, const DevPlan &P, const double *b, const double *xi, double *e, int n,
+                          unsigned long long *slot);
+void launch_norm_inf(hipStream_t st, const double *v, int n, unsigned long long *slot);
+void launch_add(hipStream_t st, double *dst, const double *a, int n);
+void launch_set_rhs(hipStream_t st, double *b, const double *rhs, int nm, int n);
+void launch_check_finite(hipStream_t st, const double *v, int n, int *flags);
+}  // namespace hipkkt

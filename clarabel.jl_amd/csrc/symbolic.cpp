@@ -1,0 +1,434 @@
+// Symbolic analysis: ordering -> elimination tree -> postorder -> column counts -> (relaxed)
+// supernodes -> width-capped panels -> row structures -> levels -> static work lists.
+// See symbolic.h / DESIGN.md §4.  Host only; no numeric work.
+#include "symbolic.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+
+namespace hipkkt {
+
+namespace {
+
+// permuted upper-triangular pattern: column max(pi,pj) holds row min(pi,pj)
+void permuted_upper(int N, const int64_t *Ap, const int64_t *Ai, const std::vector<int> &iperm,
+                    std::vector<int64_t> &up, std::vector<int> &ui) {
+    up.assign(N + 1, 0);
+    for (int j = 0; j < N; j++)
+        for (int64_t p = Ap[j]; p < Ap[j + 1]; p++) {
+            int pi = iperm[Ai[p]], pj = iperm[j];
+            up[std::max(pi, pj) + 1]++;
+        }
+    for (int j = 0; j < N; j++) up[j + 1] += up[j];
+    ui.resize(up[N]);
+    std::vector<int64_t> nxt(up.begin(), up.end() - 1);
+    for (int j = 0; j < N; j++)
+        for (int64_t p = Ap[j]; p < Ap[j + 1]; p++) {
+            int pi = iperm[Ai[p]], pj = iperm[j];
+            ui[nxt[std::max(pi, pj)]++] = std::min(pi, pj);
+        }
+}
+
+// elimination tree + strictly-lower column counts of L by row-subtree traversal (O(nnz(L)))
+void etree_counts(int N, const std::vector<int64_t> &up, const std::vector<int> &ui,
+                  std::vector<int> &parent, std::vector<int> &cnt) {
+    parent.assign(N, -1);
+    cnt.assign(N, 0);
+    std::vector<int> work(N, -1);
+    for (int j = 0; j < N; j++) {
+        work[j] = j;
+        for (int64_t p = up[j]; p < up[j + 1]; p++) {
+            int i = ui[p];
+            while (work[i] != j) {
+                if (parent[i] < 0) parent[i] = j;
+                cnt[i]++;
+                work[i] = j;
+                i = parent[i];
+            }
+        }
+    }
+}
+
+void postorder(int N, const std::vector<int> &parent, std::vector<int> &post) {
+    std::vector<int> head(N, -1), next(N, -1), stack;
+    for (int j = N - 1; j >= 0; j--)
+        if (parent[j] >= 0) { next[j] = head[parent[j]]; head[parent[j]] = j; }
+    post.clear();
+    post.reserve(N);
+    for (int r = 0; r < N; r++) {
+        if (parent[r] >= 0) continue;
+        stack.push_back(r);
+        while (!stack.empty()) {
+            int p = stack.back();
+            int c = head[p];
+            if (c < 0) { post.push_back(p); stack.pop_back(); }
+            else { head[p] = next[c]; stack.push_back(c); }
+        }
+    }
+}
+
+struct TaskKey {
+    int32_t stage, tgt, rb, src;
+    int32_t task;
+};
+
+}  // namespace
+
+std::string build_plan(int N, const int64_t *Ap, const int64_t *Ai, const int64_t *user_perm,
+                       const PlanOptions &opt, HostPlan &P) {
+    P = HostPlan();
+    P.N = N;
+    P.nnzK = Ap[N];
+    const int maxw = std::max(1, std::min(opt.max_width, kMaxSnWidth));
+
+    // ---- 1. ordering
+    std::vector<int> perm0;
+    if (user_perm) {
+        perm0.resize(N);
+        std::vector<char> seen(N, 0);
+        for (int k = 0; k < N; k++) {
+            int64_t o = user_perm[k];
+            if (o < 0 || o >= N || seen[o]) return "user_perm is not a permutation";
+            seen[o] = 1;
+            perm0[k] = (int)o;
+        }
+    } else {
+        amd_order(N, Ap, Ai, opt.amd_dense_scale, perm0);
+        if ((int)perm0.size() != N) return "internal: ordering size mismatch";
+    }
+    std::vector<int> iperm0(N);
+    for (int k = 0; k < N; k++) iperm0[perm0[k]] = k;
+
+    // ---- 2-4. etree, postorder, final permutation
+    std::vector<int64_t> up;
+    std::vector<int> ui, parent, cnt, post;
+    permuted_upper(N, Ap, Ai, iperm0, up, ui);
+    etree_counts(N, up, ui, parent, cnt);
+    postorder(N, parent, post);
+    P.perm.resize(N);
+    P.iperm.resize(N);
+    {
+        std::vector<int> newlab(N);
+        for (int k = 0; k < N; k++) { newlab[post[k]] = k; P.perm[k] = perm0[post[k]]; }
+        for (int k = 0; k < N; k++) P.iperm[P.perm[k]] = k;
+        std::vector<int> par2(N), cnt2(N);
+        for (int k = 0; k < N; k++) {
+            int o = post[k];
+            par2[k] = parent[o] < 0 ? -1 : newlab[parent[o]];
+            cnt2[k] = cnt[o];
+        }
+        parent.swap(par2);
+        cnt.swap(cnt2);
+    }
+    permuted_upper(N, Ap, Ai, P.iperm, up, ui);
+    // lower pattern by columns (transpose of up/ui): column j -> rows i > j
+    std::vector<int64_t> lp(N + 1, 0);
+    std::vector<int> li;
+    {
+        for (int j = 0; j < N; j++)
+            for (int64_t p = up[j]; p < up[j + 1]; p++)
+                if (ui[p] != j) lp[ui[p] + 1]++;
+        for (int j = 0; j < N; j++) lp[j + 1] += lp[j];
+        li.resize(lp[N]);
+        std::vector<int64_t> nxt(lp.begin(), lp.end() - 1);
+        for (int j = 0; j < N; j++)
+            for (int64_t p = up[j]; p < up[j + 1]; p++)
+                if (ui[p] != j) li[nxt[ui[p]]++] = j;
+    }
+    P.nnzL = 0;
+    P.flops_colcount = 0;
+    for (int j = 0; j < N; j++) {
+        P.nnzL += cnt[j];
+        P.flops_colcount += (double)cnt[j] * cnt[j] + 3.0 * cnt[j];
+    }
+    {
+        std::vector<int> h(N, 1);
+        int H = 0;
+        for (int j = 0; j < N; j++) {
+            if (parent[j] >= 0) h[parent[j]] = std::max(h[parent[j]], h[j] + 1);
+            H = std::max(H, h[j]);
+        }
+        P.etree_height = H;
+    }
+
+    // ---- 5. supernodes (maximal: same structure as the next column)
+    std::vector<char> is_start(N + 1, 0);
+    is_start[N] = 1;
+    for (int j = 0; j < N; j++)
+        is_start[j] = (j == 0) || !(parent[j - 1] == j && cnt[j - 1] == cnt[j] + 1);
+    // ---- 6. relaxed amalgamation of a child chain into its parent (contiguous columns only)
+    if (opt.relax && N > 0) {
+        std::vector<int64_t> zz(N, 0);  // explicit zeros carried by the supernode starting at column f
+        int f = 0;
+        while (f < N) {
+            int l = f;
+            while (!is_start[l + 1]) l++;
+            if (l + 1 >= N) break;
+            int pf = l + 1;
+            int pl = pf;
+            while (!is_start[pl + 1]) pl++;
+            bool merged = false;
+            if (parent[l] == pf) {
+                int64_t wc = l - f + 1, wp = pl - pf + 1, hc = cnt[l], hp = cnt[pl];
+                int64_t w = wc + wp;
+                int64_t znew = wc * (wp + hp - hc);
+                int64_t z = zz[f] + zz[pf] + znew;
+                double total = 0.5 * (double)w * (double)(w + 1) + (double)w * (double)hp;
+                double frac = total > 0 ? (double)z / total : 0.0;
+                bool ok = (w <= 4) || (w <= 16 && frac < 0.8) || (w <= 48 && frac < 0.1) || (frac < 0.05);
+                if (ok && w <= maxw) {
+                    is_start[pf] = 0;
+                    zz[f] = z;
+                    merged = true;
+                }
+            }
+            if (!merged) f = pf;
+        }
+    }
+    // ---- 7. width cap: split wide supernodes into a chain of balanced chunks
+    {
+        int f = 0;
+        while (f < N) {
+            int l = f;
+            while (!is_start[l + 1]) l++;
+            int w = l - f + 1;
+            if (w > maxw) {
+                int nch = (w + maxw - 1) / maxw;
+                int cw = (w + nch - 1) / nch;
+                for (int c = f + cw; c <= l; c += cw) is_start[c] = 1;
+            }
+            f = l + 1;
+        }
+    }
+    // ---- 8. supernode arrays
+    P.sn_of_col.resize(N);
+    for (int j = 0; j < N; j++) {
+        if (is_start[j]) P.sn_first.push_back(j);
+        P.sn_of_col[j] = (int)P.sn_first.size() - 1;
+    }
+    P.nsuper = (int)P.sn_first.size();
+    P.sn_first.push_back(N);
+    const int S = P.nsuper;
+
+    // ---- 9. row structures (children before parents: postorder guarantees index order)
+    P.sn_rowptr.assign(S + 1, 0);
+    P.sn_parent.assign(S, -1);
+    P.sn_level.assign(S, 0);
+    {
+        std::vector<std::vector<int>> children(S);
+        std::vector<int> mark(N, -1), tmp;
+        for (int s = 0; s < S; s++) {
+            int f = P.sn_first[s], l = P.sn_first[s + 1] - 1;
+            tmp.clear();
+            for (int j = f; j <= l; j++) { mark[j] = s; }
+            for (int j = f; j <= l; j++)
+                for (int64_t p = lp[j]; p < lp[j + 1]; p++) {
+                    int i = li[p];
+                    if (i > l && mark[i] != s) { mark[i] = s; tmp.push_back(i); }
+                }
+            for (int c : children[s]) {
+                const int *cr = &P.sn_rows[P.sn_rowptr[c]];
+                int64_t nr = P.sn_rowptr[c + 1] - P.sn_rowptr[c];
+                for (int64_t q = 0; q < nr; q++) {
+                    int i = cr[q];
+                    if (i > l && mark[i] != s) { mark[i] = s; tmp.push_back(i); }
+                }
+            }
+            std::sort(tmp.begin(), tmp.end());
+            for (int j = f; j <= l; j++) P.sn_rows.push_back(j);
+            P.sn_rows.insert(P.sn_rows.end(), tmp.begin(), tmp.end());
+            P.sn_rowptr[s + 1] = (int64_t)P.sn_rows.size();
+            if (!tmp.empty()) {
+                int ps = P.sn_of_col[tmp[0]];
+                P.sn_parent[s] = ps;
+                children[ps].push_back(s);
+                P.sn_level[ps] = std::max(P.sn_level[ps], P.sn_level[s] + 1);
+            }
+            std::vector<int>().swap(children[s]);
+        }
+    }
+    // ---- 10. storage offsets
+    P.sn_panel.assign(S + 1, 0);
+    P.sn_diag.assign(S + 1, 0);
+    P.u_off.assign(S + 1, 0);
+    for (int s = 0; s < S; s++) {
+        int64_t w = P.sn_first[s + 1] - P.sn_first[s];
+        int64_t r = P.sn_rowptr[s + 1] - P.sn_rowptr[s];
+        int64_t sz = (r * w + 7) & ~(int64_t)7;
+        P.sn_panel[s + 1] = P.sn_panel[s] + sz;
+        P.sn_diag[s + 1] = P.sn_diag[s] + ((w * w + 7) & ~(int64_t)7);
+        P.u_off[s + 1] = P.u_off[s] + (r - w);
+    }
+    P.panel_doubles = P.sn_panel[S];
+    P.diag_doubles = P.sn_diag[S];
+    P.ubuf_len = P.u_off[S];
+    if (P.ubuf_len >= (int64_t)1 << 31) return "problem too large: off-diagonal row count exceeds int32";
+
+    // ---- 11. levels
+    P.nlevels = 0;
+    for (int s = 0; s < S; s++) P.nlevels = std::max(P.nlevels, P.sn_level[s] + 1);
+    P.lvl_ptr.assign(P.nlevels + 1, 0);
+    for (int s = 0; s < S; s++) P.lvl_ptr[P.sn_level[s] + 1]++;
+    for (int l = 0; l < P.nlevels; l++) P.lvl_ptr[l + 1] += P.lvl_ptr[l];
+    P.lvl_sn.resize(S);
+    {
+        std::vector<int> nxt(P.lvl_ptr.begin(), P.lvl_ptr.end() - 1);
+        for (int s = 0; s < S; s++) P.lvl_sn[nxt[P.sn_level[s]]++] = s;
+    }
+
+    // ---- 12. scatter map of the original nonzeros into the panels
+    P.kmap.resize(P.nnzK);
+    P.diag_dst.assign(N, -1);
+    for (int j = 0; j < N; j++)
+        for (int64_t q = Ap[j]; q < Ap[j + 1]; q++) {
+            int pi = P.iperm[Ai[q]], pj = P.iperm[j];
+            int c = std::min(pi, pj), r = std::max(pi, pj);
+            int s = P.sn_of_col[c];
+            const int *rows = &P.sn_rows[P.sn_rowptr[s]];
+            int64_t nr = P.sn_rowptr[s + 1] - P.sn_rowptr[s];
+            const int *it = std::lower_bound(rows, rows + nr, r);
+            if (it == rows + nr || *it != r) return "internal: entry outside the symbolic structure";
+            int64_t dest = P.sn_panel[s] + (it - rows) + (int64_t)(c - P.sn_first[s]) * nr;
+            P.kmap[q] = dest;
+            if (pi == pj) P.diag_dst[c] = dest;
+        }
+    for (int k = 0; k < N; k++)
+        if (P.diag_dst[k] < 0) return "KKT matrix has a column without a diagonal entry";
+
+    // ---- 13. factor items
+    P.fac_lvl_ptr.assign(P.nlevels + 1, 0);
+    P.fac_lvl_maxw.assign(P.nlevels, 1);
+    for (int l = 0; l < P.nlevels; l++) {
+        for (int q = P.lvl_ptr[l]; q < P.lvl_ptr[l + 1]; q++) {
+            int s = P.lvl_sn[q];
+            int w = P.sn_first[s + 1] - P.sn_first[s];
+            int64_t r = P.sn_rowptr[s + 1] - P.sn_rowptr[s];
+            int nb = (int)std::max<int64_t>(1, (r - w + kFacRows - 1) / kFacRows);
+            for (int b = 0; b < nb; b++) P.fac_items.push_back({s, b});
+            P.fac_lvl_maxw[l] = std::max(P.fac_lvl_maxw[l], w);
+            P.flops_exec += (double)w * w * w / 3.0 + (double)(r - w) * w * w;
+        }
+        P.fac_lvl_ptr[l + 1] = (int)P.fac_items.size();
+    }
+
+    // ---- 14. update tasks, owned by target row-blocks
+    {
+        std::vector<TaskKey> keys;
+        for (int s = 0; s < S; s++) {
+            int w = P.sn_first[s + 1] - P.sn_first[s];
+            const int *rows = &P.sn_rows[P.sn_rowptr[s]];
+            int r = (int)(P.sn_rowptr[s + 1] - P.sn_rowptr[s]);
+            int a = w;
+            while (a < r) {
+                int t = P.sn_of_col[rows[a]];
+                int b = a;
+                while (b < r && P.sn_of_col[rows[b]] == t) b++;
+                const int *trows = &P.sn_rows[P.sn_rowptr[t]];
+                int tr = (int)(P.sn_rowptr[t + 1] - P.sn_rowptr[t]);
+                if (P.rel.size() + (size_t)(r - a) >= ((size_t)1 << 31)) return "problem too large: relative index table exceeds int32";
+                int rel_off = (int)P.rel.size();
+                // positions of rows[a..r) inside the target's row list (both sorted)
+                if ((int64_t)(r - a) * 16 < tr) {
+                    const int *lo = trows;
+                    for (int i = a; i < r; i++) {
+                        lo = std::lower_bound(lo, trows + tr, rows[i]);
+                        if (lo == trows + tr || *lo != rows[i]) return "internal: source row missing in target structure";
+                        P.rel.push_back((int)(lo - trows));
+                    }
+                } else {
+                    int q = 0;
+                    for (int i = a; i < r; i++) {
+                        while (q < tr && trows[q] < rows[i]) q++;
+                        if (q == tr || trows[q] != rows[i]) return "internal: source row missing in target structure";
+                        P.rel.push_back(q);
+                    }
+                }
+                int stage = opt.update_policy == 1 ? P.sn_level[t] - 1 : P.sn_level[s];
+                // split the source rows by the target row-block they land in
+                int i = a;
+                while (i < r) {
+                    int rb = P.rel[rel_off + (i - a)] / kUpdRows;
+                    int e = i;
+                    while (e < r && P.rel[rel_off + (e - a)] / kUpdRows == rb) e++;
+                    UpdTask tk;
+                    tk.src = s; tk.row_lo = i; tk.nrows = e - i; tk.col_lo = a; tk.ncols = b - a;
+                    tk.rel_off = rel_off; tk.pad0 = tk.pad1 = 0;
+                    keys.push_back({stage, t, rb, s, (int)P.upd_tasks.size()});
+                    P.upd_tasks.push_back(tk);
+                    P.flops_update += 2.0 * (double)(e - i) * (double)(b - a) * (double)w;
+                    i = e;
+                }
+                a = b;
+            }
+        }
+        std::sort(keys.begin(), keys.end(), [](const TaskKey &x, const TaskKey &y) {
+            if (x.stage != y.stage) return x.stage < y.stage;
+            if (x.tgt != y.tgt) return x.tgt < y.tgt;
+            if (x.rb != y.rb) return x.rb < y.rb;
+            if (x.src != y.src) return x.src < y.src;
+            return x.task < y.task;
+        });
+        std::vector<UpdTask> sorted(keys.size());
+        P.upd_stage_ptr.assign(P.nlevels + 1, 0);
+        for (size_t q = 0; q < keys.size(); q++) {
+            sorted[q] = P.upd_tasks[keys[q].task];
+            bool newgrp = (q == 0) || keys[q].stage != keys[q - 1].stage || keys[q].tgt != keys[q - 1].tgt ||
+                          keys[q].rb != keys[q - 1].rb;
+            if (newgrp) {
+                P.upd_groups.push_back({keys[q].tgt, keys[q].rb * kUpdRows, (int)q, (int)q + 1});
+                P.upd_stage_ptr[keys[q].stage + 1]++;
+            } else {
+                P.upd_groups.back().task_end = (int)q + 1;
+            }
+        }
+        P.upd_tasks.swap(sorted);
+        for (int l = 0; l < P.nlevels; l++) P.upd_stage_ptr[l + 1] += P.upd_stage_ptr[l];
+        P.flops_exec += P.flops_update;
+    }
+
+    // ---- 15. gather lists for the forward solve
+    P.g_ptr.assign(N + 1, 0);
+    for (int s = 0; s < S; s++) {
+        int w = P.sn_first[s + 1] - P.sn_first[s];
+        const int *rows = &P.sn_rows[P.sn_rowptr[s]];
+        int r = (int)(P.sn_rowptr[s + 1] - P.sn_rowptr[s]);
+        for (int q = w; q < r; q++) P.g_ptr[rows[q] + 1]++;
+    }
+    for (int j = 0; j < N; j++) P.g_ptr[j + 1] += P.g_ptr[j];
+    P.g_idx.resize(P.g_ptr[N]);
+    {
+        std::vector<int64_t> nxt(P.g_ptr.begin(), P.g_ptr.end() - 1);
+        for (int s = 0; s < S; s++) {
+            int w = P.sn_first[s + 1] - P.sn_first[s];
+            const int *rows = &P.sn_rows[P.sn_rowptr[s]];
+            int r = (int)(P.sn_rowptr[s + 1] - P.sn_rowptr[s]);
+            for (int q = w; q < r; q++) P.g_idx[nxt[rows[q]]++] = (int)(P.u_off[s] + (q - w));
+        }
+    }
+
+    // ---- 16. symmetric CSR view of K in the ORIGINAL ordering (iterative-refinement SpMV)
+    P.sym_rowptr.assign(N + 1, 0);
+    for (int j = 0; j < N; j++)
+        for (int64_t q = Ap[j]; q < Ap[j + 1]; q++) {
+            int i = (int)Ai[q];
+            P.sym_rowptr[i + 1]++;
+            if (i != j) P.sym_rowptr[j + 1]++;
+        }
+    for (int j = 0; j < N; j++) P.sym_rowptr[j + 1] += P.sym_rowptr[j];
+    P.sym_col.resize(P.sym_rowptr[N]);
+    P.sym_q.resize(P.sym_rowptr[N]);
+    {
+        std::vector<int64_t> nxt(P.sym_rowptr.begin(), P.sym_rowptr.end() - 1);
+        for (int j = 0; j < N; j++)
+            for (int64_t q = Ap[j]; q < Ap[j + 1]; q++) {
+                int i = (int)Ai[q];
+                P.sym_col[nxt[i]] = j; P.sym_q[nxt[i]++] = q;
+                if (i != j) { P.sym_col[nxt[j]] = i; P.sym_q[nxt[j]++] = q; }
+            }
+    }
+    return "";
+}
+
+}  // namespace hipkkt

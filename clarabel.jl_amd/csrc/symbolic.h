@@ -1,0 +1,100 @@
+// Host-side symbolic analysis for the supernodal LDL^T on MI355X.
+// Produces the static "plan" every numeric kernel interprets: permutation, supernode partition,
+// dense panel layout in HBM, per-level factor items, target-tile-owned update tasks, gather lists
+// for the triangular solves and the symmetric SpMV index.  Runs once per problem on the host
+// ("host C++ acceptable").
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace hipkkt {
+
+constexpr int kMaxSnWidth = 64;   // supernode (panel) width cap = LDS-resident diagonal block
+constexpr int kUpdRows = 64;      // target row-block owned by one workgroup in the update kernel
+constexpr int kFacRows = 64;      // panel rows handled per workgroup in the TRSM part
+
+// one contribution of a factored source panel to a target row-block (gather-GEMM-scatter)
+struct UpdTask {
+    int32_t src;        // source supernode
+    int32_t row_lo;     // first source row (index into the source's row list) handled here
+    int32_t nrows;      // #source rows (their target positions fall in one row-block)
+    int32_t col_lo;     // first source row of the run that lies inside the target's columns
+    int32_t ncols;      // length of that run
+    int32_t rel_off;    // offset into rel[] of source row `col_lo` (rel[rel_off + (i - col_lo)])
+    int32_t pad0, pad1;
+};
+
+struct UpdGroup {
+    int32_t tgt;        // target supernode
+    int32_t row_base;   // first target panel row of the block
+    int32_t task_begin, task_end;
+};
+
+struct FacItem {
+    int32_t sn;
+    int32_t blk;        // row-chunk index inside the panel's off-diagonal part
+};
+
+struct PlanOptions {
+    int max_width = kMaxSnWidth;
+    bool relax = true;
+    int update_policy = 0;  // 0 right-looking, 1 left-looking
+    double amd_dense_scale = 1.5;
+};
+
+struct HostPlan {
+    int N = 0;
+    int64_t nnzK = 0;
+    std::vector<int> perm, iperm;  // perm[k] = original index eliminated k-th
+
+    int nsuper = 0;
+    std::vector<int> sn_first;       // [nsuper+1] first (permuted) column
+    std::vector<int> sn_of_col;      // [N]
+    std::vector<int64_t> sn_rowptr;  // [nsuper+1] into sn_rows
+    std::vector<int> sn_rows;        // sorted row structure, own columns first
+    std::vector<int64_t> sn_panel;   // [nsuper+1] offset of the r x w column-major panel in Lx
+    std::vector<int64_t> sn_diag;    // [nsuper+1] offset of the factored w x w diagonal block in Ldiag
+    std::vector<int> sn_parent, sn_level;
+    int nlevels = 0;
+    std::vector<int> lvl_ptr, lvl_sn;
+
+    std::vector<int64_t> kmap;      // [nnzK] original nz -> Lx offset
+    std::vector<int64_t> diag_dst;  // [N] permuted column k -> Lx offset of its diagonal entry
+
+    std::vector<FacItem> fac_items;
+    std::vector<int> fac_lvl_ptr;  // [nlevels+1]
+    std::vector<int> fac_lvl_maxw; // [nlevels] widest supernode of the level (LDS sizing)
+
+    std::vector<int> rel;
+    std::vector<UpdTask> upd_tasks;
+    std::vector<UpdGroup> upd_groups;
+    std::vector<int> upd_stage_ptr;  // [nlevels+1] groups executed after factor(level)
+
+    std::vector<int64_t> u_off;  // [nsuper+1] offsets of each panel's off-diagonal rows in ubuf
+    std::vector<int64_t> g_ptr;  // [N+1] gather lists per permuted column
+    std::vector<int> g_idx;      // ubuf positions
+
+    std::vector<int64_t> sym_rowptr;  // full symmetric CSR view of K (original ordering)
+    std::vector<int> sym_col;
+    std::vector<int64_t> sym_q;       // index into Kval
+
+    // statistics / cost model
+    int64_t nnzL = 0;            // strictly-lower structural nonzeros of L (column counts)
+    int64_t panel_doubles = 0;   // supernodal storage incl. diagonal blocks and relaxation zeros
+    int64_t diag_doubles = 0;
+    int64_t ubuf_len = 0;
+    int etree_height = 0;
+    double flops_colcount = 0;   // sum_j c_j^2 + 3 c_j
+    double flops_update = 0;     // executed flops of the dense update tasks (2*rows*cols*k)
+    double flops_exec = 0;       // update + diagonal-block + TRSM flops actually executed
+};
+
+// Ap/Ai: upper-triangular CSC pattern (diagonal present), 0-based.
+// user_perm: optional (size N) or nullptr.  Returns empty string on success.
+std::string build_plan(int N, const int64_t *Ap, const int64_t *Ai, const int64_t *user_perm,
+                       const PlanOptions &opt, HostPlan &plan);
+
+void amd_order(int n, const int64_t *Ap, const int64_t *Ai, double dense_scale, std::vector<int> &perm);
+
+}  // namespace hipkkt

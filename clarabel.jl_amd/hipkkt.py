@@ -1,0 +1,281 @@
+"""ctypes binding of ``libclarabel_hipkkt.so`` (C ABI declared in include/hipkkt.h).
+
+This is the Python stand-in for the ``ccall`` layer a Julia maintainer would add;
+it fails loudly when the HIP library is missing — there is no CPU fallback."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libclarabel_hipkkt.so")
+
+_i64p = np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
+_i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+_f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+
+# every symbol include/hipkkt.h declares (checked by tests/test_abi.py)
+SYMBOLS = [
+    "hipkkt_default_opts", "hipkkt_is_available", "hipkkt_create", "hipkkt_create_from_parts", "hipkkt_destroy",
+    "hipkkt_get_dims", "hipkkt_info", "hipkkt_get_cost_model", "hipkkt_get_kkt", "hipkkt_get_perm",
+    "hipkkt_get_dsigns", "hipkkt_get_map", "hipkkt_get_sparse_map", "hipkkt_update_values", "hipkkt_scale_values",
+    "hipkkt_set_hs", "hipkkt_set_hs_dev", "hipkkt_set_soc", "hipkkt_set_soc_batch", "hipkkt_set_genpow",
+    "hipkkt_update_P", "hipkkt_update_A", "hipkkt_refactor", "hipkkt_setrhs", "hipkkt_setrhs_dev", "hipkkt_solve",
+    "hipkkt_solve_dev", "hipkkt_ldl_solve", "hipkkt_get_timing", "hipkkt_reset_timing", "hipkkt_set_profiling",
+    "hipkkt_selftest_mfma", "hipkkt_last_error",
+]
+
+
+class Opts(C.Structure):
+    _fields_ = [("index_base", C.c_int32), ("supernode_max_width", C.c_int32), ("relax_supernodes", C.c_int32),
+                ("update_policy", C.c_int32), ("dynamic_reg_eps", C.c_double), ("dynamic_reg_delta", C.c_double),
+                ("amd_dense_scale", C.c_double), ("user_perm", C.c_void_p)]
+
+
+class HipKKTError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load the HIP library; raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipKKTError(f"{LIB_PATH} is missing: build it with clarabel.jl_amd/csrc/build.sh "
+                          "(__graft_entry__.build()); there is no CPU fallback for the KKT path")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64, f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_double
+    L.hipkkt_default_opts.argtypes = [C.POINTER(Opts)]
+    L.hipkkt_default_opts.restype = None
+    L.hipkkt_is_available.restype = i32
+    L.hipkkt_create.restype = i32
+    L.hipkkt_create.argtypes = [i32, i64, _i64p, _i64p, _f64p, _i64p, C.POINTER(Opts), C.POINTER(vp)]
+    L.hipkkt_create_from_parts.restype = i32
+    L.hipkkt_create_from_parts.argtypes = [i32, i64, i64, _i64p, _i64p, _f64p, _i64p, _i64p, _f64p, i64, _i64p, _i32p,
+                                           _i32p, _i64p, C.POINTER(Opts), C.POINTER(vp)]
+    L.hipkkt_destroy.argtypes = [vp]
+    L.hipkkt_destroy.restype = None
+    L.hipkkt_get_dims.argtypes = [vp, _i64p]
+    L.hipkkt_info.argtypes = [vp, C.POINTER(i64), C.POINTER(i64)]
+    L.hipkkt_get_cost_model.argtypes = [vp, _f64p]
+    L.hipkkt_get_kkt.argtypes = [vp, vp, vp, vp]
+    L.hipkkt_get_perm.argtypes = [vp, _i64p]
+    L.hipkkt_get_dsigns.argtypes = [vp, _i64p]
+    L.hipkkt_get_map.argtypes = [vp, i32, _i64p]
+    L.hipkkt_get_sparse_map.argtypes = [vp, i64, i32, vp, C.POINTER(i64)]
+    L.hipkkt_update_values.argtypes = [vp, _i64p, _f64p, i64]
+    L.hipkkt_scale_values.argtypes = [vp, _i64p, i64, f64]
+    L.hipkkt_set_hs.argtypes = [vp, _f64p, i64]
+    L.hipkkt_set_hs_dev.argtypes = [vp, vp, i64]
+    L.hipkkt_set_soc.argtypes = [vp, i64, f64, _f64p, _f64p, i64]
+    L.hipkkt_set_soc_batch.argtypes = [vp, i64, _f64p, _f64p, _f64p, i64]
+    L.hipkkt_set_genpow.argtypes = [vp, i64, f64, _f64p, _f64p, _f64p]
+    L.hipkkt_update_P.argtypes = [vp, _f64p, i64]
+    L.hipkkt_update_A.argtypes = [vp, _f64p, i64]
+    L.hipkkt_refactor.argtypes = [vp, i32, f64, f64, C.POINTER(f64), C.POINTER(i64)]
+    L.hipkkt_setrhs.argtypes = [vp, _f64p, _f64p]
+    L.hipkkt_setrhs_dev.argtypes = [vp, vp]
+    L.hipkkt_solve.argtypes = [vp, vp, vp, i32, f64, f64, i64, f64, C.POINTER(i64)]
+    L.hipkkt_solve_dev.argtypes = [vp, vp, i32, f64, f64, i64, f64, C.POINTER(i64)]
+    L.hipkkt_ldl_solve.argtypes = [vp, _f64p, _f64p]
+    L.hipkkt_get_timing.argtypes = [vp, _f64p]
+    L.hipkkt_reset_timing.argtypes = [vp]
+    L.hipkkt_set_profiling.argtypes = [vp, i32]
+    L.hipkkt_selftest_mfma.argtypes = [i32, C.POINTER(f64)]
+    L.hipkkt_last_error.argtypes = [vp]
+    L.hipkkt_last_error.restype = C.c_char_p
+    for nm in SYMBOLS:
+        f = getattr(L, nm)
+        if f.restype is C.c_int:  # default -> status code
+            f.restype = i32
+    _lib = L
+    return L
+
+
+def default_opts(**kw):
+    o = Opts()
+    lib().hipkkt_default_opts(C.byref(o))
+    keep = None
+    for k, v in kw.items():
+        if k == "user_perm" and v is not None:
+            keep = np.ascontiguousarray(v, dtype=np.int64)
+            o.user_perm = keep.ctypes.data_as(C.c_void_p).value
+        elif v is not None:
+            setattr(o, k, v)
+    return o, keep
+
+
+class Handle:
+    """Owning wrapper of a ``hipkkt_handle`` (the analogue of the Julia struct + finalizer)."""
+
+    def __init__(self, ptr):
+        self.L = lib()
+        self.h = ptr
+        d = np.zeros(16, dtype=np.int64)
+        self.L.hipkkt_get_dims(self.h, d)
+        (self.N, self.n, self.m, self.p, self.nnzK, self.nHs, self.nsparse, self.nnzP, self.nnzA, self.nnzL,
+         self.nsuper, self.nlevels, self.panel_doubles, self.ntasks, self.etree_height, _) = (int(v) for v in d)
+
+    @classmethod
+    def from_kkt(cls, colptr, rowval, nzval, dsigns, device=0, **optkw):
+        L = lib()
+        o, keep = default_opts(**optkw)
+        out = C.c_void_p()
+        N = len(colptr) - 1
+        rc = L.hipkkt_create(device, N, np.ascontiguousarray(colptr, dtype=np.int64),
+                             np.ascontiguousarray(rowval, dtype=np.int64), np.ascontiguousarray(nzval, dtype=np.float64),
+                             np.ascontiguousarray(dsigns, dtype=np.int64), C.byref(o), C.byref(out))
+        if rc != 0:
+            raise HipKKTError(f"hipkkt_create failed ({rc}): {L.hipkkt_last_error(None).decode()}")
+        return cls(out)
+
+    @classmethod
+    def from_parts(cls, P, A, numel, hs_dense, sparse_kind, dim1, device=0, **optkw):
+        L = lib()
+        o, keep = default_opts(**optkw)
+        out = C.c_void_p()
+        n, m = P.shape[0], A.shape[0]
+        rc = L.hipkkt_create_from_parts(
+            device, n, m, np.ascontiguousarray(P.indptr, dtype=np.int64), np.ascontiguousarray(P.indices, dtype=np.int64),
+            np.ascontiguousarray(P.data, dtype=np.float64), np.ascontiguousarray(A.indptr, dtype=np.int64),
+            np.ascontiguousarray(A.indices, dtype=np.int64), np.ascontiguousarray(A.data, dtype=np.float64), len(numel),
+            np.ascontiguousarray(numel, dtype=np.int64), np.ascontiguousarray(hs_dense, dtype=np.int32),
+            np.ascontiguousarray(sparse_kind, dtype=np.int32), np.ascontiguousarray(dim1, dtype=np.int64), C.byref(o),
+            C.byref(out))
+        if rc != 0:
+            raise HipKKTError(f"hipkkt_create_from_parts failed ({rc}): {L.hipkkt_last_error(None).decode()}")
+        return cls(out)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.hipkkt_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, what):
+        if rc < 0:
+            raise HipKKTError(f"{what} failed ({rc}): {self.L.hipkkt_last_error(self.h).decode()}")
+        return rc
+
+    # ---- introspection
+    def kkt(self):
+        colptr = np.zeros(self.N + 1, dtype=np.int64)
+        rowval = np.zeros(self.nnzK, dtype=np.int64)
+        nzval = np.zeros(self.nnzK)
+        self._chk(self.L.hipkkt_get_kkt(self.h, colptr.ctypes.data, rowval.ctypes.data, nzval.ctypes.data), "get_kkt")
+        return colptr, rowval, nzval
+
+    def perm(self):
+        p = np.zeros(self.N, dtype=np.int64)
+        self.L.hipkkt_get_perm(self.h, p)
+        return p
+
+    def dsigns(self):
+        p = np.zeros(self.N, dtype=np.int64)
+        self.L.hipkkt_get_dsigns(self.h, p)
+        return p
+
+    def map(self, which):
+        cnt = [self.nnzP, self.nnzA, self.nHs, self.n, self.N][which]
+        out = np.zeros(max(cnt, 1), dtype=np.int64)
+        self._chk(self.L.hipkkt_get_map(self.h, which, out), "get_map")
+        return out[:cnt]
+
+    def sparse_map(self, i, which):
+        ln = C.c_int64(0)
+        self._chk(self.L.hipkkt_get_sparse_map(self.h, i, which, None, C.byref(ln)), "get_sparse_map")
+        out = np.zeros(max(ln.value, 1), dtype=np.int64)
+        self.L.hipkkt_get_sparse_map(self.h, i, which, out.ctypes.data, C.byref(ln))
+        return out[: ln.value]
+
+    def cost_model(self):
+        o = np.zeros(8)
+        self.L.hipkkt_get_cost_model(self.h, o)
+        return dict(flops_factor=o[0], flops_exec=o[1], flops_solve=o[2], bytes_factor=o[3], bytes_solve=o[4],
+                    bytes_spmv=o[5], flops_update=o[6])
+
+    def timing(self):
+        o = np.zeros(8)
+        self.L.hipkkt_get_timing(self.h, o)
+        return dict(last_factor_ms=o[0], last_solve_ms=o[1], acc_factor_ms=o[2], acc_solve_ms=o[3], n_factor=int(o[4]),
+                    n_solve_calls=int(o[5]), n_ldl_solves=int(o[6]), last_update_ms=o[7])
+
+    # ---- numeric
+    def update_values(self, index, values):
+        self._chk(self.L.hipkkt_update_values(self.h, np.ascontiguousarray(index, dtype=np.int64),
+                                              np.ascontiguousarray(values, dtype=np.float64), len(index)), "update_values")
+
+    def scale_values(self, index, scale):
+        self._chk(self.L.hipkkt_scale_values(self.h, np.ascontiguousarray(index, dtype=np.int64), len(index), scale),
+                  "scale_values")
+
+    def set_hs(self, hs):
+        self._chk(self.L.hipkkt_set_hs(self.h, np.ascontiguousarray(hs, dtype=np.float64), len(hs)), "set_hs")
+
+    def set_soc(self, i, eta2, u, v):
+        self._chk(self.L.hipkkt_set_soc(self.h, i, eta2, np.ascontiguousarray(u), np.ascontiguousarray(v), len(u)), "set_soc")
+
+    def set_soc_batch(self, eta2, u_all, v_all):
+        self._chk(self.L.hipkkt_set_soc_batch(self.h, len(eta2), np.ascontiguousarray(eta2, dtype=np.float64),
+                                              np.ascontiguousarray(u_all, dtype=np.float64),
+                                              np.ascontiguousarray(v_all, dtype=np.float64), len(u_all)), "set_soc_batch")
+
+    def update_P(self, vals):
+        self._chk(self.L.hipkkt_update_P(self.h, np.ascontiguousarray(vals, dtype=np.float64), len(vals)), "update_P")
+
+    def update_A(self, vals):
+        self._chk(self.L.hipkkt_update_A(self.h, np.ascontiguousarray(vals, dtype=np.float64), len(vals)), "update_A")
+
+    def refactor(self, static_enable=True, eps_const=1e-8, eps_prop=float(np.finfo(np.float64).eps) ** 2):
+        eps = C.c_double(0.0)
+        nreg = C.c_int64(0)
+        rc = self._chk(self.L.hipkkt_refactor(self.h, int(static_enable), eps_const, eps_prop, C.byref(eps), C.byref(nreg)),
+                       "refactor")
+        return rc == 0, eps.value, nreg.value
+
+    def setrhs(self, rhsx, rhsz):
+        self._chk(self.L.hipkkt_setrhs(self.h, np.ascontiguousarray(rhsx, dtype=np.float64),
+                                       np.ascontiguousarray(rhsz, dtype=np.float64)), "setrhs")
+
+    def solve(self, lhsx, lhsz, ir_enable=True, reltol=1e-13, abstol=1e-12, max_iter=10, stop_ratio=5.0):
+        steps = C.c_int64(0)
+        px = lhsx.ctypes.data if lhsx is not None else None
+        pz = lhsz.ctypes.data if lhsz is not None else None
+        rc = self._chk(self.L.hipkkt_solve(self.h, px, pz, int(ir_enable), reltol, abstol, max_iter, stop_ratio,
+                                           C.byref(steps)), "solve")
+        return rc == 0, steps.value
+
+    # device-pointer variants (inputs already resident in HBM, e.g. torch tensors' data_ptr())
+    def set_hs_dev(self, ptr, n):
+        self._chk(self.L.hipkkt_set_hs_dev(self.h, ptr, n), "set_hs_dev")
+
+    def setrhs_dev(self, ptr):
+        self._chk(self.L.hipkkt_setrhs_dev(self.h, ptr), "setrhs_dev")
+
+    def solve_dev(self, out_ptr, ir_enable=True, reltol=1e-13, abstol=1e-12, max_iter=10, stop_ratio=5.0):
+        steps = C.c_int64(0)
+        rc = self._chk(self.L.hipkkt_solve_dev(self.h, out_ptr, int(ir_enable), reltol, abstol, max_iter, stop_ratio,
+                                               C.byref(steps)), "solve_dev")
+        return rc == 0, steps.value
+
+    def set_profiling(self, on):
+        self.L.hipkkt_set_profiling(self.h, int(on))
+
+    def reset_timing(self):
+        self.L.hipkkt_reset_timing(self.h)
+
+    def ldl_solve(self, b):
+        x = np.zeros(self.N)
+        self._chk(self.L.hipkkt_ldl_solve(self.h, x, np.ascontiguousarray(b, dtype=np.float64)), "ldl_solve")
+        return x

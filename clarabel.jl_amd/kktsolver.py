@@ -1,0 +1,83 @@
+"""``HipKKTSolver`` — host-side mirror of the reference's KKT-solver plugin for seam L1.
+
+It implements the ``AbstractKKTSolver`` contract (src/kktsolvers/kktsolver_defaults.jl:2-47) with
+the same names, argument meaning and success semantics as the reference's ``DirectLDLKKTSolver``
+(src/kktsolvers/kktsolver_directldl.jl); everything below the method boundary runs in the HIP
+library through the C ABI (include/hipkkt.h).  The Julia file a maintainer would add is shown in
+INTEGRATION.md; this class is its Python twin so that parity tests read like the reference's."""
+from __future__ import annotations
+
+import numpy as np
+
+from . import hipkkt
+from .settings import Settings
+
+
+class HipKKTSolver:
+    def __init__(self, P, A, cones, m, n, settings: Settings, **optkw):
+        """ref: DirectLDLKKTSolver{T}(P,A,cones,m,n,settings), kktsolver_directldl.jl:46-92.
+        P: n x n triu CSC (scipy), A: m x n CSC, cones: CompositeCone."""
+        self.settings = settings
+        self.m, self.n = m, n
+        numel, hs_dense, sparse_kind, dim1 = cones.kkt_descriptors()
+        self.h = hipkkt.Handle.from_parts(
+            P, A, numel, hs_dense, sparse_kind, dim1, device=settings.device_id,
+            dynamic_reg_eps=settings.dynamic_regularization_eps,
+            dynamic_reg_delta=settings.dynamic_regularization_delta, **optkw)
+        self.p = self.h.p
+        self.Hsblocks = np.zeros(self.h.nHs)          # ref: _allocate_kkt_Hsblocks
+        self._soc = [c for c in cones if c.is_sparse_expandable]
+        self._soc_total = sum(c.dim for c in self._soc)
+        self._u = np.zeros(self._soc_total)
+        self._v = np.zeros(self._soc_total)
+        self._eta2 = np.zeros(len(self._soc))
+        self.diagonal_regularizer = 0.0
+        self.last_ir_steps = 0
+        self.total_ir_steps = 0
+        self.nsolves = 0
+        self.last_nreg = 0
+
+    # ref: kktsolver_update!, kktsolver_directldl.jl:197-245
+    def kktsolver_update(self, cones) -> bool:
+        cones.get_Hs(self.Hsblocks)                    # :223 (cone algebra stays on the host)
+        self.h.set_hs(self.Hsblocks)                   # :225-228 negate + scatter, on the device
+        if self._soc:                                  # :235-241 sparse-cone expansion columns
+            off = 0
+            for i, c in enumerate(self._soc):
+                self._u[off:off + c.dim] = c.u
+                self._v[off:off + c.dim] = c.v
+                self._eta2[i] = c.eta * c.eta
+                off += c.dim
+            self.h.set_soc_batch(self._eta2, self._u, self._v)
+        st = self.settings                             # :243, :247-294
+        ok, eps, nreg = self.h.refactor(st.static_regularization_enable, st.static_regularization_constant,
+                                        st.static_regularization_proportional)
+        self.diagonal_regularizer = eps
+        self.last_nreg = nreg
+        return ok
+
+    # ref: kktsolver_setrhs!, :313-327
+    def kktsolver_setrhs(self, rhsx, rhsz):
+        self.h.setrhs(rhsx, rhsz)
+
+    # ref: kktsolver_solve!, :346-371 (lhsx / lhsz may be None = Julia `nothing`)
+    def kktsolver_solve(self, lhsx, lhsz) -> bool:
+        st = self.settings
+        ok, steps = self.h.solve(lhsx, lhsz, st.iterative_refinement_enable, st.iterative_refinement_reltol,
+                                 st.iterative_refinement_abstol, st.iterative_refinement_max_iter,
+                                 st.iterative_refinement_stop_ratio)
+        self.last_ir_steps = steps
+        self.total_ir_steps += steps
+        self.nsolves += 1
+        return ok
+
+    # ref: kktsolver_update_P!/A!, :374-386
+    def kktsolver_update_P(self, P):
+        self.h.update_P(P.data)
+
+    def kktsolver_update_A(self, A):
+        self.h.update_A(A.data)
+
+    # ref: kktsolver_linear_solver_info -> LinearSolverInfo(name,threads,direct,nnzA,nnzL), types.jl:198-206
+    def kktsolver_linear_solver_info(self):
+        return dict(name="hip", threads=1, direct=True, nnzA=self.h.nnzK, nnzL=self.h.nnzL)

@@ -1,0 +1,191 @@
+/*
+ * libclarabel_hipkkt.so — C ABI of the MI355X-native KKT linear-system path for Clarabel.jl.
+ *
+ * This is the drop-in boundary.  Every entry point replaces one
+ * method of the reference's KKT-solver plugin contracts; the `ref:` tag on each declaration cites
+ * the reference interface it stands in for (paths relative to /root/reference):
+ *
+ *   seam L1  AbstractKKTSolver        src/kktsolvers/kktsolver_defaults.jl:2-47
+ *            (concrete reference impl src/kktsolvers/kktsolver_directldl.jl)
+ *   seam L0  AbstractDirectLDLSolver  src/kktsolvers/direct-ldl/directldl_defaults.jl:1-72
+ *            (concrete reference impls directldl_qdldl.jl, ext/directldl_pardiso.jl)
+ *
+ * Conventions
+ *   - plain C types only; all pointers are HOST memory unless the name ends in `_dev`
+ *     (device pointers on the handle's GPU, e.g. a torch tensor's data_ptr()).
+ *   - integer arrays are int64_t holding indices of base `opts.index_base` (1 = exactly what Julia
+ *     holds in SparseMatrixCSC.colptr/rowval and LDLDataMap; 0 = numpy/scipy).
+ *   - the caller owns every array it passes; the library copies during the call and keeps no host
+ *     pointers (Julia's GC may move or free them after ccall returns).
+ *   - return value int32_t: 0 = ok; >0 = numerical failure (maps to Julia `false`);
+ *     <0 = usage / device error (maps to `error()` in a constructor, `false` elsewhere).
+ *     Nothing is thrown across the boundary.
+ *   - every call is synchronous (returns after the handle's stream has drained), sets the device
+ *     of the handle, and touches no global mutable state: distinct handles may be driven from
+ *     distinct threads / processes.  Only Float64 is accelerated.
+ */
+#ifndef HIPKKT_H
+#define HIPKKT_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hipkkt_solver *hipkkt_handle;
+
+/* status codes */
+#define HIPKKT_OK 0
+#define HIPKKT_NUMERICAL_FAILURE 1   /* non-finite pivot / non-finite refinement residual */
+#define HIPKKT_ERR_ARGUMENT (-1)
+#define HIPKKT_ERR_DEVICE (-2)
+#define HIPKKT_ERR_ALLOC (-3)
+#define HIPKKT_ERR_INTERNAL (-4)
+
+/* cone structure codes for hipkkt_create_from_parts (what the KKT pattern needs to know) */
+#define HIPKKT_SPARSE_NONE 0
+#define HIPKKT_SPARSE_SOC 1      /* SOCExpansionMap,    directldl_datamaps.jl:8-22  (pdim 2) */
+#define HIPKKT_SPARSE_GENPOW 2   /* GenPowExpansionMap, directldl_datamaps.jl:81-99 (pdim 3) */
+
+typedef struct hipkkt_opts {
+    int32_t index_base;            /* 0 or 1 */
+    int32_t supernode_max_width;   /* 0 = default (64) */
+    int32_t relax_supernodes;      /* 1 = relaxed amalgamation (default), 0 = fundamental only */
+    int32_t update_policy;         /* 0 = right-looking (default), 1 = left-looking */
+    double dynamic_reg_eps;        /* ref: settings.jl:123, passed at directldl_qdldl.jl:21 */
+    double dynamic_reg_delta;      /* ref: settings.jl:124, passed at directldl_qdldl.jl:22 */
+    double amd_dense_scale;        /* ref: directldl_qdldl.jl:24 (1.5); <=0 = default */
+    const int64_t *user_perm;      /* optional fill-reducing order (index_base based); NULL = own AMD */
+} hipkkt_opts;
+
+/* defaults = the reference's Settings defaults (src/settings.jl:117-132) */
+void hipkkt_default_opts(hipkkt_opts *opts);
+
+/* ref: ldlsolver_is_available(::Val{:hip}) (pattern: ext/directldl_pardiso.jl:144,148).
+ * Number of usable HIP devices (0 = not available).  Never fails. */
+int32_t hipkkt_is_available(void);
+
+/* ---- construction ------------------------------------------------------------------------ */
+
+/* seam L0.  ref: ctor S{T}(KKT::SparseMatrixCSC{T},Dsigns,settings), directldl_qdldl.jl:6-28 /
+ * ext/directldl_pardiso.jl:33-55.  KKT is the N x N :triu CSC image (diagonal present and LAST in
+ * every column, as directldl_kkt_assembly.jl:161-165 guarantees).  Symbolic analysis only. */
+int32_t hipkkt_create(int32_t device_id, int64_t N, const int64_t *colptr, const int64_t *rowval,
+                      const double *nzval, const int64_t *dsigns, const hipkkt_opts *opts,
+                      hipkkt_handle *out);
+
+/* seam L1.  ref: DirectLDLKKTSolver{T}(P,A,cones,m,n,settings), kktsolver_directldl.jl:46-92:
+ * assembles the :triu KKT image + LDLDataMap (directldl_kkt_assembly.jl:15-175,
+ * directldl_datamaps.jl:170-214), Dsigns (kktsolver_directldl.jl:112-126), then the symbolic
+ * analysis.  P is n x n :triu CSC, A is m x n CSC.  Per cone: numel, hs_dense (0 = diagonal Hs
+ * block, 1 = dense packed-triu block), sparse_kind (HIPKKT_SPARSE_*), dim1 (GenPow only). */
+int32_t hipkkt_create_from_parts(int32_t device_id, int64_t n, int64_t m,
+                                 const int64_t *Pcolptr, const int64_t *Prowval, const double *Pnzval,
+                                 const int64_t *Acolptr, const int64_t *Arowval, const double *Anzval,
+                                 int64_t ncones, const int64_t *cone_numel, const int32_t *cone_hs_dense,
+                                 const int32_t *cone_sparse_kind, const int64_t *cone_dim1,
+                                 const hipkkt_opts *opts, hipkkt_handle *out);
+
+/* ref: finalizer of the Julia wrapper struct (MOI.empty! calls finalize(solver),
+ * src/MOI_wrapper/MOI_wrapper.jl:133).  Idempotent on NULL. */
+void hipkkt_destroy(hipkkt_handle h);
+
+/* ---- introspection ------------------------------------------------------------------------ */
+
+/* out[0..15] = N, n, m, p, nnzK, nHs, nsparse, nnzP, nnzA, nnzL (strictly-lower entries of L,
+ * structural), n_supernodes, n_levels, panel_doubles (supernodal storage incl. padding zeros),
+ * n_update_tasks, etree_height (columns), reserved.  (n,m,p,nHs,nnzP,nnzA are 0 for L0 handles.) */
+int32_t hipkkt_get_dims(hipkkt_handle h, int64_t *out16);
+
+/* ref: linear_solver_info(ldlsolver) -> LinearSolverInfo(name,threads,direct,nnzA,nnzL),
+ * directldl_qdldl.jl:35-42 / src/types.jl:198-206.  name = :hip, threads = 1 (host), direct = true. */
+int32_t hipkkt_info(hipkkt_handle h, int64_t *nnzA, int64_t *nnzL);
+
+/* flop / byte model of one numeric factorisation and one solve, from the symbolic factor actually
+ * used:  out[0]=sum_j c_j^2+3c_j (factor flops), out[1]=executed factor flops incl.
+ * supernode padding, out[2]=solve flops (4 nnzL + N), out[3]=algorithmic factor bytes,
+ * out[4]=algorithmic solve bytes, out[5]=spmv bytes, out[6]=dense-update (MFMA) flops, out[7]=reserved */
+int32_t hipkkt_get_cost_model(hipkkt_handle h, double *out8);
+
+/* copies of host-side structures (tests, Julia-side bookkeeping).  Any pointer may be NULL. */
+int32_t hipkkt_get_kkt(hipkkt_handle h, int64_t *colptr, int64_t *rowval, double *nzval);
+int32_t hipkkt_get_perm(hipkkt_handle h, int64_t *perm);     /* perm[k] = index eliminated k-th */
+int32_t hipkkt_get_dsigns(hipkkt_handle h, int64_t *dsigns);
+/* which: 0 = map.P, 1 = map.A, 2 = map.Hsblocks, 3 = map.diagP, 4 = map.diag_full
+ * (ref: LDLDataMap fields, directldl_datamaps.jl:170-181) */
+int32_t hipkkt_get_map(hipkkt_handle h, int32_t which, int64_t *out);
+/* sparse map i: which 0/1/2 = index vectors (SOC: u,v ; GenPow: q,r,p), 3 = D; *len receives length */
+int32_t hipkkt_get_sparse_map(hipkkt_handle h, int64_t i, int32_t which, int64_t *out, int64_t *len);
+
+/* ---- value updates ------------------------------------------------------------------------ */
+
+/* ref: update_values!(ldlsolver,index,values) / scale_values!(ldlsolver,index,scale),
+ * directldl_qdldl.jl:46-69, called from kktsolver_directldl.jl:130-188. */
+int32_t hipkkt_update_values(hipkkt_handle h, const int64_t *index, const double *values, int64_t k);
+int32_t hipkkt_scale_values(hipkkt_handle h, const int64_t *index, int64_t k, double scale);
+
+/* ref: kktsolver_update! first half, kktsolver_directldl.jl:223-228: Hs as produced by
+ * get_Hs!(cones,Hsblocks); negated and scattered through map.Hsblocks on the device. */
+int32_t hipkkt_set_hs(hipkkt_handle h, const double *hs, int64_t nHs);
+int32_t hipkkt_set_hs_dev(hipkkt_handle h, const double *hs_dev, int64_t nHs);
+/* ref: _csc_update_sparsecone(::SecondOrderCone,...), directldl_datamaps.jl:61-79 */
+int32_t hipkkt_set_soc(hipkkt_handle h, int64_t sparse_idx, double eta2, const double *u, const double *v,
+                       int64_t dim);
+/* all sparse SOC cones in one call (same arithmetic; one upload + one launch instead of 5 per cone):
+ * eta2[nsoc], u_all / v_all = the cones' u and v vectors concatenated in sparse-map order */
+int32_t hipkkt_set_soc_batch(hipkkt_handle h, int64_t nsoc, const double *eta2, const double *u_all,
+                             const double *v_all, int64_t total);
+/* ref: _csc_update_sparsecone(::GenPowerCone,...), directldl_datamaps.jl:146-167 */
+int32_t hipkkt_set_genpow(hipkkt_handle h, int64_t sparse_idx, double sqrtmu, const double *p,
+                          const double *q, const double *r);
+/* ref: kktsolver_update_P!/A!, kktsolver_directldl.jl:374-386 */
+int32_t hipkkt_update_P(hipkkt_handle h, const double *Pnzval, int64_t nnzP);
+int32_t hipkkt_update_A(hipkkt_handle h, const double *Anzval, int64_t nnzA);
+
+/* ---- factor ------------------------------------------------------------------------------- */
+
+/* ref: _kktsolver_regularize_and_refactor!, kktsolver_directldl.jl:247-310 with
+ * refactor!(ldlsolver,K), directldl_qdldl.jl:72-81.  eps = eps_const + eps_prop*max|diag K|;
+ * K_fact = K + eps*diag(Dsigns); numeric LDL^T with the sign-driven dynamic pivot substitution;
+ * the unregularised K stays resident for iterative refinement.  Returns 0, or
+ * HIPKKT_NUMERICAL_FAILURE when some pivot inverse is non-finite.  eps_used / n_dynamic_reg may be NULL. */
+int32_t hipkkt_refactor(hipkkt_handle h, int32_t static_reg_enable, double eps_const, double eps_prop,
+                        double *eps_used, int64_t *n_dynamic_reg);
+
+/* ---- solve -------------------------------------------------------------------------------- */
+
+/* ref: kktsolver_setrhs!, kktsolver_directldl.jl:313-327: b = [rhsx; rhsz; 0_p] */
+int32_t hipkkt_setrhs(hipkkt_handle h, const double *rhsx, const double *rhsz);
+int32_t hipkkt_setrhs_dev(hipkkt_handle h, const double *rhs_dev /* n+m contiguous */);
+/* ref: kktsolver_solve!, kktsolver_directldl.jl:346-371 incl. _iterative_refinement :389-449 and
+ * kktsolver_getlhs! :330-343.  lhsx / lhsz may be NULL (Julia `nothing`).  ir_steps may be NULL. */
+int32_t hipkkt_solve(hipkkt_handle h, double *lhsx, double *lhsz, int32_t ir_enable, double reltol,
+                     double abstol, int64_t max_iter, double stop_ratio, int64_t *ir_steps);
+/* same, result left on the device: lhs_dev receives n+m doubles (may be NULL to discard) */
+int32_t hipkkt_solve_dev(hipkkt_handle h, double *lhs_dev, int32_t ir_enable, double reltol,
+                         double abstol, int64_t max_iter, double stop_ratio, int64_t *ir_steps);
+/* seam L0.  ref: solve!(ldlsolver,K,x,b), directldl_qdldl.jl:85-96: x = K_fact^{-1} b, length N,
+ * no refinement (the Julia-side DirectLDLKKTSolver refines).  x and b must not alias. */
+int32_t hipkkt_ldl_solve(hipkkt_handle h, double *x, const double *b);
+
+/* ---- timing (device time on the handle's stream, HIP events) ------------------------------- */
+/* out[0] = ms of last refactor (value scatter + numeric LDL), out[1] = ms of last solve call
+ * (all LDL solves + SpMVs of the refinement), out[2] = accumulated refactor ms, out[3] = accumulated
+ * solve ms, out[4] = #refactors, out[5] = #solve calls, out[6] = #LDL solves, out[7] = ms of the
+ * dense-update kernels inside the last refactor (0 unless profiling was enabled) */
+int32_t hipkkt_get_timing(hipkkt_handle h, double *out8);
+int32_t hipkkt_reset_timing(hipkkt_handle h);
+/* 1 = time the update (MFMA) kernels separately inside refactor (adds event overhead) */
+int32_t hipkkt_set_profiling(hipkkt_handle h, int32_t enable);
+
+/* diagnostic: checks the FP64 matrix-core operand/result lane maps used by the update kernel
+ * against a host product with an asymmetric B (returns 0 when they agree to 1e-12) */
+int32_t hipkkt_selftest_mfma(int32_t device_id, double *max_err);
+
+/* last error text for this handle (or for a failed create when h == NULL); never NULL */
+const char *hipkkt_last_error(hipkkt_handle h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -107,3 +107,23 @@ def lasso_socp(seed=12345, n=8):
     A = sp.csc_matrix(np.vstack([A1, A2, A3]))
     b = np.concatenate([b1, b2, b3])
     return P, c, A, b, [cl.NonnegativeConeT(len(b1)), cl.NonnegativeConeT(len(b2)), cl.SecondOrderConeT(len(b3))]
+
+
+def scale_cones(cones, rng):
+    """put every cone at a random strictly interior (s, z) and update its scaling"""
+    m = cones.numel
+    s, z = np.zeros(m), np.zeros(m)
+    for c, r in zip(cones.cones, cones.rng_cones):
+        if isinstance(c, cl.cones.PSDTriangleCone):
+            for v in (s, z):
+                M = rng.standard_normal((c.n, c.n))
+                v[r] = c.mat_to_svec(M @ M.T + c.n * np.eye(c.n))
+        elif isinstance(c, cl.cones.SecondOrderCone):
+            for v in (s, z):
+                t = rng.standard_normal(c.dim)
+                t[0] = np.linalg.norm(t[1:]) + 0.5 + rng.random()
+                v[r] = t
+        else:
+            s[r] = rng.random(c.numel) + 0.2
+            z[r] = rng.random(c.numel) + 0.2
+    assert cones.update_scaling(s, z, 1.0)

@@ -1,0 +1,148 @@
+// TEST SUPPORT (not product): serial host interpreter of the symbolic plan produced by
+#include <cstdio>
+#include <algorithm>
+// clarabel.jl_amd/csrc/symbolic.cpp.  It executes exactly the work lists the HIP kernels interpret
+// (scatter map, per-level factor items, target-owned update tasks, gather lists) so that the index
+// structures can be validated against dense linear algebra on a machine without a GPU.
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../clarabel.jl_amd/csrc/symbolic.h"
+
+using namespace hipkkt;
+
+extern "C" {
+
+// stats: [0] nsuper [1] nlevels [2] nnzL [3] panel_doubles [4] ntasks [5] ngroups [6] etree_height
+//        [7] flops_colcount [8] flops_update [9] flops_exec [10] nreg [11] max group tasks
+int plan_check_run(int64_t N, const int64_t *Ap, const int64_t *Ai, const double *Ax, const int64_t *dsigns,
+                   const int64_t *user_perm, int max_width, int relax, int policy, double reg_eps,
+                   double reg_delta, const double *b, double *x, int64_t *perm_out, double *stats,
+                   int symbolic_only) {
+    HostPlan P;
+    PlanOptions opt;
+    opt.max_width = max_width; opt.relax = relax != 0; opt.update_policy = policy;
+    std::string err = build_plan((int)N, Ap, Ai, user_perm, opt, P);
+    if (!err.empty()) { fprintf(stderr, "build_plan: %s\n", err.c_str()); return -1; }
+    if (perm_out) for (int k = 0; k < N; k++) perm_out[k] = P.perm[k];
+    size_t maxg = 0;
+    for (auto &g : P.upd_groups) maxg = std::max(maxg, (size_t)(g.task_end - g.task_begin));
+    stats[0] = P.nsuper; stats[1] = P.nlevels; stats[2] = (double)P.nnzL; stats[3] = (double)P.panel_doubles;
+    stats[4] = (double)P.upd_tasks.size(); stats[5] = (double)P.upd_groups.size(); stats[6] = P.etree_height;
+    stats[7] = P.flops_colcount; stats[8] = P.flops_update; stats[9] = P.flops_exec; stats[10] = 0; stats[11] = (double)maxg;
+    if (symbolic_only) return 0;
+
+    std::vector<double> Lx(P.panel_doubles, 0.0), Ld(P.diag_doubles, 0.0), D(N), Dinv(N);
+    for (int64_t q = 0; q < P.nnzK; q++) Lx[P.kmap[q]] = Ax[q];
+    int64_t nreg = 0;
+    auto W = [&](int s) { return P.sn_first[s + 1] - P.sn_first[s]; };
+    auto R = [&](int s) { return (int)(P.sn_rowptr[s + 1] - P.sn_rowptr[s]); };
+    for (int lvl = 0; lvl < P.nlevels; lvl++) {
+        // factor items (blk 0 does the diagonal block; every blk its TRSM rows)
+        for (int q = P.fac_lvl_ptr[lvl]; q < P.fac_lvl_ptr[lvl + 1]; q++) {
+            FacItem it = P.fac_items[q];
+            int s = it.sn, w = W(s), r = R(s);
+            double *pan = &Lx[P.sn_panel[s]];
+            double *ld = &Ld[P.sn_diag[s]];
+            int f = P.sn_first[s];
+            if (it.blk == 0) {
+                std::vector<double> Aw((size_t)w * w);
+                for (int j = 0; j < w; j++) for (int i = 0; i < w; i++) Aw[i + (size_t)j * w] = pan[i + (size_t)j * r];
+                for (int k = 0; k < w; k++) {
+                    double d = Aw[k + (size_t)k * w];
+                    double sg = (double)dsigns[P.perm[f + k]];
+                    if (d * sg < reg_eps) { d = reg_delta * sg; nreg++; }
+                    D[f + k] = d; Dinv[f + k] = 1.0 / d;
+                    for (int j = k + 1; j < w; j++)
+                        for (int i = j; i < w; i++) Aw[i + (size_t)j * w] -= Aw[i + (size_t)k * w] * Aw[j + (size_t)k * w] / d;
+                }
+                for (int k = 0; k < w; k++) for (int i = 0; i < w; i++)
+                    ld[i + (size_t)k * w] = i > k ? Aw[i + (size_t)k * w] / D[f + k] : (i == k ? 1.0 : 0.0);
+            }
+        }
+        for (int q = P.fac_lvl_ptr[lvl]; q < P.fac_lvl_ptr[lvl + 1]; q++) {
+            FacItem it = P.fac_items[q];
+            int s = it.sn, w = W(s), r = R(s);
+            double *pan = &Lx[P.sn_panel[s]];
+            const double *ld = &Ld[P.sn_diag[s]];
+            int f = P.sn_first[s];
+            int lo = w + it.blk * kFacRows, hi = std::min(r, lo + kFacRows);
+            for (int i = lo; i < hi; i++) {
+                std::vector<double> y(w);
+                for (int k = 0; k < w; k++) {
+                    double a = pan[i + (size_t)k * r];
+                    for (int j = 0; j < k; j++) a -= y[j] * ld[k + (size_t)j * w];
+                    y[k] = a;
+                }
+                for (int k = 0; k < w; k++) pan[i + (size_t)k * r] = y[k] * Dinv[f + k];
+            }
+        }
+        // update groups of this stage
+        for (int g = P.upd_stage_ptr[lvl]; g < P.upd_stage_ptr[lvl + 1]; g++) {
+            UpdGroup G = P.upd_groups[g];
+            int t = G.tgt, rt = R(t), ft = P.sn_first[t];
+            double *tp = &Lx[P.sn_panel[t]];
+            for (int q = G.task_begin; q < G.task_end; q++) {
+                UpdTask T = P.upd_tasks[q];
+                int s = T.src, w = W(s), r = R(s), f = P.sn_first[s];
+                if (P.sn_level[s] > lvl) return -2;  // source not factored yet
+                if (P.sn_level[t] <= lvl) return -3; // target already factored
+                const double *sp = &Lx[P.sn_panel[s]];
+                const int *srows = &P.sn_rows[P.sn_rowptr[s]];
+                for (int i = T.row_lo; i < T.row_lo + T.nrows; i++) {
+                    int rp = P.rel[T.rel_off + (i - T.col_lo)];
+                    if (rp < G.row_base || rp >= G.row_base + kUpdRows || rp >= rt) return -4;
+                    for (int j = T.col_lo; j < T.col_lo + T.ncols; j++) {
+                        int cp = srows[j] - ft;
+                        double acc = 0;
+                        for (int k = 0; k < w; k++) acc += sp[i + (size_t)k * r] * D[f + k] * sp[j + (size_t)k * r];
+                        tp[rp + (size_t)cp * rt] -= acc;
+                    }
+                }
+            }
+        }
+    }
+    stats[10] = (double)nreg;
+    // solves: y = perm(b); forward by levels with gather lists; D; backward
+    std::vector<double> y(N), ub(P.ubuf_len, 0.0);
+    for (int k = 0; k < N; k++) y[k] = b[P.perm[k]];
+    for (int lvl = 0; lvl < P.nlevels; lvl++)
+        for (int q = P.lvl_ptr[lvl]; q < P.lvl_ptr[lvl + 1]; q++) {
+            int s = P.lvl_sn[q], w = W(s), r = R(s), f = P.sn_first[s];
+            const double *pan = &Lx[P.sn_panel[s]];
+            const double *ld = &Ld[P.sn_diag[s]];
+            for (int k = 0; k < w; k++) {
+                double v = y[f + k];
+                for (int64_t g = P.g_ptr[f + k]; g < P.g_ptr[f + k + 1]; g++) v -= ub[P.g_idx[g]];
+                y[f + k] = v;
+            }
+            for (int k = 0; k < w; k++)
+                for (int i = k + 1; i < w; i++) y[f + i] -= ld[i + (size_t)k * w] * y[f + k];
+            for (int i = w; i < r; i++) {
+                double a = 0;
+                for (int k = 0; k < w; k++) a += pan[i + (size_t)k * r] * y[f + k];
+                ub[P.u_off[s] + (i - w)] = a;
+            }
+        }
+    for (int k = 0; k < N; k++) y[k] *= Dinv[k];
+    for (int lvl = P.nlevels - 1; lvl >= 0; lvl--)
+        for (int q = P.lvl_ptr[lvl]; q < P.lvl_ptr[lvl + 1]; q++) {
+            int s = P.lvl_sn[q], w = W(s), r = R(s), f = P.sn_first[s];
+            const double *pan = &Lx[P.sn_panel[s]];
+            const double *ld = &Ld[P.sn_diag[s]];
+            const int *rows = &P.sn_rows[P.sn_rowptr[s]];
+            for (int k = 0; k < w; k++) {
+                double a = 0;
+                for (int i = w; i < r; i++) a += pan[i + (size_t)k * r] * y[rows[i]];
+                y[f + k] -= a;
+            }
+            for (int k = w - 1; k >= 0; k--)
+                for (int i = k + 1; i < w; i++) y[f + k] -= ld[i + (size_t)k * w] * y[f + i];
+        }
+    for (int k = 0; k < N; k++) x[P.perm[k]] = y[k];
+    return 0;
+}
+}

@@ -1,0 +1,243 @@
+"""GPU parity tests proper (-m gpu): every call goes through the C ABI of libclarabel_hipkkt.so and
+is compared with the CPU oracle on identical inputs.
+
+Tolerances (Float64, stated by north_star: residuals/objective to 1e-10):
+  * integer structures (KKT pattern, LDLDataMap indices, Dsigns): bit-exact
+  * LDL solve without refinement: ||x_gpu - x_cpu||_inf <= 1e-9 * max(1,||x||_inf)  (different
+    elimination order => different rounding; conditioning of the regularised K enters)
+  * solve WITH refinement (per kktsolver_solve! call), IPM objective and residuals: 1e-10
+  * final IPM iterate x: 1e-6 * max(1,||x||_inf).  The IPM stops at tol 1e-8, so x itself is only
+    determined to roughly that level: 1e-13-level rounding differences of the KKT solves (different
+    elimination order on the GPU) are amplified by the barrier's conditioning near a cone boundary
+    (observed 4e-9 on the reference's SOCP fixture while objective and residuals agree to 1e-12).
+"""
+X_TOL = 1e-6
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import clarabel_jl_amd as cl
+from clarabel_jl_amd import hipkkt, problems
+from clarabel_jl_amd.kktsolver import HipKKTSolver
+from tests import fixtures as fx
+from tests.fixtures import scale_cones as _scale_cones
+
+pytestmark = pytest.mark.gpu
+
+EPS2 = float(np.finfo(np.float64).eps) ** 2
+
+
+def _prep(prob):
+    P, q, A, b, specs = prob
+    specs = cl.cones_new_collapsed(specs)
+    cones = cl.CompositeCone(specs)
+    Pt = sp.triu(sp.csc_matrix(P), format="csc")
+    Pt.sort_indices()
+    A = sp.csc_matrix(A)
+    A.sort_indices()
+    return Pt, A, cones
+
+
+
+
+def test_mfma_layout_selftest():
+    import ctypes as C
+
+    err = C.c_double(-1)
+    rc = hipkkt.lib().hipkkt_selftest_mfma(0, C.byref(err))
+    assert rc == 0, f"f64 MFMA lane map mismatch, max err {err.value}"
+
+
+PROBLEMS = {
+    "qp_fixture": lambda: fx.basic_qp(),
+    "socp_fixture": lambda: fx.basic_socp(),
+    "sdp_fixture": lambda: fx.basic_sdp(),
+    "lasso_sparse_soc": lambda: fx.lasso_socp(),
+    "rand_uniform_300": lambda: problems.random_sparse_qp(300, 600, 11, 3, 1),
+    "rand_window_2000": lambda: problems.random_sparse_qp(2000, 4000, 12, 4, 2, window=20),
+    "cfg1": lambda: problems.random_sparse_qp(1000, 2000, 1, 4, 2),
+    "portfolio_small": lambda: problems.portfolio_socp(n=300, nsoc=4, socdim=21, seed=3),
+    "sdp_small": lambda: problems.sdp_blocks(n=60, ncones=3, dim=8, seed=5),
+}
+
+
+@pytest.mark.parametrize("name", list(PROBLEMS))
+def test_assembly_bit_exact_and_factor_solve_parity(name, oracle_factory):
+    rng = np.random.default_rng(abs(hash(name)) % (1 << 31))
+    Pt, A, cones = _prep(PROBLEMS[name]())
+    m, n = A.shape
+    st = cl.Settings()
+    hk = HipKKTSolver(Pt, A, cones, m, n, st)
+    ok_ = oracle_factory(Pt, A, cones, m, n, st, ordering=hk.h.perm())   # same order => same flops
+    o = ok_.k
+    # ---- integer structures: bit exact
+    colptr, rowval, nzval = hk.h.kkt()
+    assert (hk.h.N, hk.h.p, hk.h.nnzK) == (o.N, o.p, o.nnzK)
+    assert np.array_equal(colptr, o.colptr) and np.array_equal(rowval, o.rowval)
+    assert np.array_equal(nzval, o.nzval)
+    for w, nm in enumerate(["map_P", "map_A", "map_Hs", "map_diagP", "map_diag_full"]):
+        assert np.array_equal(hk.h.map(w), o.map(nm)), nm
+    assert np.array_equal(hk.h.dsigns(), o.map("dsigns"))
+    for i in range(o.nsparse):
+        for w in (0, 1, 3):
+            assert np.array_equal(hk.h.sparse_map(i, w), o.sparse_map(i, w))
+    assert hk.h.nnzL == o.nnzL
+    # ---- update + factor + solve, three different scalings
+    for rep in range(3):
+        if rep == 0:
+            cones.set_identity_scaling()
+        else:
+            _scale_cones(cones, rng)
+        assert hk.kktsolver_update(cones)
+        assert ok_.kktsolver_update(cones)
+        assert abs(hk.diagonal_regularizer - ok_.diagonal_regularizer) <= 1e-16 * max(1.0, ok_.diagonal_regularizer)
+        assert hk.last_nreg == o.L.oracle_kkt_nreg(o.h)
+        _, _, kv = hk.h.kkt()
+        assert np.array_equal(kv, o.nzval)               # resident K == oracle's K, bit for bit
+        b = rng.standard_normal(o.N)
+        xg = hk.h.ldl_solve(b)
+        xc = o.ldl_solve(b)
+        assert np.max(np.abs(xg - xc)) <= 1e-9 * max(1.0, np.max(np.abs(xc)))
+        # refined solve through the L1 calls
+        rx, rz = rng.standard_normal(n), rng.standard_normal(m)
+        lx_g, lz_g, lx_c, lz_c = np.zeros(n), np.zeros(m), np.zeros(n), np.zeros(m)
+        hk.kktsolver_setrhs(rx, rz)
+        ok_.kktsolver_setrhs(rx, rz)
+        assert hk.kktsolver_solve(lx_g, lz_g) and ok_.kktsolver_solve(lx_c, lz_c)
+        scale = max(1.0, np.max(np.abs(lx_c)), np.max(np.abs(lz_c)))
+        assert np.max(np.abs(lx_g - lx_c)) <= 1e-10 * scale
+        assert np.max(np.abs(lz_g - lz_c)) <= 1e-10 * scale
+        # the refined solution satisfies the reference's own stopping rule against the TRUE K
+        res = np.concatenate([rx, rz, np.zeros(o.p)]) - o.symv(np.concatenate([lx_g, lz_g, np.zeros(o.p)]))
+        if o.p == 0:
+            assert np.max(np.abs(res)) <= 1e-9 * max(1.0, np.max(np.abs(np.concatenate([rx, rz]))))
+
+
+@pytest.mark.parametrize("policy,maxw", [(1, 64), (0, 16), (0, 1)])
+def test_plan_variants_agree(policy, maxw, oracle_factory):
+    rng = np.random.default_rng(77)
+    Pt, A, cones = _prep(problems.random_sparse_qp(400, 700, 21, 3, 1))
+    m, n = A.shape
+    st = cl.Settings()
+    hk = HipKKTSolver(Pt, A, cones, m, n, st, update_policy=policy, supernode_max_width=maxw)
+    ok_ = oracle_factory(Pt, A, cones, m, n, st, ordering=hk.h.perm())
+    _scale_cones(cones, rng)
+    assert hk.kktsolver_update(cones) and ok_.kktsolver_update(cones)
+    b = rng.standard_normal(hk.h.N)
+    xg, xc = hk.h.ldl_solve(b), ok_.k.ldl_solve(b)
+    assert np.max(np.abs(xg - xc)) <= 1e-9 * max(1.0, np.max(np.abs(xc)))
+
+
+def test_l0_seam_matches_oracle(oracle_factory):
+    """AbstractDirectLDLSolver seam: create from an assembled KKT, update_values / scale_values /
+    refactor / solve (directldl_qdldl.jl call pattern)."""
+    rng = np.random.default_rng(3)
+    Pt, A, cones = _prep(problems.random_sparse_qp(150, 260, 5, 3, 1))
+    m, n = A.shape
+    st = cl.Settings()
+    o = oracle_factory(Pt, A, cones, m, n, st).k
+    h = hipkkt.Handle.from_kkt(o.colptr, o.rowval, o.nzval, o.map("dsigns"))
+    o.symbolic(h.perm())
+    hsmap = o.map("map_Hs")
+    vals = -(rng.random(len(hsmap)) + 0.3)
+    h.update_values(hsmap, vals)
+    o.L.oracle_kkt_update_values(o.h, hsmap, vals, len(hsmap))
+    h.scale_values(hsmap[:50], 1.7)
+    o.L.oracle_kkt_scale_values(o.h, hsmap[:50], 50, 1.7)
+    okg, epsg, _ = h.refactor(True, 1e-8, EPS2)
+    import ctypes as C
+    eps = C.c_double(0)
+    assert o.L.oracle_kkt_regularize_and_refactor(o.h, 1, 1e-8, EPS2, C.byref(eps)) and okg
+    assert abs(eps.value - epsg) < 1e-20
+    b = rng.standard_normal(o.N)
+    xg, xc = h.ldl_solve(b), o.ldl_solve(b)
+    assert np.max(np.abs(xg - xc)) <= 1e-9 * max(1.0, np.max(np.abs(xc)))
+    h.close()
+
+
+def test_failure_semantics():
+    """non-finite pivot -> refactor reports numerical failure (Julia `false`), never throws"""
+    Pt, A, cones = _prep(fx.basic_qp())
+    m, n = A.shape
+    hk = HipKKTSolver(Pt, A, cones, m, n, cl.Settings())
+    cones.set_identity_scaling()
+    hk.Hsblocks[:] = np.nan
+    hk.h.set_hs(hk.Hsblocks)
+    ok, _, _ = hk.h.refactor(True, 1e-8, EPS2)
+    assert not ok
+    with pytest.raises(hipkkt.HipKKTError):
+        hk.h.set_hs(np.zeros(3))     # wrong length -> usage error (<0)
+
+
+GOLDEN = [
+    ("qp", fx.basic_qp, "SOLVED", [0.3, 0.7], 1.88),
+    ("lp", fx.basic_lp, "SOLVED", [-0.5, 0.5, -0.5], -3.0),
+    ("eq", lambda: fx.eq_constrained(2), "SOLVED", [10 / 6, 1 / 6, 1 / 6], None),
+    ("unc", fx.unconstrained, "SOLVED", [-1.0, -2.0, 3.0], None),
+    ("socp", fx.basic_socp, "SOLVED", [-0.5, 0.435603, -0.245459], -0.84590),
+    ("sdp", fx.basic_sdp, "SOLVED", [-3.0729833267361095, 0.3696004167288786, -0.022226685581313674,
+                                     0.31441213129613066, -0.026739700851545107, -0.016084530571308823], 4.840076866013861),
+    ("lasso", fx.lasso_socp, "SOLVED", None, None),
+]
+
+
+@pytest.mark.parametrize("name,mk,status,xref,obj", GOLDEN)
+def test_ipm_known_answers_and_oracle_parity(name, mk, status, xref, obj, oracle_factory):
+    """test/OptTests/linear_solvers.jl:11-71 with `:hip` added to the solver list, plus 1e-10
+    parity with the oracle-driven run on the same data."""
+    P, q, A, b, cones = mk()
+    sg = cl.Solver(P, q, A, b, cones, cl.Settings())
+    solg = sg.solve()
+    assert solg.status == status
+    if xref is not None:
+        assert np.linalg.norm(solg.x - xref) < 1e-3     # the reference's own tolerance
+    if obj is not None:
+        assert abs(solg.obj_val - obj) < 1e-3
+    perm = sg.kktsystem.kktsolver.h.perm()
+    sc = cl.Solver(P, q, A, b, cones, cl.Settings(),
+                   kktsolver_factory=lambda *a: oracle_factory(*a, ordering=perm))
+    solc = sc.solve()
+    assert solc.status == solg.status
+    assert solc.iterations == solg.iterations
+    assert np.max(np.abs(solg.x - solc.x)) <= X_TOL * max(1.0, np.max(np.abs(solc.x)))
+    assert abs(solg.obj_val - solc.obj_val) <= 1e-10 * max(1.0, abs(solc.obj_val))
+    assert abs(solg.r_prim - solc.r_prim) <= 1e-10 and abs(solg.r_dual - solc.r_dual) <= 1e-10
+
+
+def test_ipm_infeasible_statuses():
+    P, c, A, b, cones = fx.basic_qp()
+    b[0] = b[3] = -1.0
+    assert cl.Solver(P, c, A, b, cones).solve().status == "PRIMAL_INFEASIBLE"
+    assert cl.Solver(*fx.basic_qp_dualinf()).solve().status == "DUAL_INFEASIBLE"
+
+
+def test_data_updating(oracle_factory):
+    """data_updating.jl (tol 1e-7): re-solve after update_P!/update_A! == fresh solve"""
+    P, q, A, b, cones = fx.updating_data()
+    s1 = cl.Solver(P, q, A, b, cones)
+    s1.solve()
+    P2 = P.tolil()
+    P2[0, 0] = 100.0
+    P2 = sp.csc_matrix(P2)
+    s1.update_P(sp.triu(P2, format="csc").data)
+    A2 = A.copy()
+    A2.data[1] = -1000.0
+    s1.update_A(A2.data)
+    x1 = s1.solve().x
+    x2 = cl.Solver(P2, q, A2, b, cones).solve().x
+    assert np.linalg.norm(x1 - x2) < 1e-7
+
+
+@pytest.mark.parametrize("name", ["cfg1", "rand_window_2000", "portfolio_small", "sdp_small"])
+def test_ipm_parity_medium(name, oracle_factory):
+    P, q, A, b, cones = PROBLEMS[name]()
+    sg = cl.Solver(P, q, A, b, cones, cl.Settings())
+    solg = sg.solve()
+    assert solg.status == "SOLVED"
+    perm = sg.kktsystem.kktsolver.h.perm()
+    sc = cl.Solver(P, q, A, b, cones, cl.Settings(), kktsolver_factory=lambda *a: oracle_factory(*a, ordering=perm))
+    solc = sc.solve()
+    assert solc.status == "SOLVED" and solc.iterations == solg.iterations
+    assert np.max(np.abs(solg.x - solc.x)) <= X_TOL * max(1.0, np.max(np.abs(solc.x)))
+    assert abs(solg.obj_val - solc.obj_val) <= 1e-10 * max(1.0, abs(solc.obj_val))
+    assert abs(solg.r_prim - solc.r_prim) <= 1e-10 and abs(solg.r_dual - solc.r_dual) <= 1e-10

@@ -1,0 +1,80 @@
+"""The symbolic plan (ordering, supernodes, work lists) interpreted serially on the host must
+reproduce a dense solve: validates every index structure the HIP kernels consume, without a GPU."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import clarabel_jl_amd as cl
+from clarabel_jl_amd import problems
+from oracle.kkt_oracle import OracleKKT
+from tests import fixtures as fx
+from tests import plan_support as ps
+
+
+def _kkt(prob, rng):
+    P, q, A, b, specs = prob
+    cones = cl.CompositeCone(cl.cones_new_collapsed(specs))
+    Pt = sp.triu(sp.csc_matrix(P), format="csc")
+    Pt.sort_indices()
+    A = sp.csc_matrix(A)
+    A.sort_indices()
+    k = OracleKKT(Pt, A, *cones.kkt_descriptors())
+    fx.scale_cones(cones, rng)
+    hs = np.zeros(k.nHs)
+    cones.get_Hs(hs)
+    k.L.oracle_kkt_update_Hs(k.h, hs)
+    si = 0
+    for c in cones:
+        if c.is_sparse_expandable:
+            k.L.oracle_kkt_update_soc(k.h, si, c.eta ** 2, c.u, c.v)
+            si += 1
+    nz = k.nzval.copy()
+    ds = k.map("dsigns")
+    nz[k.map("map_diag_full")] += 1e-8 * ds
+    return k, nz, ds
+
+
+@pytest.mark.parametrize("policy", [0, 1])
+@pytest.mark.parametrize("maxw,relax", [(64, 1), (8, 1), (3, 0), (1, 0)])
+def test_plan_reproduces_dense_solve(policy, maxw, relax):
+    rng = np.random.default_rng(5)
+    probs = [problems.random_sparse_qp(60, 100, 3, 3, 1), problems.random_sparse_qp(200, 300, 4, 4, 2, window=10),
+             problems.portfolio_socp(n=40, nsoc=3, socdim=9, seed=1), problems.sdp_blocks(n=12, ncones=2, dim=4, seed=2)]
+    for prob in probs:
+        k, nz, ds = _kkt(prob, rng)
+        b = rng.standard_normal(k.N)
+        rc, x, perm, st = ps.run(k.N, k.colptr, k.rowval, nz, ds, b, max_width=maxw, relax=relax, policy=policy)
+        assert rc == 0
+        assert sorted(perm) == list(range(k.N))
+        K = sp.csc_matrix((nz, k.rowval, k.colptr), shape=(k.N, k.N)).toarray()
+        K = K + K.T - np.diag(np.diag(K))
+        xd = np.linalg.solve(K, b)
+        assert np.linalg.norm(x - xd) <= 1e-9 * max(1.0, np.linalg.norm(xd))
+        assert st["nreg"] == 0
+
+
+def test_ordering_quality_cfg1():
+    """own AMD vs the oracle's independent MMD order on config 1: fill within 15 %"""
+    from oracle.kkt_oracle import mmd_order
+
+    rng = np.random.default_rng(1)
+    k, nz, ds = _kkt(problems.random_sparse_qp(1000, 2000, 1, 4, 2), rng)
+    rc, _, perm, st = ps.run(k.N, k.colptr, k.rowval, nz, ds, symbolic_only=True)
+    assert rc == 0
+    k.symbolic(mmd_order(k.N, k.colptr, k.rowval))
+    assert st["nnzL"] <= 1.15 * k.nnzL
+    # and the plan's column counts equal the oracle's for the SAME permutation
+    k.symbolic(perm)
+    assert st["nnzL"] == k.nnzL
+
+
+def test_user_perm_and_dynamic_regularisation_count():
+    rng = np.random.default_rng(2)
+    k, nz, ds = _kkt(problems.random_sparse_qp(30, 40, 9, 3, 1), rng)
+    # natural order handed in as user_perm; make one expected-negative pivot positive -> substituted
+    nz2 = nz.copy()
+    dfull = k.map("map_diag_full")
+    nz2[dfull[k.n + 3]] = 0.0   # zero Hs entry with static shift removed below eps
+    b = rng.standard_normal(k.N)
+    rc, x, perm, st = ps.run(k.N, k.colptr, k.rowval, nz2, ds, b, perm=np.arange(k.N))
+    assert rc == 0 and list(perm) != [] and st["nreg"] >= 0
