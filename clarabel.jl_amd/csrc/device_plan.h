@@ -18,11 +18,13 @@ struct DevPlan {
     const int64_t *sn_diag;
     const int64_t *u_off;
     const int64_t *p_off;
+    const int64_t *lt_off;
     const int *lvl_sn;
     const int *perm;
     const signed char *sgn_perm;
     const FacItem *fac_items;
     const FacItem *slv_items;
+    const FacItem *bwd_items;
     const int *rel;
     const UpdTask *upd_tasks;
     const UpdGroup *upd_groups;
@@ -37,6 +39,9 @@ struct DevPlan {
     double *kval;    // resident, UNREGULARISED triu KKT values (original nz order)
     double *Lx;      // supernodal panels
     double *Ldiag;   // factored unit-lower diagonal blocks
+    double *Linv;    // their inverses (column-major) and transposed inverses, for GEMV-style solves
+    double *LinvT;
+    double *LT;      // row-major copy of the off-diagonal panel rows (w contiguous values per row)
     double *D;
     double *Dinv;
     double *ubuf;    // forward-solve update vectors

@@ -59,8 +59,9 @@ struct hipkkt_solver {
     int N = 0;
     int64_t nnzK = 0;
     // solve item lists (256-row blocks) per level
-    std::vector<FacItem> slv_items;
-    std::vector<int> slv_lvl_ptr;
+    std::vector<FacItem> slv_items, bwd_items;
+    std::vector<int> slv_lvl_ptr, bwd_lvl_ptr;
+    int wmax_all = 1;
     std::vector<int64_t> p_off;
 
     // device index arrays for value updates
@@ -142,13 +143,14 @@ void setup_device(hipkkt_solver *S) {
     const int N = P.N;
     S->N = N;
     S->nnzK = P.nnzK;
-    // solve items: 256-row blocks
+    // solve items: 64-row blocks (kSlvRows in kernels.hip)
     S->slv_lvl_ptr.assign(P.nlevels + 1, 0);
+    S->bwd_lvl_ptr.assign(P.nlevels + 1, 0);
     S->p_off.assign(P.nsuper + 1, 0);
     for (int s = 0; s < P.nsuper; s++) {
         int w = P.sn_first[s + 1] - P.sn_first[s];
         int64_t r = P.sn_rowptr[s + 1] - P.sn_rowptr[s];
-        int64_t nb = std::max<int64_t>(1, (r - w + 255) / 256);
+        int64_t nb = std::max<int64_t>(1, (r - w + 63) / 64);
         S->p_off[s + 1] = S->p_off[s] + nb * w;
     }
     for (int l = 0; l < P.nlevels; l++) {
@@ -156,10 +158,14 @@ void setup_device(hipkkt_solver *S) {
             int s = P.lvl_sn[q];
             int w = P.sn_first[s + 1] - P.sn_first[s];
             int64_t r = P.sn_rowptr[s + 1] - P.sn_rowptr[s];
-            int nb = (int)std::max<int64_t>(1, (r - w + 255) / 256);
+            int nb = (int)std::max<int64_t>(1, (r - w + 63) / 64);
             for (int b = 0; b < nb; b++) S->slv_items.push_back({s, b});
+            if (nb > 1)
+                for (int b = 0; b < nb; b++) S->bwd_items.push_back({s, b});
+            S->wmax_all = std::max(S->wmax_all, w);
         }
         S->slv_lvl_ptr[l + 1] = (int)S->slv_items.size();
+        S->bwd_lvl_ptr[l + 1] = (int)S->bwd_items.size();
     }
     std::vector<signed char> sgn_perm(N), kdiag(S->nnzK, 0);
     for (int k = 0; k < N; k++) sgn_perm[k] = (signed char)(S->img.dsigns[P.perm[k]] >= 0 ? 1 : -1);
@@ -175,6 +181,8 @@ void setup_device(hipkkt_solver *S) {
     D.sn_diag = S->upload(P.sn_diag);
     D.u_off = S->upload(P.u_off);
     D.p_off = S->upload(S->p_off);
+    D.lt_off = S->upload(P.lt_off);
+    D.bwd_items = S->upload(S->bwd_items);
     D.lvl_sn = S->upload(P.lvl_sn);
     D.perm = S->upload(P.perm);
     D.sgn_perm = S->upload(sgn_perm);
@@ -193,6 +201,9 @@ void setup_device(hipkkt_solver *S) {
     D.kval = S->upload(S->img.nzval);
     D.Lx = S->dalloc<double>(P.panel_doubles);
     D.Ldiag = S->dalloc<double>(P.diag_doubles);
+    D.Linv = S->dalloc<double>(P.diag_doubles);
+    D.LinvT = S->dalloc<double>(P.diag_doubles);
+    D.LT = S->dalloc<double>(P.lt_off[P.nsuper]);
     D.D = S->dalloc<double>(N);
     D.Dinv = S->dalloc<double>(N);
     D.ubuf = S->dalloc<double>(P.ubuf_len);
@@ -260,6 +271,7 @@ void enqueue_factor(hipkkt_solver *S, int static_enable, double eps_const, doubl
                             S->opts.dynamic_reg_eps, S->opts.dynamic_reg_delta);
         launch_update_stage(st, S->dp, P.upd_stage_ptr[l], P.upd_stage_ptr[l + 1] - P.upd_stage_ptr[l]);
     }
+    launch_invert_diag(st, S->dp, P.nsuper, S->wmax_all);
 }
 
 // d_sin -> d_sout (original ordering on both sides)
@@ -270,7 +282,7 @@ void enqueue_ldl_solve(hipkkt_solver *S) {
     for (int l = 0; l < P.nlevels; l++)
         launch_fwd_level(st, S->dp, S->slv_lvl_ptr[l], S->slv_lvl_ptr[l + 1] - S->slv_lvl_ptr[l], S->d_y, S->d_z);
     for (int l = P.nlevels - 1; l >= 0; l--) {
-        launch_bwd_partial(st, S->dp, S->slv_lvl_ptr[l], S->slv_lvl_ptr[l + 1] - S->slv_lvl_ptr[l], S->d_xp);
+        launch_bwd_partial(st, S->dp, S->bwd_lvl_ptr[l], S->bwd_lvl_ptr[l + 1] - S->bwd_lvl_ptr[l], S->d_xp);
         launch_bwd_final(st, S->dp, P.lvl_ptr[l], P.lvl_ptr[l + 1] - P.lvl_ptr[l], S->d_z, S->d_xp, S->d_sout);
     }
 }
@@ -380,6 +392,7 @@ int32_t finish_create(hipkkt_solver *S, const hipkkt_opts *opts, hipkkt_handle *
     po.max_width = opts->supernode_max_width > 0 ? opts->supernode_max_width : kMaxSnWidth;
     po.relax = opts->relax_supernodes != 0;
     po.update_policy = opts->update_policy;
+    if (opts->update_batch > 0) po.update_batch = opts->update_batch;
     po.amd_dense_scale = opts->amd_dense_scale > 0 ? opts->amd_dense_scale : 1.5;
     std::vector<int64_t> up;
     const int64_t *uperm = nullptr;
@@ -424,7 +437,8 @@ void hipkkt_default_opts(hipkkt_opts *o) {
     o->index_base = 0;
     o->supernode_max_width = kMaxSnWidth;
     o->relax_supernodes = 1;
-    o->update_policy = 0;
+    o->update_policy = 2;
+    o->update_batch = 4;
     o->dynamic_reg_eps = 1e-13;
     o->dynamic_reg_delta = 2e-7;
     o->amd_dense_scale = 1.5;
@@ -763,6 +777,7 @@ int32_t hipkkt_refactor(hipkkt_handle h, int32_t static_reg_enable, double eps_c
                 evs.push_back(b);
             }
         }
+        launch_invert_diag(st, S->dp, P.nsuper, S->wmax_all);
         HK_CHECK(hipStreamSynchronize(st));
         double tot = 0;
         for (size_t i = 0; i + 1 < evs.size(); i += 2) {

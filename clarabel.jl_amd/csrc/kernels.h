@@ -13,6 +13,7 @@ void launch_maxabs_gather(hipStream_t st, const double *v, const int64_t *idx, i
 void launch_init_panels(hipStream_t st, const DevPlan &P, int64_t nnz, int static_enable, double eps_const, double eps_prop);
 void launch_factor_level(hipStream_t st, const DevPlan &P, int item_begin, int nitems, int wmax, double dyn_eps, double dyn_delta);
 void launch_update_stage(hipStream_t st, const DevPlan &P, int group_begin, int ngroups);
+void launch_invert_diag(hipStream_t st, const DevPlan &P, int nsuper, int wmax);
 void launch_mfma_probe(hipStream_t st, const double *A, const double *B, double *out);
 void launch_permute_in(hipStream_t st, const double *b, const int *perm, double *y, int n);
 void launch_fwd_level(hipStream_t st, const DevPlan &P, int item_begin, int nitems, double *y, double *z);

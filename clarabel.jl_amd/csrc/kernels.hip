@@ -26,12 +26,29 @@ __device__ __forceinline__ void atomic_max_abs(unsigned long long *slot, double 
     atomicMax(slot, bits);
 }
 
+__device__ __forceinline__ double wave_max(double v);
+// one same-address atomic per BLOCK (same-word atomics serialise at ~88/us on this chip)
+__device__ __forceinline__ void block_atomic_max_abs(unsigned long long *slot, double a);
+
 __device__ __forceinline__ double wave_max(double v) {
     for (int off = 32; off > 0; off >>= 1) {
         double o = __shfl_xor(v, off, 64);
         v = (o > v || o != o) ? o : v;
     }
     return v;
+}
+
+__device__ __forceinline__ void block_atomic_max_abs(unsigned long long *slot, double a) {
+    __shared__ double wm_[16];
+    a = wave_max(a);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    if (lane == 0) wm_[wave] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double m = wm_[0];
+        for (int i = 1; i < nw; i++) m = (wm_[i] > m || wm_[i] != wm_[i]) ? wm_[i] : m;
+        atomic_max_abs(slot, m);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -80,8 +97,7 @@ __global__ void k_maxabs_gather(const double *__restrict__ v, const int64_t *__r
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     double a = 0.0;
     if (i < n) a = fabs(idx ? v[idx[i]] : v[i]);
-    a = wave_max(a);
-    if ((threadIdx.x & 63) == 0) atomic_max_abs(slot, a);
+    block_atomic_max_abs(slot, a);
 }
 
 // Lx <- scatter(K) with the +-eps shift on the diagonal (the resident Kval stays unregularised:
@@ -192,7 +208,54 @@ k_factor_level(DevPlan P, int item_begin, int wmax, double dyn_eps, double dyn_d
     __syncthreads();
     for (int idx = tid; idx < nr * w; idx += 256) {
         int row = idx % nr, k = idx / nr;
-        pan[(lo + row) + (int64_t)k * r] = T[k * LDT + row] / dd[k];
+        const double v = T[k * LDT + row] / dd[k];
+        T[k * LDT + row] = v;
+        pan[(lo + row) + (int64_t)k * r] = v;
+    }
+    __syncthreads();
+    // row-major copy (w contiguous doubles per row) for the backward solve's L21^T x
+    double *lt = P.LT + P.lt_off[s] + (int64_t)(lo - w) * w;
+    for (int idx = tid; idx < nr * w; idx += 256) {
+        int k = idx % w, row = idx / w;
+        lt[idx] = T[k * LDT + row];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// after the factorisation: explicit inverses of the unit-lower diagonal blocks (and their
+// transposes) so that the solves do small GEMVs instead of w-step substitutions.  One launch.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64)
+k_invert_diag(DevPlan P, int nsuper) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int s = blockIdx.x;
+    if (s >= nsuper) return;
+    const int w = P.sn_first[s + 1] - P.sn_first[s];
+    const int LDL = w | 1;
+    double *Ls = smem;              // [w * LDL]
+    double *Xs = Ls + w * LDL;      // [w * LDL]
+    const double *ld = P.Ldiag + P.sn_diag[s];
+    const int tid = threadIdx.x;
+    for (int idx = tid; idx < w * w; idx += 64) {
+        int i = idx % w, k = idx / w;
+        Ls[i + k * LDL] = ld[idx];
+        Xs[i + k * LDL] = (i == k) ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    if (tid < w) {
+        const int j = tid;  // column j of the inverse: solve L x = e_j
+        for (int k = j; k < w; k++) {
+            const double xk = Xs[k + j * LDL];
+            for (int i = k + 1; i < w; i++) Xs[i + j * LDL] -= Ls[i + k * LDL] * xk;
+        }
+    }
+    __syncthreads();
+    double *li = P.Linv + P.sn_diag[s];
+    double *lit = P.LinvT + P.sn_diag[s];
+    for (int idx = tid; idx < w * w; idx += 64) {
+        int i = idx % w, j = idx / w;
+        li[idx] = Xs[i + j * LDL];     // Linv[i][j], column-major
+        lit[idx] = Xs[j + i * LDL];    // LinvT stored so that element (i,j) of Linv sits at [j + i*w]
     }
 }
 
@@ -204,10 +267,45 @@ k_factor_level(DevPlan P, int item_begin, int wmax, double dyn_eps, double dyn_d
 // per wave step, operands gathered straight from the source panel (rows are contiguous per k).
 // ------------------------------------------------------------------------------------------
 constexpr int LDC = kUpdRows + 1;
+constexpr int kUpdWaves = 8;   // wavefronts per workgroup in the update kernel
 
-__global__ void __launch_bounds__(256)
+template <int MT>
+__device__ __forceinline__ void upd_strip(const double *__restrict__ sp, const double *__restrict__ dv, int r, int K,
+                                          int row_lo, int nrows, int tm0, int col_row, int ncols_left, int l15, int lk,
+                                          v4f64 (&acc)[4]) {
+    // operands gathered straight from the source panel: for a fixed k the 16 rows of a tile are
+    // contiguous.  Out-of-range rows are clamped (their outputs are discarded at the scatter);
+    // out-of-range k contributes zero through the B operand.
+    const double *ap[MT];
+#pragma unroll
+    for (int t = 0; t < MT; t++) {
+        int ai = (tm0 + t) * 16 + l15;
+        ai = ai < nrows ? ai : nrows - 1;
+        ap[t] = sp + (row_lo + ai);
+    }
+    int bj = l15 < ncols_left ? l15 : ncols_left - 1;
+    const double *bp = sp + (col_row + bj);
+#pragma unroll 4
+    for (int k0 = 0; k0 < K; k0 += 4) {
+        int kk = k0 + lk;
+        const double km = kk < K ? 1.0 : 0.0;
+        kk = kk < K ? kk : K - 1;
+        const int64_t off = (int64_t)kk * r;
+        const double b = bp[off] * (dv[kk] * km);
+#pragma unroll
+        for (int t = 0; t < MT; t++) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[t][off], b, acc[t], 0, 0, 0);
+    }
+}
+
+// One workgroup owns one 64-row block of one target panel.  Its task list is cut into wave-tasks
+// (one source row range x one 16-column strip); wavefronts take wave-tasks round-robin, run the
+// contraction on the FP64 matrix core independently (their load latencies overlap) and then apply
+// their results to the LDS-resident target tile strictly in list order (LDS turn counter), so the
+// summation order - and therefore every bit of the factor - is fixed.
+__global__ void __launch_bounds__(kUpdWaves * 64)
 k_update_stage(DevPlan P, int group_begin) {
     __shared__ double Ct[kMaxSnWidth * LDC];
+    __shared__ int turn;
     const UpdGroup G = P.upd_groups[group_begin + blockIdx.x];
     const int t = G.tgt;
     const int ft = P.sn_first[t];
@@ -216,54 +314,67 @@ k_update_stage(DevPlan P, int group_begin) {
     double *tp = P.Lx + P.sn_panel[t];
     const int tid = threadIdx.x;
     const int nrt = min(kUpdRows, rt - G.row_base);
-    for (int idx = tid; idx < nrt * wt; idx += 256) {
+    for (int idx = tid; idx < nrt * wt; idx += kUpdWaves * 64) {
         int row = idx % nrt, col = idx / nrt;
         Ct[col * LDC + row] = tp[(G.row_base + row) + (int64_t)col * rt];
     }
+    if (tid == 0) turn = 0;
     __syncthreads();
     const int lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, lk = lane >> 4;
-    for (int q = G.task_begin; q < G.task_end; q++) {
-        const UpdTask T = P.upd_tasks[q];
+    int q = G.task_begin;                 // task that contains the current wave-task
+    UpdTask T = P.upd_tasks[q];
+    for (int v = wave; v < G.nvt; v += kUpdWaves) {
+        while (q + 1 < G.task_end) {       // advance to the task holding wave-task v
+            const UpdTask Tn = P.upd_tasks[q + 1];
+            if (Tn.vt_begin > v) break;
+            T = Tn;
+            q++;
+        }
+        const int tn = v - T.vt_begin;     // 16-column strip inside the task
         const int s = T.src;
         const int fs = P.sn_first[s];
         const int K = P.sn_first[s + 1] - fs;
         const int r = (int)(P.sn_rowptr[s + 1] - P.sn_rowptr[s]);
         const double *sp = P.Lx + P.sn_panel[s];
         const double *dv = P.D + fs;
+        const int mt = (T.nrows + 15) >> 4;
+        const int ncl = T.ncols - tn * 16;
+        v4f64 acc[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) acc[i] = (v4f64){0.0, 0.0, 0.0, 0.0};
+        if (mt == 1) upd_strip<1>(sp, dv, r, K, T.row_lo, T.nrows, 0, T.col_lo + tn * 16, ncl, l15, lk, acc);
+        else if (mt == 2) upd_strip<2>(sp, dv, r, K, T.row_lo, T.nrows, 0, T.col_lo + tn * 16, ncl, l15, lk, acc);
+        else upd_strip<4>(sp, dv, r, K, T.row_lo, T.nrows, 0, T.col_lo + tn * 16, ncl, l15, lk, acc);
+        // target coordinates of this lane's results (C/D layout of the f64 16x16x4 form:
+        // col = lane & 15, row = (lane >> 4) + 4 * reg)
         const int *srows = P.sn_rows + P.sn_rowptr[s];
         const int *rel = P.rel + T.rel_off;
-        const int mt = (T.nrows + 15) >> 4, nt = (T.ncols + 15) >> 4;
-        for (int tile = wave; tile < mt * nt; tile += 4) {
-            const int tm = tile % mt, tn = tile / mt;
-            const int ai = tm * 16 + l15, bj = tn * 16 + l15;
-            const bool av = ai < T.nrows, bv = bj < T.ncols;
-            const double *ap = sp + (T.row_lo + ai);
-            const double *bp = sp + (T.col_lo + bj);
-            v4f64 acc = {0.0, 0.0, 0.0, 0.0};
-            for (int k0 = 0; k0 < K; k0 += 4) {
-                const int kk = k0 + lk;
-                const bool kv = kk < K;
-                double a = 0.0, b = 0.0;
-                if (av && kv) a = ap[(int64_t)kk * r];
-                if (bv && kv) b = bp[(int64_t)kk * r] * dv[kk];
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
-            }
-            // C/D layout of the f64 16x16x4 form: col = lane & 15, row = (lane >> 4) + 4 * reg
+        const int jj = tn * 16 + l15;
+        const int cp = jj < T.ncols ? srows[T.col_lo + jj] - ft : -1;
+        int rp[16];
+#pragma unroll
+        for (int tmi = 0; tmi < 4; tmi++)
 #pragma unroll
             for (int reg = 0; reg < 4; reg++) {
-                const int ii = tm * 16 + lk + 4 * reg;
-                const int jj = tn * 16 + l15;
-                if (ii < T.nrows && jj < T.ncols) {
-                    const int rp = rel[(T.row_lo + ii) - T.col_lo] - G.row_base;
-                    const int cp = srows[T.col_lo + jj] - ft;
-                    Ct[cp * LDC + rp] -= acc[reg];
-                }
+                const int ii = tmi * 16 + lk + 4 * reg;
+                rp[tmi * 4 + reg] = (ii < T.nrows && cp >= 0) ? rel[(T.row_lo + ii) - T.col_lo] - G.row_base : -1;
             }
-        }
-        __syncthreads();
+        // ordered application
+        while (__atomic_load_n(&turn, __ATOMIC_RELAXED) != v) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#pragma unroll
+        for (int tmi = 0; tmi < 4; tmi++)
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) {
+                const int rr = rp[tmi * 4 + reg];
+                if (rr >= 0) Ct[cp * LDC + rr] -= acc[tmi][reg];
+            }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) __atomic_store_n(&turn, v + 1, __ATOMIC_RELAXED);
     }
-    for (int idx = tid; idx < nrt * wt; idx += 256) {
+    __syncthreads();
+    for (int idx = tid; idx < nrt * wt; idx += kUpdWaves * 64) {
         int row = idx % nrt, col = idx / nrt;
         tp[(G.row_base + row) + (int64_t)col * rt] = Ct[col * LDC + row];
     }
@@ -293,101 +404,177 @@ k_permute_in(const double *__restrict__ b, const int *__restrict__ perm, double 
     if (k < n) y[k] = b[perm[k]];
 }
 
+// Latency model behind these kernels (measured on MI355X, tools/ubench.hip): a dependent f64 FMA
+// costs 32 cycles, an LDS round trip 60, an L2 hit ~220, HBM/MALL ~650, and one CU pulls only
+// ~10 B/clk from HBM.  Hence: every dot product runs on 4 independent accumulators, and a panel is
+// spread over as many workgroups as possible (64 rows each) instead of a few 256-row blocks.
+constexpr int kSlvRows = 64;
+
 __global__ void __launch_bounds__(256)
 k_fwd_level(DevPlan P, int item_begin, double *__restrict__ y, double *__restrict__ z) {
-    __shared__ double yv[kMaxSnWidth];
+    __shared__ double rhs[kMaxSnWidth];
     __shared__ double part[4][kMaxSnWidth];
-    __shared__ double Ld[kMaxSnWidth * kMaxSnWidth];
+    __shared__ double yv[kMaxSnWidth];
     const FacItem it = P.slv_items[item_begin + blockIdx.x];
     const int s = it.sn;
     const int f = P.sn_first[s];
     const int w = P.sn_first[s + 1] - f;
-    const int r = (int)(P.sn_rowptr[s + 1] - P.sn_rowptr[s]);
+    const int64_t slot0 = P.sn_rowptr[s];
+    const int r = (int)(P.sn_rowptr[s + 1] - slot0);
     const double *pan = P.Lx + P.sn_panel[s];
-    const double *ld = P.Ldiag + P.sn_diag[s];
+    const double *li = P.Linv + P.sn_diag[s];
     const int tid = threadIdx.x;
-    {
-        const int c = tid & 63, pq = tid >> 6;
+    const int i = tid & 63, pq = tid >> 6;
+    // right-hand side of the diagonal block: b_J minus what the children pushed onto these rows
+    if (tid < w) {
         double acc = 0.0;
-        if (c < w) {
-            const int64_t g0 = P.g_ptr[f + c], g1 = P.g_ptr[f + c + 1];
-            for (int64_t g = g0 + pq; g < g1; g += 4) acc += P.ubuf[P.g_idx[g]];
-        }
-        part[pq][c] = acc;
+        const int64_t g0 = P.g_ptr[slot0 + tid], g1 = P.g_ptr[slot0 + tid + 1];
+        for (int64_t g = g0; g < g1; g++) acc += P.ubuf[P.g_idx[g]];
+        rhs[tid] = y[f + tid] - acc;
     }
-    for (int idx = tid; idx < w * w; idx += 256) Ld[idx] = ld[idx];
-    __syncthreads();
-    if (tid < 64) {
-        double x = 0.0;
-        if (tid < w) x = y[f + tid] - (((part[0][tid] + part[1][tid]) + part[2][tid]) + part[3][tid]);
-        for (int k = 0; k < w; k++) {
-            const double xk = __shfl(x, k, 64);
-            if (tid > k && tid < w) x -= Ld[tid + k * w] * xk;
-        }
-        if (tid < w) yv[tid] = x;
-    }
-    __syncthreads();
-    if (it.blk == 0 && tid < w) {
-        y[f + tid] = yv[tid];
-        z[f + tid] = yv[tid] * P.Dinv[f + tid];
-    }
-    const int row = w + it.blk * 256 + tid;
+    // prefetch this thread's share of the row GEMV while the diagonal block is being solved
+    const int row = w + it.blk * kSlvRows + i;
+    double pv[16];
+    double gsum = 0.0;
     if (row < r) {
-        double a = 0.0;
-        for (int k = 0; k < w; k++) a += pan[row + (int64_t)k * r] * yv[k];
-        P.ubuf[P.u_off[s] + (row - w)] = a;
+        const double *pr = pan + row;
+#pragma unroll
+        for (int t = 0; t < 16; t++) {
+            const int k = pq + 4 * t;
+            pv[t] = k < w ? pr[(int64_t)k * r] : 0.0;
+        }
+        if (pq == 0) {
+            const int64_t g0 = P.g_ptr[slot0 + row], g1 = P.g_ptr[slot0 + row + 1];
+            for (int64_t g = g0; g < g1; g++) gsum += P.ubuf[P.g_idx[g]];
+        }
     }
+    __syncthreads();
+    {   // y_J = L11^-1 rhs as a small lower-triangular GEMV (explicit inverse from k_invert_diag)
+        double a0 = 0.0, a1 = 0.0;
+        if (i < w) {
+            int k = pq;
+            for (; k + 4 <= i; k += 8) {
+                a0 += li[i + k * w] * rhs[k];
+                a1 += li[i + (k + 4) * w] * rhs[k + 4];
+            }
+            if (k <= i) a0 += li[i + k * w] * rhs[k];
+        }
+        part[pq][i] = a0 + a1;
+    }
+    __syncthreads();
+    if (tid < w) {
+        const double v = ((part[0][tid] + part[1][tid]) + part[2][tid]) + part[3][tid];
+        yv[tid] = v;
+        if (it.blk == 0) {
+            y[f + tid] = v;
+            z[f + tid] = v * P.Dinv[f + tid];
+        }
+    } else if (tid < kMaxSnWidth) {
+        yv[tid] = 0.0;   // padded columns multiply prefetched zeros: keep them finite
+    }
+    __syncthreads();
+    // this panel's update vector = children's contributions passed through + L21 * y_J
+    {
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        if (row < r) {
+#pragma unroll
+            for (int t = 0; t < 16; t += 4) {
+                a0 += pv[t] * yv[(pq + 4 * t) & 63];
+                a1 += pv[t + 1] * yv[(pq + 4 * t + 4) & 63];
+                a2 += pv[t + 2] * yv[(pq + 4 * t + 8) & 63];
+                a3 += pv[t + 3] * yv[(pq + 4 * t + 12) & 63];
+            }
+        }
+        __syncthreads();
+        part[pq][i] = (a0 + a1) + (a2 + a3);
+    }
+    __syncthreads();
+    if (pq == 0 && row < r)
+        P.ubuf[P.u_off[s] + (row - w)] = gsum + (((part[0][i] + part[1][i]) + part[2][i]) + part[3][i]);
 }
 
+// partial L21^T x over one block of <=64 off-diagonal rows, from the row-major copy LT:
+// lane = column (coalesced), the row's x value is a wave-uniform broadcast.  red[4][64] is LDS.
+__device__ __forceinline__ double bwd_block_dot(const DevPlan &P, int s, int w, int r, int blk,
+                                                const double *__restrict__ x, double (*red)[kMaxSnWidth]) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int *rows = P.sn_rows + P.sn_rowptr[s];
+    const double *lt = P.LT + P.lt_off[s];
+    const int lo = w + blk * kSlvRows + wave * 16;
+    const int hi = min(min(r, lo + 16), w + (blk + 1) * kSlvRows);
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    if (lane < w) {
+        int i = lo;
+        for (; i + 4 <= hi; i += 4) {
+            a0 += lt[(int64_t)(i - w) * w + lane] * x[rows[i]];
+            a1 += lt[(int64_t)(i + 1 - w) * w + lane] * x[rows[i + 1]];
+            a2 += lt[(int64_t)(i + 2 - w) * w + lane] * x[rows[i + 2]];
+            a3 += lt[(int64_t)(i + 3 - w) * w + lane] * x[rows[i + 3]];
+        }
+        for (; i < hi; i++) a0 += lt[(int64_t)(i - w) * w + lane] * x[rows[i]];
+    }
+    red[wave][lane] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    return ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+}
+
+// panels with more than one 64-row block: per-block partial sums
 __global__ void __launch_bounds__(256)
 k_bwd_partial(DevPlan P, int item_begin, const double *__restrict__ x) {
     __shared__ double red[4][kMaxSnWidth];
-    const FacItem it = P.slv_items[item_begin + blockIdx.x];
+    const FacItem it = P.bwd_items[item_begin + blockIdx.x];
     const int s = it.sn;
-    const int f = P.sn_first[s];
-    const int w = P.sn_first[s + 1] - f;
+    const int w = P.sn_first[s + 1] - P.sn_first[s];
     const int r = (int)(P.sn_rowptr[s + 1] - P.sn_rowptr[s]);
-    const double *pan = P.Lx + P.sn_panel[s];
-    const int *rows = P.sn_rows + P.sn_rowptr[s];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int row = w + it.blk * 256 + tid;
-    const double xr = row < r ? x[rows[row]] : 0.0;
-    // every thread owns one row; reduce each column over the 256 rows: wave shuffle then LDS
-    for (int k = 0; k < w; k++) {
-        double v = row < r ? pan[row + (int64_t)k * r] * xr : 0.0;
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-        if (lane == 0) red[wave][k] = v;
-    }
-    __syncthreads();
-    if (tid < w) P.pbuf[P.p_off[s] + (int64_t)it.blk * w + tid] = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
+    const double v = bwd_block_dot(P, s, w, r, it.blk, x, red);
+    if (threadIdx.x < w) P.pbuf[P.p_off[s] + (int64_t)it.blk * w + threadIdx.x] = v;
 }
 
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(256)
 k_bwd_final(DevPlan P, int sn_begin, const double *__restrict__ z, double *__restrict__ x,
             double *__restrict__ xout) {
-    __shared__ double Ld[kMaxSnWidth * kMaxSnWidth];
+    __shared__ double red[4][kMaxSnWidth];
+    __shared__ double tv[kMaxSnWidth];
     const int s = P.lvl_sn[sn_begin + blockIdx.x];
     const int f = P.sn_first[s];
     const int w = P.sn_first[s + 1] - f;
     const int r = (int)(P.sn_rowptr[s + 1] - P.sn_rowptr[s]);
-    const double *ld = P.Ldiag + P.sn_diag[s];
+    const double *lit = P.LinvT + P.sn_diag[s];
     const int tid = threadIdx.x;
-    for (int idx = tid; idx < w * w; idx += 64) Ld[idx] = ld[idx];
-    const int nblk = (r - w + 255) / 256;
-    double v = 0.0;
-    if (tid < w) {
-        double acc = 0.0;
-        const double *pb = P.pbuf + P.p_off[s] + tid;
-        for (int b = 0; b < nblk; b++) acc += pb[(int64_t)b * w];
-        v = z[f + tid] - acc;
+    const int k = tid & 63, pq = tid >> 6;
+    const int nblk = (r - w + kSlvRows - 1) / kSlvRows;
+    double acc = 0.0;
+    if (nblk == 1) {
+        acc = bwd_block_dot(P, s, w, r, 0, x, red);   // short panel: fused
+        __syncthreads();
+    } else if (nblk > 1) {
+        double a = 0.0;
+        if (k < w) {
+            const double *pb = P.pbuf + P.p_off[s] + k;
+            for (int b = pq; b < nblk; b += 4) a += pb[(int64_t)b * w];
+        }
+        red[pq][k] = a;
+        __syncthreads();
+        acc = ((red[0][k] + red[1][k]) + red[2][k]) + red[3][k];
+        __syncthreads();
+    }
+    if (tid < w) tv[tid] = z[f + tid] - acc;
+    __syncthreads();
+    {   // x_J = L11^-T t :  x_k = sum_{i>=k} Linv[i][k] t_i ; LinvT holds Linv[i][k] at [k + i*w]
+        double a0 = 0.0, a1 = 0.0;
+        if (k < w) {
+            int i = k + pq;
+            for (; i + 4 < w; i += 8) {
+                a0 += lit[k + i * w] * tv[i];
+                a1 += lit[k + (i + 4) * w] * tv[i + 4];
+            }
+            if (i < w) a0 += lit[k + i * w] * tv[i];
+        }
+        red[pq][k] = a0 + a1;
     }
     __syncthreads();
-    // unit-upper solve with L11^T: x_k = v_k - sum_{i>k} L11[i][k] x_i
-    for (int k = w - 1; k >= 0; k--) {
-        const double xk = __shfl(v, k, 64);
-        if (tid < k) v -= Ld[k + tid * w] * xk;
-    }
     if (tid < w) {
+        const double v = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
         x[f + tid] = v;
         xout[P.perm[f + tid]] = v;
     }
@@ -402,30 +589,31 @@ k_spmv_residual(const int64_t *__restrict__ rowptr, const int *__restrict__ col,
                 const double *__restrict__ kval, const double *__restrict__ b, const double *__restrict__ xi,
                 double *__restrict__ e, int n, unsigned long long *__restrict__ norm_slot) {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    const int row = gid >> 3, sub = gid & 7;
+    const int row = gid >> 2, sub = gid & 3;
     double acc = 0.0;
     if (row < n) {
         const int64_t p0 = rowptr[row], p1 = rowptr[row + 1];
-        for (int64_t p = p0 + sub; p < p1; p += 8) acc += kval[qidx[p]] * xi[col[p]];
+        for (int64_t p = p0 + sub; p < p1; p += 4) acc += kval[qidx[p]] * xi[col[p]];
     }
     acc += __shfl_xor(acc, 1, 64);
     acc += __shfl_xor(acc, 2, 64);
-    acc += __shfl_xor(acc, 4, 64);
     double a = 0.0;
     if (row < n && sub == 0) {
         const double ev = b[row] - acc;
         e[row] = ev;
         a = fabs(ev);
     }
-    a = wave_max(a);
-    if ((threadIdx.x & 63) == 0) atomic_max_abs(norm_slot, a);
+    block_atomic_max_abs(norm_slot, a);
 }
 
-__global__ void k_norm_inf(const double *__restrict__ v, int n, unsigned long long *__restrict__ slot) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    double a = i < n ? fabs(v[i]) : 0.0;
-    a = wave_max(a);
-    if ((threadIdx.x & 63) == 0) atomic_max_abs(slot, a);
+__global__ void __launch_bounds__(256)
+k_norm_inf(const double *__restrict__ v, int n, unsigned long long *__restrict__ slot) {
+    double a = 0.0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const double t = fabs(v[i]);
+        a = (t > a || t != t) ? t : a;
+    }
+    block_atomic_max_abs(slot, a);
 }
 
 __global__ void k_add(double *__restrict__ dst, const double *__restrict__ a, int n) {
@@ -475,7 +663,12 @@ void launch_factor_level(hipStream_t st, const DevPlan &P, int item_begin, int n
                            dyn_delta);
 }
 void launch_update_stage(hipStream_t st, const DevPlan &P, int group_begin, int ngroups) {
-    if (ngroups > 0) hipLaunchKernelGGL(k_update_stage, dim3(ngroups), dim3(256), 0, st, P, group_begin);
+    if (ngroups > 0) hipLaunchKernelGGL(k_update_stage, dim3(ngroups), dim3(kUpdWaves * 64), 0, st, P, group_begin);
+}
+void launch_invert_diag(hipStream_t st, const DevPlan &P, int nsuper, int wmax) {
+    const int ldl = wmax | 1;
+    if (nsuper > 0)
+        hipLaunchKernelGGL(k_invert_diag, dim3(nsuper), dim3(64), sizeof(double) * 2 * (size_t)wmax * ldl, st, P, nsuper);
 }
 void launch_mfma_probe(hipStream_t st, const double *A, const double *B, double *out) {
     hipLaunchKernelGGL(k_mfma_probe, dim3(1), dim3(64), 0, st, A, B, out);
@@ -490,16 +683,16 @@ void launch_bwd_partial(hipStream_t st, const DevPlan &P, int item_begin, int ni
     if (nitems > 0) hipLaunchKernelGGL(k_bwd_partial, dim3(nitems), dim3(256), 0, st, P, item_begin, x);
 }
 void launch_bwd_final(hipStream_t st, const DevPlan &P, int sn_begin, int nsn, const double *z, double *x, double *xout) {
-    if (nsn > 0) hipLaunchKernelGGL(k_bwd_final, dim3(nsn), dim3(64), 0, st, P, sn_begin, z, x, xout);
+    if (nsn > 0) hipLaunchKernelGGL(k_bwd_final, dim3(nsn), dim3(256), 0, st, P, sn_begin, z, x, xout);
 }
 void launch_spmv_residual(hipStream_t st, const DevPlan &P, const double *b, const double *xi, double *e, int n,
                           unsigned long long *slot) {
     if (n > 0)
-        hipLaunchKernelGGL(k_spmv_residual, dim3(nblk((int64_t)n * 8)), dim3(256), 0, st, P.sym_rowptr, P.sym_col, P.sym_q,
+        hipLaunchKernelGGL(k_spmv_residual, dim3(nblk((int64_t)n * 4)), dim3(256), 0, st, P.sym_rowptr, P.sym_col, P.sym_q,
                            P.kval, b, xi, e, n, slot);
 }
 void launch_norm_inf(hipStream_t st, const double *v, int n, unsigned long long *slot) {
-    if (n > 0) hipLaunchKernelGGL(k_norm_inf, dim3(nblk(n)), dim3(256), 0, st, v, n, slot);
+    if (n > 0) hipLaunchKernelGGL(k_norm_inf, dim3(min(nblk(n), 64u)), dim3(256), 0, st, v, n, slot);
 }
 void launch_add(hipStream_t st, double *dst, const double *a, int n) {
     if (n > 0) hipLaunchKernelGGL(k_add, dim3(nblk(n)), dim3(256), 0, st, dst, a, n);

@@ -253,6 +253,7 @@ std::string build_plan(int N, const int64_t *Ap, const int64_t *Ai, const int64_
     P.sn_panel.assign(S + 1, 0);
     P.sn_diag.assign(S + 1, 0);
     P.u_off.assign(S + 1, 0);
+    P.lt_off.assign(S + 1, 0);
     for (int s = 0; s < S; s++) {
         int64_t w = P.sn_first[s + 1] - P.sn_first[s];
         int64_t r = P.sn_rowptr[s + 1] - P.sn_rowptr[s];
@@ -260,6 +261,7 @@ std::string build_plan(int N, const int64_t *Ap, const int64_t *Ai, const int64_
         P.sn_panel[s + 1] = P.sn_panel[s] + sz;
         P.sn_diag[s + 1] = P.sn_diag[s] + ((w * w + 7) & ~(int64_t)7);
         P.u_off[s + 1] = P.u_off[s] + (r - w);
+        P.lt_off[s + 1] = P.lt_off[s] + (((r - w) * w + 7) & ~(int64_t)7);
     }
     P.panel_doubles = P.sn_panel[S];
     P.diag_doubles = P.sn_diag[S];
@@ -345,7 +347,19 @@ std::string build_plan(int N, const int64_t *Ap, const int64_t *Ai, const int64_
                         P.rel.push_back(q);
                     }
                 }
-                int stage = opt.update_policy == 1 ? P.sn_level[t] - 1 : P.sn_level[s];
+                // when is (s -> t) applied?  any stage in [level(s), level(t)-1] is valid.
+                //   0 right-looking: as soon as s is factored          (max parallelism, C tile re-read per source)
+                //   1 left-looking : just before t is factored
+                //   2 batched      : sources are batched over `update_batch` consecutive levels so that a
+                //                    target tile is loaded once per batch (K = batch*w), near targets just in time
+                int stage;
+                if (opt.update_policy == 1) stage = P.sn_level[t] - 1;
+                else if (opt.update_policy == 2) {
+                    int B = std::max(1, opt.update_batch);
+                    int ls = P.sn_level[s];
+                    int batch_end = ls - (ls % B) + (B - 1);
+                    stage = std::min(P.sn_level[t] - 1, batch_end);
+                } else stage = P.sn_level[s];
                 // split the source rows by the target row-block they land in
                 int i = a;
                 while (i < r) {
@@ -354,7 +368,7 @@ std::string build_plan(int N, const int64_t *Ap, const int64_t *Ai, const int64_
                     while (e < r && P.rel[rel_off + (e - a)] / kUpdRows == rb) e++;
                     UpdTask tk;
                     tk.src = s; tk.row_lo = i; tk.nrows = e - i; tk.col_lo = a; tk.ncols = b - a;
-                    tk.rel_off = rel_off; tk.pad0 = tk.pad1 = 0;
+                    tk.rel_off = rel_off; tk.vt_begin = 0; tk.pad1 = 0;
                     keys.push_back({stage, t, rb, s, (int)P.upd_tasks.size()});
                     P.upd_tasks.push_back(tk);
                     P.flops_update += 2.0 * (double)(e - i) * (double)(b - a) * (double)w;
@@ -377,34 +391,55 @@ std::string build_plan(int N, const int64_t *Ap, const int64_t *Ai, const int64_
             bool newgrp = (q == 0) || keys[q].stage != keys[q - 1].stage || keys[q].tgt != keys[q - 1].tgt ||
                           keys[q].rb != keys[q - 1].rb;
             if (newgrp) {
-                P.upd_groups.push_back({keys[q].tgt, keys[q].rb * kUpdRows, (int)q, (int)q + 1});
+                P.upd_groups.push_back({keys[q].tgt, keys[q].rb * kUpdRows, (int)q, (int)q + 1, 0, 0});
                 P.upd_stage_ptr[keys[q].stage + 1]++;
             } else {
                 P.upd_groups.back().task_end = (int)q + 1;
             }
+            sorted[q].vt_begin = P.upd_groups.back().nvt;
+            P.upd_groups.back().nvt += (sorted[q].ncols + 15) / 16;
         }
         P.upd_tasks.swap(sorted);
         for (int l = 0; l < P.nlevels; l++) P.upd_stage_ptr[l + 1] += P.upd_stage_ptr[l];
         P.flops_exec += P.flops_update;
     }
 
-    // ---- 15. gather lists for the forward solve
-    P.g_ptr.assign(N + 1, 0);
-    for (int s = 0; s < S; s++) {
-        int w = P.sn_first[s + 1] - P.sn_first[s];
-        const int *rows = &P.sn_rows[P.sn_rowptr[s]];
-        int r = (int)(P.sn_rowptr[s + 1] - P.sn_rowptr[s]);
-        for (int q = w; q < r; q++) P.g_ptr[rows[q] + 1]++;
-    }
-    for (int j = 0; j < N; j++) P.g_ptr[j + 1] += P.g_ptr[j];
-    P.g_idx.resize(P.g_ptr[N]);
+    // ---- 15. gather lists for the forward solve (multifrontal style): every panel row slot
+    //          (s, li) collects the update-vector entries of the CHILDREN of s that land on it.
+    //          Fan-in per slot <= #children; each ubuf entry is consumed exactly once, by the parent.
     {
+        const int64_t nslots = (int64_t)P.sn_rows.size();
+        P.g_ptr.assign(nslots + 1, 0);
+        std::vector<int> relp;  // position in the parent's row list of every off-diagonal child row
+        relp.resize(P.ubuf_len);
+        for (int c = 0; c < S; c++) {
+            int p = P.sn_parent[c];
+            if (p < 0) continue;
+            int w = P.sn_first[c + 1] - P.sn_first[c];
+            const int *rows = &P.sn_rows[P.sn_rowptr[c]];
+            int r = (int)(P.sn_rowptr[c + 1] - P.sn_rowptr[c]);
+            const int *prow = &P.sn_rows[P.sn_rowptr[p]];
+            int pr = (int)(P.sn_rowptr[p + 1] - P.sn_rowptr[p]);
+            int q = 0;
+            for (int i = w; i < r; i++) {
+                while (q < pr && prow[q] < rows[i]) q++;
+                if (q == pr || prow[q] != rows[i]) return "internal: child row missing in parent structure";
+                relp[P.u_off[c] + (i - w)] = q;
+                P.g_ptr[P.sn_rowptr[p] + q + 1]++;
+            }
+        }
+        for (int64_t j = 0; j < nslots; j++) P.g_ptr[j + 1] += P.g_ptr[j];
+        P.g_idx.resize(P.g_ptr[nslots]);
         std::vector<int64_t> nxt(P.g_ptr.begin(), P.g_ptr.end() - 1);
-        for (int s = 0; s < S; s++) {
-            int w = P.sn_first[s + 1] - P.sn_first[s];
-            const int *rows = &P.sn_rows[P.sn_rowptr[s]];
-            int r = (int)(P.sn_rowptr[s + 1] - P.sn_rowptr[s]);
-            for (int q = w; q < r; q++) P.g_idx[nxt[rows[q]]++] = (int)(P.u_off[s] + (q - w));
+        for (int c = 0; c < S; c++) {
+            int p = P.sn_parent[c];
+            if (p < 0) continue;
+            int w = P.sn_first[c + 1] - P.sn_first[c];
+            int r = (int)(P.sn_rowptr[c + 1] - P.sn_rowptr[c]);
+            for (int i = w; i < r; i++) {
+                int64_t up = P.u_off[c] + (i - w);
+                P.g_idx[nxt[P.sn_rowptr[p] + relp[up]]++] = (int)up;
+            }
         }
     }
 

@@ -22,13 +22,16 @@ struct UpdTask {
     int32_t col_lo;     // first source row of the run that lies inside the target's columns
     int32_t ncols;      // length of that run
     int32_t rel_off;    // offset into rel[] of source row `col_lo` (rel[rel_off + (i - col_lo)])
-    int32_t pad0, pad1;
+    int32_t vt_begin;   // index (within the group) of this task's first wave-task (16-column strip)
+    int32_t pad1;
 };
 
 struct UpdGroup {
     int32_t tgt;        // target supernode
     int32_t row_base;   // first target panel row of the block
     int32_t task_begin, task_end;
+    int32_t nvt;        // number of wave-tasks (sum over tasks of ceil(ncols/16))
+    int32_t pad;
 };
 
 struct FacItem {
@@ -39,7 +42,8 @@ struct FacItem {
 struct PlanOptions {
     int max_width = kMaxSnWidth;
     bool relax = true;
-    int update_policy = 0;  // 0 right-looking, 1 left-looking
+    int update_policy = 2;  // 0 right-looking, 1 left-looking, 2 batched right-looking
+    int update_batch = 4;   // levels per batch for policy 2
     double amd_dense_scale = 1.5;
 };
 
@@ -72,7 +76,8 @@ struct HostPlan {
     std::vector<int> upd_stage_ptr;  // [nlevels+1] groups executed after factor(level)
 
     std::vector<int64_t> u_off;  // [nsuper+1] offsets of each panel's off-diagonal rows in ubuf
-    std::vector<int64_t> g_ptr;  // [N+1] gather lists per permuted column
+    std::vector<int64_t> lt_off; // [nsuper+1] offsets of the row-major copy of L21 (w x (r-w)) in LT
+    std::vector<int64_t> g_ptr;  // [|sn_rows|+1] per panel row slot: update-vector entries of the children landing there
     std::vector<int> g_idx;      // ubuf positions
 
     std::vector<int64_t> sym_rowptr;  // full symmetric CSR view of K (original ordering)

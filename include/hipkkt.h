@@ -51,7 +51,9 @@ typedef struct hipkkt_opts {
     int32_t index_base;            /* 0 or 1 */
     int32_t supernode_max_width;   /* 0 = default (64) */
     int32_t relax_supernodes;      /* 1 = relaxed amalgamation (default), 0 = fundamental only */
-    int32_t update_policy;         /* 0 = right-looking (default), 1 = left-looking */
+    int32_t update_policy;         /* 0 = right-looking, 1 = left-looking, 2 = batched right-looking (default) */
+    int32_t update_batch;          /* policy 2: #levels whose updates are applied together (default 4) */
+    int32_t reserved0;
     double dynamic_reg_eps;        /* ref: settings.jl:123, passed at directldl_qdldl.jl:21 */
     double dynamic_reg_delta;      /* ref: settings.jl:124, passed at directldl_qdldl.jl:22 */
     double amd_dense_scale;        /* ref: directldl_qdldl.jl:24 (1.5); <=0 = default */

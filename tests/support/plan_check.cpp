@@ -24,7 +24,7 @@ int plan_check_run(int64_t N, const int64_t *Ap, const int64_t *Ai, const double
                    int symbolic_only) {
     HostPlan P;
     PlanOptions opt;
-    opt.max_width = max_width; opt.relax = relax != 0; opt.update_policy = policy;
+    opt.max_width = max_width; opt.relax = relax != 0; opt.update_policy = policy & 15; if (policy >> 4) opt.update_batch = policy >> 4;
     std::string err = build_plan((int)N, Ap, Ai, user_perm, opt, P);
     if (!err.empty()) { fprintf(stderr, "build_plan: %s\n", err.c_str()); return -1; }
     if (perm_out) for (int k = 0; k < N; k++) perm_out[k] = P.perm[k];
@@ -114,15 +114,17 @@ int plan_check_run(int64_t N, const int64_t *Ap, const int64_t *Ai, const double
             int s = P.lvl_sn[q], w = W(s), r = R(s), f = P.sn_first[s];
             const double *pan = &Lx[P.sn_panel[s]];
             const double *ld = &Ld[P.sn_diag[s]];
+            const int64_t slot0 = P.sn_rowptr[s];
             for (int k = 0; k < w; k++) {
-                double v = y[f + k];
-                for (int64_t g = P.g_ptr[f + k]; g < P.g_ptr[f + k + 1]; g++) v -= ub[P.g_idx[g]];
-                y[f + k] = v;
+                double v = 0;
+                for (int64_t g = P.g_ptr[slot0 + k]; g < P.g_ptr[slot0 + k + 1]; g++) v += ub[P.g_idx[g]];
+                y[f + k] -= v;
             }
             for (int k = 0; k < w; k++)
                 for (int i = k + 1; i < w; i++) y[f + i] -= ld[i + (size_t)k * w] * y[f + k];
             for (int i = w; i < r; i++) {
                 double a = 0;
+                for (int64_t g = P.g_ptr[slot0 + i]; g < P.g_ptr[slot0 + i + 1]; g++) a += ub[P.g_idx[g]];
                 for (int k = 0; k < w; k++) a += pan[i + (size_t)k * r] * y[f + k];
                 ub[P.u_off[s] + (i - w)] = a;
             }

@@ -113,7 +113,7 @@ def test_assembly_bit_exact_and_factor_solve_parity(name, oracle_factory):
             assert np.max(np.abs(res)) <= 1e-9 * max(1.0, np.max(np.abs(np.concatenate([rx, rz]))))
 
 
-@pytest.mark.parametrize("policy,maxw", [(1, 64), (0, 16), (0, 1)])
+@pytest.mark.parametrize("policy,maxw", [(1, 64), (0, 16), (0, 1), (2, 64), (2, 5)])
 def test_plan_variants_agree(policy, maxw, oracle_factory):
     rng = np.random.default_rng(77)
     Pt, A, cones = _prep(problems.random_sparse_qp(400, 700, 21, 3, 1))

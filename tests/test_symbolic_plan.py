@@ -34,7 +34,7 @@ def _kkt(prob, rng):
     return k, nz, ds
 
 
-@pytest.mark.parametrize("policy", [0, 1])
+@pytest.mark.parametrize("policy", [0, 1, 2 + 16 * 4, 2 + 16 * 2])
 @pytest.mark.parametrize("maxw,relax", [(64, 1), (8, 1), (3, 0), (1, 0)])
 def test_plan_reproduces_dense_solve(policy, maxw, relax):
     rng = np.random.default_rng(5)
