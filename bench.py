@@ -140,25 +140,12 @@ def main():
         if not ok:
             raise SystemExit("numerical failure inside the timed region")
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+    from clarabel_jl_amd import batch
 
-    for i in range(args.warmup):
-        step(i)
+    warm = batch.timed_steps(step, 0, args.warmup)          # warm-up only (graph capture, caches)
     h.reset_timing()
     ir_steps_total[0] = 0
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed = batch.timed_steps(step, args.steps, 0, dist=dist, device_sync=torch.cuda.synchronize, reduce_device=dev)
     tm = h.timing()
     factor_ms = tm["acc_factor_ms"] / max(1, tm["n_factor"])
     solve_ms = tm["acc_solve_ms"] / max(1, tm["n_solve_calls"])

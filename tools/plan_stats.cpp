@@ -1,0 +1,51 @@
+// Developer tool (not product): prints per-level statistics of the symbolic plan for a KKT pattern
+// read from a raw file written by tools/plan_stats.py.  Build:
+//   g++ -O2 -std=c++17 -I clarabel.jl_amd/csrc tools/plan_stats.cpp clarabel.jl_amd/csrc/symbolic.cpp clarabel.jl_amd/csrc/ordering.cpp -o /tmp/plan_stats
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <algorithm>
+#include <chrono>
+#include "symbolic.h"
+using namespace hipkkt;
+int main(int argc, char **argv) {
+    FILE *f = fopen(argv[1], "rb");
+    int64_t N, nnz;
+    fread(&N, 8, 1, f); fread(&nnz, 8, 1, f);
+    std::vector<int64_t> Ap(N + 1), Ai(nnz);
+    fread(Ap.data(), 8, N + 1, f); fread(Ai.data(), 8, nnz, f);
+    fclose(f);
+    PlanOptions opt;
+    if (argc > 2) opt.max_width = atoi(argv[2]);
+    if (argc > 3) opt.update_policy = atoi(argv[3]);
+    HostPlan P;
+    auto t0 = std::chrono::steady_clock::now();
+    std::string err = build_plan((int)N, Ap.data(), Ai.data(), nullptr, opt, P);
+    auto t1 = std::chrono::steady_clock::now();
+    if (!err.empty()) { printf("err %s\n", err.c_str()); return 1; }
+    printf("N %d nnzK %ld nnzL %ld nsuper %d nlevels %d panel_doubles %ld flops_colcount %.3e flops_update %.3e flops_exec %.3e plan_s %.3f\n",
+           P.N, (long)P.nnzK, (long)P.nnzL, P.nsuper, P.nlevels, (long)P.panel_doubles, P.flops_colcount, P.flops_update, P.flops_exec,
+           std::chrono::duration<double>(t1 - t0).count());
+    printf("ntasks %zu ngroups %zu\n", P.upd_tasks.size(), P.upd_groups.size());
+    printf("%5s %7s %7s %7s %9s %12s %8s %8s\n", "lvl", "nsn", "maxw", "maxr", "sum_rw", "upd_flops", "groups", "facitems");
+    std::vector<double> lf(P.nlevels, 0.0);
+    for (int l = 0; l < P.nlevels; l++)
+        for (int g = P.upd_stage_ptr[l]; g < P.upd_stage_ptr[l + 1]; g++)
+            for (int q = P.upd_groups[g].task_begin; q < P.upd_groups[g].task_end; q++) {
+                const UpdTask &t = P.upd_tasks[q];
+                int w = P.sn_first[t.src + 1] - P.sn_first[t.src];
+                lf[l] += 2.0 * t.nrows * t.ncols * w;
+            }
+    for (int l = 0; l < P.nlevels; l++) {
+        int maxw = 0; int64_t maxr = 0, srw = 0;
+        for (int q = P.lvl_ptr[l]; q < P.lvl_ptr[l + 1]; q++) {
+            int s = P.lvl_sn[q];
+            int w = P.sn_first[s + 1] - P.sn_first[s];
+            int64_t r = P.sn_rowptr[s + 1] - P.sn_rowptr[s];
+            maxw = std::max(maxw, w); maxr = std::max(maxr, r); srw += r * w;
+        }
+        printf("%5d %7d %7d %7ld %9ld %12.3e %8d %8d\n", l, P.lvl_ptr[l + 1] - P.lvl_ptr[l], maxw, (long)maxr, (long)srw, lf[l],
+               P.upd_stage_ptr[l + 1] - P.upd_stage_ptr[l], P.fac_lvl_ptr[l + 1] - P.fac_lvl_ptr[l]);
+    }
+    return 0;
+}
