@@ -7,7 +7,7 @@
 namespace hipkkt {
 
 enum { SC_MAXDIAG = 0, SC_NORMB = 1, SC_NORME = 2, SC_COUNT = 8 };  // 64-bit scalar slots
-enum { FL_NONFINITE = 0, FL_NREG = 1, FL_COUNT = 4 };                // int flags
+enum { FL_NONFINITE = 0, FL_NREG = 1, FL_FRONTFAIL = 2, FL_COUNT = 4 };                // int flags
 
 struct DevPlan {
     // structure (read-only after setup)
@@ -35,6 +35,10 @@ struct DevPlan {
     const int64_t *sym_rowptr;
     const int *sym_col;
     const int64_t *sym_q;
+    const FrontPanel *front_panels;
+    const int64_t *front_gptr;
+    const int *front_gidx;
+    int *front_sync;   // per front: {ticket, error, flags[np]} (zeroed before every front kernel)
     // numeric state
     double *kval;    // resident, UNREGULARISED triu KKT values (original nz order)
     double *Lx;      // supernodal panels

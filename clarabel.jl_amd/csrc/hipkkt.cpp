@@ -61,6 +61,7 @@ struct hipkkt_solver {
     // solve item lists (256-row blocks) per level
     std::vector<FacItem> slv_items, bwd_items;
     std::vector<int> slv_lvl_ptr, bwd_lvl_ptr;
+    std::vector<int> reg_lvl_sn, reg_lvl_ptr;   // supernodes of every level that are NOT front panels
     int wmax_all = 1;
     std::vector<int64_t> p_off;
 
@@ -86,6 +87,7 @@ struct hipkkt_solver {
 
     GraphSlot g_factor, g_solve;
     bool use_graph = true;
+    bool poison = false;
     bool profiling = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
     double t_last_factor = 0, t_last_solve = 0, t_acc_factor = 0, t_acc_solve = 0, t_last_update = 0;
@@ -100,6 +102,7 @@ struct hipkkt_solver {
         hipError_t e = hipMalloc(&p, n * sizeof(T));
         if (e != hipSuccess) throw std::bad_alloc();
         allocs.push_back(p);
+        if (poison) hipMemset(p, 0xFF, n * sizeof(T));   // debugging aid (HIPKKT_POISON=1): NaNs in every fresh buffer
         return (T *)p;
     }
     template <class T>
@@ -131,6 +134,7 @@ struct hipkkt_solver {
 namespace {
 
 void setup_device(hipkkt_solver *S) {
+    { const char *pz = getenv("HIPKKT_POISON"); S->poison = pz && pz[0] == '1'; }
     HK_CHECK(hipSetDevice(S->device));
     HK_CHECK(hipStreamCreateWithFlags(&S->stream, hipStreamNonBlocking));
     for (hipEvent_t *e : {&S->ev0, &S->ev1, &S->ev2, &S->ev3}) HK_CHECK(hipEventCreate(e));
@@ -153,19 +157,23 @@ void setup_device(hipkkt_solver *S) {
         int64_t nb = std::max<int64_t>(1, (r - w + 63) / 64);
         S->p_off[s + 1] = S->p_off[s] + nb * w;
     }
+    S->reg_lvl_ptr.assign(P.nlevels + 1, 0);
     for (int l = 0; l < P.nlevels; l++) {
         for (int q = P.lvl_ptr[l]; q < P.lvl_ptr[l + 1]; q++) {
             int s = P.lvl_sn[q];
             int w = P.sn_first[s + 1] - P.sn_first[s];
+            S->wmax_all = std::max(S->wmax_all, w);
+            if (P.sn_front[s] >= 0) continue;      // solved by the persistent front kernels
             int64_t r = P.sn_rowptr[s + 1] - P.sn_rowptr[s];
             int nb = (int)std::max<int64_t>(1, (r - w + 63) / 64);
             for (int b = 0; b < nb; b++) S->slv_items.push_back({s, b});
             if (nb > 1)
                 for (int b = 0; b < nb; b++) S->bwd_items.push_back({s, b});
-            S->wmax_all = std::max(S->wmax_all, w);
+            S->reg_lvl_sn.push_back(s);
         }
         S->slv_lvl_ptr[l + 1] = (int)S->slv_items.size();
         S->bwd_lvl_ptr[l + 1] = (int)S->bwd_items.size();
+        S->reg_lvl_ptr[l + 1] = (int)S->reg_lvl_sn.size();
     }
     std::vector<signed char> sgn_perm(N), kdiag(S->nnzK, 0);
     for (int k = 0; k < N; k++) sgn_perm[k] = (signed char)(S->img.dsigns[P.perm[k]] >= 0 ? 1 : -1);
@@ -183,7 +191,7 @@ void setup_device(hipkkt_solver *S) {
     D.p_off = S->upload(S->p_off);
     D.lt_off = S->upload(P.lt_off);
     D.bwd_items = S->upload(S->bwd_items);
-    D.lvl_sn = S->upload(P.lvl_sn);
+    D.lvl_sn = S->upload(S->reg_lvl_sn);
     D.perm = S->upload(P.perm);
     D.sgn_perm = S->upload(sgn_perm);
     D.fac_items = S->upload(P.fac_items);
@@ -198,6 +206,11 @@ void setup_device(hipkkt_solver *S) {
     D.sym_rowptr = S->upload(P.sym_rowptr);
     D.sym_col = S->upload(P.sym_col);
     D.sym_q = S->upload(P.sym_q);
+    D.front_panels = S->upload(P.front_panels);
+    D.front_gptr = S->upload(P.front_gptr);
+    D.front_gidx = S->upload(P.front_gidx);
+    D.front_sync = S->dalloc<int>(std::max(P.front_sync_ints, 16));
+    HK_CHECK(hipMemset(D.front_sync, 0, (size_t)std::max(P.front_sync_ints, 16) * sizeof(int)));
     D.kval = S->upload(S->img.nzval);
     D.Lx = S->dalloc<double>(P.panel_doubles);
     D.Ldiag = S->dalloc<double>(P.diag_doubles);
@@ -258,6 +271,17 @@ void setup_device(hipkkt_solver *S) {
 
 // ---- enqueue helpers (no synchronisation inside; capturable) ---------------------------------
 
+// narrow levels (w <= 8): LDS-resident kernel; wide panels: the register-resident 8-wave kernel
+void enqueue_factor_level(hipkkt_solver *S, int l) {
+    const HostPlan &P = S->plan;
+    const int n = P.fac_lvl_ptr[l + 1] - P.fac_lvl_ptr[l];
+    if (P.fac_lvl_maxw[l] <= 8)
+        launch_factor_level(S->stream, S->dp, P.fac_lvl_ptr[l], n, P.fac_lvl_maxw[l], S->opts.dynamic_reg_eps,
+                            S->opts.dynamic_reg_delta);
+    else
+        launch_factor_panel(S->stream, S->dp, P.fac_lvl_ptr[l], n, S->opts.dynamic_reg_eps, S->opts.dynamic_reg_delta);
+}
+
 void enqueue_factor(hipkkt_solver *S, int static_enable, double eps_const, double eps_prop) {
     const HostPlan &P = S->plan;
     hipStream_t st = S->stream;
@@ -267,9 +291,10 @@ void enqueue_factor(hipkkt_solver *S, int static_enable, double eps_const, doubl
     HK_CHECK(hipMemsetAsync(S->dp.Lx, 0, (size_t)P.panel_doubles * sizeof(double), st));
     launch_init_panels(st, S->dp, S->nnzK, static_enable, eps_const, eps_prop);
     for (int l = 0; l < P.nlevels; l++) {
-        launch_factor_level(st, S->dp, P.fac_lvl_ptr[l], P.fac_lvl_ptr[l + 1] - P.fac_lvl_ptr[l], P.fac_lvl_maxw[l],
-                            S->opts.dynamic_reg_eps, S->opts.dynamic_reg_delta);
-        launch_update_stage(st, S->dp, P.upd_stage_ptr[l], P.upd_stage_ptr[l + 1] - P.upd_stage_ptr[l]);
+        enqueue_factor_level(S, l);
+        launch_update_dense(st, S->dp, P.upd_stage_ptr[l], P.upd_stage_ndense[l]);
+        launch_update_stage(st, S->dp, P.upd_stage_ptr[l] + P.upd_stage_ndense[l],
+                            P.upd_stage_ptr[l + 1] - P.upd_stage_ptr[l] - P.upd_stage_ndense[l]);
     }
     launch_invert_diag(st, S->dp, P.nsuper, S->wmax_all);
 }
@@ -279,11 +304,16 @@ void enqueue_ldl_solve(hipkkt_solver *S) {
     const HostPlan &P = S->plan;
     hipStream_t st = S->stream;
     launch_permute_in(st, S->d_sin, S->dp.perm, S->d_y, S->N);
-    for (int l = 0; l < P.nlevels; l++)
+    for (int l = 0; l < P.nlevels; l++) {
         launch_fwd_level(st, S->dp, S->slv_lvl_ptr[l], S->slv_lvl_ptr[l + 1] - S->slv_lvl_ptr[l], S->d_y, S->d_z);
+        for (const FrontDesc &F : P.fronts)
+            if (F.level_last == l) launch_front_fwd(st, S->dp, F, S->d_y, S->d_z);
+    }
     for (int l = P.nlevels - 1; l >= 0; l--) {
+        for (const FrontDesc &F : P.fronts)
+            if (F.level_last == l) launch_front_bwd(st, S->dp, F, S->d_z, S->d_xp, S->d_sout);
         launch_bwd_partial(st, S->dp, S->bwd_lvl_ptr[l], S->bwd_lvl_ptr[l + 1] - S->bwd_lvl_ptr[l], S->d_xp);
-        launch_bwd_final(st, S->dp, P.lvl_ptr[l], P.lvl_ptr[l + 1] - P.lvl_ptr[l], S->d_z, S->d_xp, S->d_sout);
+        launch_bwd_final(st, S->dp, S->reg_lvl_ptr[l], S->reg_lvl_ptr[l + 1] - S->reg_lvl_ptr[l], S->d_z, S->d_xp, S->d_sout);
     }
 }
 
@@ -325,6 +355,7 @@ double slot_value(const hipkkt_solver *S, int slot) {
 }
 
 void read_scalars(hipkkt_solver *S) {
+    HK_CHECK(hipMemcpyAsync(S->h_flags, S->dp.flags, FL_COUNT * sizeof(int), hipMemcpyDeviceToHost, S->stream));
     HK_CHECK(hipMemcpyAsync(S->h_scal, S->dp.scal, SC_COUNT * sizeof(double), hipMemcpyDeviceToHost, S->stream));
     HK_CHECK(hipStreamSynchronize(S->stream));
 }
@@ -384,6 +415,7 @@ int32_t solve_core(hipkkt_solver *S, int ir_enable, double reltol, double abstol
     S->t_acc_solve += ms;
     S->n_solvecalls++;
     if (ir_steps) *ir_steps = steps;
+    if (S->h_flags[FL_FRONTFAIL]) { S->err = "front solve kernel timed out"; return HIPKKT_ERR_DEVICE; }
     return ok ? HIPKKT_OK : HIPKKT_NUMERICAL_FAILURE;
 }
 
@@ -394,6 +426,11 @@ int32_t finish_create(hipkkt_solver *S, const hipkkt_opts *opts, hipkkt_handle *
     po.update_policy = opts->update_policy;
     if (opts->update_batch > 0) po.update_batch = opts->update_batch;
     po.amd_dense_scale = opts->amd_dense_scale > 0 ? opts->amd_dense_scale : 1.5;
+    po.front_min_panels = opts->front_min_panels == 0 ? 4 : std::max(0, opts->front_min_panels);
+    {
+        const char *nf = getenv("HIPKKT_NO_FRONT");
+        if (nf && nf[0] == '1') po.front_min_panels = 0;
+    }
     std::vector<int64_t> up;
     const int64_t *uperm = nullptr;
     if (opts->user_perm) {
@@ -439,6 +476,7 @@ void hipkkt_default_opts(hipkkt_opts *o) {
     o->relax_supernodes = 1;
     o->update_policy = 2;
     o->update_batch = 4;
+    o->front_min_panels = 0;
     o->dynamic_reg_eps = 1e-13;
     o->dynamic_reg_delta = 2e-7;
     o->amd_dense_scale = 1.5;
@@ -552,7 +590,7 @@ int32_t hipkkt_get_cost_model(hipkkt_handle h, double *o) {
     o[4] = 2.0 * (8.0 + 4.0) * nnzL + 8.0 * 5.0 * N;
     o[5] = (8.0 + 4.0) * nnzK + 8.0 * 3.0 * N;
     o[6] = P.flops_update;
-    o[7] = 0;
+    o[7] = P.flops_update_dense;
     return HIPKKT_OK;
 }
 
@@ -764,14 +802,15 @@ int32_t hipkkt_refactor(hipkkt_handle h, int32_t static_reg_enable, double eps_c
         launch_init_panels(st, S->dp, S->nnzK, static_reg_enable, eps_const, eps_prop);
         std::vector<hipEvent_t> evs;
         for (int l = 0; l < P.nlevels; l++) {
-            launch_factor_level(st, S->dp, P.fac_lvl_ptr[l], P.fac_lvl_ptr[l + 1] - P.fac_lvl_ptr[l], P.fac_lvl_maxw[l],
-                                S->opts.dynamic_reg_eps, S->opts.dynamic_reg_delta);
+            enqueue_factor_level(S, l);
             if (P.upd_stage_ptr[l + 1] > P.upd_stage_ptr[l]) {
                 hipEvent_t a, b;
                 HK_CHECK(hipEventCreate(&a));
                 HK_CHECK(hipEventCreate(&b));
                 HK_CHECK(hipEventRecord(a, st));
-                launch_update_stage(st, S->dp, P.upd_stage_ptr[l], P.upd_stage_ptr[l + 1] - P.upd_stage_ptr[l]);
+                launch_update_dense(st, S->dp, P.upd_stage_ptr[l], P.upd_stage_ndense[l]);
+                launch_update_stage(st, S->dp, P.upd_stage_ptr[l] + P.upd_stage_ndense[l],
+                                    P.upd_stage_ptr[l + 1] - P.upd_stage_ptr[l] - P.upd_stage_ndense[l]);
                 HK_CHECK(hipEventRecord(b, st));
                 evs.push_back(a);
                 evs.push_back(b);
@@ -868,7 +907,9 @@ int32_t hipkkt_ldl_solve(hipkkt_handle h, double *x, const double *b) {
     ldl_solve_dev(S, S->d_sin, S->d_sout);
     HK_CHECK(hipEventRecord(S->ev3, S->stream));
     HK_CHECK(hipMemcpyAsync(x, S->d_sout, (size_t)S->N * sizeof(double), hipMemcpyDeviceToHost, S->stream));
+    HK_CHECK(hipMemcpyAsync(S->h_flags, S->dp.flags, FL_COUNT * sizeof(int), hipMemcpyDeviceToHost, S->stream));
     HK_CHECK(hipStreamSynchronize(S->stream));
+    if (S->h_flags[FL_FRONTFAIL]) { S->err = "front solve kernel timed out"; return HIPKKT_ERR_DEVICE; }
     float ms = 0;
     HK_CHECK(hipEventElapsedTime(&ms, S->ev2, S->ev3));
     S->t_last_solve = ms;

@@ -12,13 +12,17 @@ void launch_soc_batch(hipStream_t st, double *kval, const int64_t *uidx, const i
 void launch_maxabs_gather(hipStream_t st, const double *v, const int64_t *idx, int64_t n, unsigned long long *slot);
 void launch_init_panels(hipStream_t st, const DevPlan &P, int64_t nnz, int static_enable, double eps_const, double eps_prop);
 void launch_factor_level(hipStream_t st, const DevPlan &P, int item_begin, int nitems, int wmax, double dyn_eps, double dyn_delta);
+void launch_factor_panel(hipStream_t st, const DevPlan &P, int item_begin, int nitems, double dyn_eps, double dyn_delta);
 void launch_update_stage(hipStream_t st, const DevPlan &P, int group_begin, int ngroups);
+void launch_update_dense(hipStream_t st, const DevPlan &P, int group_begin, int ngroups);
 void launch_invert_diag(hipStream_t st, const DevPlan &P, int nsuper, int wmax);
 void launch_mfma_probe(hipStream_t st, const double *A, const double *B, double *out);
 void launch_permute_in(hipStream_t st, const double *b, const int *perm, double *y, int n);
 void launch_fwd_level(hipStream_t st, const DevPlan &P, int item_begin, int nitems, double *y, double *z);
 void launch_bwd_partial(hipStream_t st, const DevPlan &P, int item_begin, int nitems, const double *x);
 void launch_bwd_final(hipStream_t st, const DevPlan &P, int sn_begin, int nsn, const double *z, double *x, double *xout);
+void launch_front_fwd(hipStream_t st, const DevPlan &P, const FrontDesc &F, double *y, double *z);
+void launch_front_bwd(hipStream_t st, const DevPlan &P, const FrontDesc &F, const double *z, double *x, double *xout);
 void launch_spmv_residual(hipStream_t st, const DevPlan &P, const double *b, const double *xi, double *e, int n,
                           unsigned long long *slot);
 void launch_norm_inf(hipStream_t st, const double *v, int n, unsigned long long *slot);

@@ -222,6 +222,98 @@ k_factor_level(DevPlan P, int item_begin, int wmax, double dyn_eps, double dyn_d
 }
 
 // ------------------------------------------------------------------------------------------
+// K4a, wide panels (w > 8): register-resident right-looking LDL^T of the whole panel chunk.
+// 8 wavefronts: group D (waves 0-3) holds the w x w diagonal block, group O (waves 4-7) the chunk's
+// 64 off-diagonal rows; lane = row, wave v of a group owns the columns j = v (mod 4) (16 registers).
+// Step k: the owner waves publish column k through LDS (double buffered: one barrier per step),
+// every wave forms l_ik = a_ik / d_k for its row and applies  a_ij -= l_ik * a_jk  to its own
+// columns j > k.  The panel rows are eliminated with the same steps, so the TRSM costs no extra
+// pass: L21[:,k] leaves the kernel at step k.  The critical path per pivot is
+// LDS write -> barrier -> LDS read -> 1/d (112 clk) -> mul -> fma  (~400 clk; tools/ubench.hip).
+// Pivot rule = QDLDL's.  Every chunk repeats the diagonal block (bit-identical).
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(512)
+k_factor_panel(DevPlan P, int item_begin, double dyn_eps, double dyn_delta) {
+    __shared__ double colD[2][64];
+    __shared__ double colO[2][64];
+    __shared__ double Yt[2][64 * 65];     // [group][row * 65 + k]: L11 (group D) and L21 (group O), staged
+    __shared__ double dsave[64];
+    const FacItem it = P.fac_items[item_begin + blockIdx.x];
+    const int s = it.sn;
+    const int f = P.sn_first[s];
+    const int w = P.sn_first[s + 1] - f;
+    const int r = (int)(P.sn_rowptr[s + 1] - P.sn_rowptr[s]);
+    double *pan = P.Lx + P.sn_panel[s];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int grp = wv >> 2, v = wv & 3;
+    const int lo = w + it.blk * kFacRows;
+    const int nr = min(kFacRows, r - lo);
+    const int prow = grp ? lo + lane : lane;              // panel row of this lane
+    const bool rvalid = grp ? lane < nr : lane < w;
+    double a[16];
+#pragma unroll
+    for (int c = 0; c < 16; c++) {
+        const int j = 4 * c + v;
+        a[c] = (rvalid && j < w) ? pan[prow + (int64_t)j * r] : 0.0;
+    }
+    const unsigned long long spos = __ballot(lane < w && P.sgn_perm[f + (lane < w ? lane : 0)] > 0);
+    double *mycol0 = grp ? &colO[0][0] : &colD[0][0];
+    double *myY = &Yt[grp][lane * 65];
+    int nreg = 0;
+    // no global stores inside the pivot loop: __syncthreads() would wait for them every step
+#pragma unroll
+    for (int k = 0; k < 64; k++) {
+        if (k < w) {                                      // workgroup-uniform
+            const int ck = k >> 2, vk = k & 3, pb = k & 1;
+            if (v == vk) mycol0[pb * 64 + lane] = a[ck];
+            __syncthreads();
+            double d = colD[pb][k];
+            const double sg = ((spos >> k) & 1ull) ? 1.0 : -1.0;
+            if (d * sg < dyn_eps) { d = dyn_delta * sg; nreg++; }
+            const double dinv = 1.0 / d;
+            const double li = mycol0[pb * 64 + lane] * dinv;
+            if (v == vk) {
+                myY[k] = li;
+                if (grp == 0 && lane == k) dsave[k] = d;
+            }
+#pragma unroll
+            for (int c = ck; c < 16; c++) {
+                double cj = colD[pb][4 * c + v];
+                if (c == ck && v <= vk) cj = 0.0;         // column already eliminated
+                a[c] = fma(-li, cj, a[c]);
+            }
+        }
+    }
+    __syncthreads();
+    if (it.blk == 0) {
+        double *ld = P.Ldiag + P.sn_diag[s];
+        for (int idx = tid; idx < w * w; idx += 512) {
+            const int i = idx % w, k = idx / w;
+            ld[idx] = i > k ? Yt[0][i * 65 + k] : (i == k ? 1.0 : 0.0);
+        }
+        if (tid < w) {
+            const double d = dsave[tid], dinv = 1.0 / d;
+            P.D[f + tid] = d;
+            P.Dinv[f + tid] = dinv;
+            if (!isfinite(dinv)) atomicOr(P.flags + FL_NONFINITE, 1);
+        }
+        if (tid == 0 && nreg) atomicAdd(P.flags + FL_NREG, nreg);
+    }
+    if (nr > 0) {
+        for (int idx = tid; idx < nr * w; idx += 512) {   // column-major panel rows
+            const int row = idx % nr, k = idx / nr;
+            pan[(lo + row) + (int64_t)k * r] = Yt[1][row * 65 + k];
+        }
+        // row-major copy (w contiguous doubles per row) for the backward solve's L21^T x
+        double *lt = P.LT + P.lt_off[s] + (int64_t)(lo - w) * w;
+        for (int idx = tid; idx < nr * w; idx += 512) {
+            const int k = idx % w, row = idx / w;
+            lt[idx] = Yt[1][row * 65 + k];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // after the factorisation: explicit inverses of the unit-lower diagonal blocks (and their
 // transposes) so that the solves do small GEMVs instead of w-step substitutions.  One launch.
 // ------------------------------------------------------------------------------------------
@@ -378,6 +470,146 @@ k_update_stage(DevPlan P, int group_begin) {
         int row = idx % nrt, col = idx / nrt;
         tp[(G.row_base + row) + (int64_t)col * rt] = Ct[col * LDC + row];
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// K4b (dense tiles): one WAVEFRONT owns one 64-row x <=64-column tile of a target panel and keeps it
+// in 16 FP64 accumulators (4 x 4 tiles of v_mfma_f64_16x16x4_f64) while it sweeps ALL contributing
+// source panels (K = sum of their widths, 256 for the batched updates of a dense front).  The tile is
+// loaded once into the accumulators, the product is accumulated with a negated A operand
+// (C - sum_k L[j,k] d_k L[i,k]), and stored once.  Operands come straight from the source panels:
+// for a fixed k the 16 rows of an MFMA operand are contiguous (128 B), 4 k's per instruction.
+// The transposed product is computed (A operand = target COLUMNS, B operand = target ROWS) so that
+// the C/D layout (col = lane&15, row = (lane>>4)+4*reg) puts 16 consecutive panel rows in
+// consecutive lanes: tile loads / stores are 128-B segments too.
+// No LDS, no barriers, no inter-wave communication: 4 independent wavefronts per workgroup.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+template <class T>
+__device__ __forceinline__ T *rfl_ptr(T *p) {
+    const unsigned long long u = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    return (T *)(((unsigned long long)hi << 32) | lo);
+}
+#define HK_GLOBAL __attribute__((address_space(1)))
+__device__ __forceinline__ double ld_off(const double *base, unsigned byte_off) {
+    // uniform base + 32-bit lane offset, explicitly in the global address space (global_load ... saddr)
+    return *(const HK_GLOBAL double *)((const HK_GLOBAL char *)base + byte_off);
+}
+__device__ __forceinline__ void st_off(double *base, unsigned byte_off, double v) {
+    *(HK_GLOBAL double *)((HK_GLOBAL char *)base + byte_off) = v;
+}
+
+struct DenseRaw {
+    double a[4], b[4], d;
+};
+
+// issue the 9 loads of one k-step (4 k's): operand rows are contiguous for a fixed k
+__device__ __forceinline__ void dense_load(DenseRaw &f, const double *sp, const double *dv, const unsigned (&coff)[4],
+                                           const unsigned (&roff)[4], unsigned r8, int K, int k0, int lk) {
+    int kk = k0 + lk;
+    kk = kk < K ? kk : K - 1;
+    const unsigned ko = (unsigned)kk * r8;
+    f.d = ld_off(dv, (unsigned)kk * 8u);
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        f.a[t] = ld_off(sp, coff[t] + ko);
+        f.b[t] = ld_off(sp, roff[t] + ko);
+    }
+}
+
+__device__ __forceinline__ void dense_mma(const DenseRaw &f, v4f64 (&acc)[4][4], unsigned mbits, int K, int k0, int lk) {
+    const double dk = (k0 + lk < K) ? -f.d : 0.0;     // negated: acc = C - sum
+    double a[4], b[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) {   // mbits: bit t = column operand t valid, bit 4+t = row operand t valid
+        a[t] = ((mbits >> t) & 1u) ? f.a[t] * dk : 0.0;
+        b[t] = ((mbits >> (4 + t)) & 1u) ? f.b[t] : 0.0;
+    }
+#pragma unroll
+    for (int tj = 0; tj < 4; tj++)
+#pragma unroll
+        for (int ti = 0; ti < 4; ti++)
+            acc[tj][ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[tj], b[ti], acc[tj][ti], 0, 0, 0);
+}
+
+__global__ void __launch_bounds__(256, 2)
+k_update_dense(DevPlan P, int group_begin, int ngroups) {
+    const int lane = threadIdx.x & 63;
+    const int g = rfl(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (g >= ngroups) return;
+    const UpdGroup *Gp = P.upd_groups + group_begin + g;
+    const int t = rfl(Gp->tgt), row_base = rfl(Gp->row_base), task_begin = rfl(Gp->task_begin), task_end = rfl(Gp->task_end);
+    const int ft = rfl(P.sn_first[t]);
+    const int wt = rfl(P.sn_first[t + 1]) - ft;
+    const int rt = rfl((int)(P.sn_rowptr[t + 1] - P.sn_rowptr[t]));
+    double *tp = rfl_ptr(P.Lx + P.sn_panel[t] + row_base);
+    const int nrt = min(kUpdRows, rt - row_base);
+    const int l15 = lane & 15, lk = lane >> 4;
+
+    // accumulators <- the target tile.  acc[tj][ti][reg]: column tj*16 + lk + 4*reg, row ti*16 + l15
+    v4f64 acc[4][4];
+#pragma unroll
+    for (int tj = 0; tj < 4; tj++)
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) {
+            const int jj = tj * 16 + lk + 4 * reg;
+#pragma unroll
+            for (int ti = 0; ti < 4; ti++) {
+                const int ii = ti * 16 + l15;
+                const bool ok = ii < nrt && jj < wt;
+                const double v = ld_off(tp, ok ? (unsigned)(ii + jj * rt) * 8u : 0u);
+                acc[tj][ti][reg] = ok ? v : 0.0;
+            }
+        }
+
+    for (int q = task_begin; q < task_end; q++) {
+        const UpdTask *Tp = P.upd_tasks + q;
+        const int s = rfl(Tp->src), row_lo = rfl(Tp->row_lo), nrows = rfl(Tp->nrows), col_lo = rfl(Tp->col_lo),
+                  ncols = rfl(Tp->ncols), geom = rfl(Tp->geom);
+        const int fs = rfl(P.sn_first[s]);
+        const int K = rfl(P.sn_first[s + 1]) - fs;
+        const unsigned r8 = (unsigned)rfl((int)(P.sn_rowptr[s + 1] - P.sn_rowptr[s])) * 8u;
+        const double *sp = rfl_ptr(P.Lx + P.sn_panel[s]);
+        const double *dv = rfl_ptr(P.D + fs);
+        const int c_r = geom & 255, c_c = (geom >> 8) & 255;
+        unsigned roff[4], coff[4], mbits = 0;
+#pragma unroll
+        for (int x = 0; x < 4; x++) {
+            const int ii = x * 16 + l15 - c_r;
+            const bool okr = ii >= 0 && ii < nrows;
+            roff[x] = (unsigned)(row_lo + (okr ? ii : 0)) * 8u;
+            const int jj = x * 16 + l15 - c_c;
+            const bool okc = jj >= 0 && jj < ncols;
+            coff[x] = (unsigned)(col_lo + (okc ? jj : 0)) * 8u;
+            mbits |= (okc ? 1u << x : 0u) | (okr ? 16u << x : 0u);
+        }
+        // register double buffering: the loads of step k+1 (clamped past the end) are in flight during
+        // the 16 MFMAs of step k
+        DenseRaw fa, fb;
+        dense_load(fa, sp, dv, coff, roff, r8, K, 0, lk);
+        for (int k0 = 0; k0 < K; k0 += 8) {     // steps past K contribute zeros (dk = 0)
+            dense_load(fb, sp, dv, coff, roff, r8, K, k0 + 4, lk);
+            __builtin_amdgcn_sched_barrier(0);
+            dense_mma(fa, acc, mbits, K, k0, lk);
+            __builtin_amdgcn_sched_barrier(0);
+            dense_load(fa, sp, dv, coff, roff, r8, K, k0 + 8, lk);
+            __builtin_amdgcn_sched_barrier(0);
+            dense_mma(fb, acc, mbits, K, k0 + 4, lk);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#pragma unroll
+    for (int tj = 0; tj < 4; tj++)
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) {
+            const int jj = tj * 16 + lk + 4 * reg;
+#pragma unroll
+            for (int ti = 0; ti < 4; ti++) {
+                const int ii = ti * 16 + l15;
+                if (ii < nrt && jj < wt) st_off(tp, (unsigned)(ii + jj * rt) * 8u, acc[tj][ti][reg]);
+            }
+        }
 }
 
 // probe used by hipkkt's self test: D = A(16x4) * B(4x16) through the same MFMA form and the
@@ -581,6 +813,277 @@ k_bwd_final(DevPlan P, int sn_begin, const double *__restrict__ z, double *__res
 }
 
 // ------------------------------------------------------------------------------------------
+// K5 over a FRONT (a chain of np panels cut from one wide supernode, e.g. the dense root of a random
+// sparse QP): ONE persistent launch per sweep instead of np dependent launches.  Workgroup b owns the
+// b-th row block of the front, accumulates  sum_q L[b,q] y_q  over the panels q in order while the
+// y_q are published by their owners (8-byte agent-scope stores + one flag per panel; consumers poll
+// the flag relaxed and read the payload with agent-scope loads: MI355X_MICROARCH.md "handoff-flag"),
+// then solves its own diagonal block and publishes.  The L blocks of step q+1 are prefetched while
+// the workgroup waits for y_q, so a hop costs one hand-off + two 64x64 GEMVs.
+// Deadlock freedom: block indices are tickets taken in arrival order (a workgroup only ever waits for
+// lower tickets, whose owners are already running); every spin is bounded and aborts through the
+// front's error word, which makes the solve report a failure instead of hanging.
+// Summation order is fixed (panel order, then a fixed 4-way tree): results are deterministic.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int front_ld_flag(const int *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double front_ld(const double *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void front_st(double *p, double v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// wave-uniform wait (all lanes read the same word); false = timed out / another workgroup failed
+__device__ __forceinline__ bool front_wait(int *flag, int *err, int *failflag) {
+    for (unsigned spins = 0;; spins++) {
+        if (front_ld_flag(flag) != 0) break;
+        if ((spins & 127u) == 127u) {
+            if (spins > (1u << 20)) {
+                __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                atomicOr(failflag, 1);
+                return false;
+            }
+            if (front_ld_flag(err) != 0) return false;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    asm volatile("" ::: "memory");
+    return true;
+}
+__device__ __forceinline__ void front_publish(int *flag, int lane) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the payload stores of THIS wave have completed
+    if (lane == 0) __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ void __launch_bounds__(256)
+k_front_fwd(DevPlan P, FrontDesc F, double *__restrict__ y, double *__restrict__ z) {
+    __shared__ double red[4][64];
+    __shared__ double tv[64];
+    __shared__ int sb;
+    int *sync = P.front_sync + F.sync_off;
+    if (threadIdx.x == 0) sb = atomicAdd(sync, 1);
+    __syncthreads();
+    const int b = sb;
+    if (b >= F.nb) return;
+    if (b == 0)   // re-arm the backward sweep's block (idle during this launch)
+        for (int q = threadIdx.x; q < F.sync_blk; q += blockDim.x) sync[F.sync_blk + q] = 0;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const FrontPanel *fps = P.front_panels + F.fp_off;
+    const bool own = b < F.np;
+    FrontPanel me = fps[own ? b : 0];
+    const int i0 = own ? F.cw * b : F.W + 64 * (b - F.np);
+    const int nrows = own ? me.w : min(64, F.rF - i0);
+    const int i = i0 + lane;
+    const bool valid = lane < nrows;
+    // this row's start value: own rows  b_i - (external children), rows below the front  + (external children)
+    double base = 0.0;
+    if (wv == 0 && valid) {
+        double G = 0.0;
+        const int64_t g0 = P.front_gptr[F.gptr_off + i], g1 = P.front_gptr[F.gptr_off + i + 1];
+        for (int64_t g = g0; g < g1; g++) G += P.ubuf[P.front_gidx[g]];
+        base = own ? y[me.f + lane] - G : G;
+    }
+    // own diagonal block: row `lane` of Linv, columns j = wv + 4t (lower triangle)
+    double li[16];
+#pragma unroll
+    for (int t = 0; t < 16; t++) {
+        const int j = wv + 4 * t;
+        li[t] = (own && valid && j <= lane) ? P.Linv[me.diag_off + lane + j * me.w] : 0.0;
+    }
+    const int nq = own ? b : F.np;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    FrontPanel fq = fps[0];
+    double lv[16];
+#pragma unroll
+    for (int t = 0; t < 16; t++) {
+        const int k = wv + 4 * t;
+        lv[t] = (nq > 0 && valid && k < fq.w) ? P.Lx[fq.panel_off + i + (int64_t)k * fq.r] : 0.0;
+    }
+    bool ok = true;
+    for (int q = 0; q < nq; q++) {
+        FrontPanel fn = fq;
+        double ln[16];
+        if (q + 1 < nq) {                      // prefetch the next panel's block before waiting
+            fn = fps[q + 1];
+            const int jl = i - F.cw * (q + 1);
+#pragma unroll
+            for (int t = 0; t < 16; t++) {
+                const int k = wv + 4 * t;
+                ln[t] = (valid && k < fn.w) ? P.Lx[fn.panel_off + jl + (int64_t)k * fn.r] : 0.0;
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 16; t++) ln[t] = 0.0;
+        }
+        ok = front_wait(sync + 2 + q, sync + 1, P.flags + FL_FRONTFAIL);
+        if (!ok) break;
+        double yv[16];
+#pragma unroll
+        for (int t = 0; t < 16; t++) {
+            const int k = wv + 4 * t;
+            yv[t] = front_ld(y + fq.f + (k < fq.w ? k : 0));
+        }
+#pragma unroll
+        for (int t = 0; t < 16; t += 4) {
+            a0 = fma(lv[t], yv[t], a0);
+            a1 = fma(lv[t + 1], yv[t + 1], a1);
+            a2 = fma(lv[t + 2], yv[t + 2], a2);
+            a3 = fma(lv[t + 3], yv[t + 3], a3);
+        }
+        fq = fn;
+#pragma unroll
+        for (int t = 0; t < 16; t++) lv[t] = ln[t];
+    }
+    red[wv][lane] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    const double tot = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+    if (!own) {
+        if (wv == 0 && valid && ok) P.ubuf[F.ubelow_off + (i - F.W)] = base + tot;
+        return;
+    }
+    if (wv == 0) tv[lane] = valid ? base - tot : 0.0;
+    __syncthreads();
+    {   // y_J = Linv * t  (lower-triangular GEMV, 4-way split over j)
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int t = 0; t < 16; t += 2) {
+            s0 = fma(li[t], tv[wv + 4 * t], s0);
+            s1 = fma(li[t + 1], tv[wv + 4 * t + 4], s1);
+        }
+        red[wv][lane] = s0 + s1;
+    }
+    __syncthreads();
+    if (wv == 0) {
+        if (valid && ok) {
+            const double v = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+            front_st(y + me.f + lane, v);
+            z[me.f + lane] = v * P.Dinv[me.f + lane];
+        }
+        if (ok) front_publish(sync + 2 + b, lane);
+    }
+}
+
+// backward sweep over a front: ticket t owns panel p = np-1-t:  x_J = L_JJ^-T (z_J - L_RJ^T x_R), where R
+// = the rows below the front (final before the launch) followed by the later panels' columns in
+// descending panel order (published inside the launch).  lane = column, wave = 16-row slice.
+__global__ void __launch_bounds__(256)
+k_front_bwd(DevPlan P, FrontDesc F, const double *__restrict__ z, double *__restrict__ x, double *__restrict__ xout) {
+    __shared__ double red[4][64];
+    __shared__ double tv[64];
+    __shared__ int sb;
+    int *sync = P.front_sync + F.sync_off + F.sync_blk;
+    if (threadIdx.x == 0) sb = atomicAdd(sync, 1);
+    __syncthreads();
+    if (sb >= F.np) return;
+    if (sb == 0)   // re-arm the forward sweep's block for the next solve (idle during this launch)
+        for (int q = threadIdx.x; q < F.sync_blk; q += blockDim.x) sync[q - F.sync_blk] = 0;
+    const int p = F.np - 1 - sb;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const FrontPanel *fps = P.front_panels + F.fp_off;
+    const FrontPanel me = fps[p];
+    const int w = me.w;
+    const bool cvalid = lane < w;
+    const double *lt = P.LT + me.lt_off;            // row-major: lt[(j - w) * w + k], j = local panel row
+    // own diagonal block: column `lane` of Linv (as stored transposed), rows i2 = wv + 4t >= lane
+    double lit[16];
+#pragma unroll
+    for (int t = 0; t < 16; t++) {
+        const int i2 = wv + 4 * t;
+        lit[t] = (cvalid && i2 >= lane && i2 < w) ? P.LinvT[me.diag_off + lane + i2 * w] : 0.0;
+    }
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    // (A) rows below the front: x is final
+    {
+        const int *rows = P.sn_rows + F.rows_off;
+        for (int ib = F.W; ib < F.rF; ib += 64) {
+            const int lo = ib + 16 * wv;
+            double xv[16], l[16];
+#pragma unroll
+            for (int t = 0; t < 16; t++) {
+                const int i = lo + t;
+                const bool in = i < F.rF && i < ib + 64;
+                xv[t] = in ? x[rows[in ? i : F.W]] : 0.0;
+                l[t] = (in && cvalid) ? lt[(int64_t)(i - F.cw * p - w) * w + lane] : 0.0;
+            }
+#pragma unroll
+            for (int t = 0; t < 16; t += 4) {
+                a0 = fma(l[t], xv[t], a0);
+                a1 = fma(l[t + 1], xv[t + 1], a1);
+                a2 = fma(l[t + 2], xv[t + 2], a2);
+                a3 = fma(l[t + 3], xv[t + 3], a3);
+            }
+        }
+    }
+    // (B) later panels, descending
+    bool ok = true;
+    double lv[16];
+    {
+        const int q = F.np - 1;
+        const FrontPanel fq = fps[q];
+#pragma unroll
+        for (int t = 0; t < 16; t++) {
+            const int jr = 16 * wv + t;
+            lv[t] = (q > p && cvalid && jr < fq.w) ? lt[(int64_t)(F.cw * (q - p) + jr - w) * w + lane] : 0.0;
+        }
+    }
+    for (int q = F.np - 1; q > p; q--) {
+        const FrontPanel fq = fps[q];
+        double ln[16];
+        if (q - 1 > p) {
+            const FrontPanel fn = fps[q - 1];
+#pragma unroll
+            for (int t = 0; t < 16; t++) {
+                const int jr = 16 * wv + t;
+                ln[t] = (cvalid && jr < fn.w) ? lt[(int64_t)(F.cw * (q - 1 - p) + jr - w) * w + lane] : 0.0;
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 16; t++) ln[t] = 0.0;
+        }
+        ok = front_wait(sync + 2 + q, sync + 1, P.flags + FL_FRONTFAIL);
+        if (!ok) break;
+        double xv[16];
+#pragma unroll
+        for (int t = 0; t < 16; t++) {
+            const int jr = 16 * wv + t;
+            xv[t] = front_ld(x + fq.f + (jr < fq.w ? jr : 0));
+        }
+#pragma unroll
+        for (int t = 0; t < 16; t += 4) {
+            a0 = fma(lv[t], xv[t], a0);
+            a1 = fma(lv[t + 1], xv[t + 1], a1);
+            a2 = fma(lv[t + 2], xv[t + 2], a2);
+            a3 = fma(lv[t + 3], xv[t + 3], a3);
+        }
+#pragma unroll
+        for (int t = 0; t < 16; t++) lv[t] = ln[t];
+    }
+    red[wv][lane] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (wv == 0) tv[lane] = cvalid ? z[me.f + lane] - (((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane]) : 0.0;
+    __syncthreads();
+    {   // x_J = Linv^T t :  x_k = sum_{i >= k} Linv[i][k] t_i
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int t = 0; t < 16; t += 2) {
+            s0 = fma(lit[t], tv[wv + 4 * t], s0);
+            s1 = fma(lit[t + 1], tv[wv + 4 * t + 4], s1);
+        }
+        red[wv][lane] = s0 + s1;
+    }
+    __syncthreads();
+    if (wv == 0) {
+        if (cvalid && ok) {
+            const double v = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+            front_st(x + me.f + lane, v);
+            xout[P.perm[me.f + lane]] = v;
+        }
+        if (ok) front_publish(sync + 2 + p, lane);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // K6-K8: iterative refinement pieces (ref: kktsolver_directldl.jl:389-466)
 // e = b - K*xi with the symmetric CSR view of the unregularised K; 8 lanes per row
 // ------------------------------------------------------------------------------------------
@@ -662,8 +1165,14 @@ void launch_factor_level(hipStream_t st, const DevPlan &P, int item_begin, int n
         hipLaunchKernelGGL(k_factor_level, dim3(nitems), dim3(256), factor_lds_bytes(wmax), st, P, item_begin, wmax, dyn_eps,
                            dyn_delta);
 }
+void launch_factor_panel(hipStream_t st, const DevPlan &P, int item_begin, int nitems, double dyn_eps, double dyn_delta) {
+    if (nitems > 0) hipLaunchKernelGGL(k_factor_panel, dim3(nitems), dim3(512), 0, st, P, item_begin, dyn_eps, dyn_delta);
+}
 void launch_update_stage(hipStream_t st, const DevPlan &P, int group_begin, int ngroups) {
     if (ngroups > 0) hipLaunchKernelGGL(k_update_stage, dim3(ngroups), dim3(kUpdWaves * 64), 0, st, P, group_begin);
+}
+void launch_update_dense(hipStream_t st, const DevPlan &P, int group_begin, int ngroups) {
+    if (ngroups > 0) hipLaunchKernelGGL(k_update_dense, dim3((ngroups + 3) / 4), dim3(256), 0, st, P, group_begin, ngroups);
 }
 void launch_invert_diag(hipStream_t st, const DevPlan &P, int nsuper, int wmax) {
     const int ldl = wmax | 1;
@@ -684,6 +1193,12 @@ void launch_bwd_partial(hipStream_t st, const DevPlan &P, int item_begin, int ni
 }
 void launch_bwd_final(hipStream_t st, const DevPlan &P, int sn_begin, int nsn, const double *z, double *x, double *xout) {
     if (nsn > 0) hipLaunchKernelGGL(k_bwd_final, dim3(nsn), dim3(256), 0, st, P, sn_begin, z, x, xout);
+}
+void launch_front_fwd(hipStream_t st, const DevPlan &P, const FrontDesc &F, double *y, double *z) {
+    hipLaunchKernelGGL(k_front_fwd, dim3(F.nb), dim3(256), 0, st, P, F, y, z);
+}
+void launch_front_bwd(hipStream_t st, const DevPlan &P, const FrontDesc &F, const double *z, double *x, double *xout) {
+    hipLaunchKernelGGL(k_front_bwd, dim3(F.np), dim3(256), 0, st, P, F, z, x, xout);
 }
 void launch_spmv_residual(hipStream_t st, const DevPlan &P, const double *b, const double *xi, double *e, int n,
                           unsigned long long *slot) {

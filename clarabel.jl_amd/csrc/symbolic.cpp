@@ -4,6 +4,7 @@
 #include "symbolic.h"
 
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstring>
 #include <numeric>
@@ -188,6 +189,7 @@ std::string build_plan(int N, const int64_t *Ap, const int64_t *Ai, const int64_
         }
     }
     // ---- 7. width cap: split wide supernodes into a chain of balanced chunks
+    std::vector<std::array<int, 3>> splits;   // (first column, #chunks, chunk width)
     {
         int f = 0;
         while (f < N) {
@@ -198,6 +200,7 @@ std::string build_plan(int N, const int64_t *Ap, const int64_t *Ai, const int64_
                 int nch = (w + maxw - 1) / maxw;
                 int cw = (w + nch - 1) / nch;
                 for (int c = f + cw; c <= l; c += cw) is_start[c] = 1;
+                splits.push_back({f, (w + cw - 1) / cw, cw});
             }
             f = l + 1;
         }
@@ -368,7 +371,7 @@ std::string build_plan(int N, const int64_t *Ap, const int64_t *Ai, const int64_
                     while (e < r && P.rel[rel_off + (e - a)] / kUpdRows == rb) e++;
                     UpdTask tk;
                     tk.src = s; tk.row_lo = i; tk.nrows = e - i; tk.col_lo = a; tk.ncols = b - a;
-                    tk.rel_off = rel_off; tk.vt_begin = 0; tk.pad1 = 0;
+                    tk.rel_off = rel_off; tk.vt_begin = 0; tk.geom = 0;
                     keys.push_back({stage, t, rb, s, (int)P.upd_tasks.size()});
                     P.upd_tasks.push_back(tk);
                     P.flops_update += 2.0 * (double)(e - i) * (double)(b - a) * (double)w;
@@ -402,6 +405,38 @@ std::string build_plan(int N, const int64_t *Ap, const int64_t *Ai, const int64_
         P.upd_tasks.swap(sorted);
         for (int l = 0; l < P.nlevels; l++) P.upd_stage_ptr[l + 1] += P.upd_stage_ptr[l];
         P.flops_exec += P.flops_update;
+        // ---- 14b. classify target tiles: a tile is "dense" when every contribution lands on a
+        //           contiguous row range x contiguous column range of it (true for the panels of one
+        //           wide front, e.g. the dense root) and the tile is reasonably filled.  Dense tiles are
+        //           accumulated in registers over ALL their sources by k_update_dense; the others go
+        //           through the relative-index scatter of k_update_stage.  Dense groups are moved to the
+        //           front of their stage.
+        P.upd_stage_ndense.assign(P.nlevels, 0);
+        for (auto &G : P.upd_groups) {
+            const int t = G.tgt, ft = P.sn_first[t];
+            bool all_contig = true;
+            double covered = 0, flops = 0;
+            for (int q = G.task_begin; q < G.task_end; q++) {
+                UpdTask &T = P.upd_tasks[q];
+                const int *srows = &P.sn_rows[P.sn_rowptr[T.src]];
+                const int *rel = &P.rel[T.rel_off];
+                const int r0 = rel[T.row_lo - T.col_lo], r1 = rel[T.row_lo + T.nrows - 1 - T.col_lo];
+                const int c0 = srows[T.col_lo] - ft, c1 = srows[T.col_lo + T.ncols - 1] - ft;
+                const bool contig = (r1 - r0 == T.nrows - 1) && (c1 - c0 == T.ncols - 1);
+                T.geom = ((r0 - G.row_base) & 255) | ((c0 & 255) << 8) | (contig ? 1 << 16 : 0);
+                all_contig = all_contig && contig;
+                covered += (double)T.nrows * T.ncols;
+                flops += 2.0 * T.nrows * T.ncols * (P.sn_first[T.src + 1] - P.sn_first[T.src]);
+            }
+            const double ntasks = G.task_end - G.task_begin;
+            G.dense = (all_contig && covered >= 0.4 * ntasks * kUpdRows * kMaxSnWidth) ? 1 : 0;
+            if (G.dense) P.flops_update_dense += flops;
+        }
+        for (int l = 0; l < P.nlevels; l++) {
+            auto b = P.upd_groups.begin() + P.upd_stage_ptr[l], e = P.upd_groups.begin() + P.upd_stage_ptr[l + 1];
+            auto mid = std::stable_partition(b, e, [](const UpdGroup &g) { return g.dense != 0; });
+            P.upd_stage_ndense[l] = (int)(mid - b);
+        }
     }
 
     // ---- 15. gather lists for the forward solve (multifrontal style): every panel row slot
@@ -441,6 +476,70 @@ std::string build_plan(int N, const int64_t *Ap, const int64_t *Ai, const int64_
                 P.g_idx[nxt[P.sn_rowptr[p] + relp[up]]++] = (int)up;
             }
         }
+    }
+
+    // ---- 15b. fronts: chains of panels cut from one wide supernode, for the persistent solve kernels
+    P.sn_front.assign(S, -1);
+    if (opt.front_min_panels > 0) {
+        int sync_ints = 0;
+        for (const auto &sp : splits) {
+            const int f = sp[0], np = sp[1], cw = sp[2];
+            if (np < opt.front_min_panels) continue;
+            const int s0 = P.sn_of_col[f];
+            const int rF = (int)(P.sn_rowptr[s0 + 1] - P.sn_rowptr[s0]);
+            bool ok = true;
+            int W = 0;
+            for (int p = 0; p < np && ok; p++) {
+                const int s = s0 + p;
+                const int w = P.sn_first[s + 1] - P.sn_first[s];
+                const int r = (int)(P.sn_rowptr[s + 1] - P.sn_rowptr[s]);
+                ok = P.sn_first[s] == f + cw * p && r == rF - cw * p && (p == np - 1 ? w <= cw : w == cw) &&
+                     (p == 0 || P.sn_parent[s - 1] == s) && P.sn_level[s] == P.sn_level[s0] + p;
+                W += w;
+            }
+            if (!ok) continue;   // not a nested chain (cannot happen for fundamental supernodes): stay generic
+            FrontDesc F{};
+            F.s0 = s0; F.np = np; F.cw = cw; F.W = W; F.rF = rF;
+            F.nb = np + (rF - W + 63) / 64;
+            F.level_first = P.sn_level[s0]; F.level_last = P.sn_level[s0] + np - 1;
+            F.gptr_off = (int64_t)P.front_gptr.size();
+            F.fp_off = (int64_t)P.front_panels.size();
+            F.ubelow_off = P.u_off[s0 + np - 1];
+            F.rows_off = P.sn_rowptr[s0];
+            F.sync_off = sync_ints;
+            F.sync_blk = (2 + np + 15) & ~15;     // two blocks: forward sweep, backward sweep
+            sync_ints += 2 * F.sync_blk;
+            for (int p = 0; p < np; p++) {
+                const int s = s0 + p;
+                P.front_panels.push_back({P.sn_panel[s], P.lt_off[s], P.sn_diag[s], (int)(P.sn_rowptr[s + 1] - P.sn_rowptr[s]),
+                                          P.sn_first[s + 1] - P.sn_first[s], P.sn_first[s], s});
+                P.sn_front[s] = (int)P.fronts.size();
+            }
+            // external gathers per front row, in panel order: slot (p, i - cw*p); the chain child's own
+            // update vector (u_off[s-1] .. u_off[s]) is replaced by the in-kernel accumulation
+            std::vector<std::vector<int>> ext(rF);
+            for (int p = 0; p < np; p++) {
+                const int s = s0 + p;
+                const int r = rF - cw * p;
+                const int64_t lo = p > 0 ? P.u_off[s - 1] : -1, hi = p > 0 ? P.u_off[s] : -1;
+                for (int j = 0; j < r; j++)
+                    for (int64_t g = P.g_ptr[P.sn_rowptr[s] + j]; g < P.g_ptr[P.sn_rowptr[s] + j + 1]; g++) {
+                        const int u = P.g_idx[g];
+                        if (u >= lo && u < hi) continue;
+                        ext[cw * p + j].push_back(u);
+                    }
+            }
+            int64_t acc = 0;   // offsets relative to this front's first entry in front_gidx are made absolute
+            const int64_t base = (int64_t)P.front_gidx.size();
+            for (int i = 0; i < rF; i++) {
+                P.front_gptr.push_back(base + acc);
+                acc += (int64_t)ext[i].size();
+            }
+            P.front_gptr.push_back(base + acc);
+            for (int i = 0; i < rF; i++) P.front_gidx.insert(P.front_gidx.end(), ext[i].begin(), ext[i].end());
+            P.fronts.push_back(F);
+        }
+        P.front_sync_ints = sync_ints;
     }
 
     // ---- 16. symmetric CSR view of K in the ORIGINAL ordering (iterative-refinement SpMV)

@@ -23,7 +23,8 @@ struct UpdTask {
     int32_t ncols;      // length of that run
     int32_t rel_off;    // offset into rel[] of source row `col_lo` (rel[rel_off + (i - col_lo)])
     int32_t vt_begin;   // index (within the group) of this task's first wave-task (16-column strip)
-    int32_t pad1;
+    int32_t geom;       // dense-tile geometry: bits 0-7 tile row of source row `row_lo`, bits 8-15 tile
+                        // column of source row `col_lo`, bit 16 = rows AND columns land contiguously
 };
 
 struct UpdGroup {
@@ -31,12 +32,32 @@ struct UpdGroup {
     int32_t row_base;   // first target panel row of the block
     int32_t task_begin, task_end;
     int32_t nvt;        // number of wave-tasks (sum over tasks of ceil(ncols/16))
-    int32_t pad;
+    int32_t dense;      // 1: every task is contiguous and the tile is well filled -> k_update_dense
 };
 
 struct FacItem {
     int32_t sn;
     int32_t blk;        // row-chunk index inside the panel's off-diagonal part
+};
+
+// A "front" = one wide (fundamental) supernode that the width cap split into a chain of np panels of
+// cw columns (the last may be narrower).  Its panels have nested row structures (panel p holds the
+// front rows [cw*p, rF)), so the triangular solves over the chain are done by ONE persistent kernel
+// per sweep (k_front_fwd / k_front_bwd) instead of np dependent launches.
+struct FrontPanel {
+    int64_t panel_off, lt_off, diag_off;   // offsets into Lx / LT / Ldiag(Linv)
+    int32_t r, w, f, sn;                   // rows, width, first (permuted) column, supernode id
+};
+struct FrontDesc {
+    int32_t s0, np, cw, W;        // first panel (supernode id), #panels, panel width, own columns
+    int32_t rF, nb;               // rows of the front (= rows of panel 0), #row blocks (np + ceil((rF-W)/64))
+    int32_t level_first, level_last;
+    int64_t gptr_off;             // front_gptr[gptr_off + i .. +1]: external children's ubuf entries on front row i
+    int64_t fp_off;               // front_panels[fp_off + p]
+    int64_t ubelow_off;           // u_off of the last panel (its off-diagonal rows = the rows below the front)
+    int64_t rows_off;             // sn_rowptr[s0]: global (permuted) index of every front row
+    int32_t sync_off, sync_blk;   // sync area of this front: two blocks of sync_blk ints {ticket, error, flags[np]},
+                                  // one per sweep; each sweep's kernel re-zeroes the OTHER block for the next solve
 };
 
 struct PlanOptions {
@@ -45,6 +66,7 @@ struct PlanOptions {
     int update_policy = 2;  // 0 right-looking, 1 left-looking, 2 batched right-looking
     int update_batch = 4;   // levels per batch for policy 2
     double amd_dense_scale = 1.5;
+    int front_min_panels = 4;  // chains at least this long are solved by the persistent front kernels (0 = never)
 };
 
 struct HostPlan {
@@ -74,11 +96,20 @@ struct HostPlan {
     std::vector<UpdTask> upd_tasks;
     std::vector<UpdGroup> upd_groups;
     std::vector<int> upd_stage_ptr;  // [nlevels+1] groups executed after factor(level)
+    std::vector<int> upd_stage_ndense;  // [nlevels] the first ndense groups of a stage are dense tiles
+    double flops_update_dense = 0;   // part of flops_update executed by the dense-tile kernel
 
     std::vector<int64_t> u_off;  // [nsuper+1] offsets of each panel's off-diagonal rows in ubuf
     std::vector<int64_t> lt_off; // [nsuper+1] offsets of the row-major copy of L21 (w x (r-w)) in LT
     std::vector<int64_t> g_ptr;  // [|sn_rows|+1] per panel row slot: update-vector entries of the children landing there
     std::vector<int> g_idx;      // ubuf positions
+
+    std::vector<FrontDesc> fronts;
+    std::vector<FrontPanel> front_panels;
+    std::vector<int64_t> front_gptr;
+    std::vector<int> front_gidx;
+    std::vector<int> sn_front;        // [nsuper] front index of a panel handled by the front kernels, else -1
+    int front_sync_ints = 0;
 
     std::vector<int64_t> sym_rowptr;  // full symmetric CSR view of K (original ordering)
     std::vector<int> sym_col;

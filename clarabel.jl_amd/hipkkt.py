@@ -30,7 +30,7 @@ SYMBOLS = [
 
 class Opts(C.Structure):
     _fields_ = [("index_base", C.c_int32), ("supernode_max_width", C.c_int32), ("relax_supernodes", C.c_int32),
-                ("update_policy", C.c_int32), ("update_batch", C.c_int32), ("reserved0", C.c_int32),
+                ("update_policy", C.c_int32), ("update_batch", C.c_int32), ("front_min_panels", C.c_int32),
                 ("dynamic_reg_eps", C.c_double), ("dynamic_reg_delta", C.c_double),
                 ("amd_dense_scale", C.c_double), ("user_perm", C.c_void_p)]
 

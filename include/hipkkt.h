@@ -53,7 +53,8 @@ typedef struct hipkkt_opts {
     int32_t relax_supernodes;      /* 1 = relaxed amalgamation (default), 0 = fundamental only */
     int32_t update_policy;         /* 0 = right-looking, 1 = left-looking, 2 = batched right-looking (default) */
     int32_t update_batch;          /* policy 2: #levels whose updates are applied together (default 4) */
-    int32_t reserved0;
+    int32_t front_min_panels;      /* chains of >= this many panels of one wide supernode are solved by the
+                                      persistent front kernels; 0 = default (4), < 0 = never */
     double dynamic_reg_eps;        /* ref: settings.jl:123, passed at directldl_qdldl.jl:21 */
     double dynamic_reg_delta;      /* ref: settings.jl:124, passed at directldl_qdldl.jl:22 */
     double amd_dense_scale;        /* ref: directldl_qdldl.jl:24 (1.5); <=0 = default */
@@ -106,7 +107,7 @@ int32_t hipkkt_info(hipkkt_handle h, int64_t *nnzA, int64_t *nnzL);
 /* flop / byte model of one numeric factorisation and one solve, from the symbolic factor actually
  * used:  out[0]=sum_j c_j^2+3c_j (factor flops), out[1]=executed factor flops incl.
  * supernode padding, out[2]=solve flops (4 nnzL + N), out[3]=algorithmic factor bytes,
- * out[4]=algorithmic solve bytes, out[5]=spmv bytes, out[6]=dense-update (MFMA) flops, out[7]=reserved */
+ * out[4]=algorithmic solve bytes, out[5]=spmv bytes, out[6]=dense-update (MFMA) flops, out[7]=the part of out[6] executed by k_update_dense */
 int32_t hipkkt_get_cost_model(hipkkt_handle h, double *out8);
 
 /* copies of host-side structures (tests, Julia-side bookkeeping).  Any pointer may be NULL. */
