@@ -28,6 +28,7 @@ struct DevPlan {
     const int *rel;
     const UpdTask *upd_tasks;
     const UpdGroup *upd_groups;
+    const int16_t *upd_tmap;
     const int64_t *g_ptr;
     const int *g_idx;
     const int64_t *kmap;

@@ -199,6 +199,7 @@ void setup_device(hipkkt_solver *S) {
     D.rel = S->upload(P.rel);
     D.upd_tasks = S->upload(P.upd_tasks);
     D.upd_groups = S->upload(P.upd_groups);
+    D.upd_tmap = S->upload(P.upd_tmap);
     D.g_ptr = S->upload(P.g_ptr);
     D.g_idx = S->upload(P.g_idx);
     D.kmap = S->upload(P.kmap);

@@ -223,20 +223,21 @@ k_factor_level(DevPlan P, int item_begin, int wmax, double dyn_eps, double dyn_d
 
 // ------------------------------------------------------------------------------------------
 // K4a, wide panels (w > 8): register-resident right-looking LDL^T of the whole panel chunk.
-// 8 wavefronts: group D (waves 0-3) holds the w x w diagonal block, group O (waves 4-7) the chunk's
-// 64 off-diagonal rows; lane = row, wave v of a group owns the columns j = v (mod 4) (16 registers).
-// Step k: the owner waves publish column k through LDS (double buffered: one barrier per step),
-// every wave forms l_ik = a_ik / d_k for its row and applies  a_ij -= l_ik * a_jk  to its own
-// columns j > k.  The panel rows are eliminated with the same steps, so the TRSM costs no extra
-// pass: L21[:,k] leaves the kernel at step k.  The critical path per pivot is
-// LDS write -> barrier -> LDS read -> 1/d (112 clk) -> mul -> fma  (~400 clk; tools/ubench.hip).
+// 4 wavefronts (one per SIMD); lane = row: every lane carries row `lane` of the w x w diagonal block
+// (aD) AND row `lane` of the chunk's 64 off-diagonal rows (aO); wave v owns the columns j = v (mod 4)
+// (16 + 16 registers).  Step k: the owner wave publishes column k of both row sets through LDS (double
+// buffered: one barrier per step); every wave forms l_ik = a_ik / d_k for its two rows and applies
+// a_ij -= l_ik * a_jk to its own columns j > k.  The panel rows are eliminated by the same steps, so
+// the TRSM costs no extra pass.  The kernel is issue/latency bound (64 dependent pivots):
+// LDS write -> barrier -> LDS read -> 1/d -> mul -> fma per pivot; one wave per SIMD keeps the ~100
+// instructions of a step from queueing behind a second wave.
 // Pivot rule = QDLDL's.  Every chunk repeats the diagonal block (bit-identical).
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(512)
+__global__ void __launch_bounds__(256)
 k_factor_panel(DevPlan P, int item_begin, double dyn_eps, double dyn_delta) {
     __shared__ double colD[2][64];
     __shared__ double colO[2][64];
-    __shared__ double Yt[2][64 * 65];     // [group][row * 65 + k]: L11 (group D) and L21 (group O), staged
+    __shared__ double Yt[2][64 * 65];     // [0]: L11, [1]: L21 of this chunk; [row * 65 + k]
     __shared__ double dsave[64];
     const FacItem it = P.fac_items[item_begin + blockIdx.x];
     const int s = it.sn;
@@ -244,50 +245,57 @@ k_factor_panel(DevPlan P, int item_begin, double dyn_eps, double dyn_delta) {
     const int w = P.sn_first[s + 1] - f;
     const int r = (int)(P.sn_rowptr[s + 1] - P.sn_rowptr[s]);
     double *pan = P.Lx + P.sn_panel[s];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int grp = wv >> 2, v = wv & 3;
+    const int tid = threadIdx.x, lane = tid & 63, v = tid >> 6;
     const int lo = w + it.blk * kFacRows;
     const int nr = min(kFacRows, r - lo);
-    const int prow = grp ? lo + lane : lane;              // panel row of this lane
-    const bool rvalid = grp ? lane < nr : lane < w;
-    double a[16];
+    double aD[16], aO[16];
 #pragma unroll
     for (int c = 0; c < 16; c++) {
         const int j = 4 * c + v;
-        a[c] = (rvalid && j < w) ? pan[prow + (int64_t)j * r] : 0.0;
+        aD[c] = (lane < w && j < w) ? pan[lane + (int64_t)j * r] : 0.0;
+        aO[c] = (lane < nr && j < w) ? pan[lo + lane + (int64_t)j * r] : 0.0;
     }
     const unsigned long long spos = __ballot(lane < w && P.sgn_perm[f + (lane < w ? lane : 0)] > 0);
-    double *mycol0 = grp ? &colO[0][0] : &colD[0][0];
-    double *myY = &Yt[grp][lane * 65];
+    double *yD = &Yt[0][lane * 65], *yO = &Yt[1][lane * 65];
     int nreg = 0;
     // no global stores inside the pivot loop: __syncthreads() would wait for them every step
 #pragma unroll
     for (int k = 0; k < 64; k++) {
         if (k < w) {                                      // workgroup-uniform
             const int ck = k >> 2, vk = k & 3, pb = k & 1;
-            if (v == vk) mycol0[pb * 64 + lane] = a[ck];
+            if (v == vk) {
+                colD[pb][lane] = aD[ck];
+                colO[pb][lane] = aO[ck];
+            }
             __syncthreads();
             double d = colD[pb][k];
             const double sg = ((spos >> k) & 1ull) ? 1.0 : -1.0;
             if (d * sg < dyn_eps) { d = dyn_delta * sg; nreg++; }
             const double dinv = 1.0 / d;
-            const double li = mycol0[pb * 64 + lane] * dinv;
+            const double liD = colD[pb][lane] * dinv;
+            const double liO = colO[pb][lane] * dinv;
             if (v == vk) {
-                myY[k] = li;
-                if (grp == 0 && lane == k) dsave[k] = d;
+                yD[k] = liD;
+                yO[k] = liO;
+                if (lane == k) dsave[k] = d;
+            }
+            if (v > vk) {                                 // column 4*ck + v is still live in this wave
+                const double cj = colD[pb][4 * ck + v];
+                aD[ck] = fma(-liD, cj, aD[ck]);
+                aO[ck] = fma(-liO, cj, aO[ck]);
             }
 #pragma unroll
-            for (int c = ck; c < 16; c++) {
-                double cj = colD[pb][4 * c + v];
-                if (c == ck && v <= vk) cj = 0.0;         // column already eliminated
-                a[c] = fma(-li, cj, a[c]);
+            for (int c = ck + 1; c < 16; c++) {
+                const double cj = colD[pb][4 * c + v];
+                aD[c] = fma(-liD, cj, aD[c]);
+                aO[c] = fma(-liO, cj, aO[c]);
             }
         }
     }
     __syncthreads();
     if (it.blk == 0) {
         double *ld = P.Ldiag + P.sn_diag[s];
-        for (int idx = tid; idx < w * w; idx += 512) {
+        for (int idx = tid; idx < w * w; idx += 256) {
             const int i = idx % w, k = idx / w;
             ld[idx] = i > k ? Yt[0][i * 65 + k] : (i == k ? 1.0 : 0.0);
         }
@@ -300,13 +308,13 @@ k_factor_panel(DevPlan P, int item_begin, double dyn_eps, double dyn_delta) {
         if (tid == 0 && nreg) atomicAdd(P.flags + FL_NREG, nreg);
     }
     if (nr > 0) {
-        for (int idx = tid; idx < nr * w; idx += 512) {   // column-major panel rows
+        for (int idx = tid; idx < nr * w; idx += 256) {   // column-major panel rows
             const int row = idx % nr, k = idx / nr;
             pan[(lo + row) + (int64_t)k * r] = Yt[1][row * 65 + k];
         }
         // row-major copy (w contiguous doubles per row) for the backward solve's L21^T x
         double *lt = P.LT + P.lt_off[s] + (int64_t)(lo - w) * w;
-        for (int idx = tid; idx < nr * w; idx += 512) {
+        for (int idx = tid; idx < nr * w; idx += 256) {
             const int k = idx % w, row = idx / w;
             lt[idx] = Yt[1][row * 65 + k];
         }
@@ -500,60 +508,69 @@ __device__ __forceinline__ void st_off(double *base, unsigned byte_off, double v
     *(HK_GLOBAL double *)((HK_GLOBAL char *)base + byte_off) = v;
 }
 
+template <int NT>
 struct DenseRaw {
-    double a[4], b[4], d;
+    double a[NT], b[4], d;
 };
 
-// issue the 9 loads of one k-step (4 k's): operand rows are contiguous for a fixed k
-__device__ __forceinline__ void dense_load(DenseRaw &f, const double *sp, const double *dv, const unsigned (&coff)[4],
+// issue the loads of one k-step (4 k's): operand rows are contiguous for a fixed k
+template <int NT>
+__device__ __forceinline__ void dense_load(DenseRaw<NT> &f, const double *sp, const double *dv, const unsigned (&coff)[NT],
                                            const unsigned (&roff)[4], unsigned r8, int K, int k0, int lk) {
     int kk = k0 + lk;
     kk = kk < K ? kk : K - 1;
     const unsigned ko = (unsigned)kk * r8;
     f.d = ld_off(dv, (unsigned)kk * 8u);
 #pragma unroll
-    for (int t = 0; t < 4; t++) {
-        f.a[t] = ld_off(sp, coff[t] + ko);
-        f.b[t] = ld_off(sp, roff[t] + ko);
-    }
+    for (int t = 0; t < NT; t++) f.a[t] = ld_off(sp, coff[t] + ko);
+#pragma unroll
+    for (int t = 0; t < 4; t++) f.b[t] = ld_off(sp, roff[t] + ko);
 }
 
-__device__ __forceinline__ void dense_mma(const DenseRaw &f, v4f64 (&acc)[4][4], unsigned mbits, int K, int k0, int lk) {
+template <int NT>
+__device__ __forceinline__ void dense_mma(const DenseRaw<NT> &f, v4f64 (&acc)[NT][4], unsigned mbits, int K, int k0, int lk) {
     const double dk = (k0 + lk < K) ? -f.d : 0.0;     // negated: acc = C - sum
-    double a[4], b[4];
+    double a[NT], b[4];
 #pragma unroll
-    for (int t = 0; t < 4; t++) {   // mbits: bit t = column operand t valid, bit 4+t = row operand t valid
+    for (int t = 0; t < NT; t++)    // mbits: bit t = column operand t valid, bit 4+t = row operand t valid
         a[t] = ((mbits >> t) & 1u) ? f.a[t] * dk : 0.0;
-        b[t] = ((mbits >> (4 + t)) & 1u) ? f.b[t] : 0.0;
-    }
 #pragma unroll
-    for (int tj = 0; tj < 4; tj++)
+    for (int t = 0; t < 4; t++) b[t] = ((mbits >> (4 + t)) & 1u) ? f.b[t] : 0.0;
+#pragma unroll
+    for (int tj = 0; tj < NT; tj++)
 #pragma unroll
         for (int ti = 0; ti < 4; ti++)
             acc[tj][ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[tj], b[ti], acc[tj][ti], 0, 0, 0);
 }
 
+// NT = 4: one wavefront per tile (4 tiles per workgroup): highest operand reuse, for launches with
+//         thousands of tiles.   NT = 1: one wavefront per 16-column strip (one tile per workgroup):
+//         4x shorter critical path, for the just-in-time updates of the next panel (<= ~100 tiles).
+template <int NT>
 __global__ void __launch_bounds__(256, 2)
 k_update_dense(DevPlan P, int group_begin, int ngroups) {
     const int lane = threadIdx.x & 63;
-    const int g = rfl(blockIdx.x * 4 + (threadIdx.x >> 6));
+    const int wave = rfl(threadIdx.x >> 6);
+    const int g = NT == 4 ? rfl(blockIdx.x * 4 + wave) : (int)blockIdx.x;
+    const int tj0 = NT == 4 ? 0 : wave;               // first 16-column strip of this wavefront
     if (g >= ngroups) return;
     const UpdGroup *Gp = P.upd_groups + group_begin + g;
     const int t = rfl(Gp->tgt), row_base = rfl(Gp->row_base), task_begin = rfl(Gp->task_begin), task_end = rfl(Gp->task_end);
     const int ft = rfl(P.sn_first[t]);
     const int wt = rfl(P.sn_first[t + 1]) - ft;
+    if (tj0 * 16 >= wt) return;
     const int rt = rfl((int)(P.sn_rowptr[t + 1] - P.sn_rowptr[t]));
     double *tp = rfl_ptr(P.Lx + P.sn_panel[t] + row_base);
     const int nrt = min(kUpdRows, rt - row_base);
     const int l15 = lane & 15, lk = lane >> 4;
 
-    // accumulators <- the target tile.  acc[tj][ti][reg]: column tj*16 + lk + 4*reg, row ti*16 + l15
-    v4f64 acc[4][4];
+    // accumulators <- the target tile.  acc[tj][ti][reg]: column (tj0+tj)*16 + lk + 4*reg, row ti*16 + l15
+    v4f64 acc[NT][4];
 #pragma unroll
-    for (int tj = 0; tj < 4; tj++)
+    for (int tj = 0; tj < NT; tj++)
 #pragma unroll
         for (int reg = 0; reg < 4; reg++) {
-            const int jj = tj * 16 + lk + 4 * reg;
+            const int jj = (tj0 + tj) * 16 + lk + 4 * reg;
 #pragma unroll
             for (int ti = 0; ti < 4; ti++) {
                 const int ii = ti * 16 + l15;
@@ -573,37 +590,57 @@ k_update_dense(DevPlan P, int group_begin, int ngroups) {
         const double *sp = rfl_ptr(P.Lx + P.sn_panel[s]);
         const double *dv = rfl_ptr(P.D + fs);
         const int c_r = geom & 255, c_c = (geom >> 8) & 255;
-        unsigned roff[4], coff[4], mbits = 0;
+        unsigned roff[4], coff[NT], mbits = 0;
+        if (geom & (1 << 17)) {      // wave-uniform: operands gathered through the task's tile maps
+            const int16_t *tm = P.upd_tmap + (int64_t)rfl(Tp->vt_begin) * 128;
 #pragma unroll
-        for (int x = 0; x < 4; x++) {
-            const int ii = x * 16 + l15 - c_r;
-            const bool okr = ii >= 0 && ii < nrows;
-            roff[x] = (unsigned)(row_lo + (okr ? ii : 0)) * 8u;
-            const int jj = x * 16 + l15 - c_c;
-            const bool okc = jj >= 0 && jj < ncols;
-            coff[x] = (unsigned)(col_lo + (okc ? jj : 0)) * 8u;
-            mbits |= (okc ? 1u << x : 0u) | (okr ? 16u << x : 0u);
+            for (int x = 0; x < 4; x++) {
+                const int m = tm[x * 16 + l15];
+                roff[x] = (unsigned)(row_lo + (m >= 0 ? m : 0)) * 8u;
+                mbits |= m >= 0 ? 16u << x : 0u;
+            }
+#pragma unroll
+            for (int x = 0; x < NT; x++) {
+                const int m = tm[64 + (tj0 + x) * 16 + l15];
+                coff[x] = (unsigned)(col_lo + (m >= 0 ? m : 0)) * 8u;
+                mbits |= m >= 0 ? 1u << x : 0u;
+            }
+        } else {
+#pragma unroll
+            for (int x = 0; x < 4; x++) {
+                const int ii = x * 16 + l15 - c_r;
+                const bool okr = ii >= 0 && ii < nrows;
+                roff[x] = (unsigned)(row_lo + (okr ? ii : 0)) * 8u;
+                mbits |= okr ? 16u << x : 0u;
+            }
+#pragma unroll
+            for (int x = 0; x < NT; x++) {
+                const int jj = (tj0 + x) * 16 + l15 - c_c;
+                const bool okc = jj >= 0 && jj < ncols;
+                coff[x] = (unsigned)(col_lo + (okc ? jj : 0)) * 8u;
+                mbits |= okc ? 1u << x : 0u;
+            }
         }
         // register double buffering: the loads of step k+1 (clamped past the end) are in flight during
-        // the 16 MFMAs of step k
-        DenseRaw fa, fb;
-        dense_load(fa, sp, dv, coff, roff, r8, K, 0, lk);
+        // the MFMAs of step k
+        DenseRaw<NT> fa, fb;
+        dense_load<NT>(fa, sp, dv, coff, roff, r8, K, 0, lk);
         for (int k0 = 0; k0 < K; k0 += 8) {     // steps past K contribute zeros (dk = 0)
-            dense_load(fb, sp, dv, coff, roff, r8, K, k0 + 4, lk);
+            dense_load<NT>(fb, sp, dv, coff, roff, r8, K, k0 + 4, lk);
             __builtin_amdgcn_sched_barrier(0);
-            dense_mma(fa, acc, mbits, K, k0, lk);
+            dense_mma<NT>(fa, acc, mbits, K, k0, lk);
             __builtin_amdgcn_sched_barrier(0);
-            dense_load(fa, sp, dv, coff, roff, r8, K, k0 + 8, lk);
+            dense_load<NT>(fa, sp, dv, coff, roff, r8, K, k0 + 8, lk);
             __builtin_amdgcn_sched_barrier(0);
-            dense_mma(fb, acc, mbits, K, k0 + 4, lk);
+            dense_mma<NT>(fb, acc, mbits, K, k0 + 4, lk);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
 #pragma unroll
-    for (int tj = 0; tj < 4; tj++)
+    for (int tj = 0; tj < NT; tj++)
 #pragma unroll
         for (int reg = 0; reg < 4; reg++) {
-            const int jj = tj * 16 + lk + 4 * reg;
+            const int jj = (tj0 + tj) * 16 + lk + 4 * reg;
 #pragma unroll
             for (int ti = 0; ti < 4; ti++) {
                 const int ii = ti * 16 + l15;
@@ -1166,13 +1203,17 @@ void launch_factor_level(hipStream_t st, const DevPlan &P, int item_begin, int n
                            dyn_delta);
 }
 void launch_factor_panel(hipStream_t st, const DevPlan &P, int item_begin, int nitems, double dyn_eps, double dyn_delta) {
-    if (nitems > 0) hipLaunchKernelGGL(k_factor_panel, dim3(nitems), dim3(512), 0, st, P, item_begin, dyn_eps, dyn_delta);
+    if (nitems > 0) hipLaunchKernelGGL(k_factor_panel, dim3(nitems), dim3(256), 0, st, P, item_begin, dyn_eps, dyn_delta);
 }
 void launch_update_stage(hipStream_t st, const DevPlan &P, int group_begin, int ngroups) {
     if (ngroups > 0) hipLaunchKernelGGL(k_update_stage, dim3(ngroups), dim3(kUpdWaves * 64), 0, st, P, group_begin);
 }
 void launch_update_dense(hipStream_t st, const DevPlan &P, int group_begin, int ngroups) {
-    if (ngroups > 0) hipLaunchKernelGGL(k_update_dense, dim3((ngroups + 3) / 4), dim3(256), 0, st, P, group_begin, ngroups);
+    if (ngroups <= 0) return;
+    if (ngroups > 384)   // plenty of tiles: one wavefront per tile
+        hipLaunchKernelGGL(k_update_dense<4>, dim3((ngroups + 3) / 4), dim3(256), 0, st, P, group_begin, ngroups);
+    else                 // few tiles (just-in-time updates): split every tile over 4 wavefronts
+        hipLaunchKernelGGL(k_update_dense<1>, dim3(ngroups), dim3(256), 0, st, P, group_begin, ngroups);
 }
 void launch_invert_diag(hipStream_t st, const DevPlan &P, int nsuper, int wmax) {
     const int ldl = wmax | 1;

@@ -429,8 +429,24 @@ std::string build_plan(int N, const int64_t *Ap, const int64_t *Ai, const int64_
                 flops += 2.0 * T.nrows * T.ncols * (P.sn_first[T.src + 1] - P.sn_first[T.src]);
             }
             const double ntasks = G.task_end - G.task_begin;
-            G.dense = (all_contig && covered >= 0.4 * ntasks * kUpdRows * kMaxSnWidth) ? 1 : 0;
-            if (G.dense) P.flops_update_dense += flops;
+            const double fill = covered / (ntasks * kUpdRows * kMaxSnWidth);
+            G.dense = ((all_contig && fill >= 0.4) || fill >= 0.3) ? 1 : 0;
+            if (!G.dense) continue;
+            P.flops_update_dense += flops;
+            // contributions that do not land contiguously get explicit tile maps (tile row / column ->
+            // source row offset or -1): k_update_dense then gathers its operands through them
+            for (int q = G.task_begin; q < G.task_end; q++) {
+                UpdTask &T = P.upd_tasks[q];
+                if (T.geom & (1 << 16)) continue;
+                const int *srows = &P.sn_rows[P.sn_rowptr[T.src]];
+                const int *rel = &P.rel[T.rel_off];
+                T.vt_begin = (int)(P.upd_tmap.size() / 128);
+                T.geom |= 1 << 17;
+                const size_t base = P.upd_tmap.size();
+                P.upd_tmap.resize(base + 128, (int16_t)-1);
+                for (int i = 0; i < T.nrows; i++) P.upd_tmap[base + (rel[T.row_lo + i - T.col_lo] - G.row_base)] = (int16_t)i;
+                for (int j = 0; j < T.ncols; j++) P.upd_tmap[base + 64 + (srows[T.col_lo + j] - ft)] = (int16_t)j;
+            }
         }
         for (int l = 0; l < P.nlevels; l++) {
             auto b = P.upd_groups.begin() + P.upd_stage_ptr[l], e = P.upd_groups.begin() + P.upd_stage_ptr[l + 1];

@@ -22,9 +22,12 @@ struct UpdTask {
     int32_t col_lo;     // first source row of the run that lies inside the target's columns
     int32_t ncols;      // length of that run
     int32_t rel_off;    // offset into rel[] of source row `col_lo` (rel[rel_off + (i - col_lo)])
-    int32_t vt_begin;   // index (within the group) of this task's first wave-task (16-column strip)
+    int32_t vt_begin;   // sparse groups: index (within the group) of this task's first wave-task (16-column
+                        // strip); dense groups with bit 17 of geom set: index of this task's tile map
     int32_t geom;       // dense-tile geometry: bits 0-7 tile row of source row `row_lo`, bits 8-15 tile
-                        // column of source row `col_lo`, bit 16 = rows AND columns land contiguously
+                        // column of source row `col_lo`, bit 16 = rows AND columns land contiguously,
+                        // bit 17 = gathered through upd_tmap[128 * vt_begin ..]: [0,64) tile row -> source row
+                        // offset from row_lo (or -1), [64,128) tile column -> offset from col_lo (or -1)
 };
 
 struct UpdGroup {
@@ -96,6 +99,7 @@ struct HostPlan {
     std::vector<UpdTask> upd_tasks;
     std::vector<UpdGroup> upd_groups;
     std::vector<int> upd_stage_ptr;  // [nlevels+1] groups executed after factor(level)
+    std::vector<int16_t> upd_tmap;
     std::vector<int> upd_stage_ndense;  // [nlevels] the first ndense groups of a stage are dense tiles
     double flops_update_dense = 0;   // part of flops_update executed by the dense-tile kernel
 

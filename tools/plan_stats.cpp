@@ -28,13 +28,15 @@ int main(int argc, char **argv) {
            std::chrono::duration<double>(t1 - t0).count());
     printf("ntasks %zu ngroups %zu\n", P.upd_tasks.size(), P.upd_groups.size());
     printf("%5s %7s %7s %7s %9s %12s %8s %8s\n", "lvl", "nsn", "maxw", "maxr", "sum_rw", "upd_flops", "groups", "facitems");
-    std::vector<double> lf(P.nlevels, 0.0);
+    std::vector<double> lf(P.nlevels, 0.0), lfd(P.nlevels, 0.0), fills(P.nlevels, 0.0);
     for (int l = 0; l < P.nlevels; l++)
         for (int g = P.upd_stage_ptr[l]; g < P.upd_stage_ptr[l + 1]; g++)
             for (int q = P.upd_groups[g].task_begin; q < P.upd_groups[g].task_end; q++) {
                 const UpdTask &t = P.upd_tasks[q];
                 int w = P.sn_first[t.src + 1] - P.sn_first[t.src];
                 lf[l] += 2.0 * t.nrows * t.ncols * w;
+                if (P.upd_groups[g].dense) lfd[l] += 2.0 * t.nrows * t.ncols * w;
+                fills[l] += (double)t.nrows * t.ncols / 4096.0;
             }
     for (int l = 0; l < P.nlevels; l++) {
         int maxw = 0; int64_t maxr = 0, srw = 0;
@@ -44,8 +46,10 @@ int main(int argc, char **argv) {
             int64_t r = P.sn_rowptr[s + 1] - P.sn_rowptr[s];
             maxw = std::max(maxw, w); maxr = std::max(maxr, r); srw += r * w;
         }
-        printf("%5d %7d %7d %7ld %9ld %12.3e %8d %8d\n", l, P.lvl_ptr[l + 1] - P.lvl_ptr[l], maxw, (long)maxr, (long)srw, lf[l],
-               P.upd_stage_ptr[l + 1] - P.upd_stage_ptr[l], P.fac_lvl_ptr[l + 1] - P.fac_lvl_ptr[l]);
+        int ntk = 0;
+        for (int g = P.upd_stage_ptr[l]; g < P.upd_stage_ptr[l + 1]; g++) ntk += P.upd_groups[g].task_end - P.upd_groups[g].task_begin;
+        printf("%5d %7d %7d %7ld %9ld %12.3e %8d %8d   dense: %6d groups %10.3e flops; tasks %7d avgfill %.2f\n", l, P.lvl_ptr[l + 1] - P.lvl_ptr[l], maxw, (long)maxr, (long)srw, lf[l],
+               P.upd_stage_ptr[l + 1] - P.upd_stage_ptr[l], P.fac_lvl_ptr[l + 1] - P.fac_lvl_ptr[l], P.upd_stage_ndense[l], lfd[l], ntk, ntk ? fills[l] / ntk : 0.0);
     }
     return 0;
 }
