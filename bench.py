@@ -167,8 +167,10 @@ def main():
     achieved = cm["flops_update"] / (upd * 1e-3) / 1e12 if upd > 0 else 0.0
     roofline = dict(bound="mfma", achieved=round(achieved, 3), peak=F64_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
                     frac=round(achieved / F64_MFMA_PEAK_TFLOPS, 4), traffic=None,
-                    kernel="k_update_stage", flops_per_refactor=cm["flops_update"],
-                    launches_per_refactor=h.nlevels - 1, ms_per_refactor=round(upd, 4))
+                    kernel="k_update_dense (+ k_update_gather / k_update_stage for the sparse tiles)",
+                    flops_per_refactor=cm["flops_update"], flops_dense_tiles=cm.get("flops_update_dense"),
+                    launches_per_refactor=h.nlevels - 1, ms_per_refactor=round(upd, 4),
+                    peak_source="MI355X datasheet FP64 matrix; tools/ubench.hip measures 72-77 TFLOP/s on the box")
 
     result = {
         "metric": "IPM iterations/sec + KKT factor+solve ms, 10k-var sparse QP, 1/2/4/8 GPU",

@@ -29,6 +29,11 @@ struct DevPlan {
     const UpdTask *upd_tasks;
     const UpdGroup *upd_groups;
     const int16_t *upd_tmap;
+    const int64_t *gath_tgt;
+    const int64_t *gath_pptr;
+    const int64_t *gath_src;
+    const int32_t *gath_dj;
+    const int32_t *gath_sn;
     const int64_t *g_ptr;
     const int *g_idx;
     const int64_t *kmap;

@@ -88,6 +88,8 @@ struct hipkkt_solver {
     GraphSlot g_factor, g_solve;
     bool use_graph = true;
     bool poison = false;
+    PlanOptions plan_opts;       // as used for the current plan
+    bool ordering_fallback_done = false;
     bool profiling = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
     double t_last_factor = 0, t_last_solve = 0, t_acc_factor = 0, t_acc_solve = 0, t_last_update = 0;
@@ -133,7 +135,7 @@ struct hipkkt_solver {
 
 namespace {
 
-void setup_device(hipkkt_solver *S) {
+void init_runtime(hipkkt_solver *S) {
     { const char *pz = getenv("HIPKKT_POISON"); S->poison = pz && pz[0] == '1'; }
     HK_CHECK(hipSetDevice(S->device));
     HK_CHECK(hipStreamCreateWithFlags(&S->stream, hipStreamNonBlocking));
@@ -142,6 +144,21 @@ void setup_device(hipkkt_solver *S) {
     HK_CHECK(hipHostMalloc((void **)&S->h_flags, FL_COUNT * sizeof(int), hipHostMallocDefault));
     const char *ng = getenv("HIPKKT_NO_GRAPH");
     if (ng && ng[0] == '1') S->use_graph = false;
+}
+
+// (re)builds every device-resident structure from S->plan and S->img (values included)
+void setup_device(hipkkt_solver *S) {
+    HK_CHECK(hipSetDevice(S->device));
+    for (GraphSlot *g : {&S->g_factor, &S->g_solve}) {
+        if (g->exec) hipGraphExecDestroy(g->exec);
+        *g = GraphSlot();
+    }
+    for (void *p : S->allocs) hipFree(p);
+    S->allocs.clear();
+    S->slv_items.clear(); S->bwd_items.clear(); S->reg_lvl_sn.clear();
+    S->soc_off.clear(); S->soc_of_sparse.clear();
+    S->nsoc = 0; S->soc_total = 0; S->wmax_all = 1;
+    S->stage_cap = 0; S->d_stage = nullptr; S->d_stage_idx = nullptr;
 
     HostPlan &P = S->plan;
     const int N = P.N;
@@ -200,6 +217,11 @@ void setup_device(hipkkt_solver *S) {
     D.upd_tasks = S->upload(P.upd_tasks);
     D.upd_groups = S->upload(P.upd_groups);
     D.upd_tmap = S->upload(P.upd_tmap);
+    D.gath_tgt = S->upload(P.gath_tgt);
+    D.gath_pptr = S->upload(P.gath_pptr);
+    D.gath_src = S->upload(P.gath_src);
+    D.gath_dj = S->upload(P.gath_dj);
+    D.gath_sn = S->upload(P.gath_sn);
     D.g_ptr = S->upload(P.g_ptr);
     D.g_idx = S->upload(P.g_idx);
     D.kmap = S->upload(P.kmap);
@@ -283,6 +305,18 @@ void enqueue_factor_level(hipkkt_solver *S, int l) {
         launch_factor_panel(S->stream, S->dp, P.fac_lvl_ptr[l], n, S->opts.dynamic_reg_eps, S->opts.dynamic_reg_delta);
 }
 
+// Schur-complement updates applied after level l is factored: dense register tiles (matrix cores),
+// per-entry gather lists (tiny scattered contributions), relative-index scatter (whatever is left).
+// The three kinds own disjoint target tiles, so their order inside a stage is immaterial.
+void enqueue_updates(hipkkt_solver *S, int l) {
+    const HostPlan &P = S->plan;
+    hipStream_t st = S->stream;
+    const int g0 = P.upd_stage_ptr[l], nd = P.upd_stage_ndense[l], ng = P.upd_stage_ngather[l];
+    launch_update_dense(st, S->dp, g0, nd);
+    launch_update_gather(st, S->dp, P.gath_stage_ptr[l], P.gath_stage_ptr[l + 1] - P.gath_stage_ptr[l]);
+    launch_update_stage(st, S->dp, g0 + nd + ng, P.upd_stage_ptr[l + 1] - g0 - nd - ng);
+}
+
 void enqueue_factor(hipkkt_solver *S, int static_enable, double eps_const, double eps_prop) {
     const HostPlan &P = S->plan;
     hipStream_t st = S->stream;
@@ -293,9 +327,7 @@ void enqueue_factor(hipkkt_solver *S, int static_enable, double eps_const, doubl
     launch_init_panels(st, S->dp, S->nnzK, static_enable, eps_const, eps_prop);
     for (int l = 0; l < P.nlevels; l++) {
         enqueue_factor_level(S, l);
-        launch_update_dense(st, S->dp, P.upd_stage_ptr[l], P.upd_stage_ndense[l]);
-        launch_update_stage(st, S->dp, P.upd_stage_ptr[l] + P.upd_stage_ndense[l],
-                            P.upd_stage_ptr[l + 1] - P.upd_stage_ptr[l] - P.upd_stage_ndense[l]);
+        enqueue_updates(S, l);
     }
     launch_invert_diag(st, S->dp, P.nsuper, S->wmax_all);
 }
@@ -428,6 +460,11 @@ int32_t finish_create(hipkkt_solver *S, const hipkkt_opts *opts, hipkkt_handle *
     if (opts->update_batch > 0) po.update_batch = opts->update_batch;
     po.amd_dense_scale = opts->amd_dense_scale > 0 ? opts->amd_dense_scale : 1.5;
     po.front_min_panels = opts->front_min_panels == 0 ? 4 : std::max(0, opts->front_min_panels);
+    po.n_hold = S->l1 ? (int)S->img.n : 0;
+    {
+        const char *nh = getenv("HIPKKT_ORDERING");   // "amd": minimum degree on K only
+        if (nh && nh[0] == 'a') po.n_hold = 0;
+    }
     {
         const char *nf = getenv("HIPKKT_NO_FRONT");
         if (nf && nf[0] == '1') po.front_min_panels = 0;
@@ -442,7 +479,9 @@ int32_t finish_create(hipkkt_solver *S, const hipkkt_opts *opts, hipkkt_handle *
     if (S->img.N >= ((int64_t)1 << 31)) { g_create_error = "N exceeds int32"; delete S; return HIPKKT_ERR_ARGUMENT; }
     std::string err = build_plan((int)S->img.N, S->img.colptr.data(), S->img.rowval.data(), uperm, po, S->plan);
     if (!err.empty()) { g_create_error = err; delete S; return HIPKKT_ERR_ARGUMENT; }
+    S->plan_opts = po;
     try {
+        init_runtime(S);
         setup_device(S);
     } catch (const DeviceError &e) {
         g_create_error = e.msg; delete S; return HIPKKT_ERR_DEVICE;
@@ -788,8 +827,39 @@ int32_t hipkkt_update_A(hipkkt_handle h, const double *Anzval, int64_t nnzA) {
 
 // ---- factor ------------------------------------------------------------------------------------
 
+static int32_t refactor_once(hipkkt_handle h, int32_t static_reg_enable, double eps_const, double eps_prop,
+                             double *eps_used, int64_t *n_dynamic_reg);
+
+// The "variables last" order (plan.ordering_used == 1) can be far cheaper than minimum degree on K but
+// eliminates the ill-conditioned cone blocks first; if a factorisation in that order ends with a
+// non-finite pivot, the handle is rebuilt ONCE with the minimum-degree order on K (the reference's
+// choice) and the factorisation is repeated, so robustness is never worse than with that order.
 int32_t hipkkt_refactor(hipkkt_handle h, int32_t static_reg_enable, double eps_const, double eps_prop,
                         double *eps_used, int64_t *n_dynamic_reg) {
+    int32_t rc = refactor_once(h, static_reg_enable, eps_const, eps_prop, eps_used, n_dynamic_reg);
+    if (rc != HIPKKT_NUMERICAL_FAILURE || !h || h->plan.ordering_used != 1 || h->ordering_fallback_done) return rc;
+    hipkkt_solver *S = h;
+    try {
+        if (hipSetDevice(S->device) != hipSuccess) return rc;
+        HK_CHECK(hipMemcpy(S->img.nzval.data(), S->dp.kval, (size_t)S->nnzK * sizeof(double), hipMemcpyDeviceToHost));
+        S->ordering_fallback_done = true;
+        PlanOptions po = S->plan_opts;
+        po.n_hold = 0;
+        HostPlan np;
+        std::string err = build_plan((int)S->img.N, S->img.colptr.data(), S->img.rowval.data(), nullptr, po, np);
+        if (!err.empty()) return rc;
+        S->plan = std::move(np);
+        S->plan_opts = po;
+        setup_device(S);
+    } catch (...) {
+        S->err = "rebuilding the plan with the fallback ordering failed";
+        return HIPKKT_ERR_DEVICE;
+    }
+    return refactor_once(h, static_reg_enable, eps_const, eps_prop, eps_used, n_dynamic_reg);
+}
+
+static int32_t refactor_once(hipkkt_handle h, int32_t static_reg_enable, double eps_const, double eps_prop,
+                             double *eps_used, int64_t *n_dynamic_reg) {
     HK_ENTER(h)
     HK_CHECK(hipEventRecord(S->ev0, S->stream));
     if (S->profiling) {
@@ -809,9 +879,7 @@ int32_t hipkkt_refactor(hipkkt_handle h, int32_t static_reg_enable, double eps_c
                 HK_CHECK(hipEventCreate(&a));
                 HK_CHECK(hipEventCreate(&b));
                 HK_CHECK(hipEventRecord(a, st));
-                launch_update_dense(st, S->dp, P.upd_stage_ptr[l], P.upd_stage_ndense[l]);
-                launch_update_stage(st, S->dp, P.upd_stage_ptr[l] + P.upd_stage_ndense[l],
-                                    P.upd_stage_ptr[l + 1] - P.upd_stage_ptr[l] - P.upd_stage_ndense[l]);
+                enqueue_updates(S, l);
                 HK_CHECK(hipEventRecord(b, st));
                 evs.push_back(a);
                 evs.push_back(b);

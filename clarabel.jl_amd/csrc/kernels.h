@@ -15,6 +15,7 @@ void launch_factor_level(hipStream_t st, const DevPlan &P, int item_begin, int n
 void launch_factor_panel(hipStream_t st, const DevPlan &P, int item_begin, int nitems, double dyn_eps, double dyn_delta);
 void launch_update_stage(hipStream_t st, const DevPlan &P, int group_begin, int ngroups);
 void launch_update_dense(hipStream_t st, const DevPlan &P, int group_begin, int ngroups);
+void launch_update_gather(hipStream_t st, const DevPlan &P, int64_t ebegin, int64_t n);
 void launch_invert_diag(hipStream_t st, const DevPlan &P, int nsuper, int wmax);
 void launch_mfma_probe(hipStream_t st, const double *A, const double *B, double *out);
 void launch_permute_in(hipStream_t st, const double *b, const int *perm, double *y, int n);

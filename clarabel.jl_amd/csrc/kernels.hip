@@ -223,21 +223,20 @@ k_factor_level(DevPlan P, int item_begin, int wmax, double dyn_eps, double dyn_d
 
 // ------------------------------------------------------------------------------------------
 // K4a, wide panels (w > 8): register-resident right-looking LDL^T of the whole panel chunk.
-// 4 wavefronts (one per SIMD); lane = row: every lane carries row `lane` of the w x w diagonal block
-// (aD) AND row `lane` of the chunk's 64 off-diagonal rows (aO); wave v owns the columns j = v (mod 4)
-// (16 + 16 registers).  Step k: the owner wave publishes column k of both row sets through LDS (double
-// buffered: one barrier per step); every wave forms l_ik = a_ik / d_k for its two rows and applies
-// a_ij -= l_ik * a_jk to its own columns j > k.  The panel rows are eliminated by the same steps, so
-// the TRSM costs no extra pass.  The kernel is issue/latency bound (64 dependent pivots):
-// LDS write -> barrier -> LDS read -> 1/d -> mul -> fma per pivot; one wave per SIMD keeps the ~100
-// instructions of a step from queueing behind a second wave.
+// 8 wavefronts: group D (waves 0-3) holds the w x w diagonal block, group O (waves 4-7) the chunk's
+// 64 off-diagonal rows; lane = row, wave v of a group owns the columns j = v (mod 4) (16 registers).
+// Step k: the owner waves publish column k through LDS (double buffered: one barrier per step),
+// every wave forms l_ik = a_ik / d_k for its row and applies  a_ij -= l_ik * a_jk  to its own
+// columns j > k.  The panel rows are eliminated with the same steps, so the TRSM costs no extra
+// pass: L21[:,k] leaves the kernel at step k.  The critical path per pivot is
+// LDS write -> barrier -> LDS read -> 1/d (112 clk) -> mul -> fma  (~400 clk; tools/ubench.hip).
 // Pivot rule = QDLDL's.  Every chunk repeats the diagonal block (bit-identical).
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(512)
 k_factor_panel(DevPlan P, int item_begin, double dyn_eps, double dyn_delta) {
     __shared__ double colD[2][64];
     __shared__ double colO[2][64];
-    __shared__ double Yt[2][64 * 65];     // [0]: L11, [1]: L21 of this chunk; [row * 65 + k]
+    __shared__ double Yt[2][64 * 65];     // [group][row * 65 + k]: L11 (group D) and L21 (group O), staged
     __shared__ double dsave[64];
     const FacItem it = P.fac_items[item_begin + blockIdx.x];
     const int s = it.sn;
@@ -245,57 +244,50 @@ k_factor_panel(DevPlan P, int item_begin, double dyn_eps, double dyn_delta) {
     const int w = P.sn_first[s + 1] - f;
     const int r = (int)(P.sn_rowptr[s + 1] - P.sn_rowptr[s]);
     double *pan = P.Lx + P.sn_panel[s];
-    const int tid = threadIdx.x, lane = tid & 63, v = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int grp = wv >> 2, v = wv & 3;
     const int lo = w + it.blk * kFacRows;
     const int nr = min(kFacRows, r - lo);
-    double aD[16], aO[16];
+    const int prow = grp ? lo + lane : lane;              // panel row of this lane
+    const bool rvalid = grp ? lane < nr : lane < w;
+    double a[16];
 #pragma unroll
     for (int c = 0; c < 16; c++) {
         const int j = 4 * c + v;
-        aD[c] = (lane < w && j < w) ? pan[lane + (int64_t)j * r] : 0.0;
-        aO[c] = (lane < nr && j < w) ? pan[lo + lane + (int64_t)j * r] : 0.0;
+        a[c] = (rvalid && j < w) ? pan[prow + (int64_t)j * r] : 0.0;
     }
     const unsigned long long spos = __ballot(lane < w && P.sgn_perm[f + (lane < w ? lane : 0)] > 0);
-    double *yD = &Yt[0][lane * 65], *yO = &Yt[1][lane * 65];
+    double *mycol0 = grp ? &colO[0][0] : &colD[0][0];
+    double *myY = &Yt[grp][lane * 65];
     int nreg = 0;
     // no global stores inside the pivot loop: __syncthreads() would wait for them every step
 #pragma unroll
     for (int k = 0; k < 64; k++) {
         if (k < w) {                                      // workgroup-uniform
             const int ck = k >> 2, vk = k & 3, pb = k & 1;
-            if (v == vk) {
-                colD[pb][lane] = aD[ck];
-                colO[pb][lane] = aO[ck];
-            }
+            if (v == vk) mycol0[pb * 64 + lane] = a[ck];
             __syncthreads();
             double d = colD[pb][k];
             const double sg = ((spos >> k) & 1ull) ? 1.0 : -1.0;
             if (d * sg < dyn_eps) { d = dyn_delta * sg; nreg++; }
             const double dinv = 1.0 / d;
-            const double liD = colD[pb][lane] * dinv;
-            const double liO = colO[pb][lane] * dinv;
+            const double li = mycol0[pb * 64 + lane] * dinv;
             if (v == vk) {
-                yD[k] = liD;
-                yO[k] = liO;
-                if (lane == k) dsave[k] = d;
-            }
-            if (v > vk) {                                 // column 4*ck + v is still live in this wave
-                const double cj = colD[pb][4 * ck + v];
-                aD[ck] = fma(-liD, cj, aD[ck]);
-                aO[ck] = fma(-liO, cj, aO[ck]);
+                myY[k] = li;
+                if (grp == 0 && lane == k) dsave[k] = d;
             }
 #pragma unroll
-            for (int c = ck + 1; c < 16; c++) {
-                const double cj = colD[pb][4 * c + v];
-                aD[c] = fma(-liD, cj, aD[c]);
-                aO[c] = fma(-liO, cj, aO[c]);
+            for (int c = ck; c < 16; c++) {
+                double cj = colD[pb][4 * c + v];
+                if (c == ck && v <= vk) cj = 0.0;         // column already eliminated
+                a[c] = fma(-li, cj, a[c]);
             }
         }
     }
     __syncthreads();
     if (it.blk == 0) {
         double *ld = P.Ldiag + P.sn_diag[s];
-        for (int idx = tid; idx < w * w; idx += 256) {
+        for (int idx = tid; idx < w * w; idx += 512) {
             const int i = idx % w, k = idx / w;
             ld[idx] = i > k ? Yt[0][i * 65 + k] : (i == k ? 1.0 : 0.0);
         }
@@ -308,13 +300,13 @@ k_factor_panel(DevPlan P, int item_begin, double dyn_eps, double dyn_delta) {
         if (tid == 0 && nreg) atomicAdd(P.flags + FL_NREG, nreg);
     }
     if (nr > 0) {
-        for (int idx = tid; idx < nr * w; idx += 256) {   // column-major panel rows
+        for (int idx = tid; idx < nr * w; idx += 512) {   // column-major panel rows
             const int row = idx % nr, k = idx / nr;
             pan[(lo + row) + (int64_t)k * r] = Yt[1][row * 65 + k];
         }
         // row-major copy (w contiguous doubles per row) for the backward solve's L21^T x
         double *lt = P.LT + P.lt_off[s] + (int64_t)(lo - w) * w;
-        for (int idx = tid; idx < nr * w; idx += 256) {
+        for (int idx = tid; idx < nr * w; idx += 512) {
             const int k = idx % w, row = idx / w;
             lt[idx] = Yt[1][row * 65 + k];
         }
@@ -647,6 +639,31 @@ k_update_dense(DevPlan P, int group_begin, int ngroups) {
                 if (ii < nrt && jj < wt) st_off(tp, (unsigned)(ii + jj * rt) * 8u, acc[tj][ti][reg]);
             }
         }
+}
+
+// ------------------------------------------------------------------------------------------
+// K4b (tiny contributions): the leaves of the elimination tree are 1-2 column supernodes whose few
+// rows land on scattered single entries of far ancestors (the dense root front).  One thread per
+// TARGET ENTRY sums its (source, row i, row j) pairs  sum_k L_s[i,k] d_k L_s[j,k]  in the fixed order
+// of the plan's gather list and subtracts once: no atomics, deterministic, fully parallel.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_update_gather(DevPlan P, int64_t ebegin, int64_t n) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const int64_t p0 = P.gath_pptr[ebegin + e], p1 = P.gath_pptr[ebegin + e + 1];
+    double acc = 0.0;
+    for (int64_t p = p0; p < p1; p++) {
+        const int s = P.gath_sn[p];
+        const int fs = P.sn_first[s];
+        const int K = P.sn_first[s + 1] - fs;
+        const int64_t r = P.sn_rowptr[s + 1] - P.sn_rowptr[s];
+        const double *li = P.Lx + P.gath_src[p];
+        const double *lj = li + P.gath_dj[p];
+        const double *dv = P.D + fs;
+        for (int k = 0; k < K; k++) acc = fma(li[k * r] * dv[k], lj[k * r], acc);
+    }
+    P.Lx[P.gath_tgt[ebegin + e]] -= acc;
 }
 
 // probe used by hipkkt's self test: D = A(16x4) * B(4x16) through the same MFMA form and the
@@ -1203,7 +1220,7 @@ void launch_factor_level(hipStream_t st, const DevPlan &P, int item_begin, int n
                            dyn_delta);
 }
 void launch_factor_panel(hipStream_t st, const DevPlan &P, int item_begin, int nitems, double dyn_eps, double dyn_delta) {
-    if (nitems > 0) hipLaunchKernelGGL(k_factor_panel, dim3(nitems), dim3(256), 0, st, P, item_begin, dyn_eps, dyn_delta);
+    if (nitems > 0) hipLaunchKernelGGL(k_factor_panel, dim3(nitems), dim3(512), 0, st, P, item_begin, dyn_eps, dyn_delta);
 }
 void launch_update_stage(hipStream_t st, const DevPlan &P, int group_begin, int ngroups) {
     if (ngroups > 0) hipLaunchKernelGGL(k_update_stage, dim3(ngroups), dim3(kUpdWaves * 64), 0, st, P, group_begin);
@@ -1214,6 +1231,9 @@ void launch_update_dense(hipStream_t st, const DevPlan &P, int group_begin, int 
         hipLaunchKernelGGL(k_update_dense<4>, dim3((ngroups + 3) / 4), dim3(256), 0, st, P, group_begin, ngroups);
     else                 // few tiles (just-in-time updates): split every tile over 4 wavefronts
         hipLaunchKernelGGL(k_update_dense<1>, dim3(ngroups), dim3(256), 0, st, P, group_begin, ngroups);
+}
+void launch_update_gather(hipStream_t st, const DevPlan &P, int64_t ebegin, int64_t n) {
+    if (n > 0) hipLaunchKernelGGL(k_update_gather, dim3(nblk(n)), dim3(256), 0, st, P, ebegin, n);
 }
 void launch_invert_diag(hipStream_t st, const DevPlan &P, int nsuper, int wmax) {
     const int ldl = wmax | 1;

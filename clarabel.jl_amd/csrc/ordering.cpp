@@ -39,7 +39,10 @@ enum : unsigned char { ST_VAR = 0, ST_ELEM = 1, ST_DEAD = 2, ST_DENSE = 3 };
 }  // namespace
 
 // Ap/Ai: upper-triangular (or any) CSC pattern of a symmetric matrix, 0-based; diagonal ignored.
-void amd_order(int n, const int64_t *Ap, const int64_t *Ai, double dense_scale, std::vector<int> &perm) {
+// hold (optional, size n): nodes with hold[i] != 0 are not eligible as pivots until every other node
+// has been eliminated ("variables last": the x-block of the KKT matrix is ordered after the cone
+// rows, i.e. the Schur-complement / normal-equations order, still with minimum-degree inside each part)
+void amd_order(int n, const int64_t *Ap, const int64_t *Ai, double dense_scale, std::vector<int> &perm, const char *hold) {
     perm.clear();
     perm.reserve(n);
     if (n == 0) return;
@@ -78,20 +81,34 @@ void amd_order(int n, const int64_t *Ap, const int64_t *Ai, double dense_scale, 
         if ((double)vadj[i].size() > thr) { state[i] = ST_DENSE; dense_nodes.push_back(i); }
     int nlive = n - (int)dense_nodes.size();
     DegreeLists dl(n);
+    std::vector<char> held(n, 0), inlist(n, 0);
+    bool holding = false;
     for (int i = 0; i < n; i++) {
         if (state[i] != ST_VAR) continue;
         int d = 0;
         for (int j : vadj[i]) d += (state[j] == ST_VAR);
         deg[i] = d;
+        if (hold && hold[i]) { held[i] = 1; holding = true; continue; }
         dl.insert(i, d);
+        inlist[i] = 1;
     }
 
     std::vector<int> Lp, newE, newA, bucket;
     int nel = 0;
     while (nel < nlive) {
         while (dl.mindeg < n && dl.head[dl.mindeg] < 0) dl.mindeg++;
+        if (dl.mindeg >= n) {
+            if (!holding) break;       // cannot happen: nel < nlive implies a live variable exists
+            holding = false;           // phase 2: release the held variables with their current degrees
+            dl.mindeg = n;
+            for (int i = 0; i < n; i++)
+                if (held[i] && state[i] == ST_VAR && nv[i] > 0) { dl.insert(i, deg[i]); inlist[i] = 1; }
+            std::fill(held.begin(), held.end(), 0);
+            continue;
+        }
         int p = dl.head[dl.mindeg];
         dl.remove(p, deg[p]);
+        inlist[p] = 0;
         // ---- form the new element Lp
         tag++;
         mark[p] = tag;
@@ -122,7 +139,7 @@ void amd_order(int n, const int64_t *Ap, const int64_t *Ai, double dense_scale, 
             }
         // ---- update the variables of Lp
         for (int i : Lp) {
-            dl.remove(i, deg[i]);
+            if (inlist[i]) { dl.remove(i, deg[i]); inlist[i] = 0; }
             newE.clear();
             newA.clear();
             int dsum = 0;
@@ -213,7 +230,7 @@ void amd_order(int n, const int64_t *Ap, const int64_t *Ai, double dense_scale, 
             d = std::min(d, nleft - nv[i]);
             if (d < 0) d = 0;
             deg[i] = d;
-            dl.insert(i, d);
+            if (!(holding && held[i])) { dl.insert(i, d); inlist[i] = 1; }
         }
         esize[p] = degme;
         if (ev.empty()) state[p] = ST_DEAD;

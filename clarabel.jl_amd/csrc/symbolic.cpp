@@ -95,9 +95,34 @@ std::string build_plan(int N, const int64_t *Ap, const int64_t *Ai, const int64_
             seen[o] = 1;
             perm0[k] = (int)o;
         }
+        P.ordering_used = 2;
     } else {
         amd_order(N, Ap, Ai, opt.amd_dense_scale, perm0);
         if ((int)perm0.size() != N) return "internal: ordering size mismatch";
+        if (opt.n_hold > 0 && opt.n_hold < N) {
+            // second candidate: eliminate the cone rows first, the variables last; keep the cheaper one
+            std::vector<int> perm1;
+            std::vector<char> hold(N, 0);
+            for (int i = 0; i < opt.n_hold; i++) hold[i] = 1;
+            amd_order(N, Ap, Ai, opt.amd_dense_scale, perm1, hold.data());
+            if ((int)perm1.size() == N) {
+                double cost[2];
+                const std::vector<int> *cand[2] = {&perm0, &perm1};
+                for (int c = 0; c < 2; c++) {
+                    std::vector<int> ip(N);
+                    for (int k = 0; k < N; k++) ip[(*cand[c])[k]] = k;
+                    std::vector<int64_t> up_;
+                    std::vector<int> ui_, par_, cnt_;
+                    permuted_upper(N, Ap, Ai, ip, up_, ui_);
+                    etree_counts(N, up_, ui_, par_, cnt_);
+                    double fl = 0;
+                    for (int j = 0; j < N; j++) fl += (double)cnt_[j] * cnt_[j] + 3.0 * cnt_[j];
+                    cost[c] = fl;
+                }
+                // only worth a different elimination order when the factorisation is expensive at all
+                if (cost[0] > 1e9 && cost[1] < 0.7 * cost[0]) { perm0.swap(perm1); P.ordering_used = 1; }
+            }
+        }
     }
     std::vector<int> iperm0(N);
     for (int k = 0; k < N; k++) iperm0[perm0[k]] = k;
@@ -430,8 +455,10 @@ std::string build_plan(int N, const int64_t *Ap, const int64_t *Ai, const int64_
             }
             const double ntasks = G.task_end - G.task_begin;
             const double fill = covered / (ntasks * kUpdRows * kMaxSnWidth);
-            G.dense = ((all_contig && fill >= 0.4) || fill >= 0.3) ? 1 : 0;
-            if (!G.dense) continue;
+            // dense enough per contribution -> matrix-core path; otherwise the contributions are single
+            // entries of tiny leaf supernodes -> per-entry gather
+            G.dense = ((all_contig && fill >= 0.4) || fill >= 0.3 || covered >= 64.0 * ntasks) ? 1 : 2;
+            if (G.dense != 1) continue;
             P.flops_update_dense += flops;
             // contributions that do not land contiguously get explicit tile maps (tile row / column ->
             // source row offset or -1): k_update_dense then gathers its operands through them
@@ -448,10 +475,51 @@ std::string build_plan(int N, const int64_t *Ap, const int64_t *Ai, const int64_
                 for (int j = 0; j < T.ncols; j++) P.upd_tmap[base + 64 + (srows[T.col_lo + j] - ft)] = (int16_t)j;
             }
         }
+        P.upd_stage_ngather.assign(P.nlevels, 0);
+        P.gath_stage_ptr.assign(P.nlevels + 1, 0);
+        P.gath_pptr.push_back(0);
+        struct Pair { int64_t tgt, src; int32_t dj, sn; };
+        std::vector<Pair> pairs;
         for (int l = 0; l < P.nlevels; l++) {
             auto b = P.upd_groups.begin() + P.upd_stage_ptr[l], e = P.upd_groups.begin() + P.upd_stage_ptr[l + 1];
-            auto mid = std::stable_partition(b, e, [](const UpdGroup &g) { return g.dense != 0; });
+            auto mid = std::stable_partition(b, e, [](const UpdGroup &g) { return g.dense == 1; });
+            auto mid2 = std::stable_partition(mid, e, [](const UpdGroup &g) { return g.dense == 2; });
             P.upd_stage_ndense[l] = (int)(mid - b);
+            P.upd_stage_ngather[l] = (int)(mid2 - mid);
+            // gather lists of this stage: every (target entry, source) pair, ordered by target entry and,
+            // within an entry, by the task order (fixed summation order)
+            pairs.clear();
+            for (auto it = mid; it != mid2; ++it) {
+                const UpdGroup &G = *it;
+                const int t = G.tgt, ft = P.sn_first[t], wt = P.sn_first[t + 1] - ft;
+                const int64_t rt = P.sn_rowptr[t + 1] - P.sn_rowptr[t];
+                for (int q = G.task_begin; q < G.task_end; q++) {
+                    const UpdTask &T = P.upd_tasks[q];
+                    const int *srows = &P.sn_rows[P.sn_rowptr[T.src]];
+                    const int *rel = &P.rel[T.rel_off];
+                    for (int j = 0; j < T.ncols; j++) {
+                        const int cpos = srows[T.col_lo + j] - ft;
+                        for (int i = 0; i < T.nrows; i++) {
+                            const int rpos = rel[T.row_lo + i - T.col_lo];
+                            if (rpos < wt && rpos < cpos) continue;     // strictly upper part of the diagonal block
+                            pairs.push_back({P.sn_panel[t] + rpos + (int64_t)cpos * rt, P.sn_panel[T.src] + T.row_lo + i,
+                                             (int32_t)(T.col_lo + j - (T.row_lo + i)), (int32_t)T.src});
+                        }
+                    }
+                }
+            }
+            std::stable_sort(pairs.begin(), pairs.end(), [](const Pair &x, const Pair &y) { return x.tgt < y.tgt; });
+            for (size_t q = 0; q < pairs.size(); q++) {
+                if (q == 0 || pairs[q].tgt != pairs[q - 1].tgt) {
+                    if (q) P.gath_pptr.push_back((int64_t)P.gath_src.size());
+                    P.gath_tgt.push_back(pairs[q].tgt);
+                }
+                P.gath_src.push_back(pairs[q].src);
+                P.gath_dj.push_back(pairs[q].dj);
+                P.gath_sn.push_back(pairs[q].sn);
+            }
+            if (!pairs.empty()) P.gath_pptr.push_back((int64_t)P.gath_src.size());
+            P.gath_stage_ptr[l + 1] = (int64_t)P.gath_tgt.size();
         }
     }
 

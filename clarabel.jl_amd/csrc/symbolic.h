@@ -35,7 +35,9 @@ struct UpdGroup {
     int32_t row_base;   // first target panel row of the block
     int32_t task_begin, task_end;
     int32_t nvt;        // number of wave-tasks (sum over tasks of ceil(ncols/16))
-    int32_t dense;      // 1: every task is contiguous and the tile is well filled -> k_update_dense
+    int32_t dense;      // 0: relative-index scatter (k_update_stage); 1: register tile, all sources accumulated
+                        // (k_update_dense, tile maps where a source does not land contiguously); 2: tiny scattered
+                        // contributions, summed per target entry (k_update_gather)
 };
 
 struct FacItem {
@@ -69,6 +71,8 @@ struct PlanOptions {
     int update_policy = 2;  // 0 right-looking, 1 left-looking, 2 batched right-looking
     int update_batch = 4;   // levels per batch for policy 2
     double amd_dense_scale = 1.5;
+    int n_hold = 0;            // > 0: also try the "variables last" order (nodes < n_hold held back) and keep
+                               // whichever order predicts fewer factor flops
     int front_min_panels = 4;  // chains at least this long are solved by the persistent front kernels (0 = never)
 };
 
@@ -100,7 +104,15 @@ struct HostPlan {
     std::vector<UpdGroup> upd_groups;
     std::vector<int> upd_stage_ptr;  // [nlevels+1] groups executed after factor(level)
     std::vector<int16_t> upd_tmap;
-    std::vector<int> upd_stage_ndense;  // [nlevels] the first ndense groups of a stage are dense tiles
+    std::vector<int> upd_stage_ndense;  // [nlevels] the first ndense groups of a stage are dense tiles,
+    std::vector<int> upd_stage_ngather; // [nlevels] the next ngather groups go through the per-entry gather lists
+    // per-entry gather lists (groups of kind 2): entries of one stage are contiguous
+    std::vector<int64_t> gath_stage_ptr;   // [nlevels+1] into gath_tgt
+    std::vector<int64_t> gath_tgt;         // Lx offset of the target entry
+    std::vector<int64_t> gath_pptr;        // [nentries+1] into the pair arrays
+    std::vector<int64_t> gath_src;         // Lx offset of L_s[i, 0]
+    std::vector<int32_t> gath_dj;          // offset of L_s[j, 0] relative to gath_src
+    std::vector<int32_t> gath_sn;          // source supernode (stride, width, pivots)
     double flops_update_dense = 0;   // part of flops_update executed by the dense-tile kernel
 
     std::vector<int64_t> u_off;  // [nsuper+1] offsets of each panel's off-diagonal rows in ubuf
@@ -125,6 +137,7 @@ struct HostPlan {
     int64_t diag_doubles = 0;
     int64_t ubuf_len = 0;
     int etree_height = 0;
+    int ordering_used = 0;       // 0 = minimum degree on K, 1 = cone rows first / variables last, 2 = user
     double flops_colcount = 0;   // sum_j c_j^2 + 3 c_j
     double flops_update = 0;     // executed flops of the dense update tasks (2*rows*cols*k)
     double flops_exec = 0;       // update + diagonal-block + TRSM flops actually executed
@@ -135,6 +148,7 @@ struct HostPlan {
 std::string build_plan(int N, const int64_t *Ap, const int64_t *Ai, const int64_t *user_perm,
                        const PlanOptions &opt, HostPlan &plan);
 
-void amd_order(int n, const int64_t *Ap, const int64_t *Ai, double dense_scale, std::vector<int> &perm);
+void amd_order(int n, const int64_t *Ap, const int64_t *Ai, double dense_scale, std::vector<int> &perm,
+               const char *hold = nullptr);
 
 }  // namespace hipkkt

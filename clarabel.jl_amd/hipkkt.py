@@ -204,7 +204,7 @@ class Handle:
         o = np.zeros(8)
         self.L.hipkkt_get_cost_model(self.h, o)
         return dict(flops_factor=o[0], flops_exec=o[1], flops_solve=o[2], bytes_factor=o[3], bytes_solve=o[4],
-                    bytes_spmv=o[5], flops_update=o[6])
+                    bytes_spmv=o[5], flops_update=o[6], flops_update_dense=o[7])
 
     def timing(self):
         o = np.zeros(8)

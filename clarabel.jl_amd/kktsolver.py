@@ -7,10 +7,15 @@ library through the C ABI (include/hipkkt.h).  The Julia file a maintainer would
 INTEGRATION.md; this class is its Python twin so that parity tests read like the reference's."""
 from __future__ import annotations
 
+import os
+
 import numpy as np
 
 from . import hipkkt
 from .settings import Settings
+
+
+_DEBUG = os.environ.get("HIPKKT_DEBUG", "0") == "1"
 
 
 class HipKKTSolver:
@@ -54,6 +59,8 @@ class HipKKTSolver:
                                         st.static_regularization_proportional)
         self.diagonal_regularizer = eps
         self.last_nreg = nreg
+        if _DEBUG:
+            print(f"[hipkkt] refactor ok={ok} eps={eps:.3e} dynamic_regularisations={nreg}")
         return ok
 
     # ref: kktsolver_setrhs!, :313-327
@@ -69,6 +76,8 @@ class HipKKTSolver:
         self.last_ir_steps = steps
         self.total_ir_steps += steps
         self.nsolves += 1
+        if _DEBUG:
+            print(f"[hipkkt] solve ok={ok} ir_steps={steps}")
         return ok
 
     # ref: kktsolver_update_P!/A!, :374-386

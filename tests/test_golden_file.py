@@ -81,11 +81,15 @@ def test_hip_path_meets_golden_file(e):
     assert isinstance(s.kktsystem.kktsolver, HipKKTSolver)
     sol = s.solve()
     check_reference_entry(e, sol)
+    # regression against the oracle's stored run.  The stored run used the NATURAL elimination order, the
+    # product uses its own fill-reducing order, so the two IPM runs differ by rounding amplified through the
+    # iterations: they agree to the IPM's own stopping tolerance (1e-8), not to the same-order parity bound
+    # (1e-10, enforced in tests/test_gpu_kkt.py where the oracle is handed the product's permutation).
     o = next(r for r in GOLD["oracle"] if r["name"] == e["name"])
     assert sol.iterations == o["iterations"]
     if o["obj"] is not None:
-        assert abs(sol.obj_val - o["obj"]) <= 1e-10 * max(1.0, abs(o["obj"]))
-        assert abs(sol.r_prim - o["r_prim"]) <= 1e-10 and abs(sol.r_dual - o["r_dual"]) <= 1e-10
+        assert abs(sol.obj_val - o["obj"]) <= 1e-8 * max(1.0, abs(o["obj"]))
+        assert abs(sol.r_prim - o["r_prim"]) <= 1e-8 and abs(sol.r_dual - o["r_dual"]) <= 1e-8
 
 
 @pytest.mark.gpu

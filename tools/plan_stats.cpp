@@ -18,6 +18,7 @@ int main(int argc, char **argv) {
     PlanOptions opt;
     if (argc > 2) opt.max_width = atoi(argv[2]);
     if (argc > 3) opt.update_policy = atoi(argv[3]);
+    if (argc > 4) opt.n_hold = atoi(argv[4]);
     HostPlan P;
     auto t0 = std::chrono::steady_clock::now();
     std::string err = build_plan((int)N, Ap.data(), Ai.data(), nullptr, opt, P);
@@ -26,7 +27,7 @@ int main(int argc, char **argv) {
     printf("N %d nnzK %ld nnzL %ld nsuper %d nlevels %d panel_doubles %ld flops_colcount %.3e flops_update %.3e flops_exec %.3e plan_s %.3f\n",
            P.N, (long)P.nnzK, (long)P.nnzL, P.nsuper, P.nlevels, (long)P.panel_doubles, P.flops_colcount, P.flops_update, P.flops_exec,
            std::chrono::duration<double>(t1 - t0).count());
-    printf("ntasks %zu ngroups %zu\n", P.upd_tasks.size(), P.upd_groups.size());
+    printf("ntasks %zu ngroups %zu ordering_used %d fronts %zu\n", P.upd_tasks.size(), P.upd_groups.size(), P.ordering_used, P.fronts.size());
     printf("%5s %7s %7s %7s %9s %12s %8s %8s\n", "lvl", "nsn", "maxw", "maxr", "sum_rw", "upd_flops", "groups", "facitems");
     std::vector<double> lf(P.nlevels, 0.0), lfd(P.nlevels, 0.0), fills(P.nlevels, 0.0);
     for (int l = 0; l < P.nlevels; l++)
@@ -38,6 +39,20 @@ int main(int argc, char **argv) {
                 if (P.upd_groups[g].dense) lfd[l] += 2.0 * t.nrows * t.ncols * w;
                 fills[l] += (double)t.nrows * t.ncols / 4096.0;
             }
+    {   // pair statistics of the non-dense groups: sum nrows*ncols, by stage
+        for (int l = 0; l < P.nlevels; l++) {
+            double pairs = 0, pk = 0; int ng = 0;
+            for (int g = P.upd_stage_ptr[l] + P.upd_stage_ndense[l]; g < P.upd_stage_ptr[l + 1]; g++) {
+                ng++;
+                for (int q = P.upd_groups[g].task_begin; q < P.upd_groups[g].task_end; q++) {
+                    const UpdTask &t = P.upd_tasks[q];
+                    pairs += (double)t.nrows * t.ncols;
+                    pk += (double)t.nrows * t.ncols * (P.sn_first[t.src + 1] - P.sn_first[t.src]);
+                }
+            }
+            if (ng) printf("sparse stage %d: groups %d pairs %.3e fma %.3e\n", l, ng, pairs, pk);
+        }
+    }
     for (int l = 0; l < P.nlevels; l++) {
         int maxw = 0; int64_t maxr = 0, srw = 0;
         for (int q = P.lvl_ptr[l]; q < P.lvl_ptr[l + 1]; q++) {
