@@ -48,6 +48,9 @@ struct GraphSlot {
 struct hipkkt_solver {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t side = nullptr;          // far Schur updates run here, overlapped with the critical path
+    std::vector<hipEvent_t> fork_events;
+    bool use_side = true;
     hipkkt_opts opts{};
     bool l1 = false;
     KKTImage img;      // L1: assembled image; L0: colptr/rowval/nzval/dsigns copied in
@@ -129,6 +132,8 @@ struct hipkkt_solver {
         if (h_flags) hipHostFree(h_flags);
         for (hipEvent_t e : {ev0, ev1, ev2, ev3})
             if (e) hipEventDestroy(e);
+        for (hipEvent_t e : fork_events) hipEventDestroy(e);
+        if (side) hipStreamDestroy(side);
         if (stream) hipStreamDestroy(stream);
     }
 };
@@ -138,7 +143,17 @@ namespace {
 void init_runtime(hipkkt_solver *S) {
     { const char *pz = getenv("HIPKKT_POISON"); S->poison = pz && pz[0] == '1'; }
     HK_CHECK(hipSetDevice(S->device));
-    HK_CHECK(hipStreamCreateWithFlags(&S->stream, hipStreamNonBlocking));
+    {
+        int lo = 0, hi = 0;   // the critical path (panel factorisations) gets the higher priority
+        HK_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        HK_CHECK(hipStreamCreateWithPriority(&S->stream, hipStreamNonBlocking, hi));
+        HK_CHECK(hipStreamCreateWithPriority(&S->side, hipStreamNonBlocking, lo));
+        // measured on MI355X (cfg 2a): forking the far updates gives no net gain inside a hipGraph -- the far
+        // kernel fills every CU and the panel kernels on the critical path slow down by what the overlap
+        // saves -- so the fork is opt-in (HIPKKT_SIDE_STREAM=1)
+        const char *ns = getenv("HIPKKT_SIDE_STREAM");
+        S->use_side = ns && ns[0] == '1';
+    }
     for (hipEvent_t *e : {&S->ev0, &S->ev1, &S->ev2, &S->ev3}) HK_CHECK(hipEventCreate(e));
     HK_CHECK(hipHostMalloc((void **)&S->h_scal, SC_COUNT * sizeof(double), hipHostMallocDefault));
     HK_CHECK(hipHostMalloc((void **)&S->h_flags, FL_COUNT * sizeof(int), hipHostMallocDefault));
@@ -308,11 +323,11 @@ void enqueue_factor_level(hipkkt_solver *S, int l) {
 // Schur-complement updates applied after level l is factored: dense register tiles (matrix cores),
 // per-entry gather lists (tiny scattered contributions), relative-index scatter (whatever is left).
 // The three kinds own disjoint target tiles, so their order inside a stage is immaterial.
-void enqueue_updates(hipkkt_solver *S, int l) {
+void enqueue_updates(hipkkt_solver *S, int l, bool split_far = false) {
     const HostPlan &P = S->plan;
     hipStream_t st = S->stream;
     const int g0 = P.upd_stage_ptr[l], nd = P.upd_stage_ndense[l], ng = P.upd_stage_ngather[l];
-    launch_update_dense(st, S->dp, g0, nd);
+    launch_update_dense(st, S->dp, g0, nd - (split_far ? P.upd_stage_nfar[l] : 0));
     launch_update_gather(st, S->dp, P.gath_stage_ptr[l], P.gath_stage_ptr[l + 1] - P.gath_stage_ptr[l]);
     launch_update_stage(st, S->dp, g0 + nd + ng, P.upd_stage_ptr[l + 1] - g0 - nd - ng);
 }
@@ -325,10 +340,36 @@ void enqueue_factor(hipkkt_solver *S, int static_enable, double eps_const, doubl
     launch_maxabs_gather(st, S->dp.kval, S->d_diag_full, S->N, (unsigned long long *)S->dp.scal + SC_MAXDIAG);
     HK_CHECK(hipMemsetAsync(S->dp.Lx, 0, (size_t)P.panel_doubles * sizeof(double), st));
     launch_init_panels(st, S->dp, S->nnzK, static_enable, eps_const, eps_prop);
+    // Far updates (targets more than `lookahead` levels ahead) are forked to the side stream right after the
+    // level's factorisation and joined before the next batch end touches the same targets (symbolic.h).
+    auto new_event = [&]() {
+        hipEvent_t e = nullptr;
+        HK_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        S->fork_events.push_back(e);
+        return e;
+    };
+    const bool fork = S->use_side && P.lookahead > 0;
+    hipEvent_t pending = nullptr;
+    int pending_level = -1;
     for (int l = 0; l < P.nlevels; l++) {
         enqueue_factor_level(S, l);
-        enqueue_updates(S, l);
+        const int nfar = fork ? P.upd_stage_nfar[l] : 0;
+        if (pending && (nfar > 0 || l >= pending_level + P.lookahead)) {
+            HK_CHECK(hipStreamWaitEvent(st, pending, 0));
+            pending = nullptr;
+        }
+        enqueue_updates(S, l, nfar > 0);
+        if (nfar > 0) {   // forked AFTER the near updates: the far tiles must not compete with them for the CUs
+            hipEvent_t e1 = new_event(), e2 = new_event();
+            HK_CHECK(hipEventRecord(e1, st));
+            HK_CHECK(hipStreamWaitEvent(S->side, e1, 0));
+            launch_update_dense(S->side, S->dp, P.upd_stage_ptr[l] + P.upd_stage_ndense[l] - nfar, nfar);
+            HK_CHECK(hipEventRecord(e2, S->side));
+            pending = e2;
+            pending_level = l;
+        }
     }
+    if (pending) HK_CHECK(hipStreamWaitEvent(st, pending, 0));
     launch_invert_diag(st, S->dp, P.nsuper, S->wmax_all);
 }
 

@@ -476,6 +476,7 @@ std::string build_plan(int N, const int64_t *Ap, const int64_t *Ai, const int64_
             }
         }
         P.upd_stage_ngather.assign(P.nlevels, 0);
+        P.upd_stage_nfar.assign(P.nlevels, 0);
         P.gath_stage_ptr.assign(P.nlevels + 1, 0);
         P.gath_pptr.push_back(0);
         struct Pair { int64_t tgt, src; int32_t dj, sn; };
@@ -483,6 +484,12 @@ std::string build_plan(int N, const int64_t *Ap, const int64_t *Ai, const int64_
         for (int l = 0; l < P.nlevels; l++) {
             auto b = P.upd_groups.begin() + P.upd_stage_ptr[l], e = P.upd_groups.begin() + P.upd_stage_ptr[l + 1];
             auto mid = std::stable_partition(b, e, [](const UpdGroup &g) { return g.dense == 1; });
+            if (opt.update_policy == 2) {   // dense tiles: near targets first, far targets last
+                const int B = std::max(1, opt.update_batch);
+                auto midf = std::stable_partition(b, mid, [&](const UpdGroup &g) { return P.sn_level[g.tgt] <= l + B; });
+                P.upd_stage_nfar[l] = (int)(mid - midf);
+                P.lookahead = B;
+            }
             auto mid2 = std::stable_partition(mid, e, [](const UpdGroup &g) { return g.dense == 2; });
             P.upd_stage_ndense[l] = (int)(mid - b);
             P.upd_stage_ngather[l] = (int)(mid2 - mid);

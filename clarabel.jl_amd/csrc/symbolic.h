@@ -106,6 +106,10 @@ struct HostPlan {
     std::vector<int16_t> upd_tmap;
     std::vector<int> upd_stage_ndense;  // [nlevels] the first ndense groups of a stage are dense tiles,
     std::vector<int> upd_stage_ngather; // [nlevels] the next ngather groups go through the per-entry gather lists
+    std::vector<int> upd_stage_nfar;    // [nlevels] the LAST nfar dense groups of a stage update targets more than
+                                        // `update_batch` levels ahead: nothing needs them before the next batch end,
+                                        // so they run on a side stream concurrently with the next panels' critical path
+    int lookahead = 0;                  // = update_batch when far groups were separated, else 0
     // per-entry gather lists (groups of kind 2): entries of one stage are contiguous
     std::vector<int64_t> gath_stage_ptr;   // [nlevels+1] into gath_tgt
     std::vector<int64_t> gath_tgt;         // Lx offset of the target entry

@@ -63,8 +63,8 @@ int main(int argc, char **argv) {
         }
         int ntk = 0;
         for (int g = P.upd_stage_ptr[l]; g < P.upd_stage_ptr[l + 1]; g++) ntk += P.upd_groups[g].task_end - P.upd_groups[g].task_begin;
-        printf("%5d %7d %7d %7ld %9ld %12.3e %8d %8d   dense: %6d groups %10.3e flops; tasks %7d avgfill %.2f\n", l, P.lvl_ptr[l + 1] - P.lvl_ptr[l], maxw, (long)maxr, (long)srw, lf[l],
-               P.upd_stage_ptr[l + 1] - P.upd_stage_ptr[l], P.fac_lvl_ptr[l + 1] - P.fac_lvl_ptr[l], P.upd_stage_ndense[l], lfd[l], ntk, ntk ? fills[l] / ntk : 0.0);
+        printf("%5d %7d %7d %7ld %9ld %12.3e %8d %8d   dense: %6d groups (far %5d) %10.3e flops; tasks %7d avgfill %.2f\n", l, P.lvl_ptr[l + 1] - P.lvl_ptr[l], maxw, (long)maxr, (long)srw, lf[l],
+               P.upd_stage_ptr[l + 1] - P.upd_stage_ptr[l], P.fac_lvl_ptr[l + 1] - P.fac_lvl_ptr[l], P.upd_stage_ndense[l], P.upd_stage_nfar[l], lfd[l], ntk, ntk ? fills[l] / ntk : 0.0);
     }
     return 0;
 }
