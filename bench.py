@@ -43,6 +43,64 @@ def make_problem(cfg, seed_shift=0):
     raise SystemExit(f"unknown config {cfg}")
 
 
+def pmc_traffic(cfg):
+    """HBM bytes per launch of the dominant kernel (k_update_dense<4>) from the committed rocprofv3 PMC passes
+    (FETCH_SIZE and WRITE_SIZE collected in separate runs of this very command, tools/pmc_summary.py; read side
+    doubled = the gfx950 FETCH_SIZE correction).  The counters cannot be collected from inside the timed run,
+    so the figure is read from profiles/ for the workload it was measured on, else null."""
+    if cfg != "2a":
+        return None
+    path = os.path.join(ROOT, "profiles", "r01_c_cfg2a_pmc_hbm_traffic.txt")
+    try:
+        for line in open(path):
+            if "k_update_denseILi4" in line:
+                f = line.split()
+                return {"bytes_per_launch": round((float(f[4]) + float(f[5])) * 1e6), "read_x2_MB": float(f[4]),
+                        "write_MB": float(f[5]), "source": "profiles/r01_c_cfg2a_pmc_hbm_traffic.txt"}
+    except OSError:
+        pass
+    return None
+
+
+def bench_batch(args, cl, torch, dist, rank, world, local):
+    """cfg 4: the 256 seeded Maros-Meszaros-like QPs (problems.batch_problem, seeds 100..355) sharded round-robin
+    over the ranks; a step = one problem solved end-to-end on the HIP path (symbolic set-up + IPM loop with the
+    numpy stand-in caller).  value = IPM iterations / s over the whole job."""
+    from clarabel_jl_amd import batch, problems
+
+    dev = torch.device("cuda", local)
+    mine = batch.shard(256, rank, world)
+    steps = min(args.steps, len(mine)) if args.steps > 0 else len(mine)
+    iters = [0]
+    stats = {"solved": 0}
+
+    def step(i):
+        P, q, A, b, cones = problems.batch_problem(100 + mine[i % len(mine)])
+        sol = cl.Solver(P, q, A, b, cones, cl.Settings(device_id=local)).solve()
+        iters[0] += sol.iterations
+        stats["solved"] += sol.status == "SOLVED"
+
+    batch.timed_steps(step, 0, args.warmup)
+    iters[0] = 0
+    stats["solved"] = 0
+    elapsed = batch.timed_steps(lambda i: step(i + args.warmup), steps, 0, dist=dist, device_sync=torch.cuda.synchronize, reduce_device=dev)
+    total_iters = batch.gather_counts(iters[0], dist, dev)
+    total_solved = batch.gather_counts(stats["solved"], dist, dev)
+    total_probs = batch.gather_counts(steps, dist, dev)
+    if rank == 0:
+        print(json.dumps({
+            "metric": "IPM iterations/sec + KKT factor+solve ms, 10k-var sparse QP, 1/2/4/8 GPU",
+            "value": round(total_iters / elapsed, 3), "unit": "IPM-iterations/s (whole solves incl. set-up, batch of independent problems)",
+            "n_gpus": world, "steps": steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / max(1, steps), 3),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "batch of 256 Maros-Meszaros-like QPs (cfg 4), seeds 100..355, sharded round-robin",
+                       "problems_solved": total_probs, "status_solved": total_solved,
+                       "parallelism": f"{world} rank(s), {len(mine)} problems on rank 0"},
+            "problems_per_s": round(total_probs / elapsed, 3), "roofline": None, "cpu_baseline": None}))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -73,6 +131,9 @@ def main():
 
     import clarabel_jl_amd as cl
     from clarabel_jl_amd.kktsolver import HipKKTSolver
+
+    if args.config == "4":
+        return bench_batch(args, cl, torch, dist, rank, world, local)
 
     (P, q, A, b, cones), workload = make_problem(args.config, seed_shift=rank)
 
@@ -166,7 +227,7 @@ def main():
     upd = float(np.median(upd_ms))
     achieved = cm["flops_update"] / (upd * 1e-3) / 1e12 if upd > 0 else 0.0
     roofline = dict(bound="mfma", achieved=round(achieved, 3), peak=F64_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
-                    frac=round(achieved / F64_MFMA_PEAK_TFLOPS, 4), traffic=None,
+                    frac=round(achieved / F64_MFMA_PEAK_TFLOPS, 4), traffic=pmc_traffic(args.config),
                     kernel="k_update_dense (+ k_update_gather / k_update_stage for the sparse tiles)",
                     flops_per_refactor=cm["flops_update"], flops_dense_tiles=cm.get("flops_update_dense"),
                     launches_per_refactor=h.nlevels - 1, ms_per_refactor=round(upd, 4),

@@ -1,0 +1,100 @@
+"""BASELINE.json's configs at FULL size on the GPU, checked through size-independent properties (the oracle
+needs minutes per factorisation at these sizes, so it is not run here):
+  * the refined solve satisfies the reference's own stopping rule against the TRUE (unregularised) K,
+    recomputed on the host with scipy from the library's resident image;
+  * linearity of the factorisation's solve operator;
+  * determinism: refactor + solve twice -> bit-identical results;
+  * the end-to-end IPM ends SOLVED with consistent primal/dual objectives.
+Plus the batch config (cfg 4): a sample of the 256 seeded problems against the oracle."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import clarabel_jl_amd as cl
+from clarabel_jl_amd import problems
+from clarabel_jl_amd.kktsolver import HipKKTSolver
+from tests.fixtures import scale_cones
+
+pytestmark = pytest.mark.gpu
+
+FULL = {
+    "cfg2a": lambda: problems.random_sparse_qp(10000, 20000, 2, 3, 1),
+    "cfg2b": lambda: problems.random_sparse_qp(10000, 20000, 2, 4, 2, window=50),
+    "cfg3": lambda: problems.portfolio_socp(seed=3),
+    "cfg5": lambda: problems.sdp_blocks(seed=5),
+}
+
+
+def _prep(prob):
+    P, q, A, b, specs = prob
+    cones = cl.CompositeCone(cl.cones_new_collapsed(specs))
+    Pt = sp.triu(sp.csc_matrix(P), format="csc")
+    Pt.sort_indices()
+    A = sp.csc_matrix(A)
+    A.sort_indices()
+    return Pt, A, cones
+
+
+def _sym_K(h):
+    colptr, rowval, nzval = h.kkt()
+    U = sp.csc_matrix((nzval, rowval, colptr), shape=(h.N, h.N))
+    return U + U.T - sp.diags(U.diagonal())
+
+
+@pytest.mark.parametrize("name", list(FULL))
+def test_full_size_solve_properties(name):
+    rng = np.random.default_rng(11)
+    Pt, A, cones = _prep(FULL[name]())
+    m, n = A.shape
+    st = cl.Settings()
+    hk = HipKKTSolver(Pt, A, cones, m, n, st)
+    scale_cones(cones, rng)
+    assert hk.kktsolver_update(cones)
+    K = _sym_K(hk.h)
+    N, p = hk.h.N, hk.h.p
+    # refined solve vs the true K (reference stopping rule: abstol 1e-12 + reltol 1e-13 * |b|, or no further
+    # improvement by the stop ratio; 1e-9 relative is the bound asserted at every size)
+    rx, rz = rng.standard_normal(n), rng.standard_normal(m)
+    lx, lz = np.zeros(n), np.zeros(m)
+    hk.kktsolver_setrhs(rx, rz)
+    assert hk.kktsolver_solve(lx, lz)
+    if p == 0:
+        b = np.concatenate([rx, rz])
+        res = b - K @ np.concatenate([lx, lz])
+        assert np.max(np.abs(res)) <= 1e-9 * max(1.0, np.max(np.abs(b)))
+    # linearity of x = K_fact^-1 b
+    b1, b2 = rng.standard_normal(N), rng.standard_normal(N)
+    x1, x2, x12 = hk.h.ldl_solve(b1), hk.h.ldl_solve(b2), hk.h.ldl_solve(2.0 * b1 - 3.0 * b2)
+    scale = max(1.0, np.max(np.abs(x1)), np.max(np.abs(x2)))
+    assert np.max(np.abs(x12 - (2.0 * x1 - 3.0 * x2))) <= 1e-8 * scale
+    # K_fact x = b up to the static regulariser: residual against K + eps*diag(signs)
+    eps = hk.diagonal_regularizer
+    Kf = K + sp.diags(eps * hk.h.dsigns().astype(float))
+    assert np.max(np.abs(Kf @ x1 - b1)) <= 1e-7 * max(1.0, np.max(np.abs(x1)) * abs(K).sum(axis=1).max())
+    # determinism
+    assert hk.kktsolver_update(cones)
+    assert np.array_equal(hk.h.ldl_solve(b1), x1)
+
+
+@pytest.mark.parametrize("name", ["cfg2a", "cfg3", "cfg5"])
+def test_full_size_ipm_end_to_end(name):
+    P, q, A, b, cones = FULL[name]()
+    sol = cl.Solver(P, q, A, b, cones, cl.Settings()).solve()
+    assert sol.status == "SOLVED"
+    assert abs(sol.obj_val - sol.obj_val_dual) <= 1e-6 * max(1.0, abs(sol.obj_val))
+    assert sol.r_prim < 1e-8 and sol.r_dual < 1e-8
+
+
+@pytest.mark.parametrize("seed", [100, 137, 201, 255, 300, 355])
+def test_batch_config_sample_matches_oracle(seed, oracle_factory):
+    """cfg 4: seeds 100..355 are the 256 problems of the batch; a sample against the oracle (same order)"""
+    P, q, A, b, cones = problems.batch_problem(seed)
+    sg = cl.Solver(P, q, A, b, cones, cl.Settings())
+    solg = sg.solve()
+    perm = sg.kktsystem.kktsolver.h.perm()
+    solc = cl.Solver(P, q, A, b, cones, cl.Settings(), kktsolver_factory=lambda *a: oracle_factory(*a, ordering=perm)).solve()
+    assert solg.status == solc.status
+    assert abs(solg.iterations - solc.iterations) <= 1
+    if solg.status == "SOLVED" and solg.iterations == solc.iterations:
+        assert abs(solg.obj_val - solc.obj_val) <= 1e-8 * max(1.0, abs(solc.obj_val))
+        assert abs(solg.r_prim - solc.r_prim) <= 1e-9 and abs(solg.r_dual - solc.r_dual) <= 1e-9
