@@ -44,7 +44,14 @@ struct DevPlan {
     const FrontPanel *front_panels;
     const int64_t *front_gptr;
     const int *front_gidx;
-    int *front_sync;   // per front: {ticket, error, flags[np]} (zeroed before every front kernel)
+    int *front_sync;
+    // persistent level-free sweeps over the regular (non-front) supernodes: dependency counters and lists
+    const FacItem *pbwd_items;   // backward order: per level (descending) partial items, then finals (blk = -1)
+    const int *dep_total;        // [nsuper] forward items of all same-segment regular children (what fdone[s] must reach)
+    const int *sn_nitems;        // forward items (64-row blocks) of a supernode
+    const int *sn_bparent;       // same-segment regular parent, or -1
+    int *seg_sync;               // [0,nseg) forward tickets, [nseg,2nseg) backward tickets, then per-supernode counters:
+    int nseg;                    //   fdone[nsuper], bdone[nsuper], pdone[nsuper]; error word last   // per front: {ticket, error, flags[np]} (zeroed before every front kernel)
     // numeric state
     double *kval;    // resident, UNREGULARISED triu KKT values (original nz order)
     double *Lx;      // supernodal panels

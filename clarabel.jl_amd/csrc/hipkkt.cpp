@@ -65,6 +65,14 @@ struct hipkkt_solver {
     std::vector<FacItem> slv_items, bwd_items;
     std::vector<int> slv_lvl_ptr, bwd_lvl_ptr;
     std::vector<int> reg_lvl_sn, reg_lvl_ptr;   // supernodes of every level that are NOT front panels
+    // persistent sweeps over the regular supernodes: segments = level ranges between front kernels
+    bool use_persist = true;
+    int nseg = 0;
+    std::vector<int> seg_of_level;               // [nlevels]
+    std::vector<int> fseg_ptr, bseg_ptr;         // [nseg+1] into slv_items / pbwd_items
+    std::vector<int> seg_lo, seg_hi, seg_lstar;  // per segment: level range [lo, hi] and the first level handled by the
+                                                 // persistent kernels (wide bottom levels keep one launch per level)
+    std::vector<FacItem> pbwd_items;
     int wmax_all = 1;
     std::vector<int64_t> p_off;
 
@@ -170,7 +178,11 @@ void setup_device(hipkkt_solver *S) {
     }
     for (void *p : S->allocs) hipFree(p);
     S->allocs.clear();
-    S->slv_items.clear(); S->bwd_items.clear(); S->reg_lvl_sn.clear();
+    S->slv_items.clear(); S->bwd_items.clear(); S->reg_lvl_sn.clear(); S->pbwd_items.clear();
+    {
+        const char *np_ = getenv("HIPKKT_NO_PERSIST");
+        S->use_persist = !(np_ && np_[0] == '1');
+    }
     S->soc_off.clear(); S->soc_of_sparse.clear();
     S->nsoc = 0; S->soc_total = 0; S->wmax_all = 1;
     S->stage_cap = 0; S->d_stage = nullptr; S->d_stage_idx = nullptr;
@@ -206,6 +218,70 @@ void setup_device(hipkkt_solver *S) {
         S->slv_lvl_ptr[l + 1] = (int)S->slv_items.size();
         S->bwd_lvl_ptr[l + 1] = (int)S->bwd_items.size();
         S->reg_lvl_ptr[l + 1] = (int)S->reg_lvl_sn.size();
+    }
+    // ---- persistent sweeps: segments, dependency lists, backward item order
+    std::vector<int> dep_ptr(P.nsuper + 1, 0), dep_idx, sn_nitems(P.nsuper, 0), sn_bparent(P.nsuper, -1);
+    {
+        S->seg_of_level.assign(P.nlevels, 0);
+        std::vector<char> boundary(P.nlevels + 1, 0);
+        for (const FrontDesc &F : P.fronts) boundary[F.level_last] = 1;   // the front runs after regular level level_last
+        int sg = 0;
+        for (int l = 0; l < P.nlevels; l++) { S->seg_of_level[l] = sg; if (boundary[l]) sg++; }
+        S->nseg = sg + 1;
+        auto seg_of = [&](int s) { return S->seg_of_level[P.sn_level[s]]; };
+        // wide bottom levels (thousands of leaf supernodes) are cheaper as one launch per level; the persistent
+        // kernels take over from the first level with fewer than kPersistMaxItems items
+        const int kPersistMaxItems = 1024;
+        S->seg_lo.assign(S->nseg, P.nlevels); S->seg_hi.assign(S->nseg, -1); S->seg_lstar.assign(S->nseg, 0);
+        for (int l = 0; l < P.nlevels; l++) {
+            const int g = S->seg_of_level[l];
+            S->seg_lo[g] = std::min(S->seg_lo[g], l);
+            S->seg_hi[g] = std::max(S->seg_hi[g], l);
+        }
+        for (int g = 0; g < S->nseg; g++) {
+            int ls = S->seg_lo[g];
+            while (ls <= S->seg_hi[g] && S->slv_lvl_ptr[ls + 1] - S->slv_lvl_ptr[ls] >= kPersistMaxItems) ls++;
+            S->seg_lstar[g] = ls;
+        }
+        auto persistent = [&](int s) { return P.sn_level[s] >= S->seg_lstar[seg_of(s)]; };
+        std::vector<std::vector<int>> kids(P.nsuper);
+        for (int c = 0; c < P.nsuper; c++) {
+            const int p = P.sn_parent[c];
+            if (P.sn_front[c] >= 0) continue;
+            const int64_t r = P.sn_rowptr[c + 1] - P.sn_rowptr[c];
+            const int w = P.sn_first[c + 1] - P.sn_first[c];
+            sn_nitems[c] = (int)std::max<int64_t>(1, (r - w + 63) / 64);
+            if (p >= 0 && P.sn_front[p] < 0 && seg_of(p) == seg_of(c) && persistent(c) && persistent(p)) {
+                kids[p].push_back(c);
+                sn_bparent[c] = p;
+            }
+        }
+        for (int s = 0; s < P.nsuper; s++) {
+            dep_ptr[s + 1] = dep_ptr[s] + (int)kids[s].size();
+            dep_idx.insert(dep_idx.end(), kids[s].begin(), kids[s].end());
+        }
+        // forward segments: slv_items is level-ordered, a segment is a level range
+        S->fseg_ptr.assign(2 * S->nseg, 0);   // [2g] first persistent item, [2g+1] end, of segment g
+        for (int g = 0; g < S->nseg; g++) {
+            const int ls = std::min(S->seg_lstar[g], P.nlevels);
+            S->fseg_ptr[2 * g] = S->seg_hi[g] >= 0 ? S->slv_lvl_ptr[std::min(ls, S->seg_hi[g] + 1)] : 0;
+            S->fseg_ptr[2 * g + 1] = S->seg_hi[g] >= 0 ? S->slv_lvl_ptr[S->seg_hi[g] + 1] : 0;
+        }
+        // backward items: segments in DESCENDING order of level; inside a segment levels descending, partial
+        // blocks of a level before its finalisers
+        S->bseg_ptr.assign(S->nseg + 1, 0);
+        for (int g = S->nseg - 1; g >= 0; g--) {
+            for (int l = P.nlevels - 1; l >= 0; l--) {
+                if (S->seg_of_level[l] != g || l < S->seg_lstar[g]) continue;
+                for (int q = S->reg_lvl_ptr[l]; q < S->reg_lvl_ptr[l + 1]; q++) {
+                    const int s = S->reg_lvl_sn[q];
+                    if (sn_nitems[s] > 1)
+                        for (int b = 0; b < sn_nitems[s]; b++) S->pbwd_items.push_back({s, b});
+                }
+                for (int q = S->reg_lvl_ptr[l]; q < S->reg_lvl_ptr[l + 1]; q++) S->pbwd_items.push_back({S->reg_lvl_sn[q], -1});
+            }
+            S->bseg_ptr[S->nseg - g] = (int)S->pbwd_items.size();   // bseg_ptr is indexed by launch order
+        }
     }
     std::vector<signed char> sgn_perm(N), kdiag(S->nnzK, 0);
     for (int k = 0; k < N; k++) sgn_perm[k] = (signed char)(S->img.dsigns[P.perm[k]] >= 0 ? 1 : -1);
@@ -247,6 +323,21 @@ void setup_device(hipkkt_solver *S) {
     D.front_panels = S->upload(P.front_panels);
     D.front_gptr = S->upload(P.front_gptr);
     D.front_gidx = S->upload(P.front_gidx);
+    D.pbwd_items = S->upload(S->pbwd_items);
+    {
+        std::vector<int> dep_total(P.nsuper, 0);
+        for (int s = 0; s < P.nsuper; s++)
+            for (int q = dep_ptr[s]; q < dep_ptr[s + 1]; q++) dep_total[s] += sn_nitems[dep_idx[q]];
+        D.dep_total = S->upload(dep_total);
+    }
+    D.sn_nitems = S->upload(sn_nitems);
+    D.sn_bparent = S->upload(sn_bparent);
+    D.nseg = S->nseg;
+    {
+        const size_t nsync = 2 * (size_t)S->nseg + 3 * (size_t)P.nsuper + 16;
+        D.seg_sync = S->dalloc<int>(nsync);
+        HK_CHECK(hipMemset(D.seg_sync, 0, nsync * sizeof(int)));
+    }
     D.front_sync = S->dalloc<int>(std::max(P.front_sync_ints, 16));
     HK_CHECK(hipMemset(D.front_sync, 0, (size_t)std::max(P.front_sync_ints, 16) * sizeof(int)));
     D.kval = S->upload(S->img.nzval);
@@ -378,6 +469,31 @@ void enqueue_ldl_solve(hipkkt_solver *S) {
     const HostPlan &P = S->plan;
     hipStream_t st = S->stream;
     launch_permute_in(st, S->d_sin, S->dp.perm, S->d_y, S->N);
+    if (S->use_persist) {
+        // one persistent launch per segment of regular levels, front kernels in between
+        bool first = true;
+        for (int g = 0; g < S->nseg; g++) {
+            for (int l = S->seg_lo[g]; l < std::min(S->seg_lstar[g], S->seg_hi[g] + 1); l++)   // wide bottom levels
+                launch_fwd_level(st, S->dp, S->slv_lvl_ptr[l], S->slv_lvl_ptr[l + 1] - S->slv_lvl_ptr[l], S->d_y, S->d_z);
+            const int n = S->fseg_ptr[2 * g + 1] - S->fseg_ptr[2 * g];
+            if (n > 0) { launch_fwd_seg(st, S->dp, g, S->fseg_ptr[2 * g], n, P.nsuper, first ? 1 : 0, S->d_y, S->d_z); first = false; }
+            for (const FrontDesc &F : P.fronts)
+                if (S->seg_of_level[F.level_last] == g) launch_front_fwd(st, S->dp, F, S->d_y, S->d_z);
+        }
+        first = true;
+        for (int g = S->nseg - 1; g >= 0; g--) {
+            for (const FrontDesc &F : P.fronts)
+                if (S->seg_of_level[F.level_last] == g) launch_front_bwd(st, S->dp, F, S->d_z, S->d_xp, S->d_sout);
+            const int k = S->nseg - 1 - g;     // launch order index
+            const int n = S->bseg_ptr[k + 1] - S->bseg_ptr[k];
+            if (n > 0) { launch_bwd_seg(st, S->dp, g, S->bseg_ptr[k], n, P.nsuper, first ? 1 : 0, S->d_z, S->d_xp, S->d_sout); first = false; }
+            for (int l = std::min(S->seg_lstar[g], S->seg_hi[g] + 1) - 1; l >= S->seg_lo[g]; l--) {
+                launch_bwd_partial(st, S->dp, S->bwd_lvl_ptr[l], S->bwd_lvl_ptr[l + 1] - S->bwd_lvl_ptr[l], S->d_xp);
+                launch_bwd_final(st, S->dp, S->reg_lvl_ptr[l], S->reg_lvl_ptr[l + 1] - S->reg_lvl_ptr[l], S->d_z, S->d_xp, S->d_sout);
+            }
+        }
+        return;
+    }
     for (int l = 0; l < P.nlevels; l++) {
         launch_fwd_level(st, S->dp, S->slv_lvl_ptr[l], S->slv_lvl_ptr[l + 1] - S->slv_lvl_ptr[l], S->d_y, S->d_z);
         for (const FrontDesc &F : P.fronts)
@@ -445,9 +561,38 @@ double refine_error(hipkkt_solver *S, const double *xi, bool also_normb, double 
     return slot_value(S, SC_NORME);
 }
 
+// A persistent sweep kernel gave up (bounded spin expired: the workgroups were not dispatched in the order the
+// fast path relies on, or a front hand-off stalled).  Re-arm every hand-off word, drop to the per-level kernels
+// for the rest of this handle's life and tell the caller to repeat the solve.  Returns false when there is
+// nothing left to fall back to.
+bool recover_from_sweep_failure(hipkkt_solver *S) {
+    if (!S->use_persist) return false;
+    const HostPlan &P = S->plan;
+    HK_CHECK(hipStreamSynchronize(S->stream));
+    const size_t nsync = 2 * (size_t)S->nseg + 3 * (size_t)P.nsuper + 16;
+    HK_CHECK(hipMemset(S->dp.seg_sync, 0, nsync * sizeof(int)));
+    HK_CHECK(hipMemset(S->dp.front_sync, 0, (size_t)std::max(P.front_sync_ints, 16) * sizeof(int)));
+    HK_CHECK(hipMemset(S->dp.flags + FL_FRONTFAIL, 0, sizeof(int)));
+    S->h_flags[FL_FRONTFAIL] = 0;
+    S->use_persist = false;
+    S->g_solve.valid = false;
+    return true;
+}
+
+int32_t solve_core_once(hipkkt_solver *S, int ir_enable, double reltol, double abstol, int64_t max_iter,
+                        double stop_ratio, int64_t *ir_steps);
+
 // ref: kktsolver_solve! + _iterative_refinement (kktsolver_directldl.jl:346-449); d_b holds b
 int32_t solve_core(hipkkt_solver *S, int ir_enable, double reltol, double abstol, int64_t max_iter,
                    double stop_ratio, int64_t *ir_steps) {
+    int32_t rc = solve_core_once(S, ir_enable, reltol, abstol, max_iter, stop_ratio, ir_steps);
+    if (rc == HIPKKT_ERR_DEVICE && S->h_flags[FL_FRONTFAIL] && recover_from_sweep_failure(S))
+        rc = solve_core_once(S, ir_enable, reltol, abstol, max_iter, stop_ratio, ir_steps);
+    return rc;
+}
+
+int32_t solve_core_once(hipkkt_solver *S, int ir_enable, double reltol, double abstol, int64_t max_iter,
+                        double stop_ratio, int64_t *ir_steps) {
     HK_CHECK(hipEventRecord(S->ev2, S->stream));
     int64_t steps = 0;
     bool ok = true;
@@ -502,6 +647,12 @@ int32_t finish_create(hipkkt_solver *S, const hipkkt_opts *opts, hipkkt_handle *
     po.amd_dense_scale = opts->amd_dense_scale > 0 ? opts->amd_dense_scale : 1.5;
     po.front_min_panels = opts->front_min_panels == 0 ? 4 : std::max(0, opts->front_min_panels);
     po.n_hold = S->l1 ? (int)S->img.n : 0;
+    {
+        const char *ns = getenv("HIPKKT_SIDE_STREAM");
+        po.split_far = ns && ns[0] == '1';
+        const char *nx = getenv("HIPKKT_XCD_ORDER");   // measured: no effect on cfg 2a (L2 locality is not the limiter)
+        po.xcd_order = nx && nx[0] == '1';
+    }
     {
         const char *nh = getenv("HIPKKT_ORDERING");   // "amd": minimum degree on K only
         if (nh && nh[0] == 'a') po.n_hold = 0;
@@ -1019,6 +1170,13 @@ int32_t hipkkt_ldl_solve(hipkkt_handle h, double *x, const double *b) {
     HK_CHECK(hipMemcpyAsync(x, S->d_sout, (size_t)S->N * sizeof(double), hipMemcpyDeviceToHost, S->stream));
     HK_CHECK(hipMemcpyAsync(S->h_flags, S->dp.flags, FL_COUNT * sizeof(int), hipMemcpyDeviceToHost, S->stream));
     HK_CHECK(hipStreamSynchronize(S->stream));
+    if (S->h_flags[FL_FRONTFAIL] && recover_from_sweep_failure(S)) {   // repeat once on the per-level kernels
+        HK_CHECK(hipMemcpyAsync(S->d_sin, b, (size_t)S->N * sizeof(double), hipMemcpyHostToDevice, S->stream));
+        ldl_solve_dev(S, S->d_sin, S->d_sout);
+        HK_CHECK(hipMemcpyAsync(x, S->d_sout, (size_t)S->N * sizeof(double), hipMemcpyDeviceToHost, S->stream));
+        HK_CHECK(hipMemcpyAsync(S->h_flags, S->dp.flags, FL_COUNT * sizeof(int), hipMemcpyDeviceToHost, S->stream));
+        HK_CHECK(hipStreamSynchronize(S->stream));
+    }
     if (S->h_flags[FL_FRONTFAIL]) { S->err = "front solve kernel timed out"; return HIPKKT_ERR_DEVICE; }
     float ms = 0;
     HK_CHECK(hipEventElapsedTime(&ms, S->ev2, S->ev3));

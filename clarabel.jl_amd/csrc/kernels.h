@@ -22,6 +22,9 @@ void launch_permute_in(hipStream_t st, const double *b, const int *perm, double 
 void launch_fwd_level(hipStream_t st, const DevPlan &P, int item_begin, int nitems, double *y, double *z);
 void launch_bwd_partial(hipStream_t st, const DevPlan &P, int item_begin, int nitems, const double *x);
 void launch_bwd_final(hipStream_t st, const DevPlan &P, int sn_begin, int nsn, const double *z, double *x, double *xout);
+void launch_fwd_seg(hipStream_t st, const DevPlan &P, int seg, int item_begin, int nitems, int nsuper, int first, double *y, double *z);
+void launch_bwd_seg(hipStream_t st, const DevPlan &P, int seg, int item_begin, int nitems, int nsuper, int first, const double *z,
+                    double *x, double *xout);
 void launch_front_fwd(hipStream_t st, const DevPlan &P, const FrontDesc &F, double *y, double *z);
 void launch_front_bwd(hipStream_t st, const DevPlan &P, const FrontDesc &F, const double *z, double *x, double *xout);
 void launch_spmv_residual(hipStream_t st, const DevPlan &P, const double *b, const double *xi, double *e, int n,

@@ -512,11 +512,19 @@ __device__ __forceinline__ void dense_load(DenseRaw<NT> &f, const double *sp, co
     int kk = k0 + lk;
     kk = kk < K ? kk : K - 1;
     const unsigned ko = (unsigned)kk * r8;
+#ifdef HIPKKT_EXPERIMENT_NOLOAD
+    f.d = 1.0 + ko * 1e-9;
+#pragma unroll
+    for (int t = 0; t < NT; t++) f.a[t] = 1e-3 * (coff[t] + 1);
+#pragma unroll
+    for (int t = 0; t < 4; t++) f.b[t] = 1e-3 * (roff[t] + 1);
+#else
     f.d = ld_off(dv, (unsigned)kk * 8u);
 #pragma unroll
     for (int t = 0; t < NT; t++) f.a[t] = ld_off(sp, coff[t] + ko);
 #pragma unroll
     for (int t = 0; t < 4; t++) f.b[t] = ld_off(sp, roff[t] + ko);
+#endif
 }
 
 template <int NT>
@@ -938,6 +946,7 @@ k_front_fwd(DevPlan P, FrontDesc F, double *__restrict__ y, double *__restrict__
         for (int64_t g = g0; g < g1; g++) G += P.ubuf[P.front_gidx[g]];
         base = own ? y[me.f + lane] - G : G;
     }
+    const double dinv_own = (own && valid) ? P.Dinv[me.f + lane] : 0.0;   // static: fetched before any wait
     // own diagonal block: row `lane` of Linv, columns j = wv + 4t (lower triangle)
     double li[16];
 #pragma unroll
@@ -1012,7 +1021,7 @@ k_front_fwd(DevPlan P, FrontDesc F, double *__restrict__ y, double *__restrict__
         if (valid && ok) {
             const double v = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
             front_st(y + me.f + lane, v);
-            z[me.f + lane] = v * P.Dinv[me.f + lane];
+            z[me.f + lane] = v * dinv_own;
         }
         if (ok) front_publish(sync + 2 + b, lane);
     }
@@ -1039,6 +1048,7 @@ k_front_bwd(DevPlan P, FrontDesc F, const double *__restrict__ z, double *__rest
     const int w = me.w;
     const bool cvalid = lane < w;
     const double *lt = P.LT + me.lt_off;            // row-major: lt[(j - w) * w + k], j = local panel row
+    const int perm_own = cvalid ? P.perm[me.f + lane] : 0;                // static: fetched before any wait
     // own diagonal block: column `lane` of Linv (as stored transposed), rows i2 = wv + 4t >= lane
     double lit[16];
 #pragma unroll
@@ -1131,10 +1141,298 @@ k_front_bwd(DevPlan P, FrontDesc F, const double *__restrict__ z, double *__rest
         if (cvalid && ok) {
             const double v = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
             front_st(x + me.f + lane, v);
-            xout[P.perm[me.f + lane]] = v;
+            xout[perm_own] = v;
         }
         if (ok) front_publish(sync + 2 + p, lane);
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// K5 over the REGULAR supernodes (everything that is not a front panel): level-free persistent sweeps.
+// One launch per segment (= the levels between two front kernels) instead of one launch per level
+// and kernel: workgroup tickets are handed out in level order, an item first waits for the completion
+// counters of the supernodes it depends on (forward: its same-segment children; backward: its parent and,
+// for the finaliser, the partial blocks of its own panel), then runs the same arithmetic as the
+// level-scheduled kernels.  Data produced inside the launch (update vectors, partial sums, x) is written
+// with agent-scope stores and read with agent-scope loads; counters are device-scope atomics.
+// Deadlock freedom and bounded spins: as for the front kernels.  The forward launch re-arms the backward
+// counters and vice versa.
+// ------------------------------------------------------------------------------------------
+struct SegSync {
+    int *ftick, *btick, *fdone, *bdone, *pdone, *err;
+};
+__device__ __forceinline__ SegSync seg_sync(const DevPlan &P, int nsuper) {
+    SegSync s;
+    s.ftick = P.seg_sync;
+    s.btick = P.seg_sync + P.nseg;
+    s.fdone = P.seg_sync + 2 * P.nseg;
+    s.bdone = s.fdone + nsuper;
+    s.pdone = s.bdone + nsuper;
+    s.err = s.pdone + nsuper;
+    return s;
+}
+// thread 0 waits until *ctr >= want (relaxed polls); false on time-out / foreign failure
+__device__ __forceinline__ bool seg_wait(int *ctr, int want, int *err, int *failflag) {
+    for (unsigned spins = 0;; spins++) {
+        if (front_ld_flag(ctr) >= want) return true;
+        if ((spins & 127u) == 127u) {
+            if (spins > (1u << 20)) {
+                __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                atomicOr(failflag, 1);
+                return false;
+            }
+            if (front_ld_flag(err) != 0) return false;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_fwd_seg(DevPlan P, int seg, int item_begin, int nitems, int nsuper, int first_launch, double *__restrict__ y,
+          double *__restrict__ z) {
+    __shared__ double rhs[kMaxSnWidth];
+    __shared__ double part[4][kMaxSnWidth];
+    __shared__ double yv[kMaxSnWidth];
+    __shared__ int sb;
+    const SegSync Y = seg_sync(P, nsuper);
+    const int tid = threadIdx.x;
+    // item = blockIdx (level order).  A shared ticket word would serialise the ~2*10^4 leaf items of a random
+    // sparse QP at ~88 tickets/us, so the in-order dispatch of workgroups is relied upon for SPEED only: every
+    // spin is bounded, a time-out fails the solve and the host then falls back to the per-level kernels.
+    const int t = blockIdx.x;
+    if (t >= nitems) return;
+    if (first_launch && t == 0) {   // re-arm the backward sweep's state (idle during the forward sweep)
+        for (int q = tid; q < P.nseg; q += 256) Y.btick[q] = 0;
+        for (int q = tid; q < 2 * nsuper; q += 256) Y.bdone[q] = 0;   // bdone and pdone are adjacent
+    }
+    const FacItem it = P.slv_items[item_begin + t];
+    const int s = it.sn;
+    const int f = P.sn_first[s];
+    const int w = P.sn_first[s + 1] - f;
+    const int64_t slot0 = P.sn_rowptr[s];
+    const int r = (int)(P.sn_rowptr[s + 1] - slot0);
+    const double *pan = P.Lx + P.sn_panel[s];
+    const double *li = P.Linv + P.sn_diag[s];
+    const int i = tid & 63, pq = tid >> 6;
+    const int row = w + it.blk * kSlvRows + i;
+    // ---- everything that does not depend on other workgroups is fetched BEFORE the dependency wait:
+    //      Linv row, panel row, gather-list bounds and first indices, right-hand side
+    double liv[16], pv[16];
+#pragma unroll
+    for (int t2 = 0; t2 < 16; t2++) {
+        const int k = pq + 4 * t2;
+        liv[t2] = (i < w && k <= i) ? li[i + k * w] : 0.0;
+        pv[t2] = (row < r && k < w) ? pan[row + (int64_t)k * r] : 0.0;
+    }
+    int64_t ga0 = 0, ga1 = 0, gb0 = 0, gb1 = 0;
+    int ia[4] = {0, 0, 0, 0}, ib[4] = {0, 0, 0, 0};   // the first gather indices of this thread's slots
+    double yin = 0.0, dinv_own = 0.0;
+    if (tid < w) {
+        dinv_own = P.Dinv[f + tid];
+        ga0 = P.g_ptr[slot0 + tid];
+        ga1 = P.g_ptr[slot0 + tid + 1];
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            if (ga0 + q < ga1) ia[q] = P.g_idx[ga0 + q];
+        yin = y[f + tid];
+    }
+    if (pq == 0 && row < r) {
+        gb0 = P.g_ptr[slot0 + row];
+        gb1 = P.g_ptr[slot0 + row + 1];
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            if (gb0 + q < gb1) ib[q] = P.g_idx[gb0 + q];
+    }
+    // ---- dependencies: every block of every same-segment child has been published; the children count
+    //      themselves into THIS supernode's counter, so the wait is one poll loop on one word
+    const int want = P.dep_total[s], fpar = P.sn_bparent[s];
+    if (tid == 0) {
+        sb = (want == 0 || seg_wait(Y.fdone + s, want, Y.err, P.flags + FL_FRONTFAIL)) ? 1 : 0;
+        asm volatile("" ::: "memory");
+    }
+    __syncthreads();
+    if (!sb) return;
+    if (tid < w) {
+        double u4[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) u4[q] = ga0 + q < ga1 ? front_ld(P.ubuf + ia[q]) : 0.0;   // in flight together
+        double acc = ((u4[0] + u4[1]) + u4[2]) + u4[3];
+        for (int64_t g = ga0 + 4; g < ga1; g++) acc += front_ld(P.ubuf + P.g_idx[g]);
+        rhs[tid] = yin - acc;
+    } else if (tid < kMaxSnWidth) {
+        rhs[tid] = 0.0;   // padded columns meet zero weights: keep them finite
+    }
+    double gsum = 0.0;
+    if (pq == 0 && row < r) {
+        double u4[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) u4[q] = gb0 + q < gb1 ? front_ld(P.ubuf + ib[q]) : 0.0;
+        gsum = ((u4[0] + u4[1]) + u4[2]) + u4[3];
+        for (int64_t g = gb0 + 4; g < gb1; g++) gsum += front_ld(P.ubuf + P.g_idx[g]);
+    }
+    __syncthreads();
+    {   // y_J = L11^-1 rhs (explicit inverse; thread (i, pq) owns the columns k = pq + 4t <= i)
+        double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+        for (int t2 = 0; t2 < 16; t2 += 2) {
+            a0 += liv[t2] * rhs[(pq + 4 * t2) & 63];
+            a1 += liv[t2 + 1] * rhs[(pq + 4 * t2 + 4) & 63];
+        }
+        part[pq][i] = a0 + a1;
+    }
+    __syncthreads();
+    if (tid < w) {
+        const double v = ((part[0][tid] + part[1][tid]) + part[2][tid]) + part[3][tid];
+        yv[tid] = v;
+        if (it.blk == 0) {
+            y[f + tid] = v;
+            z[f + tid] = v * dinv_own;
+        }
+    } else if (tid < kMaxSnWidth) {
+        yv[tid] = 0.0;
+    }
+    __syncthreads();
+    {
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+        for (int t2 = 0; t2 < 16; t2 += 4) {
+            a0 += pv[t2] * yv[(pq + 4 * t2) & 63];
+            a1 += pv[t2 + 1] * yv[(pq + 4 * t2 + 4) & 63];
+            a2 += pv[t2 + 2] * yv[(pq + 4 * t2 + 8) & 63];
+            a3 += pv[t2 + 3] * yv[(pq + 4 * t2 + 12) & 63];
+        }
+        __syncthreads();
+        part[pq][i] = (a0 + a1) + (a2 + a3);
+    }
+    __syncthreads();
+    if (pq == 0 && row < r)
+        front_st(P.ubuf + P.u_off[s] + (row - w), gsum + (((part[0][i] + part[1][i]) + part[2][i]) + part[3][i]));
+    // publish: the storing wave drains its stores, then one device-scope increment
+    if (pq == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (tid == 0 && fpar >= 0) atomicAdd(Y.fdone + fpar, 1);
+}
+
+// backward: item.blk >= 0 = partial dot products of one 64-row block of a long panel, item.blk == -1 = the
+// supernode's finaliser (short panels: fused dot product)
+__global__ void __launch_bounds__(256)
+k_bwd_seg(DevPlan P, int seg, int item_begin, int nitems, int nsuper, int first_launch, const double *__restrict__ z,
+          double *__restrict__ x, double *__restrict__ xout) {
+    __shared__ double red[4][kMaxSnWidth];
+    __shared__ double tv[kMaxSnWidth];
+    __shared__ int sb;
+    const SegSync Y = seg_sync(P, nsuper);
+    const int tid = threadIdx.x;
+    const int t = blockIdx.x;     // see k_fwd_seg
+    if (t >= nitems) return;
+    if (first_launch && t == 0) {   // re-arm the forward sweep's state for the next solve
+        for (int q = tid; q < P.nseg; q += 256) Y.ftick[q] = 0;
+        for (int q = tid; q < nsuper; q += 256) Y.fdone[q] = 0;
+    }
+    const FacItem it = P.pbwd_items[item_begin + t];
+    const int s = it.sn;
+    const int f = P.sn_first[s];
+    const int w = P.sn_first[s + 1] - f;
+    const int r = (int)(P.sn_rowptr[s + 1] - P.sn_rowptr[s]);
+    const int nblk = (r - w + kSlvRows - 1) / kSlvRows;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int *rows = P.sn_rows + P.sn_rowptr[s];
+    const double *lt = P.LT + P.lt_off[s];
+    // ---- static data first: the 16 rows x 1 column of L21^T this thread multiplies, their row indices,
+    //      the column of Linv^T and z (finaliser)
+    const bool dot_here = it.blk >= 0 || nblk == 1;
+    const int blk = it.blk >= 0 ? it.blk : 0;
+    const int lo = w + blk * kSlvRows + wave * 16;
+    double lv[16];
+    int ri[16];
+#pragma unroll
+    for (int t2 = 0; t2 < 16; t2++) {
+        const int i = lo + t2;
+        const bool in = dot_here && i < r && i < w + (blk + 1) * kSlvRows;
+        ri[t2] = in ? rows[i] : -1;
+        lv[t2] = (in && lane < w) ? lt[(int64_t)(i - w) * w + lane] : 0.0;
+    }
+    double litv[16];
+    double zin = 0.0;
+    int perm_own = 0;
+    if (it.blk < 0) {
+        if (tid < w) perm_own = P.perm[f + tid];
+        const double *lit = P.LinvT + P.sn_diag[s];
+#pragma unroll
+        for (int t2 = 0; t2 < 16; t2++) {
+            const int i2 = wave + 4 * t2;
+            litv[t2] = (lane < w && i2 >= lane && i2 < w) ? lit[lane + i2 * w] : 0.0;
+        }
+        if (tid < w) zin = z[f + tid];
+    } else {
+#pragma unroll
+        for (int t2 = 0; t2 < 16; t2++) litv[t2] = 0.0;
+    }
+    // ---- dependencies
+    if (tid == 0) {
+        bool ok = true;
+        const int par = P.sn_bparent[s];
+        if (par >= 0) ok = seg_wait(Y.bdone + par, 1, Y.err, P.flags + FL_FRONTFAIL);
+        if (ok && it.blk < 0 && nblk > 1) ok = seg_wait(Y.pdone + s, nblk, Y.err, P.flags + FL_FRONTFAIL);
+        sb = ok ? 1 : 0;
+        asm volatile("" ::: "memory");
+    }
+    __syncthreads();
+    if (!sb) return;
+    double dotv = 0.0;
+    if (dot_here) {
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        double xv[16];
+#pragma unroll
+        for (int t2 = 0; t2 < 16; t2++) xv[t2] = ri[t2] >= 0 ? front_ld(x + ri[t2]) : 0.0;
+#pragma unroll
+        for (int t2 = 0; t2 < 16; t2 += 4) {
+            a0 = fma(lv[t2], xv[t2], a0);
+            a1 = fma(lv[t2 + 1], xv[t2 + 1], a1);
+            a2 = fma(lv[t2 + 2], xv[t2 + 2], a2);
+            a3 = fma(lv[t2 + 3], xv[t2 + 3], a3);
+        }
+        red[wave][lane] = (a0 + a1) + (a2 + a3);
+        __syncthreads();
+        dotv = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+        __syncthreads();
+    }
+    if (it.blk >= 0) {
+        if (tid < w) front_st(P.pbuf + P.p_off[s] + (int64_t)it.blk * w + tid, dotv);
+        if (wave == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tid == 0) atomicAdd(Y.pdone + s, 1);
+        return;
+    }
+    double acc = dotv;
+    if (nblk > 1) {
+        double a = 0.0;
+        if (lane < w) {
+            const double *pb = P.pbuf + P.p_off[s] + lane;
+            for (int b2 = wave; b2 < nblk; b2 += 4) a += front_ld(pb + (int64_t)b2 * w);
+        }
+        red[wave][lane] = a;
+        __syncthreads();
+        acc = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+        __syncthreads();
+    }
+    if (tid < kMaxSnWidth) tv[tid] = tid < w ? zin - acc : 0.0;
+    __syncthreads();
+    {   // x_J = Linv^T t
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int t2 = 0; t2 < 16; t2 += 2) {
+            s0 = fma(litv[t2], tv[(wave + 4 * t2) & 63], s0);
+            s1 = fma(litv[t2 + 1], tv[(wave + 4 * t2 + 4) & 63], s1);
+        }
+        red[wave][lane] = s0 + s1;
+    }
+    __syncthreads();
+    if (tid < w) {
+        const double v = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
+        front_st(x + f + tid, v);
+        xout[perm_own] = v;
+    }
+    if (wave == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (tid == 0) atomicAdd(Y.bdone + s, 1);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1254,6 +1552,13 @@ void launch_bwd_partial(hipStream_t st, const DevPlan &P, int item_begin, int ni
 }
 void launch_bwd_final(hipStream_t st, const DevPlan &P, int sn_begin, int nsn, const double *z, double *x, double *xout) {
     if (nsn > 0) hipLaunchKernelGGL(k_bwd_final, dim3(nsn), dim3(256), 0, st, P, sn_begin, z, x, xout);
+}
+void launch_fwd_seg(hipStream_t st, const DevPlan &P, int seg, int item_begin, int nitems, int nsuper, int first, double *y, double *z) {
+    if (nitems > 0) hipLaunchKernelGGL(k_fwd_seg, dim3(nitems), dim3(256), 0, st, P, seg, item_begin, nitems, nsuper, first, y, z);
+}
+void launch_bwd_seg(hipStream_t st, const DevPlan &P, int seg, int item_begin, int nitems, int nsuper, int first, const double *z,
+                    double *x, double *xout) {
+    if (nitems > 0) hipLaunchKernelGGL(k_bwd_seg, dim3(nitems), dim3(256), 0, st, P, seg, item_begin, nitems, nsuper, first, z, x, xout);
 }
 void launch_front_fwd(hipStream_t st, const DevPlan &P, const FrontDesc &F, double *y, double *z) {
     hipLaunchKernelGGL(k_front_fwd, dim3(F.nb), dim3(256), 0, st, P, F, y, z);

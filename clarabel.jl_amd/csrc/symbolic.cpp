@@ -484,7 +484,31 @@ std::string build_plan(int N, const int64_t *Ap, const int64_t *Ai, const int64_
         for (int l = 0; l < P.nlevels; l++) {
             auto b = P.upd_groups.begin() + P.upd_stage_ptr[l], e = P.upd_groups.begin() + P.upd_stage_ptr[l + 1];
             auto mid = std::stable_partition(b, e, [](const UpdGroup &g) { return g.dense == 1; });
-            if (opt.update_policy == 2) {   // dense tiles: near targets first, far targets last
+            if (opt.xcd_order && mid - b >= 256) {
+                // XCD-aware order (performance only): workgroup k of k_update_dense<4> takes 4 consecutive tiles and is
+                // observed to run on XCD k % 8.  Tiles are bucketed by (global row block) % 8 and the buckets are
+                // interleaved 4 tiles at a time, so one XCD's L2 keeps re-using 1/8 of the source panels' rows (its A
+                // operands) while the 64-row column operands stream through.
+                std::vector<std::vector<UpdGroup>> bucket(8);
+                for (auto it = b; it != mid; ++it) {
+                    const int grow = P.sn_rows[P.sn_rowptr[it->tgt] + it->row_base];
+                    bucket[(grow / kUpdRows) & 7].push_back(*it);
+                }
+                std::vector<size_t> pos(8, 0);
+                auto out = b;
+                size_t remaining = (size_t)(mid - b);
+                while (remaining > 0)
+                    for (int x = 0; x < 8 && remaining > 0; x++) {
+                        int src = x;
+                        if (pos[src] >= bucket[src].size()) {   // this bucket is exhausted: borrow from the fullest one
+                            size_t best = 0;
+                            for (int y = 0; y < 8; y++)
+                                if (bucket[y].size() - pos[y] > best) { best = bucket[y].size() - pos[y]; src = y; }
+                        }
+                        for (int c = 0; c < 4 && pos[src] < bucket[src].size(); c++) { *out++ = bucket[src][pos[src]++]; remaining--; }
+                    }
+            }
+            if (opt.update_policy == 2 && opt.split_far) {   // dense tiles: near targets first, far targets last
                 const int B = std::max(1, opt.update_batch);
                 auto midf = std::stable_partition(b, mid, [&](const UpdGroup &g) { return P.sn_level[g.tgt] <= l + B; });
                 P.upd_stage_nfar[l] = (int)(mid - midf);

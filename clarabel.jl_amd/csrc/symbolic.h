@@ -71,6 +71,8 @@ struct PlanOptions {
     int update_policy = 2;  // 0 right-looking, 1 left-looking, 2 batched right-looking
     int update_batch = 4;   // levels per batch for policy 2
     double amd_dense_scale = 1.5;
+    bool split_far = false;    // separate the far dense tiles of a stage (side-stream experiments)
+    bool xcd_order = false;    // order the dense tiles of a stage so that each XCD's L2 sees 1/8 of the source rows
     int n_hold = 0;            // > 0: also try the "variables last" order (nodes < n_hold held back) and keep
                                // whichever order predicts fewer factor flops
     int front_min_panels = 4;  // chains at least this long are solved by the persistent front kernels (0 = never)
