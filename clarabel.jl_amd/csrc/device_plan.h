@@ -29,6 +29,7 @@ struct DevPlan {
     const UpdTask *upd_tasks;
     const UpdGroup *upd_groups;
     const int16_t *upd_tmap;
+    const DenseTask *dtasks;      // parallel to upd_tasks
     const int64_t *gath_tgt;
     const int64_t *gath_pptr;
     const int64_t *gath_src;

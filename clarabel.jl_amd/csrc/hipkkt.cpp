@@ -311,6 +311,16 @@ void setup_device(hipkkt_solver *S) {
     D.upd_tasks = S->upload(P.upd_tasks);
     D.upd_groups = S->upload(P.upd_groups);
     D.upd_tmap = S->upload(P.upd_tmap);
+    {
+        std::vector<DenseTask> dt(P.upd_tasks.size());
+        for (size_t q = 0; q < dt.size(); q++) {
+            const UpdTask &T = P.upd_tasks[q];
+            const int s = T.src;
+            dt[q] = {P.sn_panel[s], (int32_t)((P.sn_rowptr[s + 1] - P.sn_rowptr[s]) * 8), P.sn_first[s + 1] - P.sn_first[s],
+                     P.sn_first[s], T.row_lo, T.nrows, T.col_lo, T.ncols, T.geom, T.vt_begin, 0};
+        }
+        D.dtasks = S->upload(dt);
+    }
     D.gath_tgt = S->upload(P.gath_tgt);
     D.gath_pptr = S->upload(P.gath_pptr);
     D.gath_src = S->upload(P.gath_src);

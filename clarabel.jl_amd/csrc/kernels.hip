@@ -580,19 +580,20 @@ k_update_dense(DevPlan P, int group_begin, int ngroups) {
             }
         }
 
+    // task records are 48-byte packed structs; the NEXT record is requested at the top of an iteration and only
+    // made wave-uniform (readfirstlane = the wait) at its end, so its latency hides under this task's MFMAs
+    DenseTask Tc = P.dtasks[task_begin];
     for (int q = task_begin; q < task_end; q++) {
-        const UpdTask *Tp = P.upd_tasks + q;
-        const int s = rfl(Tp->src), row_lo = rfl(Tp->row_lo), nrows = rfl(Tp->nrows), col_lo = rfl(Tp->col_lo),
-                  ncols = rfl(Tp->ncols), geom = rfl(Tp->geom);
-        const int fs = rfl(P.sn_first[s]);
-        const int K = rfl(P.sn_first[s + 1]) - fs;
-        const unsigned r8 = (unsigned)rfl((int)(P.sn_rowptr[s + 1] - P.sn_rowptr[s])) * 8u;
-        const double *sp = rfl_ptr(P.Lx + P.sn_panel[s]);
-        const double *dv = rfl_ptr(P.D + fs);
+        const DenseTask Tn = P.dtasks[q + 1 < task_end ? q + 1 : q];
+        const int row_lo = rfl(Tc.row_lo), nrows = rfl(Tc.nrows), col_lo = rfl(Tc.col_lo), ncols = rfl(Tc.ncols),
+                  geom = rfl(Tc.geom), K = rfl(Tc.K), tmap_idx = rfl(Tc.map);
+        const unsigned r8 = (unsigned)rfl(Tc.r8);
+        const double *sp = rfl_ptr(P.Lx + Tc.panel_off);
+        const double *dv = rfl_ptr(P.D + Tc.dfirst);
         const int c_r = geom & 255, c_c = (geom >> 8) & 255;
         unsigned roff[4], coff[NT], mbits = 0;
         if (geom & (1 << 17)) {      // wave-uniform: operands gathered through the task's tile maps
-            const int16_t *tm = P.upd_tmap + (int64_t)rfl(Tp->vt_begin) * 128;
+            const int16_t *tm = P.upd_tmap + (int64_t)tmap_idx * 128;
 #pragma unroll
             for (int x = 0; x < 4; x++) {
                 const int m = tm[x * 16 + l15];
@@ -635,6 +636,7 @@ k_update_dense(DevPlan P, int group_begin, int ngroups) {
             dense_mma<NT>(fb, acc, mbits, K, k0 + 4, lk);
             __builtin_amdgcn_sched_barrier(0);
         }
+        Tc = Tn;
     }
 #pragma unroll
     for (int tj = 0; tj < NT; tj++)

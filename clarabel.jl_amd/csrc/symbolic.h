@@ -30,6 +30,14 @@ struct UpdTask {
                         // offset from row_lo (or -1), [64,128) tile column -> offset from col_lo (or -1)
 };
 
+// device-side packed record of one contribution to a dense tile: everything k_update_dense needs in ONE 48-byte
+// load (built at set-up from UpdTask + the supernode arrays), so that the next task's record can be prefetched
+struct DenseTask {
+    int64_t panel_off;             // source panel in Lx
+    int32_t r8, K, dfirst;         // source row count * 8 (byte stride of a column), width, first pivot
+    int32_t row_lo, nrows, col_lo, ncols, geom, map, pad;
+};
+
 struct UpdGroup {
     int32_t tgt;        // target supernode
     int32_t row_base;   // first target panel row of the block

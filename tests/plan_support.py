@@ -24,7 +24,8 @@ def lib():
 
 
 STAT_NAMES = ["nsuper", "nlevels", "nnzL", "panel_doubles", "ntasks", "ngroups", "etree_height",
-              "flops_colcount", "flops_update", "flops_exec", "nreg", "max_group_tasks"]
+              "flops_colcount", "flops_update", "flops_exec", "nreg", "max_group_tasks",
+              "nfronts", "ngather_entries", "ndense_groups", "nmapped_tasks"]
 
 
 def run(N, colptr, rowval, nzval, dsigns, b=None, perm=None, max_width=64, relax=1, policy=0,

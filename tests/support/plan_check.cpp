@@ -33,6 +33,12 @@ int plan_check_run(int64_t N, const int64_t *Ap, const int64_t *Ai, const double
     stats[0] = P.nsuper; stats[1] = P.nlevels; stats[2] = (double)P.nnzL; stats[3] = (double)P.panel_doubles;
     stats[4] = (double)P.upd_tasks.size(); stats[5] = (double)P.upd_groups.size(); stats[6] = P.etree_height;
     stats[7] = P.flops_colcount; stats[8] = P.flops_update; stats[9] = P.flops_exec; stats[10] = 0; stats[11] = (double)maxg;
+    {
+        size_t nmapped = 0, ndense = 0;
+        for (auto &t : P.upd_tasks) nmapped += (t.geom >> 17) & 1;
+        for (auto &g : P.upd_groups) ndense += g.dense == 1;
+        stats[12] = (double)P.fronts.size(); stats[13] = (double)P.gath_tgt.size(); stats[14] = (double)ndense; stats[15] = (double)nmapped;
+    }
     if (symbolic_only) return 0;
 
     std::vector<double> Lx(P.panel_doubles, 0.0), Ld(P.diag_doubles, 0.0), D(N), Dinv(N);
@@ -80,11 +86,18 @@ int plan_check_run(int64_t N, const int64_t *Ap, const int64_t *Ai, const double
                 for (int k = 0; k < w; k++) pan[i + (size_t)k * r] = y[k] * Dinv[f + k];
             }
         }
-        // update groups of this stage
+        // update groups of this stage, interpreted the way the device kernels do:
+        //   kind 1 (k_update_dense): tile coordinates; a source that does not land contiguously is gathered
+        //          through its tile map;  kind 2 (k_update_gather): the per-target-entry pair lists;
+        //   kind 0 (k_update_stage): relative-index scatter
         for (int g = P.upd_stage_ptr[lvl]; g < P.upd_stage_ptr[lvl + 1]; g++) {
             UpdGroup G = P.upd_groups[g];
-            int t = G.tgt, rt = R(t), ft = P.sn_first[t];
+            int t = G.tgt, rt = R(t), ft = P.sn_first[t], wt = W(t);
             double *tp = &Lx[P.sn_panel[t]];
+            const int pos = g - P.upd_stage_ptr[lvl];
+            const int nd = P.upd_stage_ndense[lvl], ng = P.upd_stage_ngather[lvl];
+            if ((G.dense == 1) != (pos < nd) || (G.dense == 2) != (pos >= nd && pos < nd + ng)) return -7;
+            if (G.dense == 2) continue;   // applied below from the gather lists
             for (int q = G.task_begin; q < G.task_end; q++) {
                 UpdTask T = P.upd_tasks[q];
                 int s = T.src, w = W(s), r = R(s), f = P.sn_first[s];
@@ -92,6 +105,29 @@ int plan_check_run(int64_t N, const int64_t *Ap, const int64_t *Ai, const double
                 if (P.sn_level[t] <= lvl) return -3; // target already factored
                 const double *sp = &Lx[P.sn_panel[s]];
                 const int *srows = &P.sn_rows[P.sn_rowptr[s]];
+                if (G.dense == 1) {
+                    const int nrt = std::min(kUpdRows, rt - G.row_base);
+                    const bool mapped = (T.geom >> 17) & 1;
+                    const int16_t *tm = mapped ? &P.upd_tmap[(size_t)T.vt_begin * 128] : nullptr;
+                    const int c_r = T.geom & 255, c_c = (T.geom >> 8) & 255;
+                    int touched = 0;
+                    for (int ii = 0; ii < nrt; ii++) {
+                        const int mi = mapped ? tm[ii] : (ii - c_r >= 0 && ii - c_r < T.nrows ? ii - c_r : -1);
+                        if (mi < 0) continue;
+                        for (int jj = 0; jj < wt; jj++) {
+                            const int mj = mapped ? tm[64 + jj] : (jj - c_c >= 0 && jj - c_c < T.ncols ? jj - c_c : -1);
+                            if (mj < 0) continue;
+                            const int i = T.row_lo + mi, j = T.col_lo + mj;
+                            if (P.rel[T.rel_off + (i - T.col_lo)] != G.row_base + ii || srows[j] - ft != jj) return -8;
+                            double acc = 0;
+                            for (int k = 0; k < w; k++) acc += sp[i + (size_t)k * r] * D[f + k] * sp[j + (size_t)k * r];
+                            tp[(G.row_base + ii) + (size_t)jj * rt] -= acc;
+                            touched++;
+                        }
+                    }
+                    if (touched != T.nrows * T.ncols) return -9;   // the tile coordinates cover the whole task
+                    continue;
+                }
                 for (int i = T.row_lo; i < T.row_lo + T.nrows; i++) {
                     int rp = P.rel[T.rel_off + (i - T.col_lo)];
                     if (rp < G.row_base || rp >= G.row_base + kUpdRows || rp >= rt) return -4;
@@ -104,14 +140,25 @@ int plan_check_run(int64_t N, const int64_t *Ap, const int64_t *Ai, const double
                 }
             }
         }
+        for (int64_t e = P.gath_stage_ptr[lvl]; e < P.gath_stage_ptr[lvl + 1]; e++) {
+            double acc = 0;
+            for (int64_t pq = P.gath_pptr[e]; pq < P.gath_pptr[e + 1]; pq++) {
+                const int s = P.gath_sn[pq], w = W(s), r = R(s), f = P.sn_first[s];
+                if (P.sn_level[s] > lvl) return -5;
+                const double *li = &Lx[P.gath_src[pq]], *lj = li + P.gath_dj[pq];
+                for (int k = 0; k < w; k++) acc += li[(size_t)k * r] * D[f + k] * lj[(size_t)k * r];
+            }
+            Lx[P.gath_tgt[e]] -= acc;
+        }
     }
     stats[10] = (double)nreg;
     // solves: y = perm(b); forward by levels with gather lists; D; backward
     std::vector<double> y(N), ub(P.ubuf_len, 0.0);
     for (int k = 0; k < N; k++) y[k] = b[P.perm[k]];
-    for (int lvl = 0; lvl < P.nlevels; lvl++)
+    for (int lvl = 0; lvl < P.nlevels; lvl++) {
         for (int q = P.lvl_ptr[lvl]; q < P.lvl_ptr[lvl + 1]; q++) {
             int s = P.lvl_sn[q], w = W(s), r = R(s), f = P.sn_first[s];
+            if (P.sn_front[s] >= 0) continue;   // handled by the front sweep below (k_front_fwd)
             const double *pan = &Lx[P.sn_panel[s]];
             const double *ld = &Ld[P.sn_diag[s]];
             const int64_t slot0 = P.sn_rowptr[s];
@@ -129,6 +176,30 @@ int plan_check_run(int64_t N, const int64_t *Ap, const int64_t *Ai, const double
                 ub[P.u_off[s] + (i - w)] = a;
             }
         }
+        // fronts that end at this level: the persistent sweep (external gathers + panel-ordered accumulation)
+        for (const FrontDesc &F : P.fronts) {
+            if (F.level_last != lvl) continue;
+            const FrontPanel *fp = &P.front_panels[F.fp_off];
+            std::vector<double> acc(F.rF, 0.0);
+            for (int i = 0; i < F.rF; i++)
+                for (int64_t g = P.front_gptr[F.gptr_off + i]; g < P.front_gptr[F.gptr_off + i + 1]; g++) acc[i] += ub[P.front_gidx[g]];
+            for (int p = 0; p < F.np; p++) {
+                const FrontPanel &me = fp[p];
+                if (me.sn != F.s0 + p || me.f != P.sn_first[me.sn] || me.w != W(me.sn) || me.r != R(me.sn)) return -10;
+                const double *ld = &Ld[P.sn_diag[me.sn]];
+                const double *pan = &Lx[me.panel_off];
+                for (int k = 0; k < me.w; k++) y[me.f + k] -= acc[F.cw * p + k];
+                for (int k = 0; k < me.w; k++)
+                    for (int i = k + 1; i < me.w; i++) y[me.f + i] -= ld[i + (size_t)k * me.w] * y[me.f + k];
+                for (int j = me.w; j < me.r; j++) {      // local row j = front row cw*p + j
+                    double a = 0;
+                    for (int k = 0; k < me.w; k++) a += pan[j + (size_t)k * me.r] * y[me.f + k];
+                    acc[F.cw * p + j] += a;
+                }
+            }
+            for (int i = F.W; i < F.rF; i++) ub[F.ubelow_off + (i - F.W)] = acc[i];
+        }
+    }
     for (int k = 0; k < N; k++) y[k] *= Dinv[k];
     for (int lvl = P.nlevels - 1; lvl >= 0; lvl--)
         for (int q = P.lvl_ptr[lvl]; q < P.lvl_ptr[lvl + 1]; q++) {
