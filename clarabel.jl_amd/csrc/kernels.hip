@@ -624,17 +624,41 @@ k_update_dense(DevPlan P, int group_begin, int ngroups) {
         }
         // register double buffering: the loads of step k+1 (clamped past the end) are in flight during
         // the MFMAs of step k
-        DenseRaw<NT> fa, fb;
-        dense_load<NT>(fa, sp, dv, coff, roff, r8, K, 0, lk);
-        for (int k0 = 0; k0 < K; k0 += 8) {     // steps past K contribute zeros (dk = 0)
-            dense_load<NT>(fb, sp, dv, coff, roff, r8, K, k0 + 4, lk);
-            __builtin_amdgcn_sched_barrier(0);
-            dense_mma<NT>(fa, acc, mbits, K, k0, lk);
-            __builtin_amdgcn_sched_barrier(0);
-            dense_load<NT>(fa, sp, dv, coff, roff, r8, K, k0 + 8, lk);
-            __builtin_amdgcn_sched_barrier(0);
-            dense_mma<NT>(fb, acc, mbits, K, k0 + 4, lk);
-            __builtin_amdgcn_sched_barrier(0);
+        if (NT == 1) {
+            // a 16-column strip has only 4 MFMAs (256 clocks) per k-step, less than one memory latency: keep FOUR
+            // k-steps of operands in flight (ring of 4 register buffers; steps past K contribute zeros)
+            DenseRaw<NT> f0, f1, f2, f3;
+            dense_load<NT>(f0, sp, dv, coff, roff, r8, K, 0, lk);
+            dense_load<NT>(f1, sp, dv, coff, roff, r8, K, 4, lk);
+            dense_load<NT>(f2, sp, dv, coff, roff, r8, K, 8, lk);
+            dense_load<NT>(f3, sp, dv, coff, roff, r8, K, 12, lk);
+            for (int k0 = 0; k0 < K; k0 += 16) {
+                __builtin_amdgcn_sched_barrier(0);
+                dense_mma<NT>(f0, acc, mbits, K, k0, lk);
+                dense_load<NT>(f0, sp, dv, coff, roff, r8, K, k0 + 16, lk);
+                __builtin_amdgcn_sched_barrier(0);
+                dense_mma<NT>(f1, acc, mbits, K, k0 + 4, lk);
+                dense_load<NT>(f1, sp, dv, coff, roff, r8, K, k0 + 20, lk);
+                __builtin_amdgcn_sched_barrier(0);
+                dense_mma<NT>(f2, acc, mbits, K, k0 + 8, lk);
+                dense_load<NT>(f2, sp, dv, coff, roff, r8, K, k0 + 24, lk);
+                __builtin_amdgcn_sched_barrier(0);
+                dense_mma<NT>(f3, acc, mbits, K, k0 + 12, lk);
+                dense_load<NT>(f3, sp, dv, coff, roff, r8, K, k0 + 28, lk);
+            }
+        } else {
+            DenseRaw<NT> fa, fb;
+            dense_load<NT>(fa, sp, dv, coff, roff, r8, K, 0, lk);
+            for (int k0 = 0; k0 < K; k0 += 8) {     // steps past K contribute zeros (dk = 0)
+                dense_load<NT>(fb, sp, dv, coff, roff, r8, K, k0 + 4, lk);
+                __builtin_amdgcn_sched_barrier(0);
+                dense_mma<NT>(fa, acc, mbits, K, k0, lk);
+                __builtin_amdgcn_sched_barrier(0);
+                dense_load<NT>(fa, sp, dv, coff, roff, r8, K, k0 + 8, lk);
+                __builtin_amdgcn_sched_barrier(0);
+                dense_mma<NT>(fb, acc, mbits, K, k0 + 4, lk);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         Tc = Tn;
     }
