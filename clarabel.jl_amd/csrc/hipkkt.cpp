@@ -101,12 +101,17 @@ struct hipkkt_solver {
     bool use_graph = true;
     bool poison = false;
     PlanOptions plan_opts;       // as used for the current plan
-    bool ordering_fallback_done = false;
+    // robust-order twin (minimum degree on K), created on the first factorisation that fails in the
+    // "variables last" order; every later factorisation still tries the fast order first
+    hipkkt_solver *fallback = nullptr;
+    bool using_fallback = false;
     bool profiling = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
     double t_last_factor = 0, t_last_solve = 0, t_acc_factor = 0, t_acc_solve = 0, t_last_update = 0;
     int64_t n_factor = 0, n_solvecalls = 0, n_ldlsolves = 0;
     double last_eps = 0;
+    double prof_dense4_ms = 0, prof_dense4_flops = 0;   // last profiled refactorisation: k_update_dense<4> alone
+    int prof_dense4_launches = 0;
     int64_t last_nreg = 0;
 
     template <class T>
@@ -133,6 +138,7 @@ struct hipkkt_solver {
         stage_cap = cap;
     }
     ~hipkkt_solver() {
+        delete fallback;
         hipSetDevice(device);
         if (g_factor.exec) hipGraphExecDestroy(g_factor.exec);
         if (g_solve.exec) hipGraphExecDestroy(g_solve.exec);
@@ -654,6 +660,21 @@ int32_t solve_core_once(hipkkt_solver *S, int ir_enable, double reltol, double a
     return ok ? HIPKKT_OK : HIPKKT_NUMERICAL_FAILURE;
 }
 
+// the solver that holds the current factorisation (the robust-order twin after a fallback); its right-hand side
+// is refreshed from the primary's
+hipkkt_solver *solve_target(hipkkt_solver *S) {
+    if (!(S->using_fallback && S->fallback)) return S;
+    hipkkt_solver *T = S->fallback;
+    HK_CHECK(hipMemcpy(T->d_b, S->d_b, (size_t)S->N * sizeof(double), hipMemcpyDeviceToDevice));
+    return T;
+}
+void account_fallback_solve(hipkkt_solver *S, hipkkt_solver *T) {
+    if (T == S) return;
+    S->t_last_solve = T->t_last_solve;
+    S->t_acc_solve += T->t_last_solve;
+    S->n_solvecalls++;
+}
+
 int32_t finish_create(hipkkt_solver *S, const hipkkt_opts *opts, hipkkt_handle *out) {
     PlanOptions po;
     po.max_width = opts->supernode_max_width > 0 ? opts->supernode_max_width : kMaxSnWidth;
@@ -1044,26 +1065,39 @@ static int32_t refactor_once(hipkkt_handle h, int32_t static_reg_enable, double 
 // choice) and the factorisation is repeated, so robustness is never worse than with that order.
 int32_t hipkkt_refactor(hipkkt_handle h, int32_t static_reg_enable, double eps_const, double eps_prop,
                         double *eps_used, int64_t *n_dynamic_reg) {
+    if (h) h->using_fallback = false;
     int32_t rc = refactor_once(h, static_reg_enable, eps_const, eps_prop, eps_used, n_dynamic_reg);
-    if (rc != HIPKKT_NUMERICAL_FAILURE || !h || h->plan.ordering_used != 1 || h->ordering_fallback_done) return rc;
+    if (rc != HIPKKT_NUMERICAL_FAILURE || !h || h->plan.ordering_used != 1) return rc;
     hipkkt_solver *S = h;
     try {
         if (hipSetDevice(S->device) != hipSuccess) return rc;
-        HK_CHECK(hipMemcpy(S->img.nzval.data(), S->dp.kval, (size_t)S->nnzK * sizeof(double), hipMemcpyDeviceToHost));
-        S->ordering_fallback_done = true;
-        PlanOptions po = S->plan_opts;
-        po.n_hold = 0;
-        HostPlan np;
-        std::string err = build_plan((int)S->img.N, S->img.colptr.data(), S->img.rowval.data(), nullptr, po, np);
-        if (!err.empty()) return rc;
-        S->plan = std::move(np);
-        S->plan_opts = po;
-        setup_device(S);
+        if (!S->fallback) {
+            hipkkt_solver *T = new hipkkt_solver();
+            S->fallback = T;
+            T->device = S->device;
+            T->opts = S->opts;
+            T->l1 = S->l1;
+            T->img = S->img;
+            PlanOptions po = S->plan_opts;
+            po.n_hold = 0;
+            std::string err = build_plan((int)T->img.N, T->img.colptr.data(), T->img.rowval.data(), nullptr, po, T->plan);
+            if (!err.empty()) { delete T; S->fallback = nullptr; return rc; }
+            T->plan_opts = po;
+            init_runtime(T);
+            setup_device(T);
+        }
+        HK_CHECK(hipMemcpy(S->fallback->dp.kval, S->dp.kval, (size_t)S->nnzK * sizeof(double), hipMemcpyDeviceToDevice));
     } catch (...) {
-        S->err = "rebuilding the plan with the fallback ordering failed";
+        S->err = "building the fallback (minimum-degree) factorisation failed";
         return HIPKKT_ERR_DEVICE;
     }
-    return refactor_once(h, static_reg_enable, eps_const, eps_prop, eps_used, n_dynamic_reg);
+    rc = refactor_once(S->fallback, static_reg_enable, eps_const, eps_prop, eps_used, n_dynamic_reg);
+    S->using_fallback = true;
+    S->last_eps = S->fallback->last_eps;
+    S->last_nreg = S->fallback->last_nreg;
+    S->t_last_factor += S->fallback->t_last_factor;      // the failed attempt + the repeated one
+    S->t_acc_factor += S->fallback->t_last_factor;
+    return rc;
 }
 
 static int32_t refactor_once(hipkkt_handle h, int32_t static_reg_enable, double eps_const, double eps_prop,
@@ -1079,15 +1113,26 @@ static int32_t refactor_once(hipkkt_handle h, int32_t static_reg_enable, double 
         launch_maxabs_gather(st, S->dp.kval, S->d_diag_full, S->N, (unsigned long long *)S->dp.scal + SC_MAXDIAG);
         HK_CHECK(hipMemsetAsync(S->dp.Lx, 0, (size_t)P.panel_doubles * sizeof(double), st));
         launch_init_panels(st, S->dp, S->nnzK, static_reg_enable, eps_const, eps_prop);
-        std::vector<hipEvent_t> evs;
+        std::vector<hipEvent_t> evs, evd;   // evs: all update kernels of a stage; evd: its k_update_dense<4> launch alone
+        std::vector<int> evd_level;
         for (int l = 0; l < P.nlevels; l++) {
             enqueue_factor_level(S, l);
             if (P.upd_stage_ptr[l + 1] > P.upd_stage_ptr[l]) {
-                hipEvent_t a, b;
+                hipEvent_t a, b, c2;
                 HK_CHECK(hipEventCreate(&a));
                 HK_CHECK(hipEventCreate(&b));
                 HK_CHECK(hipEventRecord(a, st));
-                enqueue_updates(S, l);
+                const int g0 = P.upd_stage_ptr[l], nd = P.upd_stage_ndense[l], ng = P.upd_stage_ngather[l];
+                launch_update_dense(st, S->dp, g0, nd);
+                if (nd > 384) {   // the one-wavefront-per-tile variant (see launch_update_dense)
+                    HK_CHECK(hipEventCreate(&c2));
+                    HK_CHECK(hipEventRecord(c2, st));
+                    evd.push_back(a);
+                    evd.push_back(c2);
+                    evd_level.push_back(l);
+                }
+                launch_update_gather(st, S->dp, P.gath_stage_ptr[l], P.gath_stage_ptr[l + 1] - P.gath_stage_ptr[l]);
+                launch_update_stage(st, S->dp, g0 + nd + ng, P.upd_stage_ptr[l + 1] - g0 - nd - ng);
                 HK_CHECK(hipEventRecord(b, st));
                 evs.push_back(a);
                 evs.push_back(b);
@@ -1103,6 +1148,15 @@ static int32_t refactor_once(hipkkt_handle h, int32_t static_reg_enable, double 
             hipEventElapsedTime(&ms, evs[i], evs[i + 1]);
             tot += ms;
         }
+        S->prof_dense4_ms = 0; S->prof_dense4_flops = 0; S->prof_dense4_launches = 0;
+        for (size_t i = 0; i + 1 < evd.size(); i += 2) {
+            float ms = 0;
+            hipEventElapsedTime(&ms, evd[i], evd[i + 1]);
+            S->prof_dense4_ms += ms;
+            S->prof_dense4_flops += P.upd_stage_flops_dense[evd_level[i / 2]];
+            S->prof_dense4_launches++;
+        }
+        for (size_t i = 1; i < evd.size(); i += 2) hipEventDestroy(evd[i]);
         for (hipEvent_t e : evs) hipEventDestroy(e);
         S->t_last_update = tot;
     } else {
@@ -1155,11 +1209,13 @@ int32_t hipkkt_solve(hipkkt_handle h, double *lhsx, double *lhsz, int32_t ir_ena
                      int64_t max_iter, double stop_ratio, int64_t *ir_steps) {
     HK_ENTER(h)
     if (!S->l1) return HIPKKT_ERR_ARGUMENT;
-    int32_t rc = solve_core(S, ir_enable, reltol, abstol, max_iter, stop_ratio, ir_steps);
+    hipkkt_solver *T = solve_target(S);
+    int32_t rc = solve_core(T, ir_enable, reltol, abstol, max_iter, stop_ratio, ir_steps);
+    account_fallback_solve(S, T);
     if (rc == HIPKKT_OK) {  // ref: kktsolver_getlhs! only on success
         const int64_t n = S->img.n, m = S->img.m;
-        if (lhsx && n) HK_CHECK(hipMemcpy(lhsx, S->d_x, n * sizeof(double), hipMemcpyDeviceToHost));
-        if (lhsz && m) HK_CHECK(hipMemcpy(lhsz, S->d_x + n, m * sizeof(double), hipMemcpyDeviceToHost));
+        if (lhsx && n) HK_CHECK(hipMemcpy(lhsx, T->d_x, n * sizeof(double), hipMemcpyDeviceToHost));
+        if (lhsz && m) HK_CHECK(hipMemcpy(lhsz, T->d_x + n, m * sizeof(double), hipMemcpyDeviceToHost));
     }
     return rc;
     HK_LEAVE
@@ -1169,16 +1225,19 @@ int32_t hipkkt_solve_dev(hipkkt_handle h, double *lhs_dev, int32_t ir_enable, do
                          int64_t max_iter, double stop_ratio, int64_t *ir_steps) {
     HK_ENTER(h)
     if (!S->l1) return HIPKKT_ERR_ARGUMENT;
-    int32_t rc = solve_core(S, ir_enable, reltol, abstol, max_iter, stop_ratio, ir_steps);
+    hipkkt_solver *T = solve_target(S);
+    int32_t rc = solve_core(T, ir_enable, reltol, abstol, max_iter, stop_ratio, ir_steps);
+    account_fallback_solve(S, T);
     if (rc == HIPKKT_OK && lhs_dev) {
-        HK_CHECK(hipMemcpyAsync(lhs_dev, S->d_x, (S->img.n + S->img.m) * sizeof(double), hipMemcpyDeviceToDevice, S->stream));
-        HK_CHECK(hipStreamSynchronize(S->stream));
+        HK_CHECK(hipMemcpyAsync(lhs_dev, T->d_x, (S->img.n + S->img.m) * sizeof(double), hipMemcpyDeviceToDevice, T->stream));
+        HK_CHECK(hipStreamSynchronize(T->stream));
     }
     return rc;
     HK_LEAVE
 }
 
 int32_t hipkkt_ldl_solve(hipkkt_handle h, double *x, const double *b) {
+    if (h && h->using_fallback && h->fallback) return hipkkt_ldl_solve(h->fallback, x, b);
     HK_ENTER(h)
     if (!x || !b) return HIPKKT_ERR_ARGUMENT;
     HK_CHECK(hipEventRecord(S->ev2, S->stream));
@@ -1209,6 +1268,13 @@ int32_t hipkkt_get_timing(hipkkt_handle h, double *o) {
     if (!h || !o) return HIPKKT_ERR_ARGUMENT;
     o[0] = h->t_last_factor; o[1] = h->t_last_solve; o[2] = h->t_acc_factor; o[3] = h->t_acc_solve;
     o[4] = (double)h->n_factor; o[5] = (double)h->n_solvecalls; o[6] = (double)h->n_ldlsolves; o[7] = h->t_last_update;
+    return HIPKKT_OK;
+}
+
+int32_t hipkkt_get_profile(hipkkt_handle h, double *o) {
+    if (!h || !o) return HIPKKT_ERR_ARGUMENT;
+    o[0] = h->t_last_update; o[1] = h->prof_dense4_ms; o[2] = h->prof_dense4_flops; o[3] = (double)h->prof_dense4_launches;
+    o[4] = o[5] = o[6] = o[7] = 0;
     return HIPKKT_OK;
 }
 

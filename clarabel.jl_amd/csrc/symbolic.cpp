@@ -437,6 +437,10 @@ std::string build_plan(int N, const int64_t *Ap, const int64_t *Ai, const int64_
         //           through the relative-index scatter of k_update_stage.  Dense groups are moved to the
         //           front of their stage.
         P.upd_stage_ndense.assign(P.nlevels, 0);
+        P.upd_stage_flops_dense.assign(P.nlevels, 0.0);
+        {
+            // stage of a group = position in upd_stage_ptr (groups are stage-ordered at this point)
+        }
         for (auto &G : P.upd_groups) {
             const int t = G.tgt, ft = P.sn_first[t];
             bool all_contig = true;
@@ -517,6 +521,11 @@ std::string build_plan(int N, const int64_t *Ap, const int64_t *Ai, const int64_
             auto mid2 = std::stable_partition(mid, e, [](const UpdGroup &g) { return g.dense == 2; });
             P.upd_stage_ndense[l] = (int)(mid - b);
             P.upd_stage_ngather[l] = (int)(mid2 - mid);
+            for (auto it = b; it != mid; ++it)
+                for (int q = it->task_begin; q < it->task_end; q++) {
+                    const UpdTask &T = P.upd_tasks[q];
+                    P.upd_stage_flops_dense[l] += 2.0 * T.nrows * T.ncols * (P.sn_first[T.src + 1] - P.sn_first[T.src]);
+                }
             // gather lists of this stage: every (target entry, source) pair, ordered by target entry and,
             // within an entry, by the task order (fixed summation order)
             pairs.clear();

@@ -129,6 +129,7 @@ struct HostPlan {
     std::vector<int64_t> gath_src;         // Lx offset of L_s[i, 0]
     std::vector<int32_t> gath_dj;          // offset of L_s[j, 0] relative to gath_src
     std::vector<int32_t> gath_sn;          // source supernode (stride, width, pivots)
+    std::vector<double> upd_stage_flops_dense;   // [nlevels] flops of the dense tiles of a stage
     double flops_update_dense = 0;   // part of flops_update executed by the dense-tile kernel
 
     std::vector<int64_t> u_off;  // [nsuper+1] offsets of each panel's off-diagonal rows in ubuf

@@ -23,7 +23,7 @@ SYMBOLS = [
     "hipkkt_get_dsigns", "hipkkt_get_map", "hipkkt_get_sparse_map", "hipkkt_update_values", "hipkkt_scale_values",
     "hipkkt_set_hs", "hipkkt_set_hs_dev", "hipkkt_set_soc", "hipkkt_set_soc_batch", "hipkkt_set_genpow",
     "hipkkt_update_P", "hipkkt_update_A", "hipkkt_refactor", "hipkkt_setrhs", "hipkkt_setrhs_dev", "hipkkt_solve",
-    "hipkkt_solve_dev", "hipkkt_ldl_solve", "hipkkt_get_timing", "hipkkt_reset_timing", "hipkkt_set_profiling",
+    "hipkkt_solve_dev", "hipkkt_ldl_solve", "hipkkt_get_timing", "hipkkt_reset_timing", "hipkkt_get_profile", "hipkkt_set_profiling",
     "hipkkt_selftest_mfma", "hipkkt_last_error",
 ]
 
@@ -87,6 +87,7 @@ def lib():
     L.hipkkt_ldl_solve.argtypes = [vp, _f64p, _f64p]
     L.hipkkt_get_timing.argtypes = [vp, _f64p]
     L.hipkkt_reset_timing.argtypes = [vp]
+    L.hipkkt_get_profile.argtypes = [vp, _f64p]
     L.hipkkt_set_profiling.argtypes = [vp, i32]
     L.hipkkt_selftest_mfma.argtypes = [i32, C.POINTER(f64)]
     L.hipkkt_last_error.argtypes = [vp]
@@ -211,6 +212,11 @@ class Handle:
         self.L.hipkkt_get_timing(self.h, o)
         return dict(last_factor_ms=o[0], last_solve_ms=o[1], acc_factor_ms=o[2], acc_solve_ms=o[3], n_factor=int(o[4]),
                     n_solve_calls=int(o[5]), n_ldl_solves=int(o[6]), last_update_ms=o[7])
+
+    def profile(self):
+        o = np.zeros(8)
+        self.L.hipkkt_get_profile(self.h, o)
+        return dict(update_ms=o[0], dense4_ms=o[1], dense4_flops=o[2], dense4_launches=int(o[3]))
 
     # ---- numeric
     def update_values(self, index, values):
