@@ -232,10 +232,24 @@ k_factor_level(DevPlan P, int item_begin, int wmax, double dyn_eps, double dyn_d
 // LDS write -> barrier -> LDS read -> 1/d (112 clk) -> mul -> fma  (~400 clk; tools/ubench.hip).
 // Pivot rule = QDLDL's.  Every chunk repeats the diagonal block (bit-identical).
 // ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double readlane_f64(double x, int l) {   // l wave-uniform
+    const unsigned long long u = (unsigned long long)__double_as_longlong(x);
+    const unsigned lo = __builtin_amdgcn_readlane((unsigned)u, l), hi = __builtin_amdgcn_readlane((unsigned)(u >> 32), l);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+// Blocked by 8 pivots: wave v of a group owns the column blocks {v, v+4} (8 columns each).  The owner of block B
+// eliminates its 8 columns WITHOUT leaving the wavefront (pivot and the entries a_jk come from the lanes that hold
+// them: v_readlane), publishes the block's L columns / raw columns / 1/d through LDS, and after ONE barrier every
+// wave applies the rank-8 update to its own live blocks; the chunk rows (group O) follow with the published
+// values and a second barrier.  16 barriers per 64-column panel instead of 64, and only the 8x8 triangle of the
+// current block sits on the pivot-to-pivot critical path.
 __global__ void __launch_bounds__(512)
 k_factor_panel(DevPlan P, int item_begin, double dyn_eps, double dyn_delta) {
-    __shared__ double colD[2][64];
-    __shared__ double colO[2][64];
+    __shared__ double colL[2][8][64];     // l_ik of the diagonal-block rows, current block (double buffered)
+    __shared__ double colC[2][8][64];     // raw a_ik = d_k l_ik of the diagonal-block rows (c_jk for any column j)
+    __shared__ double colLO[2][8][64];    // l_ik of the chunk rows
+    __shared__ double dinvs[2][8];
     __shared__ double Yt[2][64 * 65];     // [group][row * 65 + k]: L11 (group D) and L21 (group O), staged
     __shared__ double dsave[64];
     const FacItem it = P.fac_items[item_begin + blockIdx.x];
@@ -250,37 +264,83 @@ k_factor_panel(DevPlan P, int item_begin, double dyn_eps, double dyn_delta) {
     const int nr = min(kFacRows, r - lo);
     const int prow = grp ? lo + lane : lane;              // panel row of this lane
     const bool rvalid = grp ? lane < nr : lane < w;
-    double a[16];
+    double a[16];                                         // a[8*h + jj] = column 8*(v + 4h) + jj of this lane's row
 #pragma unroll
     for (int c = 0; c < 16; c++) {
-        const int j = 4 * c + v;
+        const int j = 8 * (v + 4 * (c >> 3)) + (c & 7);
         a[c] = (rvalid && j < w) ? pan[prow + (int64_t)j * r] : 0.0;
     }
     const unsigned long long spos = __ballot(lane < w && P.sgn_perm[f + (lane < w ? lane : 0)] > 0);
-    double *mycol0 = grp ? &colO[0][0] : &colD[0][0];
     double *myY = &Yt[grp][lane * 65];
     int nreg = 0;
     // no global stores inside the pivot loop: __syncthreads() would wait for them every step
 #pragma unroll
-    for (int k = 0; k < 64; k++) {
-        if (k < w) {                                      // workgroup-uniform
-            const int ck = k >> 2, vk = k & 3, pb = k & 1;
-            if (v == vk) mycol0[pb * 64 + lane] = a[ck];
-            __syncthreads();
-            double d = colD[pb][k];
-            const double sg = ((spos >> k) & 1ull) ? 1.0 : -1.0;
-            if (d * sg < dyn_eps) { d = dyn_delta * sg; nreg++; }
-            const double dinv = 1.0 / d;
-            const double li = mycol0[pb * 64 + lane] * dinv;
-            if (v == vk) {
-                myY[k] = li;
-                if (grp == 0 && lane == k) dsave[k] = d;
-            }
+    for (int B = 0; B < 8; B++) {
+        if (8 * B < w) {                                  // workgroup-uniform
+            const int vb = B & 3, rb = 8 * (B >> 2), pb = B & 1;
+            if (grp == 0 && v == vb) {                    // owner of the block, diagonal rows: 8 pivots in-wave
 #pragma unroll
-            for (int c = ck; c < 16; c++) {
-                double cj = colD[pb][4 * c + v];
-                if (c == ck && v <= vk) cj = 0.0;         // column already eliminated
-                a[c] = fma(-li, cj, a[c]);
+                for (int kk = 0; kk < 8; kk++) {
+                    const int k = 8 * B + kk;
+                    const double reg = a[rb + kk];
+                    double d = readlane_f64(reg, k);
+                    const double sg = ((spos >> k) & 1ull) ? 1.0 : -1.0;
+                    if (k < w && d * sg < dyn_eps) { d = dyn_delta * sg; nreg++; }
+                    const double dinv = k < w ? 1.0 / d : 0.0;
+                    const double li = reg * dinv;
+                    colL[pb][kk][lane] = li;
+                    colC[pb][kk][lane] = k < w ? reg : 0.0;
+                    myY[k] = li;
+                    if (lane == k) dsave[k] = d;
+                    if (lane == 0) dinvs[pb][kk] = dinv;
+#pragma unroll
+                    for (int jj = kk + 1; jj < 8; jj++) {
+                        const double cj = readlane_f64(reg, 8 * B + jj);
+                        a[rb + jj] = fma(-li, cj, a[rb + jj]);
+                    }
+                }
+            }
+            __syncthreads();
+            if (grp == 0) {                               // rank-8 update of this wave's live blocks
+                double lk_[8];
+#pragma unroll
+                for (int kk = 0; kk < 8; kk++) lk_[kk] = colL[pb][kk][lane];
+#pragma unroll
+                for (int h = 0; h < 2; h++)
+                    if (v + 4 * h > B) {
+#pragma unroll
+                        for (int jj = 0; jj < 8; jj++) {
+                            const int j = 8 * (v + 4 * h) + jj;
+#pragma unroll
+                            for (int kk = 0; kk < 8; kk++) a[8 * h + jj] = fma(-lk_[kk], colC[pb][kk][j], a[8 * h + jj]);
+                        }
+                    }
+            } else if (v == vb) {                         // owner of the block, chunk rows: same pivots, published operands
+#pragma unroll
+                for (int kk = 0; kk < 8; kk++) {
+                    const int k = 8 * B + kk;
+                    const double li = a[rb + kk] * dinvs[pb][kk];
+                    colLO[pb][kk][lane] = li;
+                    myY[k] = li;
+#pragma unroll
+                    for (int jj = kk + 1; jj < 8; jj++) a[rb + jj] = fma(-li, colC[pb][kk][8 * B + jj], a[rb + jj]);
+                }
+            }
+            __syncthreads();
+            if (grp == 1) {
+                double lk_[8];
+#pragma unroll
+                for (int kk = 0; kk < 8; kk++) lk_[kk] = colLO[pb][kk][lane];
+#pragma unroll
+                for (int h = 0; h < 2; h++)
+                    if (v + 4 * h > B) {
+#pragma unroll
+                        for (int jj = 0; jj < 8; jj++) {
+                            const int j = 8 * (v + 4 * h) + jj;
+#pragma unroll
+                            for (int kk = 0; kk < 8; kk++) a[8 * h + jj] = fma(-lk_[kk], colC[pb][kk][j], a[8 * h + jj]);
+                        }
+                    }
             }
         }
     }
@@ -297,7 +357,7 @@ k_factor_panel(DevPlan P, int item_begin, double dyn_eps, double dyn_delta) {
             P.Dinv[f + tid] = dinv;
             if (!isfinite(dinv)) atomicOr(P.flags + FL_NONFINITE, 1);
         }
-        if (tid == 0 && nreg) atomicAdd(P.flags + FL_NREG, nreg);
+        if (grp == 0 && lane == 0 && nreg) atomicAdd(P.flags + FL_NREG, nreg);   // each owner wave counted its own blocks
     }
     if (nr > 0) {
         for (int idx = tid; idx < nr * w; idx += 512) {   // column-major panel rows
