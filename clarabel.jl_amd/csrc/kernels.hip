@@ -246,10 +246,10 @@ __device__ __forceinline__ double readlane_f64(double x, int l) {   // l wave-un
 // current block sits on the pivot-to-pivot critical path.
 __global__ void __launch_bounds__(512)
 k_factor_panel(DevPlan P, int item_begin, double dyn_eps, double dyn_delta) {
-    __shared__ double colL[2][8][64];     // l_ik of the diagonal-block rows, current block (double buffered)
-    __shared__ double colC[2][8][64];     // raw a_ik = d_k l_ik of the diagonal-block rows (c_jk for any column j)
-    __shared__ double colLO[2][8][64];    // l_ik of the chunk rows
-    __shared__ double dinvs[2][8];
+    __shared__ double colL[2][8][64];     // l_ik of the diagonal-block rows of block B          (parity B & 1)
+    __shared__ double colC[3][8][64];     // raw a_ik = d_k l_ik of the diagonal-block rows        (B % 3: read for two iterations)
+    __shared__ double colLO[2][8][64];    // l_ik of the chunk rows                                (parity B & 1)
+    __shared__ double dinvs[3][8];
     __shared__ double Yt[2][64 * 65];     // [group][row * 65 + k]: L11 (group D) and L21 (group O), staged
     __shared__ double dsave[64];
     const FacItem it = P.fac_items[item_begin + blockIdx.x];
@@ -273,12 +273,16 @@ k_factor_panel(DevPlan P, int item_begin, double dyn_eps, double dyn_delta) {
     const unsigned long long spos = __ballot(lane < w && P.sgn_perm[f + (lane < w ? lane : 0)] > 0);
     double *myY = &Yt[grp][lane * 65];
     int nreg = 0;
-    // no global stores inside the pivot loop: __syncthreads() would wait for them every step
+    const int nB = (w + 7) >> 3;
+    // Software pipeline with ONE barrier per block: in iteration B the diagonal-row owner eliminates block B while
+    // the chunk-row owner eliminates block B-1 with the values published one barrier earlier; after the barrier
+    // the diagonal-row waves apply block B and the chunk-row waves apply block B-1 to their live blocks.
+    // No global stores inside the loop: __syncthreads() would wait for them every step.
 #pragma unroll
-    for (int B = 0; B < 8; B++) {
-        if (8 * B < w) {                                  // workgroup-uniform
-            const int vb = B & 3, rb = 8 * (B >> 2), pb = B & 1;
-            if (grp == 0 && v == vb) {                    // owner of the block, diagonal rows: 8 pivots in-wave
+    for (int B = 0; B <= 8; B++) {
+        if (B <= nB) {                                    // workgroup-uniform
+            if (grp == 0 && B < 8 && B < nB && v == (B & 3)) {   // diagonal rows, block B: 8 pivots in-wave
+                const int rb = 8 * (B >> 2), pb = B & 1, p3 = B % 3;
 #pragma unroll
                 for (int kk = 0; kk < 8; kk++) {
                     const int k = 8 * B + kk;
@@ -289,10 +293,10 @@ k_factor_panel(DevPlan P, int item_begin, double dyn_eps, double dyn_delta) {
                     const double dinv = k < w ? 1.0 / d : 0.0;
                     const double li = reg * dinv;
                     colL[pb][kk][lane] = li;
-                    colC[pb][kk][lane] = k < w ? reg : 0.0;
+                    colC[p3][kk][lane] = k < w ? reg : 0.0;
                     myY[k] = li;
                     if (lane == k) dsave[k] = d;
-                    if (lane == 0) dinvs[pb][kk] = dinv;
+                    if (lane == 0) dinvs[p3][kk] = dinv;
 #pragma unroll
                     for (int jj = kk + 1; jj < 8; jj++) {
                         const double cj = readlane_f64(reg, 8 * B + jj);
@@ -300,45 +304,34 @@ k_factor_panel(DevPlan P, int item_begin, double dyn_eps, double dyn_delta) {
                     }
                 }
             }
-            __syncthreads();
-            if (grp == 0) {                               // rank-8 update of this wave's live blocks
-                double lk_[8];
-#pragma unroll
-                for (int kk = 0; kk < 8; kk++) lk_[kk] = colL[pb][kk][lane];
-#pragma unroll
-                for (int h = 0; h < 2; h++)
-                    if (v + 4 * h > B) {
-#pragma unroll
-                        for (int jj = 0; jj < 8; jj++) {
-                            const int j = 8 * (v + 4 * h) + jj;
-#pragma unroll
-                            for (int kk = 0; kk < 8; kk++) a[8 * h + jj] = fma(-lk_[kk], colC[pb][kk][j], a[8 * h + jj]);
-                        }
-                    }
-            } else if (v == vb) {                         // owner of the block, chunk rows: same pivots, published operands
+            if (grp == 1 && B >= 1 && v == ((B - 1) & 3)) {       // chunk rows, block B-1: published operands
+                const int Bo = B - 1, rb = 8 * (Bo >> 2), pb = Bo & 1, p3 = Bo % 3;
 #pragma unroll
                 for (int kk = 0; kk < 8; kk++) {
-                    const int k = 8 * B + kk;
-                    const double li = a[rb + kk] * dinvs[pb][kk];
+                    const int k = 8 * Bo + kk;
+                    const double li = a[rb + kk] * dinvs[p3][kk];
                     colLO[pb][kk][lane] = li;
                     myY[k] = li;
 #pragma unroll
-                    for (int jj = kk + 1; jj < 8; jj++) a[rb + jj] = fma(-li, colC[pb][kk][8 * B + jj], a[rb + jj]);
+                    for (int jj = kk + 1; jj < 8; jj++) a[rb + jj] = fma(-li, colC[p3][kk][8 * Bo + jj], a[rb + jj]);
                 }
             }
             __syncthreads();
-            if (grp == 1) {
+            const int Bu = grp == 0 ? B : B - 1;          // block this wave applies now
+            if (Bu >= 0 && Bu < nB && Bu < 8) {
+                const double(*Lsrc)[64] = grp == 0 ? colL[Bu & 1] : colLO[Bu & 1];
+                const int p3 = Bu % 3;
                 double lk_[8];
 #pragma unroll
-                for (int kk = 0; kk < 8; kk++) lk_[kk] = colLO[pb][kk][lane];
+                for (int kk = 0; kk < 8; kk++) lk_[kk] = Lsrc[kk][lane];
 #pragma unroll
                 for (int h = 0; h < 2; h++)
-                    if (v + 4 * h > B) {
+                    if (v + 4 * h > Bu) {
 #pragma unroll
                         for (int jj = 0; jj < 8; jj++) {
                             const int j = 8 * (v + 4 * h) + jj;
 #pragma unroll
-                            for (int kk = 0; kk < 8; kk++) a[8 * h + jj] = fma(-lk_[kk], colC[pb][kk][j], a[8 * h + jj]);
+                            for (int kk = 0; kk < 8; kk++) a[8 * h + jj] = fma(-lk_[kk], colC[p3][kk][j], a[8 * h + jj]);
                         }
                     }
             }
