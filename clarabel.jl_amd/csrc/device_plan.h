@@ -23,6 +23,7 @@ struct DevPlan {
     const int *perm;
     const signed char *sgn_perm;
     const FacItem *fac_items;
+    const FacJit *fac_jit;       // [fac_items] pending updates applied by k_factor_panel<true> (symbolic.h)
     const FacItem *slv_items;
     const FacItem *bwd_items;
     const int *rel;

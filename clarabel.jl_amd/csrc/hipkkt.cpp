@@ -51,6 +51,7 @@ struct hipkkt_solver {
     hipStream_t side = nullptr;          // far Schur updates run here, overlapped with the critical path
     std::vector<hipEvent_t> fork_events;
     bool use_side = true;
+    int far_wgs = 256;   // grid bound of the look-ahead (far) update launches; 0 = one workgroup per 4 tiles
     hipkkt_opts opts{};
     bool l1 = false;
     KKTImage img;      // L1: assembled image; L0: colptr/rowval/nzval/dsigns copied in
@@ -168,6 +169,8 @@ void init_runtime(hipkkt_solver *S) {
         // saves -- so the fork is opt-in (HIPKKT_SIDE_STREAM=1)
         const char *ns = getenv("HIPKKT_SIDE_STREAM");
         S->use_side = ns && ns[0] == '1';
+        const char *fw = getenv("HIPKKT_FAR_WGS");
+        if (fw) S->far_wgs = atoi(fw);
     }
     for (hipEvent_t *e : {&S->ev0, &S->ev1, &S->ev2, &S->ev3}) HK_CHECK(hipEventCreate(e));
     HK_CHECK(hipHostMalloc((void **)&S->h_scal, SC_COUNT * sizeof(double), hipHostMallocDefault));
@@ -312,6 +315,7 @@ void setup_device(hipkkt_solver *S) {
     D.perm = S->upload(P.perm);
     D.sgn_perm = S->upload(sgn_perm);
     D.fac_items = S->upload(P.fac_items);
+    D.fac_jit = S->upload(P.fac_jit);
     D.slv_items = S->upload(S->slv_items);
     D.rel = S->upload(P.rel);
     D.upd_tasks = S->upload(P.upd_tasks);
@@ -428,7 +432,8 @@ void enqueue_factor_level(hipkkt_solver *S, int l) {
         launch_factor_level(S->stream, S->dp, P.fac_lvl_ptr[l], n, P.fac_lvl_maxw[l], S->opts.dynamic_reg_eps,
                             S->opts.dynamic_reg_delta);
     else
-        launch_factor_panel(S->stream, S->dp, P.fac_lvl_ptr[l], n, S->opts.dynamic_reg_eps, S->opts.dynamic_reg_delta);
+        launch_factor_panel(S->stream, S->dp, P.fac_lvl_ptr[l], n, S->opts.dynamic_reg_eps, S->opts.dynamic_reg_delta,
+                            P.lvl_fused[l] != 0);
 }
 
 // Schur-complement updates applied after level l is factored: dense register tiles (matrix cores),
@@ -437,6 +442,7 @@ void enqueue_factor_level(hipkkt_solver *S, int l) {
 void enqueue_updates(hipkkt_solver *S, int l, bool split_far = false) {
     const HostPlan &P = S->plan;
     hipStream_t st = S->stream;
+    if (l + 1 < P.nlevels && P.lvl_fused[l + 1]) return;   // applied inside the next level's panel kernel
     const int g0 = P.upd_stage_ptr[l], nd = P.upd_stage_ndense[l], ng = P.upd_stage_ngather[l];
     launch_update_dense(st, S->dp, g0, nd - (split_far ? P.upd_stage_nfar[l] : 0));
     launch_update_gather(st, S->dp, P.gath_stage_ptr[l], P.gath_stage_ptr[l + 1] - P.gath_stage_ptr[l]);
@@ -474,7 +480,7 @@ void enqueue_factor(hipkkt_solver *S, int static_enable, double eps_const, doubl
             hipEvent_t e1 = new_event(), e2 = new_event();
             HK_CHECK(hipEventRecord(e1, st));
             HK_CHECK(hipStreamWaitEvent(S->side, e1, 0));
-            launch_update_dense(S->side, S->dp, P.upd_stage_ptr[l] + P.upd_stage_ndense[l] - nfar, nfar);
+            launch_update_dense(S->side, S->dp, P.upd_stage_ptr[l] + P.upd_stage_ndense[l] - nfar, nfar, S->far_wgs);
             HK_CHECK(hipEventRecord(e2, S->side));
             pending = e2;
             pending_level = l;
@@ -687,6 +693,8 @@ int32_t finish_create(hipkkt_solver *S, const hipkkt_opts *opts, hipkkt_handle *
     {
         const char *ns = getenv("HIPKKT_SIDE_STREAM");
         po.split_far = ns && ns[0] == '1';
+        const char *nf = getenv("HIPKKT_FUSE_JIT");    // experiment: just-in-time updates inside the panel kernel
+        if (nf && nf[0] == '1') po.fuse_jit = true;
         const char *nx = getenv("HIPKKT_XCD_ORDER");   // measured: no effect on cfg 2a (L2 locality is not the limiter)
         po.xcd_order = nx && nx[0] == '1';
     }
@@ -1117,7 +1125,8 @@ static int32_t refactor_once(hipkkt_handle h, int32_t static_reg_enable, double 
         std::vector<int> evd_level;
         for (int l = 0; l < P.nlevels; l++) {
             enqueue_factor_level(S, l);
-            if (P.upd_stage_ptr[l + 1] > P.upd_stage_ptr[l]) {
+            const bool fused_next = l + 1 < P.nlevels && P.lvl_fused[l + 1];   // applied by the next panel kernel
+            if (P.upd_stage_ptr[l + 1] > P.upd_stage_ptr[l] && !fused_next) {
                 hipEvent_t a, b, c2;
                 HK_CHECK(hipEventCreate(&a));
                 HK_CHECK(hipEventCreate(&b));

@@ -12,9 +12,10 @@ void launch_soc_batch(hipStream_t st, double *kval, const int64_t *uidx, const i
 void launch_maxabs_gather(hipStream_t st, const double *v, const int64_t *idx, int64_t n, unsigned long long *slot);
 void launch_init_panels(hipStream_t st, const DevPlan &P, int64_t nnz, int static_enable, double eps_const, double eps_prop);
 void launch_factor_level(hipStream_t st, const DevPlan &P, int item_begin, int nitems, int wmax, double dyn_eps, double dyn_delta);
-void launch_factor_panel(hipStream_t st, const DevPlan &P, int item_begin, int nitems, double dyn_eps, double dyn_delta);
+void launch_factor_panel(hipStream_t st, const DevPlan &P, int item_begin, int nitems, double dyn_eps, double dyn_delta,
+                         bool fused = false);
 void launch_update_stage(hipStream_t st, const DevPlan &P, int group_begin, int ngroups);
-void launch_update_dense(hipStream_t st, const DevPlan &P, int group_begin, int ngroups);
+void launch_update_dense(hipStream_t st, const DevPlan &P, int group_begin, int ngroups, int max_wgs = 0);
 void launch_update_gather(hipStream_t st, const DevPlan &P, int64_t ebegin, int64_t n);
 void launch_invert_diag(hipStream_t st, const DevPlan &P, int nsuper, int wmax);
 void launch_mfma_probe(hipStream_t st, const double *A, const double *B, double *out);

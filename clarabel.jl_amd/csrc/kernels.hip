@@ -244,6 +244,16 @@ __device__ __forceinline__ double readlane_f64(double x, int l) {   // l wave-un
 // wave applies the rank-8 update to its own live blocks; the chunk rows (group O) follow with the published
 // values and a second barrier.  16 barriers per 64-column panel instead of 64, and only the 8x8 triangle of the
 // current block sits on the pivot-to-pivot critical path.
+__device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+template <int NT, bool LDS_OUT>
+__device__ __forceinline__ void dense_tile_core(const DevPlan &P, double *tp, int rt, int nrt, int wt, int task_begin,
+                                                int task_end, int lane, int tj0, double *lds_out);
+
+// FUSED (experiment, off by default: symbolic.h PlanOptions::fuse_jit): the panel's pending just-in-time updates
+// (FacJit) are applied here first, on the matrix cores: waves 0-3 take the diagonal tile, waves 4-7 the workgroup's
+// row chunk, one 16-column strip each (the code of k_update_dense<1>), and hand the updated rows over through the
+// staging buffer instead of through the panel.
+template <bool FUSED>
 __global__ void __launch_bounds__(512)
 k_factor_panel(DevPlan P, int item_begin, double dyn_eps, double dyn_delta) {
     __shared__ double colL[2][8][64];     // l_ik of the diagonal-block rows of block B          (parity B & 1)
@@ -265,10 +275,24 @@ k_factor_panel(DevPlan P, int item_begin, double dyn_eps, double dyn_delta) {
     const int prow = grp ? lo + lane : lane;              // panel row of this lane
     const bool rvalid = grp ? lane < nr : lane < w;
     double a[16];                                         // a[8*h + jj] = column 8*(v + 4h) + jj of this lane's row
+    if (FUSED) {
+        const FacJit J = P.fac_jit[item_begin + blockIdx.x];
+        if (grp == 0 || nr > 0)                           // wave-uniform
+            dense_tile_core<1, true>(P, pan + (grp ? lo : 0), r, grp ? nr : w, w, rfl(grp ? J.c_begin : J.d_begin),
+                                     rfl(grp ? J.c_end : J.d_end), lane, v, Yt[grp]);
+        __syncthreads();
 #pragma unroll
-    for (int c = 0; c < 16; c++) {
-        const int j = 8 * (v + 4 * (c >> 3)) + (c & 7);
-        a[c] = (rvalid && j < w) ? pan[prow + (int64_t)j * r] : 0.0;
+        for (int c = 0; c < 16; c++) {
+            const int j = 8 * (v + 4 * (c >> 3)) + (c & 7);
+            a[c] = (rvalid && j < w) ? Yt[grp][lane * 65 + j] : 0.0;
+        }
+        __syncthreads();                                  // the pivot loop stages its results in Yt
+    } else {
+#pragma unroll
+        for (int c = 0; c < 16; c++) {
+            const int j = 8 * (v + 4 * (c >> 3)) + (c & 7);
+            a[c] = (rvalid && j < w) ? pan[prow + (int64_t)j * r] : 0.0;
+        }
     }
     const unsigned long long spos = __ballot(lane < w && P.sgn_perm[f + (lane < w ? lane : 0)] > 0);
     double *myY = &Yt[grp][lane * 65];
@@ -537,7 +561,6 @@ k_update_stage(DevPlan P, int group_begin) {
 // consecutive lanes: tile loads / stores are 128-B segments too.
 // No LDS, no barriers, no inter-wave communication: 4 independent wavefronts per workgroup.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
 template <class T>
 __device__ __forceinline__ T *rfl_ptr(T *p) {
     const unsigned long long u = (unsigned long long)p;
@@ -599,22 +622,11 @@ __device__ __forceinline__ void dense_mma(const DenseRaw<NT> &f, v4f64 (&acc)[NT
 // NT = 4: one wavefront per tile (4 tiles per workgroup): highest operand reuse, for launches with
 //         thousands of tiles.   NT = 1: one wavefront per 16-column strip (one tile per workgroup):
 //         4x shorter critical path, for the just-in-time updates of the next panel (<= ~100 tiles).
-template <int NT>
-__global__ void __launch_bounds__(256, 2)
-k_update_dense(DevPlan P, int group_begin, int ngroups) {
-    const int lane = threadIdx.x & 63;
-    const int wave = rfl(threadIdx.x >> 6);
-    const int g = NT == 4 ? rfl(blockIdx.x * 4 + wave) : (int)blockIdx.x;
-    const int tj0 = NT == 4 ? 0 : wave;               // first 16-column strip of this wavefront
-    if (g >= ngroups) return;
-    const UpdGroup *Gp = P.upd_groups + group_begin + g;
-    const int t = rfl(Gp->tgt), row_base = rfl(Gp->row_base), task_begin = rfl(Gp->task_begin), task_end = rfl(Gp->task_end);
-    const int ft = rfl(P.sn_first[t]);
-    const int wt = rfl(P.sn_first[t + 1]) - ft;
-    if (tj0 * 16 >= wt) return;
-    const int rt = rfl((int)(P.sn_rowptr[t + 1] - P.sn_rowptr[t]));
-    double *tp = rfl_ptr(P.Lx + P.sn_panel[t] + row_base);
-    const int nrt = min(kUpdRows, rt - row_base);
+// LDS_OUT: the finished strip goes to lds_out[row * 65 + column] (the panel kernel's staging layout) instead of
+//          back to the panel -- used by k_factor_panel<true>, which applies a panel's pending updates itself.
+template <int NT, bool LDS_OUT>
+__device__ __forceinline__ void dense_tile_core(const DevPlan &P, double *tp, int rt, int nrt, int wt, int task_begin,
+                                                int task_end, int lane, int tj0, double *lds_out) {
     const int l15 = lane & 15, lk = lane >> 4;
 
     // accumulators <- the target tile.  acc[tj][ti][reg]: column (tj0+tj)*16 + lk + 4*reg, row ti*16 + l15
@@ -723,9 +735,34 @@ k_update_dense(DevPlan P, int group_begin, int ngroups) {
 #pragma unroll
             for (int ti = 0; ti < 4; ti++) {
                 const int ii = ti * 16 + l15;
-                if (ii < nrt && jj < wt) st_off(tp, (unsigned)(ii + jj * rt) * 8u, acc[tj][ti][reg]);
+                if (LDS_OUT) lds_out[ii * 65 + jj] = acc[tj][ti][reg];
+                else if (ii < nrt && jj < wt) st_off(tp, (unsigned)(ii + jj * rt) * 8u, acc[tj][ti][reg]);
             }
         }
+}
+
+template <int NT>
+__device__ __forceinline__ void dense_tile(const DevPlan &P, const UpdGroup *Gp, int lane, int tj0) {
+    const int t = rfl(Gp->tgt), row_base = rfl(Gp->row_base), task_begin = rfl(Gp->task_begin), task_end = rfl(Gp->task_end);
+    const int ft = rfl(P.sn_first[t]);
+    const int wt = rfl(P.sn_first[t + 1]) - ft;
+    if (tj0 * 16 >= wt) return;
+    const int rt = rfl((int)(P.sn_rowptr[t + 1] - P.sn_rowptr[t]));
+    double *tp = rfl_ptr(P.Lx + P.sn_panel[t] + row_base);
+    const int nrt = min(kUpdRows, rt - row_base);
+    dense_tile_core<NT, false>(P, tp, rt, nrt, wt, task_begin, task_end, lane, tj0, nullptr);
+}
+
+// Grid-stride over the tiles of a launch (a bounded grid is used by the look-ahead experiments, hipkkt.cpp).
+template <int NT>
+__global__ void __launch_bounds__(256, NT == 2 ? 4 : 2)
+k_update_dense(DevPlan P, int group_begin, int ngroups) {
+    const int lane = threadIdx.x & 63;
+    const int wave = rfl(threadIdx.x >> 6);
+    // NT 16-column strips per wavefront: 4/NT wavefronts share a tile, NT tiles per workgroup
+    const int tj0 = (wave % (4 / NT)) * NT;           // first 16-column strip of this wavefront
+    for (int g = rfl(blockIdx.x * NT + wave / (4 / NT)); g < ngroups; g += gridDim.x * NT)
+        dense_tile<NT>(P, P.upd_groups + group_begin + g, lane, tj0);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1890,16 +1927,26 @@ void launch_factor_level(hipStream_t st, const DevPlan &P, int item_begin, int n
         hipLaunchKernelGGL(k_factor_level, dim3(nitems), dim3(256), factor_lds_bytes(wmax), st, P, item_begin, wmax, dyn_eps,
                            dyn_delta);
 }
-void launch_factor_panel(hipStream_t st, const DevPlan &P, int item_begin, int nitems, double dyn_eps, double dyn_delta) {
-    if (nitems > 0) hipLaunchKernelGGL(k_factor_panel, dim3(nitems), dim3(512), 0, st, P, item_begin, dyn_eps, dyn_delta);
+void launch_factor_panel(hipStream_t st, const DevPlan &P, int item_begin, int nitems, double dyn_eps, double dyn_delta, bool fused) {
+    if (nitems <= 0) return;
+    if (fused) hipLaunchKernelGGL(k_factor_panel<true>, dim3(nitems), dim3(512), 0, st, P, item_begin, dyn_eps, dyn_delta);
+    else hipLaunchKernelGGL(k_factor_panel<false>, dim3(nitems), dim3(512), 0, st, P, item_begin, dyn_eps, dyn_delta);
 }
 void launch_update_stage(hipStream_t st, const DevPlan &P, int group_begin, int ngroups) {
     if (ngroups > 0) hipLaunchKernelGGL(k_update_stage, dim3(ngroups), dim3(kUpdWaves * 64), 0, st, P, group_begin);
 }
-void launch_update_dense(hipStream_t st, const DevPlan &P, int group_begin, int ngroups) {
+#ifndef HIPKKT_DENSE_BIG_NT
+#define HIPKKT_DENSE_BIG_NT 4
+#endif
+void launch_update_dense(hipStream_t st, const DevPlan &P, int group_begin, int ngroups, int max_wgs) {
     if (ngroups <= 0) return;
+    if (max_wgs > 0) {   // look-ahead launch: a bounded grid that strides over the tiles
+        hipLaunchKernelGGL(k_update_dense<4>, dim3(std::min((ngroups + 3) / 4, max_wgs)), dim3(256), 0, st, P, group_begin, ngroups);
+        return;
+    }
     if (ngroups > 384)   // plenty of tiles: one wavefront per tile
-        hipLaunchKernelGGL(k_update_dense<4>, dim3((ngroups + 3) / 4), dim3(256), 0, st, P, group_begin, ngroups);
+        hipLaunchKernelGGL(k_update_dense<HIPKKT_DENSE_BIG_NT>, dim3((ngroups + HIPKKT_DENSE_BIG_NT - 1) / HIPKKT_DENSE_BIG_NT),
+                           dim3(256), 0, st, P, group_begin, ngroups);
     else                 // few tiles (just-in-time updates): split every tile over 4 wavefronts
         hipLaunchKernelGGL(k_update_dense<1>, dim3(ngroups), dim3(256), 0, st, P, group_begin, ngroups);
 }

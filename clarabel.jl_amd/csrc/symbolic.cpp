@@ -563,6 +563,41 @@ std::string build_plan(int N, const int64_t *Ap, const int64_t *Ai, const int64_
         }
     }
 
+    // ---- 14b. fused just-in-time updates: inside a front, the stage before panel p+1 holds nothing but the dense
+    //           tiles of that one panel (sources: the batch-mates factored just before it).  The panel kernel of
+    //           p+1 then applies them to the rows it owns (every workgroup: the diagonal tile, redundantly, and
+    //           its own row chunk) and the stage needs no kernel of its own -- one launch and one store/reload of
+    //           the panel less on the critical path of the factorisation.
+    P.fac_jit.assign(P.fac_items.size(), FacJit{0, 0, 0, 0});
+    P.lvl_fused.assign(P.nlevels, 0);
+    if (opt.fuse_jit && kFacRows == kUpdRows)
+        for (int l = 1; l < P.nlevels; l++) {
+            if (P.lvl_ptr[l + 1] - P.lvl_ptr[l] != 1) continue;
+            const int s = P.lvl_sn[P.lvl_ptr[l]];
+            if (P.sn_first[s + 1] - P.sn_first[s] != kUpdRows) continue;
+            const int g0 = P.upd_stage_ptr[l - 1], g1 = P.upd_stage_ptr[l];
+            if (g1 == g0 || P.upd_stage_ndense[l - 1] != g1 - g0 || P.upd_stage_nfar[l - 1] != 0) continue;
+            bool ok = true;
+            for (int g = g0; g < g1 && ok; g++)
+                ok = P.upd_groups[g].tgt == s && P.upd_groups[g].dense == 1 && P.upd_groups[g].row_base % kUpdRows == 0;
+            if (!ok) continue;
+            const int64_t r = P.sn_rowptr[s + 1] - P.sn_rowptr[s];
+            std::vector<int> by_tile((size_t)((r + kUpdRows - 1) / kUpdRows), -1);
+            for (int g = g0; g < g1; g++) by_tile[P.upd_groups[g].row_base / kUpdRows] = g;
+            for (int i = P.fac_lvl_ptr[l]; i < P.fac_lvl_ptr[l + 1]; i++) {
+                const FacItem &it = P.fac_items[i];
+                FacJit J{0, 0, 0, 0};
+                if (by_tile[0] >= 0) { J.d_begin = P.upd_groups[by_tile[0]].task_begin; J.d_end = P.upd_groups[by_tile[0]].task_end; }
+                const size_t ct = (size_t)it.blk + 1;
+                if (ct < by_tile.size() && by_tile[ct] >= 0) {
+                    J.c_begin = P.upd_groups[by_tile[ct]].task_begin;
+                    J.c_end = P.upd_groups[by_tile[ct]].task_end;
+                }
+                P.fac_jit[i] = J;
+            }
+            P.lvl_fused[l] = 1;
+        }
+
     // ---- 15. gather lists for the forward solve (multifrontal style): every panel row slot
     //          (s, li) collects the update-vector entries of the CHILDREN of s that land on it.
     //          Fan-in per slot <= #children; each ubuf entry is consumed exactly once, by the parent.

@@ -53,6 +53,13 @@ struct FacItem {
     int32_t blk;        // row-chunk index inside the panel's off-diagonal part
 };
 
+// Pending (just-in-time) updates of one factor item, applied by the panel kernel itself before it eliminates:
+// task ranges (into upd_tasks) of the item's diagonal tile and of its row chunk.  Used for the panels of a front
+// whose only pending updates come from the batch-mates factored just before them (lvl_fused).
+struct FacJit {
+    int32_t d_begin, d_end, c_begin, c_end;
+};
+
 // A "front" = one wide (fundamental) supernode that the width cap split into a chain of np panels of
 // cw columns (the last may be narrower).  Its panels have nested row structures (panel p holds the
 // front rows [cw*p, rF)), so the triangular solves over the chain are done by ONE persistent kernel
@@ -81,6 +88,8 @@ struct PlanOptions {
     int update_policy = 2;  // 0 right-looking, 1 left-looking, 2 batched right-looking
     int update_batch = 4;   // levels per batch for policy 2
     double amd_dense_scale = 1.5;
+    bool fuse_jit = false;     // apply the just-in-time updates of a front panel inside its panel kernel
+                               // (measured slower on MI355X, DESIGN.md section 9: every workgroup repeats the diagonal tile)
     bool split_far = false;    // separate the far dense tiles of a stage (side-stream experiments)
     bool xcd_order = false;    // order the dense tiles of a stage so that each XCD's L2 sees 1/8 of the source rows
     int n_hold = 0;            // > 0: also try the "variables last" order (nodes < n_hold held back) and keep
@@ -110,6 +119,9 @@ struct HostPlan {
     std::vector<FacItem> fac_items;
     std::vector<int> fac_lvl_ptr;  // [nlevels+1]
     std::vector<int> fac_lvl_maxw; // [nlevels] widest supernode of the level (LDS sizing)
+    std::vector<FacJit> fac_jit;   // [fac_items] see FacJit (all-zero ranges where unused)
+    std::vector<char> lvl_fused;   // [nlevels] 1: stage l-1's updates all land on level l's single 64-column panel and
+                                   // are applied inside its panel kernel; the stage has no launch of its own
 
     std::vector<int> rel;
     std::vector<UpdTask> upd_tasks;
