@@ -245,9 +245,9 @@ __device__ __forceinline__ double readlane_f64(double x, int l) {   // l wave-un
 // values and a second barrier.  16 barriers per 64-column panel instead of 64, and only the 8x8 triangle of the
 // current block sits on the pivot-to-pivot critical path.
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
-template <int NT, bool LDS_OUT>
+template <int NT, int NR, bool LDS_OUT>
 __device__ __forceinline__ void dense_tile_core(const DevPlan &P, double *tp, int rt, int nrt, int wt, int task_begin,
-                                                int task_end, int lane, int tj0, double *lds_out);
+                                                int task_end, int lane, int tj0, int ti0, double *lds_out);
 
 // FUSED (experiment, off by default: symbolic.h PlanOptions::fuse_jit): the panel's pending just-in-time updates
 // (FacJit) are applied here first, on the matrix cores: waves 0-3 take the diagonal tile, waves 4-7 the workgroup's
@@ -278,8 +278,8 @@ k_factor_panel(DevPlan P, int item_begin, double dyn_eps, double dyn_delta) {
     if (FUSED) {
         const FacJit J = P.fac_jit[item_begin + blockIdx.x];
         if (grp == 0 || nr > 0)                           // wave-uniform
-            dense_tile_core<1, true>(P, pan + (grp ? lo : 0), r, grp ? nr : w, w, rfl(grp ? J.c_begin : J.d_begin),
-                                     rfl(grp ? J.c_end : J.d_end), lane, v, Yt[grp]);
+            dense_tile_core<1, 4, true>(P, pan + (grp ? lo : 0), r, grp ? nr : w, w, rfl(grp ? J.c_begin : J.d_begin),
+                                        rfl(grp ? J.c_end : J.d_end), lane, v, 0, Yt[grp]);
         __syncthreads();
 #pragma unroll
         for (int c = 0; c < 16; c++) {
@@ -576,15 +576,16 @@ __device__ __forceinline__ void st_off(double *base, unsigned byte_off, double v
     *(HK_GLOBAL double *)((HK_GLOBAL char *)base + byte_off) = v;
 }
 
-template <int NT>
+// NT 16-column strips x NR 16-row blocks of a tile per wavefront
+template <int NT, int NR>
 struct DenseRaw {
-    double a[NT], b[4], d;
+    double a[NT], b[NR], d;
 };
 
 // issue the loads of one k-step (4 k's): operand rows are contiguous for a fixed k
-template <int NT>
-__device__ __forceinline__ void dense_load(DenseRaw<NT> &f, const double *sp, const double *dv, const unsigned (&coff)[NT],
-                                           const unsigned (&roff)[4], unsigned r8, int K, int k0, int lk) {
+template <int NT, int NR>
+__device__ __forceinline__ void dense_load(DenseRaw<NT, NR> &f, const double *sp, const double *dv, const unsigned (&coff)[NT],
+                                           const unsigned (&roff)[NR], unsigned r8, int K, int k0, int lk) {
     int kk = k0 + lk;
     kk = kk < K ? kk : K - 1;
     const unsigned ko = (unsigned)kk * r8;
@@ -593,52 +594,53 @@ __device__ __forceinline__ void dense_load(DenseRaw<NT> &f, const double *sp, co
 #pragma unroll
     for (int t = 0; t < NT; t++) f.a[t] = 1e-3 * (coff[t] + 1);
 #pragma unroll
-    for (int t = 0; t < 4; t++) f.b[t] = 1e-3 * (roff[t] + 1);
+    for (int t = 0; t < NR; t++) f.b[t] = 1e-3 * (roff[t] + 1);
 #else
     f.d = ld_off(dv, (unsigned)kk * 8u);
 #pragma unroll
     for (int t = 0; t < NT; t++) f.a[t] = ld_off(sp, coff[t] + ko);
 #pragma unroll
-    for (int t = 0; t < 4; t++) f.b[t] = ld_off(sp, roff[t] + ko);
+    for (int t = 0; t < NR; t++) f.b[t] = ld_off(sp, roff[t] + ko);
 #endif
 }
 
-template <int NT>
-__device__ __forceinline__ void dense_mma(const DenseRaw<NT> &f, v4f64 (&acc)[NT][4], unsigned mbits, int K, int k0, int lk) {
+template <int NT, int NR>
+__device__ __forceinline__ void dense_mma(const DenseRaw<NT, NR> &f, v4f64 (&acc)[NT][NR], unsigned mbits, int K, int k0, int lk) {
     const double dk = (k0 + lk < K) ? -f.d : 0.0;     // negated: acc = C - sum
-    double a[NT], b[4];
+    double a[NT], b[NR];
 #pragma unroll
     for (int t = 0; t < NT; t++)    // mbits: bit t = column operand t valid, bit 4+t = row operand t valid
         a[t] = ((mbits >> t) & 1u) ? f.a[t] * dk : 0.0;
 #pragma unroll
-    for (int t = 0; t < 4; t++) b[t] = ((mbits >> (4 + t)) & 1u) ? f.b[t] : 0.0;
+    for (int t = 0; t < NR; t++) b[t] = ((mbits >> (4 + t)) & 1u) ? f.b[t] : 0.0;
 #pragma unroll
     for (int tj = 0; tj < NT; tj++)
 #pragma unroll
-        for (int ti = 0; ti < 4; ti++)
+        for (int ti = 0; ti < NR; ti++)
             acc[tj][ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[tj], b[ti], acc[tj][ti], 0, 0, 0);
 }
 
 // NT = 4: one wavefront per tile (4 tiles per workgroup): highest operand reuse, for launches with
 //         thousands of tiles.   NT = 1: one wavefront per 16-column strip (one tile per workgroup):
-//         4x shorter critical path, for the just-in-time updates of the next panel (<= ~100 tiles).
+//         4x shorter critical path, for the just-in-time updates of the next panel (<= ~100 tiles); these may
+//         also split the tile's rows over 4/NR workgroups (NR 16-row blocks per wavefront).
 // LDS_OUT: the finished strip goes to lds_out[row * 65 + column] (the panel kernel's staging layout) instead of
 //          back to the panel -- used by k_factor_panel<true>, which applies a panel's pending updates itself.
-template <int NT, bool LDS_OUT>
+template <int NT, int NR, bool LDS_OUT>
 __device__ __forceinline__ void dense_tile_core(const DevPlan &P, double *tp, int rt, int nrt, int wt, int task_begin,
-                                                int task_end, int lane, int tj0, double *lds_out) {
+                                                int task_end, int lane, int tj0, int ti0, double *lds_out) {
     const int l15 = lane & 15, lk = lane >> 4;
 
-    // accumulators <- the target tile.  acc[tj][ti][reg]: column (tj0+tj)*16 + lk + 4*reg, row ti*16 + l15
-    v4f64 acc[NT][4];
+    // accumulators <- the target tile.  acc[tj][ti][reg]: column (tj0+tj)*16 + lk + 4*reg, row (ti0+ti)*16 + l15
+    v4f64 acc[NT][NR];
 #pragma unroll
     for (int tj = 0; tj < NT; tj++)
 #pragma unroll
         for (int reg = 0; reg < 4; reg++) {
             const int jj = (tj0 + tj) * 16 + lk + 4 * reg;
 #pragma unroll
-            for (int ti = 0; ti < 4; ti++) {
-                const int ii = ti * 16 + l15;
+            for (int ti = 0; ti < NR; ti++) {
+                const int ii = (ti0 + ti) * 16 + l15;
                 const bool ok = ii < nrt && jj < wt;
                 const double v = ld_off(tp, ok ? (unsigned)(ii + jj * rt) * 8u : 0u);
                 acc[tj][ti][reg] = ok ? v : 0.0;
@@ -656,12 +658,12 @@ __device__ __forceinline__ void dense_tile_core(const DevPlan &P, double *tp, in
         const double *sp = rfl_ptr(P.Lx + Tc.panel_off);
         const double *dv = rfl_ptr(P.D + Tc.dfirst);
         const int c_r = geom & 255, c_c = (geom >> 8) & 255;
-        unsigned roff[4], coff[NT], mbits = 0;
+        unsigned roff[NR], coff[NT], mbits = 0;
         if (geom & (1 << 17)) {      // wave-uniform: operands gathered through the task's tile maps
             const int16_t *tm = P.upd_tmap + (int64_t)tmap_idx * 128;
 #pragma unroll
-            for (int x = 0; x < 4; x++) {
-                const int m = tm[x * 16 + l15];
+            for (int x = 0; x < NR; x++) {
+                const int m = tm[(ti0 + x) * 16 + l15];
                 roff[x] = (unsigned)(row_lo + (m >= 0 ? m : 0)) * 8u;
                 mbits |= m >= 0 ? 16u << x : 0u;
             }
@@ -673,8 +675,8 @@ __device__ __forceinline__ void dense_tile_core(const DevPlan &P, double *tp, in
             }
         } else {
 #pragma unroll
-            for (int x = 0; x < 4; x++) {
-                const int ii = x * 16 + l15 - c_r;
+            for (int x = 0; x < NR; x++) {
+                const int ii = (ti0 + x) * 16 + l15 - c_r;
                 const bool okr = ii >= 0 && ii < nrows;
                 roff[x] = (unsigned)(row_lo + (okr ? ii : 0)) * 8u;
                 mbits |= okr ? 16u << x : 0u;
@@ -692,36 +694,36 @@ __device__ __forceinline__ void dense_tile_core(const DevPlan &P, double *tp, in
         if (NT == 1) {
             // a 16-column strip has only 4 MFMAs (256 clocks) per k-step, less than one memory latency: keep FOUR
             // k-steps of operands in flight (ring of 4 register buffers; steps past K contribute zeros)
-            DenseRaw<NT> f0, f1, f2, f3;
-            dense_load<NT>(f0, sp, dv, coff, roff, r8, K, 0, lk);
-            dense_load<NT>(f1, sp, dv, coff, roff, r8, K, 4, lk);
-            dense_load<NT>(f2, sp, dv, coff, roff, r8, K, 8, lk);
-            dense_load<NT>(f3, sp, dv, coff, roff, r8, K, 12, lk);
+            DenseRaw<NT, NR> f0, f1, f2, f3;
+            dense_load<NT, NR>(f0, sp, dv, coff, roff, r8, K, 0, lk);
+            dense_load<NT, NR>(f1, sp, dv, coff, roff, r8, K, 4, lk);
+            dense_load<NT, NR>(f2, sp, dv, coff, roff, r8, K, 8, lk);
+            dense_load<NT, NR>(f3, sp, dv, coff, roff, r8, K, 12, lk);
             for (int k0 = 0; k0 < K; k0 += 16) {
                 __builtin_amdgcn_sched_barrier(0);
-                dense_mma<NT>(f0, acc, mbits, K, k0, lk);
-                dense_load<NT>(f0, sp, dv, coff, roff, r8, K, k0 + 16, lk);
+                dense_mma<NT, NR>(f0, acc, mbits, K, k0, lk);
+                dense_load<NT, NR>(f0, sp, dv, coff, roff, r8, K, k0 + 16, lk);
                 __builtin_amdgcn_sched_barrier(0);
-                dense_mma<NT>(f1, acc, mbits, K, k0 + 4, lk);
-                dense_load<NT>(f1, sp, dv, coff, roff, r8, K, k0 + 20, lk);
+                dense_mma<NT, NR>(f1, acc, mbits, K, k0 + 4, lk);
+                dense_load<NT, NR>(f1, sp, dv, coff, roff, r8, K, k0 + 20, lk);
                 __builtin_amdgcn_sched_barrier(0);
-                dense_mma<NT>(f2, acc, mbits, K, k0 + 8, lk);
-                dense_load<NT>(f2, sp, dv, coff, roff, r8, K, k0 + 24, lk);
+                dense_mma<NT, NR>(f2, acc, mbits, K, k0 + 8, lk);
+                dense_load<NT, NR>(f2, sp, dv, coff, roff, r8, K, k0 + 24, lk);
                 __builtin_amdgcn_sched_barrier(0);
-                dense_mma<NT>(f3, acc, mbits, K, k0 + 12, lk);
-                dense_load<NT>(f3, sp, dv, coff, roff, r8, K, k0 + 28, lk);
+                dense_mma<NT, NR>(f3, acc, mbits, K, k0 + 12, lk);
+                dense_load<NT, NR>(f3, sp, dv, coff, roff, r8, K, k0 + 28, lk);
             }
         } else {
-            DenseRaw<NT> fa, fb;
-            dense_load<NT>(fa, sp, dv, coff, roff, r8, K, 0, lk);
+            DenseRaw<NT, NR> fa, fb;
+            dense_load<NT, NR>(fa, sp, dv, coff, roff, r8, K, 0, lk);
             for (int k0 = 0; k0 < K; k0 += 8) {     // steps past K contribute zeros (dk = 0)
-                dense_load<NT>(fb, sp, dv, coff, roff, r8, K, k0 + 4, lk);
+                dense_load<NT, NR>(fb, sp, dv, coff, roff, r8, K, k0 + 4, lk);
                 __builtin_amdgcn_sched_barrier(0);
-                dense_mma<NT>(fa, acc, mbits, K, k0, lk);
+                dense_mma<NT, NR>(fa, acc, mbits, K, k0, lk);
                 __builtin_amdgcn_sched_barrier(0);
-                dense_load<NT>(fa, sp, dv, coff, roff, r8, K, k0 + 8, lk);
+                dense_load<NT, NR>(fa, sp, dv, coff, roff, r8, K, k0 + 8, lk);
                 __builtin_amdgcn_sched_barrier(0);
-                dense_mma<NT>(fb, acc, mbits, K, k0 + 4, lk);
+                dense_mma<NT, NR>(fb, acc, mbits, K, k0 + 4, lk);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -733,16 +735,16 @@ __device__ __forceinline__ void dense_tile_core(const DevPlan &P, double *tp, in
         for (int reg = 0; reg < 4; reg++) {
             const int jj = (tj0 + tj) * 16 + lk + 4 * reg;
 #pragma unroll
-            for (int ti = 0; ti < 4; ti++) {
-                const int ii = ti * 16 + l15;
+            for (int ti = 0; ti < NR; ti++) {
+                const int ii = (ti0 + ti) * 16 + l15;
                 if (LDS_OUT) lds_out[ii * 65 + jj] = acc[tj][ti][reg];
                 else if (ii < nrt && jj < wt) st_off(tp, (unsigned)(ii + jj * rt) * 8u, acc[tj][ti][reg]);
             }
         }
 }
 
-template <int NT>
-__device__ __forceinline__ void dense_tile(const DevPlan &P, const UpdGroup *Gp, int lane, int tj0) {
+template <int NT, int NR>
+__device__ __forceinline__ void dense_tile(const DevPlan &P, const UpdGroup *Gp, int lane, int tj0, int ti0) {
     const int t = rfl(Gp->tgt), row_base = rfl(Gp->row_base), task_begin = rfl(Gp->task_begin), task_end = rfl(Gp->task_end);
     const int ft = rfl(P.sn_first[t]);
     const int wt = rfl(P.sn_first[t + 1]) - ft;
@@ -750,19 +752,28 @@ __device__ __forceinline__ void dense_tile(const DevPlan &P, const UpdGroup *Gp,
     const int rt = rfl((int)(P.sn_rowptr[t + 1] - P.sn_rowptr[t]));
     double *tp = rfl_ptr(P.Lx + P.sn_panel[t] + row_base);
     const int nrt = min(kUpdRows, rt - row_base);
-    dense_tile_core<NT, false>(P, tp, rt, nrt, wt, task_begin, task_end, lane, tj0, nullptr);
+    if (ti0 * 16 >= nrt) return;
+    dense_tile_core<NT, NR, false>(P, tp, rt, nrt, wt, task_begin, task_end, lane, tj0, ti0, nullptr);
 }
 
 // Grid-stride over the tiles of a launch (a bounded grid is used by the look-ahead experiments, hipkkt.cpp).
-template <int NT>
+template <int NT, int NR>
 __global__ void __launch_bounds__(256, NT == 2 ? 4 : 2)
 k_update_dense(DevPlan P, int group_begin, int ngroups) {
+    static_assert(NR == 4 || NT == 1, "rows are split only between the workgroups of a one-strip-per-wave launch");
     const int lane = threadIdx.x & 63;
     const int wave = rfl(threadIdx.x >> 6);
-    // NT 16-column strips per wavefront: 4/NT wavefronts share a tile, NT tiles per workgroup
+    // NT 16-column strips per wavefront: 4/NT wavefronts share a tile, NT tiles per workgroup;
+    // NR < 4: 4/NR consecutive workgroups share a tile, each takes NR of its four 16-row blocks
     const int tj0 = (wave % (4 / NT)) * NT;           // first 16-column strip of this wavefront
-    for (int g = rfl(blockIdx.x * NT + wave / (4 / NT)); g < ngroups; g += gridDim.x * NT)
-        dense_tile<NT>(P, P.upd_groups + group_begin + g, lane, tj0);
+    if (NR == 4) {
+        for (int g = rfl(blockIdx.x * NT + wave / (4 / NT)); g < ngroups; g += gridDim.x * NT)
+            dense_tile<NT, NR>(P, P.upd_groups + group_begin + g, lane, tj0, 0);
+    } else {
+        constexpr int RS = 4 / NR;
+        for (int u = blockIdx.x; u < ngroups * RS; u += gridDim.x)
+            dense_tile<NT, NR>(P, P.upd_groups + group_begin + u / RS, lane, tj0, (u % RS) * NR);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1034,6 +1045,51 @@ __device__ __forceinline__ void front_publish(int *flag, int lane) {
     if (lane == 0) __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// Hand-off slots: the 64 values of a panel travel as 64 x 16 bytes {value, bits(value) ^ KEY}, written with ONE
+// agent-scope 16-byte store per lane and polled with one 16-byte load per lane.  A slot is valid when its tag
+// checks against its value, so no separate flag is needed (no "payload complete" wait before the flag, no second
+// round trip for the payload after it: 0.7 us per hop instead of 1.3 us in tools/ubench_chain.hip), a torn or
+// stale read can only fail the check, and a zeroed slot is invalid.
+struct __attribute__((aligned(16))) FrontSlot {
+    double v;
+    unsigned long long h;
+};
+constexpr unsigned long long kSlotKey = 0x5bd1e995a5a5a5a5ull;
+__device__ __forceinline__ FrontSlot front_slot_ld(const FrontSlot *p) {
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    v4u r;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(r) : "v"(p) : "memory");
+    FrontSlot s;
+    s.v = __longlong_as_double((long long)(((unsigned long long)r[1] << 32) | r[0]));
+    s.h = ((unsigned long long)r[3] << 32) | r[2];
+    return s;
+}
+__device__ __forceinline__ void front_slot_st(FrontSlot *p, double v) {
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v), h = b ^ kSlotKey;
+    v4u r = {(unsigned)b, (unsigned)(b >> 32), (unsigned)h, (unsigned)(h >> 32)};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(r) : "memory");
+}
+// whole-wave wait for the 64 slots of one panel (lane = slot); false = timed out / another workgroup failed
+__device__ __forceinline__ bool front_slot_wait(const FrontSlot *p, double &v, int *err, int *failflag) {
+    for (unsigned spins = 0;; spins++) {
+        const FrontSlot s = front_slot_ld(p);
+        const bool okl = ((unsigned long long)__double_as_longlong(s.v) ^ s.h) == kSlotKey;
+        if (__ballot(okl) == ~0ull) { v = s.v; return true; }
+        if ((spins & 127u) == 127u) {
+            if (spins > (1u << 20)) {
+                __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                atomicOr(failflag, 1);
+                return false;
+            }
+            if (front_ld_flag(err) != 0) return false;
+        }
+    }
+}
+__device__ __forceinline__ FrontSlot *front_slots(int *sync_block, int np) {
+    return (FrontSlot *)(sync_block + ((2 + np + 15) & ~15));
+}
+
 __global__ void __launch_bounds__(256)
 k_front_fwd(DevPlan P, FrontDesc F, double *__restrict__ y, double *__restrict__ z) {
     __shared__ double red[4][64];
@@ -1045,8 +1101,9 @@ k_front_fwd(DevPlan P, FrontDesc F, double *__restrict__ y, double *__restrict__
     __syncthreads();
     const int b = sb;
     if (b >= F.nb) return;
-    if (b == 0)   // re-arm the backward sweep's block (idle during this launch)
-        for (int q = threadIdx.x; q < F.sync_blk; q += blockDim.x) sync[F.sync_blk + q] = 0;
+    // re-arm the backward sweep's block (idle during this launch), every workgroup a share
+    for (int q = b * 256 + threadIdx.x; q < F.sync_blk; q += F.nb * 256) sync[F.sync_blk + q] = 0;
+    FrontSlot *slots = front_slots(sync, F.np);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const FrontPanel *fps = P.front_panels + F.fp_off;
     const bool own = b < F.np;
@@ -1096,13 +1153,13 @@ k_front_fwd(DevPlan P, FrontDesc F, double *__restrict__ y, double *__restrict__
 #pragma unroll
             for (int t = 0; t < 16; t++) ln[t] = 0.0;
         }
-        // ONE wave polls the flag and fetches y_q with ONE coalesced agent-scope load; the workgroup reads it
-        // from LDS (double buffered by hop parity: one barrier per hop).  The hop cost was found to scale with
-        // the number of agent-scope load instructions a workgroup issues (~30 ns each), not with a fixed latency.
+        // ONE wave polls the panel's hand-off slots (value and validity in one 16-byte load per lane); the
+        // workgroup reads y_q from LDS (double buffered by hop parity: one barrier per hop)
         double *yb = ybuf[q & 1];
         if (wv == 0) {
-            ok = front_wait(sync + 2 + q, sync + 1, P.flags + FL_FRONTFAIL);
-            yb[lane] = ok ? front_ld(y + fq.f + (lane < fq.w ? lane : 0)) : 0.0;
+            double yv = 0.0;
+            ok = front_slot_wait(slots + q * 64 + lane, yv, sync + 1, P.flags + FL_FRONTFAIL);
+            yb[lane] = ok ? yv : 0.0;
             if (lane == 0) okflag = ok ? 1 : 0;
         }
         __syncthreads();
@@ -1138,12 +1195,12 @@ k_front_fwd(DevPlan P, FrontDesc F, double *__restrict__ y, double *__restrict__
     }
     __syncthreads();
     if (wv == 0) {
+        const double v = valid ? ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane] : 0.0;
+        if (ok) front_slot_st(slots + b * 64 + lane, v);     // first: the next panel's owner is waiting for it
         if (valid && ok) {
-            const double v = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
-            front_st(y + me.f + lane, v);
+            y[me.f + lane] = v;
             z[me.f + lane] = v * dinv_own;
         }
-        if (ok) front_publish(sync + 2 + b, lane);
     }
 }
 
@@ -1160,8 +1217,9 @@ k_front_bwd(DevPlan P, FrontDesc F, const double *__restrict__ z, double *__rest
     if (threadIdx.x == 0) sb = atomicAdd(sync, 1);
     __syncthreads();
     if (sb >= F.np) return;
-    if (sb == 0)   // re-arm the forward sweep's block for the next solve (idle during this launch)
-        for (int q = threadIdx.x; q < F.sync_blk; q += blockDim.x) sync[q - F.sync_blk] = 0;
+    // re-arm the forward sweep's block for the next solve (idle during this launch), every workgroup a share
+    for (int q = sb * 256 + threadIdx.x; q < F.sync_blk; q += F.np * 256) sync[q - F.sync_blk] = 0;
+    FrontSlot *slots = front_slots(sync, F.np);
     const int p = F.np - 1 - sb;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const FrontPanel *fps = P.front_panels + F.fp_off;
@@ -1213,7 +1271,6 @@ k_front_bwd(DevPlan P, FrontDesc F, const double *__restrict__ z, double *__rest
         }
     }
     for (int q = F.np - 1; q > p; q--) {
-        const FrontPanel fq = fps[q];
         double ln[16];
         if (q - 1 > p) {
             const FrontPanel fn = fps[q - 1];
@@ -1227,9 +1284,10 @@ k_front_bwd(DevPlan P, FrontDesc F, const double *__restrict__ z, double *__rest
             for (int t = 0; t < 16; t++) ln[t] = 0.0;
         }
         double *xb = xbuf[q & 1];
-        if (wv == 0) {   // one poller, one coalesced agent-scope load, broadcast through LDS (see k_front_fwd)
-            ok = front_wait(sync + 2 + q, sync + 1, P.flags + FL_FRONTFAIL);
-            xb[lane] = ok ? front_ld(x + fq.f + (lane < fq.w ? lane : 0)) : 0.0;
+        if (wv == 0) {   // one polling wave, broadcast through LDS (see k_front_fwd)
+            double xv = 0.0;
+            ok = front_slot_wait(slots + q * 64 + lane, xv, sync + 1, P.flags + FL_FRONTFAIL);
+            xb[lane] = ok ? xv : 0.0;
             if (lane == 0) okflag = ok ? 1 : 0;
         }
         __syncthreads();
@@ -1259,12 +1317,12 @@ k_front_bwd(DevPlan P, FrontDesc F, const double *__restrict__ z, double *__rest
     }
     __syncthreads();
     if (wv == 0) {
+        const double v = cvalid ? ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane] : 0.0;
+        if (ok) front_slot_st(slots + p * 64 + lane, v);     // first: the previous panel's owner is waiting for it
         if (cvalid && ok) {
-            const double v = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
-            front_st(x + me.f + lane, v);
+            x[me.f + lane] = v;
             xout[perm_own] = v;
         }
-        if (ok) front_publish(sync + 2 + p, lane);
     }
 }
 
@@ -1935,20 +1993,27 @@ void launch_factor_panel(hipStream_t st, const DevPlan &P, int item_begin, int n
 void launch_update_stage(hipStream_t st, const DevPlan &P, int group_begin, int ngroups) {
     if (ngroups > 0) hipLaunchKernelGGL(k_update_stage, dim3(ngroups), dim3(kUpdWaves * 64), 0, st, P, group_begin);
 }
+// 16-row blocks per wavefront in the just-in-time launches (4: one workgroup per tile; 2 / 1: two / four workgroups).
+// Measured on cfg 2a (factorisation): 5.81 ms / 5.65 ms / 5.65 ms for 4 / 2 / 1.
+static const int g_jit_nr = [] { const char *e = getenv("HIPKKT_JIT_NR"); return e ? atoi(e) : 2; }();
 #ifndef HIPKKT_DENSE_BIG_NT
 #define HIPKKT_DENSE_BIG_NT 4
 #endif
 void launch_update_dense(hipStream_t st, const DevPlan &P, int group_begin, int ngroups, int max_wgs) {
     if (ngroups <= 0) return;
     if (max_wgs > 0) {   // look-ahead launch: a bounded grid that strides over the tiles
-        hipLaunchKernelGGL(k_update_dense<4>, dim3(std::min((ngroups + 3) / 4, max_wgs)), dim3(256), 0, st, P, group_begin, ngroups);
+        hipLaunchKernelGGL((k_update_dense<4, 4>), dim3(std::min((ngroups + 3) / 4, max_wgs)), dim3(256), 0, st, P, group_begin, ngroups);
         return;
     }
     if (ngroups > 384)   // plenty of tiles: one wavefront per tile
-        hipLaunchKernelGGL(k_update_dense<HIPKKT_DENSE_BIG_NT>, dim3((ngroups + HIPKKT_DENSE_BIG_NT - 1) / HIPKKT_DENSE_BIG_NT),
+        hipLaunchKernelGGL((k_update_dense<HIPKKT_DENSE_BIG_NT, 4>), dim3((ngroups + HIPKKT_DENSE_BIG_NT - 1) / HIPKKT_DENSE_BIG_NT),
                            dim3(256), 0, st, P, group_begin, ngroups);
     else                 // few tiles (just-in-time updates): split every tile over 4 wavefronts
-        hipLaunchKernelGGL(k_update_dense<1>, dim3(ngroups), dim3(256), 0, st, P, group_begin, ngroups);
+        switch (g_jit_nr) {
+        case 1: hipLaunchKernelGGL((k_update_dense<1, 1>), dim3(ngroups * 4), dim3(256), 0, st, P, group_begin, ngroups); break;
+        case 2: hipLaunchKernelGGL((k_update_dense<1, 2>), dim3(ngroups * 2), dim3(256), 0, st, P, group_begin, ngroups); break;
+        default: hipLaunchKernelGGL((k_update_dense<1, 4>), dim3(ngroups), dim3(256), 0, st, P, group_begin, ngroups);
+        }
 }
 void launch_update_gather(hipStream_t st, const DevPlan &P, int64_t ebegin, int64_t n) {
     if (n > 0) hipLaunchKernelGGL(k_update_gather, dim3(nblk(n)), dim3(256), 0, st, P, ebegin, n);

@@ -78,7 +78,7 @@ struct FrontDesc {
     int64_t rows_off;             // sn_rowptr[s0]: global (permuted) index of every front row
     int32_t npair, nb2;           // panels are solved in PAIRS (128-column hops): #pairs, #128-row blocks
     int64_t wp_off;               // Wpair[wp_off + 4096 * pair]: the off-diagonal block of the pair's explicit inverse
-    int32_t sync_off, sync_blk;   // sync area of this front: two blocks of sync_blk ints {ticket, error, flags[np]},
+    int32_t sync_off, sync_blk;   // sync area of this front: two blocks of sync_blk ints {ticket, error, flags[np], slots},
                                   // one per sweep; each sweep's kernel re-zeroes the OTHER block for the next solve
 };
 
