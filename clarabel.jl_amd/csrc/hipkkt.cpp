@@ -66,6 +66,7 @@ struct hipkkt_solver {
     std::vector<FacItem> slv_items, bwd_items;
     std::vector<int> slv_lvl_ptr, bwd_lvl_ptr;
     std::vector<int> reg_lvl_sn, reg_lvl_ptr;   // supernodes of every level that are NOT front panels
+    std::vector<char> lvl_narrow;                // [nlevels] every regular supernode is narrow (k_fwd_narrow / k_bwd_narrow)
     // persistent sweeps over the regular supernodes: segments = level ranges between front kernels
     bool use_persist = true;
     bool use_pairs = true;      // fronts solved two panels per hop (k_front_fwd2 / k_front_bwd2)
@@ -214,13 +215,18 @@ void setup_device(hipkkt_solver *S) {
         S->p_off[s + 1] = S->p_off[s] + nb * w;
     }
     S->reg_lvl_ptr.assign(P.nlevels + 1, 0);
+    S->lvl_narrow.assign(P.nlevels, 0);
+    const char *nn = getenv("HIPKKT_NO_NARROW");
+    const bool allow_narrow = !(nn && nn[0] == '1');
     for (int l = 0; l < P.nlevels; l++) {
+        bool narrow = allow_narrow;
         for (int q = P.lvl_ptr[l]; q < P.lvl_ptr[l + 1]; q++) {
             int s = P.lvl_sn[q];
             int w = P.sn_first[s + 1] - P.sn_first[s];
             S->wmax_all = std::max(S->wmax_all, w);
             if (P.sn_front[s] >= 0) continue;      // solved by the persistent front kernels
             int64_t r = P.sn_rowptr[s + 1] - P.sn_rowptr[s];
+            if (w > kNarrowW || r - w > kNarrowR) narrow = false;
             int nb = (int)std::max<int64_t>(1, (r - w + 63) / 64);
             for (int b = 0; b < nb; b++) S->slv_items.push_back({s, b});
             if (nb > 1)
@@ -230,6 +236,7 @@ void setup_device(hipkkt_solver *S) {
         S->slv_lvl_ptr[l + 1] = (int)S->slv_items.size();
         S->bwd_lvl_ptr[l + 1] = (int)S->bwd_items.size();
         S->reg_lvl_ptr[l + 1] = (int)S->reg_lvl_sn.size();
+        S->lvl_narrow[l] = narrow && S->reg_lvl_ptr[l + 1] - S->reg_lvl_ptr[l] >= 256;
     }
     // ---- persistent sweeps: segments, dependency lists, backward item order
     std::vector<int> dep_ptr(P.nsuper + 1, 0), dep_idx, sn_nitems(P.nsuper, 0), sn_bparent(P.nsuper, -1);
@@ -497,12 +504,25 @@ void enqueue_ldl_solve(hipkkt_solver *S) {
     const HostPlan &P = S->plan;
     hipStream_t st = S->stream;
     launch_permute_in(st, S->d_sin, S->dp.perm, S->d_y, S->N);
+    // one launch per level (wide bottom levels, and every level on the fallback path); levels of narrow supernodes
+    // take the thread-per-supernode kernels
+    auto fwd_level = [&](int l) {
+        if (S->lvl_narrow[l]) launch_fwd_narrow(st, S->dp, S->reg_lvl_ptr[l], S->reg_lvl_ptr[l + 1] - S->reg_lvl_ptr[l], S->d_y, S->d_z);
+        else launch_fwd_level(st, S->dp, S->slv_lvl_ptr[l], S->slv_lvl_ptr[l + 1] - S->slv_lvl_ptr[l], S->d_y, S->d_z);
+    };
+    auto bwd_level = [&](int l) {
+        if (S->lvl_narrow[l]) {
+            launch_bwd_narrow(st, S->dp, S->reg_lvl_ptr[l], S->reg_lvl_ptr[l + 1] - S->reg_lvl_ptr[l], S->d_z, S->d_xp, S->d_sout);
+            return;
+        }
+        launch_bwd_partial(st, S->dp, S->bwd_lvl_ptr[l], S->bwd_lvl_ptr[l + 1] - S->bwd_lvl_ptr[l], S->d_xp);
+        launch_bwd_final(st, S->dp, S->reg_lvl_ptr[l], S->reg_lvl_ptr[l + 1] - S->reg_lvl_ptr[l], S->d_z, S->d_xp, S->d_sout);
+    };
     if (S->use_persist) {
         // one persistent launch per segment of regular levels, front kernels in between
         bool first = true;
         for (int g = 0; g < S->nseg; g++) {
-            for (int l = S->seg_lo[g]; l < std::min(S->seg_lstar[g], S->seg_hi[g] + 1); l++)   // wide bottom levels
-                launch_fwd_level(st, S->dp, S->slv_lvl_ptr[l], S->slv_lvl_ptr[l + 1] - S->slv_lvl_ptr[l], S->d_y, S->d_z);
+            for (int l = S->seg_lo[g]; l < std::min(S->seg_lstar[g], S->seg_hi[g] + 1); l++) fwd_level(l);   // wide bottom levels
             const int n = S->fseg_ptr[2 * g + 1] - S->fseg_ptr[2 * g];
             if (n > 0) { launch_fwd_seg(st, S->dp, g, S->fseg_ptr[2 * g], n, P.nsuper, first ? 1 : 0, S->d_y, S->d_z); first = false; }
             for (const FrontDesc &F : P.fronts)
@@ -515,23 +535,19 @@ void enqueue_ldl_solve(hipkkt_solver *S) {
             const int k = S->nseg - 1 - g;     // launch order index
             const int n = S->bseg_ptr[k + 1] - S->bseg_ptr[k];
             if (n > 0) { launch_bwd_seg(st, S->dp, g, S->bseg_ptr[k], n, P.nsuper, first ? 1 : 0, S->d_z, S->d_xp, S->d_sout); first = false; }
-            for (int l = std::min(S->seg_lstar[g], S->seg_hi[g] + 1) - 1; l >= S->seg_lo[g]; l--) {
-                launch_bwd_partial(st, S->dp, S->bwd_lvl_ptr[l], S->bwd_lvl_ptr[l + 1] - S->bwd_lvl_ptr[l], S->d_xp);
-                launch_bwd_final(st, S->dp, S->reg_lvl_ptr[l], S->reg_lvl_ptr[l + 1] - S->reg_lvl_ptr[l], S->d_z, S->d_xp, S->d_sout);
-            }
+            for (int l = std::min(S->seg_lstar[g], S->seg_hi[g] + 1) - 1; l >= S->seg_lo[g]; l--) bwd_level(l);
         }
         return;
     }
     for (int l = 0; l < P.nlevels; l++) {
-        launch_fwd_level(st, S->dp, S->slv_lvl_ptr[l], S->slv_lvl_ptr[l + 1] - S->slv_lvl_ptr[l], S->d_y, S->d_z);
+        fwd_level(l);
         for (const FrontDesc &F : P.fronts)
             if (F.level_last == l) (S->use_pairs ? launch_front_fwd2 : launch_front_fwd)(st, S->dp, F, S->d_y, S->d_z);
     }
     for (int l = P.nlevels - 1; l >= 0; l--) {
         for (const FrontDesc &F : P.fronts)
             if (F.level_last == l) (S->use_pairs ? launch_front_bwd2 : launch_front_bwd)(st, S->dp, F, S->d_z, S->d_xp, S->d_sout);
-        launch_bwd_partial(st, S->dp, S->bwd_lvl_ptr[l], S->bwd_lvl_ptr[l + 1] - S->bwd_lvl_ptr[l], S->d_xp);
-        launch_bwd_final(st, S->dp, S->reg_lvl_ptr[l], S->reg_lvl_ptr[l + 1] - S->reg_lvl_ptr[l], S->d_z, S->d_xp, S->d_sout);
+        bwd_level(l);
     }
 }
 

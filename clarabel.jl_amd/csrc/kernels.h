@@ -16,6 +16,8 @@ void launch_factor_panel(hipStream_t st, const DevPlan &P, int item_begin, int n
                          bool fused = false);
 void launch_update_stage(hipStream_t st, const DevPlan &P, int group_begin, int ngroups);
 void launch_update_dense(hipStream_t st, const DevPlan &P, int group_begin, int ngroups, int max_wgs = 0);
+void launch_fwd_narrow(hipStream_t st, const DevPlan &P, int sn_begin, int n, double *y, double *z);
+void launch_bwd_narrow(hipStream_t st, const DevPlan &P, int sn_begin, int n, const double *z, double *x, double *xout);
 void launch_update_gather(hipStream_t st, const DevPlan &P, int64_t ebegin, int64_t n);
 void launch_invert_diag(hipStream_t st, const DevPlan &P, int nsuper, int wmax);
 void launch_mfma_probe(hipStream_t st, const double *A, const double *B, double *out);

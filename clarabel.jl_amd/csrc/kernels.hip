@@ -238,6 +238,17 @@ __device__ __forceinline__ double readlane_f64(double x, int l) {   // l wave-un
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
+// 1/d on the pivot-to-pivot critical path: hardware reciprocal + two Newton steps (~50 clocks) instead of the IEEE
+// division sequence (~112 clocks, tools/ubench.hip).  |relative error| <= 1 ulp; the D and 1/D that are stored for
+// the solves are formed with the exact division after the loop.  d is never zero or subnormal here (the pivot rule
+// has replaced such values by +-delta); an infinite or NaN d propagates and is caught by the non-finite check.
+__device__ __forceinline__ double pivot_rcp(double d) {
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma(fma(-d, r, 1.0), r, r);
+    r = fma(fma(-d, r, 1.0), r, r);
+    return r;
+}
+
 // Blocked by 8 pivots: wave v of a group owns the column blocks {v, v+4} (8 columns each).  The owner of block B
 // eliminates its 8 columns WITHOUT leaving the wavefront (pivot and the entries a_jk come from the lanes that hold
 // them: v_readlane), publishes the block's L columns / raw columns / 1/d through LDS, and after ONE barrier every
@@ -314,7 +325,7 @@ k_factor_panel(DevPlan P, int item_begin, double dyn_eps, double dyn_delta) {
                     double d = readlane_f64(reg, k);
                     const double sg = ((spos >> k) & 1ull) ? 1.0 : -1.0;
                     if (k < w && d * sg < dyn_eps) { d = dyn_delta * sg; nreg++; }
-                    const double dinv = k < w ? 1.0 / d : 0.0;
+                    const double dinv = k < w ? pivot_rcp(d) : 0.0;
                     const double li = reg * dinv;
                     colL[pb][kk][lane] = li;
                     colC[p3][kk][lane] = k < w ? reg : 0.0;
@@ -723,7 +734,7 @@ __device__ __forceinline__ void dense_tile_core(const DevPlan &P, double *tp, in
                 __builtin_amdgcn_sched_barrier(0);
                 dense_load<NT, NR>(fa, sp, dv, coff, roff, r8, K, k0 + 8, lk);
                 __builtin_amdgcn_sched_barrier(0);
-                dense_mma<NT, NR>(fb, acc, mbits, K, k0 + 4, lk);
+                if (k0 + 4 < K) dense_mma<NT, NR>(fb, acc, mbits, K, k0 + 4, lk);   // narrow sources (K <= 4): one step
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -937,6 +948,88 @@ __device__ __forceinline__ double bwd_block_dot(const DevPlan &P, int s, int w, 
     red[wave][lane] = (a0 + a1) + (a2 + a3);
     __syncthreads();
     return ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+}
+
+// K5 on a level of NARROW supernodes (w <= kNarrowW columns, <= kNarrowR rows below the diagonal block; the
+// thousands of 1-2 column leaves of a sparse QP): one THREAD per supernode instead of one 256-thread workgroup --
+// a level-0 launch of cfg 2a drops from 17884 workgroups (39 us) to 70.  Same arithmetic as k_fwd_level /
+// k_bwd_final, sums taken in index order.
+__global__ void __launch_bounds__(256)
+k_fwd_narrow(DevPlan P, int sn_begin, int n, double *__restrict__ y, double *__restrict__ z) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const int s = P.lvl_sn[sn_begin + t];
+    const int f = P.sn_first[s];
+    const int w = P.sn_first[s + 1] - f;
+    const int64_t slot0 = P.sn_rowptr[s];
+    const int r = (int)(P.sn_rowptr[s + 1] - slot0);
+    const double *pan = P.Lx + P.sn_panel[s];
+    const double *li = P.Linv + P.sn_diag[s];
+    double rhs[kNarrowW], yv[kNarrowW];
+#pragma unroll
+    for (int k = 0; k < kNarrowW; k++) {
+        rhs[k] = 0.0;
+        if (k < w) {
+            double acc = 0.0;
+            for (int64_t g = P.g_ptr[slot0 + k]; g < P.g_ptr[slot0 + k + 1]; g++) acc += P.ubuf[P.g_idx[g]];
+            rhs[k] = y[f + k] - acc;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < kNarrowW; i++) {
+        double v = 0.0;
+#pragma unroll
+        for (int k = 0; k <= i; k++)
+            if (i < w) v += li[i + k * w] * rhs[k];
+        yv[i] = v;
+        if (i < w) {
+            y[f + i] = v;
+            z[f + i] = v * P.Dinv[f + i];
+        }
+    }
+    double *u = P.ubuf + P.u_off[s];
+    for (int row = w; row < r; row++) {
+        double a = 0.0;
+        for (int64_t g = P.g_ptr[slot0 + row]; g < P.g_ptr[slot0 + row + 1]; g++) a += P.ubuf[P.g_idx[g]];
+#pragma unroll
+        for (int k = 0; k < kNarrowW; k++)
+            if (k < w) a += pan[row + (int64_t)k * r] * yv[k];
+        u[row - w] = a;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_bwd_narrow(DevPlan P, int sn_begin, int n, const double *__restrict__ z, double *__restrict__ x, double *__restrict__ xout) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const int s = P.lvl_sn[sn_begin + t];
+    const int f = P.sn_first[s];
+    const int w = P.sn_first[s + 1] - f;
+    const int64_t slot0 = P.sn_rowptr[s];
+    const int r = (int)(P.sn_rowptr[s + 1] - slot0);
+    const int *rows = P.sn_rows + slot0;
+    const double *lt = P.LT + P.lt_off[s];          // row-major: lt[(i - w) * w + k]
+    const double *lit = P.LinvT + P.sn_diag[s];     // Linv[i][k] at [k + i * w]
+    double tv[kNarrowW];
+#pragma unroll
+    for (int k = 0; k < kNarrowW; k++) tv[k] = k < w ? z[f + k] : 0.0;
+    for (int i = w; i < r; i++) {
+        const double xi = x[rows[i]];
+#pragma unroll
+        for (int k = 0; k < kNarrowW; k++)
+            if (k < w) tv[k] -= lt[(int64_t)(i - w) * w + k] * xi;
+    }
+#pragma unroll
+    for (int k = 0; k < kNarrowW; k++) {
+        double v = 0.0;
+#pragma unroll
+        for (int i = k; i < kNarrowW; i++)
+            if (i < w) v += lit[k + i * w] * tv[i];
+        if (k < w) {
+            x[f + k] = v;
+            xout[P.perm[f + k]] = v;
+        }
+    }
 }
 
 // panels with more than one 64-row block: per-block partial sums
@@ -2014,6 +2107,12 @@ void launch_update_dense(hipStream_t st, const DevPlan &P, int group_begin, int 
         case 2: hipLaunchKernelGGL((k_update_dense<1, 2>), dim3(ngroups * 2), dim3(256), 0, st, P, group_begin, ngroups); break;
         default: hipLaunchKernelGGL((k_update_dense<1, 4>), dim3(ngroups), dim3(256), 0, st, P, group_begin, ngroups);
         }
+}
+void launch_fwd_narrow(hipStream_t st, const DevPlan &P, int sn_begin, int n, double *y, double *z) {
+    if (n > 0) hipLaunchKernelGGL(k_fwd_narrow, dim3(nblk(n)), dim3(256), 0, st, P, sn_begin, n, y, z);
+}
+void launch_bwd_narrow(hipStream_t st, const DevPlan &P, int sn_begin, int n, const double *z, double *x, double *xout) {
+    if (n > 0) hipLaunchKernelGGL(k_bwd_narrow, dim3(nblk(n)), dim3(256), 0, st, P, sn_begin, n, z, x, xout);
 }
 void launch_update_gather(hipStream_t st, const DevPlan &P, int64_t ebegin, int64_t n) {
     if (n > 0) hipLaunchKernelGGL(k_update_gather, dim3(nblk(n)), dim3(256), 0, st, P, ebegin, n);

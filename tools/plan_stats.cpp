@@ -66,5 +66,26 @@ int main(int argc, char **argv) {
         printf("%5d %7d %7d %7ld %9ld %12.3e %8d %8d   dense: %6d groups (far %5d) %10.3e flops; tasks %7d avgfill %.2f\n", l, P.lvl_ptr[l + 1] - P.lvl_ptr[l], maxw, (long)maxr, (long)srw, lf[l],
                P.upd_stage_ptr[l + 1] - P.upd_stage_ptr[l], P.fac_lvl_ptr[l + 1] - P.fac_lvl_ptr[l], P.upd_stage_ndense[l], P.upd_stage_nfar[l], lfd[l], ntk, ntk ? fills[l] / ntk : 0.0);
     }
+    // K (source width) histogram of the dense tasks of the stage with the most dense tasks
+    {
+        int best = 0; int64_t bestn = -1;
+        for (int l = 0; l < P.nlevels; l++) {
+            int64_t n = 0;
+            for (int g = P.upd_stage_ptr[l]; g < P.upd_stage_ptr[l] + P.upd_stage_ndense[l]; g++) n += P.upd_groups[g].task_end - P.upd_groups[g].task_begin;
+            if (n > bestn) { bestn = n; best = l; }
+        }
+        std::vector<int64_t> hk(65, 0), hr(65, 0);
+        for (int g = P.upd_stage_ptr[best]; g < P.upd_stage_ptr[best] + P.upd_stage_ndense[best]; g++)
+            for (int q = P.upd_groups[g].task_begin; q < P.upd_groups[g].task_end; q++) {
+                const UpdTask &t = P.upd_tasks[q];
+                hk[std::min(64, P.sn_first[t.src + 1] - P.sn_first[t.src])]++;
+                hr[std::min(64, (int)t.nrows)]++;
+            }
+        printf("stage %d dense-task K histogram:", best);
+        for (int k = 1; k <= 64; k++) if (hk[k]) printf(" %d:%ld", k, (long)hk[k]);
+        printf("\nstage %d dense-task nrows histogram:", best);
+        for (int k = 1; k <= 64; k++) if (hr[k]) printf(" %d:%ld", k, (long)hr[k]);
+        printf("\n");
+    }
     return 0;
 }
