@@ -19,6 +19,7 @@ struct DevPlan {
     const int64_t *u_off;
     const int64_t *p_off;
     const int64_t *lt_off;
+    const int *inv_list;         // supernodes for k_invert_diag (narrow ones first) / k_invert_diag_wide
     const int *lvl_sn;
     const int *perm;
     const signed char *sgn_perm;

@@ -77,6 +77,7 @@ struct hipkkt_solver {
                                                  // persistent kernels (wide bottom levels keep one launch per level)
     std::vector<FacItem> pbwd_items;
     int wmax_all = 1;
+    int inv_nsmall = 0, inv_wsmall = 1, inv_nwide = 0;   // split of the diagonal-block inversions (kernels.hip)
     std::vector<int64_t> p_off;
 
     // device index arrays for value updates
@@ -321,6 +322,21 @@ void setup_device(hipkkt_solver *S) {
     D.lvl_sn = S->upload(S->reg_lvl_sn);
     D.perm = S->upload(P.perm);
     D.sgn_perm = S->upload(sgn_perm);
+    {
+        // diagonal blocks wider than 16 columns (and at most 64, the blocked kernel's size) are inverted by
+        // k_invert_diag_wide, the rest by the one-wave kernel with LDS sized for the widest of them
+        std::vector<int> small, wide;
+        S->inv_wsmall = 1;
+        for (int s = 0; s < P.nsuper; s++) {
+            const int w = P.sn_first[s + 1] - P.sn_first[s];
+            if (w > 16 && w <= 64) wide.push_back(s);
+            else { small.push_back(s); S->inv_wsmall = std::max(S->inv_wsmall, w); }
+        }
+        S->inv_nsmall = (int)small.size();
+        S->inv_nwide = (int)wide.size();
+        small.insert(small.end(), wide.begin(), wide.end());
+        D.inv_list = S->upload(small);
+    }
     D.fac_items = S->upload(P.fac_items);
     D.fac_jit = S->upload(P.fac_jit);
     D.slv_items = S->upload(S->slv_items);
@@ -494,7 +510,7 @@ void enqueue_factor(hipkkt_solver *S, int static_enable, double eps_const, doubl
         }
     }
     if (pending) HK_CHECK(hipStreamWaitEvent(st, pending, 0));
-    launch_invert_diag(st, S->dp, P.nsuper, S->wmax_all);
+    launch_invert_diag(st, S->dp, S->inv_nsmall, S->inv_wsmall, S->inv_nwide);
     if (S->use_pairs)
         for (const FrontDesc &F : P.fronts) launch_front_pair_inv(st, S->dp, F);
 }
@@ -1163,7 +1179,7 @@ static int32_t refactor_once(hipkkt_handle h, int32_t static_reg_enable, double 
                 evs.push_back(b);
             }
         }
-        launch_invert_diag(st, S->dp, P.nsuper, S->wmax_all);
+        launch_invert_diag(st, S->dp, S->inv_nsmall, S->inv_wsmall, S->inv_nwide);
         if (S->use_pairs)
             for (const FrontDesc &F : P.fronts) launch_front_pair_inv(st, S->dp, F);
         HK_CHECK(hipStreamSynchronize(st));

@@ -406,10 +406,10 @@ k_factor_panel(DevPlan P, int item_begin, double dyn_eps, double dyn_delta) {
 // transposes) so that the solves do small GEMVs instead of w-step substitutions.  One launch.
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(64)
-k_invert_diag(DevPlan P, int nsuper) {
+k_invert_diag(DevPlan P, int list_begin, int n) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int s = blockIdx.x;
-    if (s >= nsuper) return;
+    if ((int)blockIdx.x >= n) return;
+    const int s = P.inv_list[list_begin + blockIdx.x];
     const int w = P.sn_first[s + 1] - P.sn_first[s];
     const int LDL = w | 1;
     double *Ls = smem;              // [w * LDL]
@@ -436,6 +436,78 @@ k_invert_diag(DevPlan P, int nsuper) {
         int i = idx % w, j = idx / w;
         li[idx] = Xs[i + j * LDL];     // Linv[i][j], column-major
         lit[idx] = Xs[j + i * LDL];    // LinvT stored so that element (i,j) of Linv sits at [j + i*w]
+    }
+}
+
+// Wide diagonal blocks (16 < w <= 64, the panels of the fronts): the column-by-column substitution above is a
+// 2048-step read-modify-write chain through LDS (~200 us, after the last panel of the factorisation, with nothing
+// to overlap it).  Blocked instead, 256 threads: the four 16x16 diagonal blocks are inverted in registers (one
+// thread per column), then  X21 = -X22 (L21 X11)  is applied at block size 16 and at block size 32 -- small dense
+// products with all operands in LDS.  The block is padded to 64 with the identity.
+__global__ void __launch_bounds__(256)
+k_invert_diag_wide(DevPlan P, int list_begin) {
+    __shared__ double Ls[64 * 65], Xs[64 * 65], Ts[64 * 65];   // [row * 65 + col]
+    const int s = P.inv_list[list_begin + blockIdx.x];
+    const int w = P.sn_first[s + 1] - P.sn_first[s];
+    const double *ld = P.Ldiag + P.sn_diag[s];
+    const int tid = threadIdx.x;
+    for (int idx = tid; idx < 64 * 64; idx += 256) {
+        const int i = idx & 63, k = idx >> 6;
+        Ls[i * 65 + k] = (i < w && k < w) ? ld[i + k * w] : (i == k ? 1.0 : 0.0);
+        Xs[i * 65 + k] = 0.0;
+    }
+    __syncthreads();
+    if (tid < 64) {   // 16x16 diagonal blocks: thread = column j of block bq, forward substitution in registers
+        const int bq = tid >> 4, j = tid & 15, o = 16 * bq;
+        double x[16];
+#pragma unroll
+        for (int c = 0; c < 16; c++) x[c] = c == j ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+#pragma unroll
+            for (int i = k + 1; i < 16; i++) x[i] = fma(-Ls[(o + i) * 65 + o + k], x[k], x[i]);
+#pragma unroll
+        for (int c = 0; c < 16; c++) Xs[(o + c) * 65 + o + j] = x[c];
+    }
+    __syncthreads();
+    // block size 16: pairs (0,1) and (2,3).  T = L21 X11, then X21 = -X22 T
+    for (int e = tid; e < 512; e += 256) {
+        const int pr = e >> 8, i = (e >> 4) & 15, j = e & 15, o = 32 * pr;
+        double a = 0.0;
+#pragma unroll
+        for (int m = 0; m < 16; m++) a = fma(Ls[(o + 16 + i) * 65 + o + m], Xs[(o + m) * 65 + o + j], a);
+        Ts[(o + 16 + i) * 65 + o + j] = a;
+    }
+    __syncthreads();
+    for (int e = tid; e < 512; e += 256) {
+        const int pr = e >> 8, i = (e >> 4) & 15, j = e & 15, o = 32 * pr;
+        double a = 0.0;
+#pragma unroll
+        for (int m = 0; m < 16; m++) a = fma(Xs[(o + 16 + i) * 65 + o + 16 + m], Ts[(o + 16 + m) * 65 + o + j], a);
+        Xs[(o + 16 + i) * 65 + o + j] = -a;
+    }
+    __syncthreads();
+    // block size 32: T = L21 X11 (32x32 each, X11 lower triangular), X21 = -X22 T
+    for (int e = tid; e < 1024; e += 256) {
+        const int i = e >> 5, j = e & 31;
+        double a = 0.0;
+        for (int m = j; m < 32; m++) a = fma(Ls[(32 + i) * 65 + m], Xs[m * 65 + j], a);
+        Ts[(32 + i) * 65 + j] = a;
+    }
+    __syncthreads();
+    for (int e = tid; e < 1024; e += 256) {
+        const int i = e >> 5, j = e & 31;
+        double a = 0.0;
+        for (int m = 0; m <= i; m++) a = fma(Xs[(32 + i) * 65 + 32 + m], Ts[(32 + m) * 65 + j], a);
+        Xs[(32 + i) * 65 + j] = -a;
+    }
+    __syncthreads();
+    double *li = P.Linv + P.sn_diag[s];
+    double *lit = P.LinvT + P.sn_diag[s];
+    for (int idx = tid; idx < w * w; idx += 256) {
+        const int i = idx % w, j = idx / w;
+        li[idx] = Xs[i * 65 + j];      // Linv[i][j], column-major
+        lit[idx] = Xs[j * 65 + i];     // LinvT: element (i,j) of Linv at [j + i*w]
     }
 }
 
@@ -2117,10 +2189,12 @@ void launch_bwd_narrow(hipStream_t st, const DevPlan &P, int sn_begin, int n, co
 void launch_update_gather(hipStream_t st, const DevPlan &P, int64_t ebegin, int64_t n) {
     if (n > 0) hipLaunchKernelGGL(k_update_gather, dim3(nblk(n)), dim3(256), 0, st, P, ebegin, n);
 }
-void launch_invert_diag(hipStream_t st, const DevPlan &P, int nsuper, int wmax) {
-    const int ldl = wmax | 1;
-    if (nsuper > 0)
-        hipLaunchKernelGGL(k_invert_diag, dim3(nsuper), dim3(64), sizeof(double) * 2 * (size_t)wmax * ldl, st, P, nsuper);
+// inv_list = [n_small supernodes of width <= wmax_small | n_wide supernodes of width in (16, 64]]
+void launch_invert_diag(hipStream_t st, const DevPlan &P, int n_small, int wmax_small, int n_wide) {
+    const int ldl = wmax_small | 1;
+    if (n_small > 0)
+        hipLaunchKernelGGL(k_invert_diag, dim3(n_small), dim3(64), sizeof(double) * 2 * (size_t)wmax_small * ldl, st, P, 0, n_small);
+    if (n_wide > 0) hipLaunchKernelGGL(k_invert_diag_wide, dim3(n_wide), dim3(256), 0, st, P, n_small);
 }
 void launch_mfma_probe(hipStream_t st, const double *A, const double *B, double *out) {
     hipLaunchKernelGGL(k_mfma_probe, dim3(1), dim3(64), 0, st, A, B, out);
