@@ -44,19 +44,19 @@ def make_problem(cfg, seed_shift=0):
 
 
 def pmc_traffic(cfg):
-    """HBM bytes per launch of the dominant kernel (k_update_dense<4>) from the committed rocprofv3 PMC passes
+    """HBM bytes per launch of the dominant kernel (k_update_dense<4,4>) from the committed rocprofv3 PMC passes
     (FETCH_SIZE and WRITE_SIZE collected in separate runs of this very command, tools/pmc_summary.py; read side
     doubled = the gfx950 FETCH_SIZE correction).  The counters cannot be collected from inside the timed run,
     so the figure is read from profiles/ for the workload it was measured on, else null."""
     if cfg != "2a":
         return None
-    path = os.path.join(ROOT, "profiles", "r01_d_cfg2a_pmc_hbm_traffic.txt")
+    path = os.path.join(ROOT, "profiles", "r01_e_cfg2a_pmc_hbm_traffic.txt")
     try:
         for line in open(path):
             if "k_update_denseILi4" in line:
                 f = line.split()
                 return {"bytes_per_launch": round((float(f[4]) + float(f[5])) * 1e6), "read_x2_MB": float(f[4]),
-                        "write_MB": float(f[5]), "source": "profiles/r01_d_cfg2a_pmc_hbm_traffic.txt"}
+                        "write_MB": float(f[5]), "source": "profiles/r01_e_cfg2a_pmc_hbm_traffic.txt"}
     except OSError:
         pass
     return None
@@ -229,9 +229,9 @@ def main():
     agg = cm["flops_update"] / (upd * 1e-3) / 1e12 if upd > 0 else 0.0
     p4 = sorted(d4, key=lambda p: p["dense4_ms"])[len(d4) // 2]
     if p4["dense4_launches"] > 0 and p4["dense4_ms"] > 0:
-        # dominant kernel alone: k_update_dense<4> (one wavefront per 64x64 tile), HIP events around each launch
+        # dominant kernel alone: k_update_dense<4,4> (one wavefront per 64x64 tile), HIP events around each launch
         achieved = p4["dense4_flops"] / (p4["dense4_ms"] * 1e-3) / 1e12
-        kern = "k_update_dense<4>"
+        kern = "k_update_dense<4,4>"
         per_launch = dict(launches_per_refactor=p4["dense4_launches"],
                           avg_launch_us=round(1e3 * p4["dense4_ms"] / p4["dense4_launches"], 2),
                           flops_per_launch=p4["dense4_flops"] / p4["dense4_launches"])

@@ -24,12 +24,14 @@ struct DevPlan {
     const int *perm;
     const signed char *sgn_perm;
     const FacItem *fac_items;
+    const FacRec *fac_recs;      // [fac_items] the same items, self-contained (k_factor_panel)
     const FacJit *fac_jit;       // [fac_items] pending updates applied by k_factor_panel<true> (symbolic.h)
     const FacItem *slv_items;
     const FacItem *bwd_items;
     const int *rel;
     const UpdTask *upd_tasks;
     const UpdGroup *upd_groups;
+    const DenseGroup *dgroups;   // [upd_groups] self-contained records of the dense groups (k_update_dense)
     const int16_t *upd_tmap;
     const DenseTask *dtasks;      // parallel to upd_tasks
     const int64_t *gath_tgt;

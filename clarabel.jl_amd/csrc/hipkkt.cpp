@@ -338,11 +338,31 @@ void setup_device(hipkkt_solver *S) {
         D.inv_list = S->upload(small);
     }
     D.fac_items = S->upload(P.fac_items);
+    {
+        std::vector<FacRec> recs(P.fac_items.size());
+        for (size_t q = 0; q < recs.size(); q++) {
+            const int s = P.fac_items[q].sn;
+            recs[q] = {P.sn_panel[s], P.sn_diag[s], P.lt_off[s], P.sn_first[s], P.sn_first[s + 1] - P.sn_first[s],
+                       (int32_t)(P.sn_rowptr[s + 1] - P.sn_rowptr[s]), P.fac_items[q].blk};
+        }
+        D.fac_recs = S->upload(recs);
+    }
     D.fac_jit = S->upload(P.fac_jit);
     D.slv_items = S->upload(S->slv_items);
     D.rel = S->upload(P.rel);
     D.upd_tasks = S->upload(P.upd_tasks);
     D.upd_groups = S->upload(P.upd_groups);
+    {
+        std::vector<DenseGroup> dg(P.upd_groups.size());
+        for (size_t q = 0; q < dg.size(); q++) {
+            const UpdGroup &G = P.upd_groups[q];
+            const int t = G.tgt;
+            const int rt = (int)(P.sn_rowptr[t + 1] - P.sn_rowptr[t]);
+            dg[q] = {P.sn_panel[t] + G.row_base, rt, std::min(kUpdRows, rt - G.row_base), P.sn_first[t + 1] - P.sn_first[t],
+                     G.task_begin, G.task_end, 0};
+        }
+        D.dgroups = S->upload(dg);
+    }
     D.upd_tmap = S->upload(P.upd_tmap);
     {
         std::vector<DenseTask> dt(P.upd_tasks.size());

@@ -273,12 +273,11 @@ k_factor_panel(DevPlan P, int item_begin, double dyn_eps, double dyn_delta) {
     __shared__ double dinvs[3][8];
     __shared__ double Yt[2][64 * 65];     // [group][row * 65 + k]: L11 (group D) and L21 (group O), staged
     __shared__ double dsave[64];
-    const FacItem it = P.fac_items[item_begin + blockIdx.x];
-    const int s = it.sn;
-    const int f = P.sn_first[s];
-    const int w = P.sn_first[s + 1] - f;
-    const int r = (int)(P.sn_rowptr[s + 1] - P.sn_rowptr[s]);
-    double *pan = P.Lx + P.sn_panel[s];
+    // one self-contained record per item: the panel kernels are the critical path of the factorisation, and the
+    // chain  item -> supernode tables -> panel  cost two extra dependent memory round trips per launch
+    const FacRec it = P.fac_recs[item_begin + blockIdx.x];
+    const int f = it.f, w = it.w, r = it.r;
+    double *pan = P.Lx + it.panel_off;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int grp = wv >> 2, v = wv & 3;
     const int lo = w + it.blk * kFacRows;
@@ -374,7 +373,7 @@ k_factor_panel(DevPlan P, int item_begin, double dyn_eps, double dyn_delta) {
     }
     __syncthreads();
     if (it.blk == 0) {
-        double *ld = P.Ldiag + P.sn_diag[s];
+        double *ld = P.Ldiag + it.diag_off;
         for (int idx = tid; idx < w * w; idx += 512) {
             const int i = idx % w, k = idx / w;
             ld[idx] = i > k ? Yt[0][i * 65 + k] : (i == k ? 1.0 : 0.0);
@@ -393,7 +392,7 @@ k_factor_panel(DevPlan P, int item_begin, double dyn_eps, double dyn_delta) {
             pan[(lo + row) + (int64_t)k * r] = Yt[1][row * 65 + k];
         }
         // row-major copy (w contiguous doubles per row) for the backward solve's L21^T x
-        double *lt = P.LT + P.lt_off[s] + (int64_t)(lo - w) * w;
+        double *lt = P.LT + it.lt_off + (int64_t)(lo - w) * w;
         for (int idx = tid; idx < nr * w; idx += 512) {
             const int k = idx % w, row = idx / w;
             lt[idx] = Yt[1][row * 65 + k];
@@ -827,14 +826,15 @@ __device__ __forceinline__ void dense_tile_core(const DevPlan &P, double *tp, in
 }
 
 template <int NT, int NR>
-__device__ __forceinline__ void dense_tile(const DevPlan &P, const UpdGroup *Gp, int lane, int tj0, int ti0) {
-    const int t = rfl(Gp->tgt), row_base = rfl(Gp->row_base), task_begin = rfl(Gp->task_begin), task_end = rfl(Gp->task_end);
-    const int ft = rfl(P.sn_first[t]);
-    const int wt = rfl(P.sn_first[t + 1]) - ft;
+__device__ __forceinline__ void dense_tile(const DevPlan &P, const DenseGroup *Gp, int lane, int tj0, int ti0) {
+    // one self-contained record per tile (no group -> supernode tables -> panel chain of dependent loads)
+    const DenseGroup G = *Gp;
+    const int task_begin = rfl(G.task_begin), task_end = rfl(G.task_end);
+    const int wt = rfl(G.wt);
     if (tj0 * 16 >= wt) return;
-    const int rt = rfl((int)(P.sn_rowptr[t + 1] - P.sn_rowptr[t]));
-    double *tp = rfl_ptr(P.Lx + P.sn_panel[t] + row_base);
-    const int nrt = min(kUpdRows, rt - row_base);
+    const int rt = rfl(G.rt);
+    double *tp = rfl_ptr(P.Lx + G.tile_off);
+    const int nrt = rfl(G.nrt);
     if (ti0 * 16 >= nrt) return;
     dense_tile_core<NT, NR, false>(P, tp, rt, nrt, wt, task_begin, task_end, lane, tj0, ti0, nullptr);
 }
@@ -851,11 +851,11 @@ k_update_dense(DevPlan P, int group_begin, int ngroups) {
     const int tj0 = (wave % (4 / NT)) * NT;           // first 16-column strip of this wavefront
     if (NR == 4) {
         for (int g = rfl(blockIdx.x * NT + wave / (4 / NT)); g < ngroups; g += gridDim.x * NT)
-            dense_tile<NT, NR>(P, P.upd_groups + group_begin + g, lane, tj0, 0);
+            dense_tile<NT, NR>(P, P.dgroups + group_begin + g, lane, tj0, 0);
     } else {
         constexpr int RS = 4 / NR;
         for (int u = blockIdx.x; u < ngroups * RS; u += gridDim.x)
-            dense_tile<NT, NR>(P, P.upd_groups + group_begin + u / RS, lane, tj0, (u % RS) * NR);
+            dense_tile<NT, NR>(P, P.dgroups + group_begin + u / RS, lane, tj0, (u % RS) * NR);
     }
 }
 

@@ -55,6 +55,19 @@ struct FacItem {
     int32_t blk;        // row-chunk index inside the panel's off-diagonal part
 };
 
+// Device-side record of a dense update group (target tile) for k_update_dense: everything in one 32-byte load.
+struct DenseGroup {
+    int64_t tile_off;                      // Lx offset of the tile's first row in the target panel
+    int32_t rt, nrt, wt;                   // target panel rows, rows of this tile (<= 64), target width
+    int32_t task_begin, task_end, pad;
+};
+
+// Device-side record of a factor item for k_factor_panel: everything the kernel needs in one load.
+struct FacRec {
+    int64_t panel_off, diag_off, lt_off;   // offsets into Lx / Ldiag / LT
+    int32_t f, w, r, blk;                  // first column, width, rows, row-chunk index
+};
+
 // Pending (just-in-time) updates of one factor item, applied by the panel kernel itself before it eliminates:
 // task ranges (into upd_tasks) of the item's diagonal tile and of its row chunk.  Used for the panels of a front
 // whose only pending updates come from the batch-mates factored just before them (lvl_fused).
