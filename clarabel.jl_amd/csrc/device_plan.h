@@ -49,7 +49,6 @@ struct DevPlan {
     const FrontPanel *front_panels;
     const int64_t *front_gptr;
     const int *front_gidx;
-    double *Wpair;      // per front pair: W21 = -Linv1 * L[p1 cols, p0 cols] * Linv0 (64 x 64, column-major)
     int *front_sync;
     // persistent level-free sweeps over the regular (non-front) supernodes: dependency counters and lists
     const FacItem *pbwd_items;   // backward order: per level (descending) partial items, then finals (blk = -1)

@@ -69,7 +69,6 @@ struct hipkkt_solver {
     std::vector<char> lvl_narrow;                // [nlevels] every regular supernode is narrow (k_fwd_narrow / k_bwd_narrow)
     // persistent sweeps over the regular supernodes: segments = level ranges between front kernels
     bool use_persist = true;
-    bool use_pairs = true;      // fronts solved two panels per hop (k_front_fwd2 / k_front_bwd2)
     int nseg = 0;
     std::vector<int> seg_of_level;               // [nlevels]
     std::vector<int> fseg_ptr, bseg_ptr;         // [nseg+1] into slv_items / pbwd_items
@@ -194,8 +193,6 @@ void setup_device(hipkkt_solver *S) {
     {
         const char *np_ = getenv("HIPKKT_NO_PERSIST");
         S->use_persist = !(np_ && np_[0] == '1');
-        const char *npr = getenv("HIPKKT_PAIRS");   // two panels per hop: measured slower than one
-        S->use_pairs = npr && npr[0] == '1';
     }
     S->soc_off.clear(); S->soc_of_sparse.clear();
     S->nsoc = 0; S->soc_total = 0; S->wmax_all = 1;
@@ -404,7 +401,6 @@ void setup_device(hipkkt_solver *S) {
         D.seg_sync = S->dalloc<int>(nsync);
         HK_CHECK(hipMemset(D.seg_sync, 0, nsync * sizeof(int)));
     }
-    D.Wpair = S->dalloc<double>((size_t)std::max<int64_t>(P.front_wpair_doubles, 8));
     D.front_sync = S->dalloc<int>(std::max(P.front_sync_ints, 16));
     HK_CHECK(hipMemset(D.front_sync, 0, (size_t)std::max(P.front_sync_ints, 16) * sizeof(int)));
     D.kval = S->upload(S->img.nzval);
@@ -531,8 +527,6 @@ void enqueue_factor(hipkkt_solver *S, int static_enable, double eps_const, doubl
     }
     if (pending) HK_CHECK(hipStreamWaitEvent(st, pending, 0));
     launch_invert_diag(st, S->dp, S->inv_nsmall, S->inv_wsmall, S->inv_nwide);
-    if (S->use_pairs)
-        for (const FrontDesc &F : P.fronts) launch_front_pair_inv(st, S->dp, F);
 }
 
 // d_sin -> d_sout (original ordering on both sides)
@@ -562,12 +556,12 @@ void enqueue_ldl_solve(hipkkt_solver *S) {
             const int n = S->fseg_ptr[2 * g + 1] - S->fseg_ptr[2 * g];
             if (n > 0) { launch_fwd_seg(st, S->dp, g, S->fseg_ptr[2 * g], n, P.nsuper, first ? 1 : 0, S->d_y, S->d_z); first = false; }
             for (const FrontDesc &F : P.fronts)
-                if (S->seg_of_level[F.level_last] == g) (S->use_pairs ? launch_front_fwd2 : launch_front_fwd)(st, S->dp, F, S->d_y, S->d_z);
+                if (S->seg_of_level[F.level_last] == g) launch_front_fwd(st, S->dp, F, S->d_y, S->d_z);
         }
         first = true;
         for (int g = S->nseg - 1; g >= 0; g--) {
             for (const FrontDesc &F : P.fronts)
-                if (S->seg_of_level[F.level_last] == g) (S->use_pairs ? launch_front_bwd2 : launch_front_bwd)(st, S->dp, F, S->d_z, S->d_xp, S->d_sout);
+                if (S->seg_of_level[F.level_last] == g) launch_front_bwd(st, S->dp, F, S->d_z, S->d_xp, S->d_sout);
             const int k = S->nseg - 1 - g;     // launch order index
             const int n = S->bseg_ptr[k + 1] - S->bseg_ptr[k];
             if (n > 0) { launch_bwd_seg(st, S->dp, g, S->bseg_ptr[k], n, P.nsuper, first ? 1 : 0, S->d_z, S->d_xp, S->d_sout); first = false; }
@@ -578,11 +572,11 @@ void enqueue_ldl_solve(hipkkt_solver *S) {
     for (int l = 0; l < P.nlevels; l++) {
         fwd_level(l);
         for (const FrontDesc &F : P.fronts)
-            if (F.level_last == l) (S->use_pairs ? launch_front_fwd2 : launch_front_fwd)(st, S->dp, F, S->d_y, S->d_z);
+            if (F.level_last == l) launch_front_fwd(st, S->dp, F, S->d_y, S->d_z);
     }
     for (int l = P.nlevels - 1; l >= 0; l--) {
         for (const FrontDesc &F : P.fronts)
-            if (F.level_last == l) (S->use_pairs ? launch_front_bwd2 : launch_front_bwd)(st, S->dp, F, S->d_z, S->d_xp, S->d_sout);
+            if (F.level_last == l) launch_front_bwd(st, S->dp, F, S->d_z, S->d_xp, S->d_sout);
         bwd_level(l);
     }
 }
@@ -1200,8 +1194,6 @@ static int32_t refactor_once(hipkkt_handle h, int32_t static_reg_enable, double 
             }
         }
         launch_invert_diag(st, S->dp, S->inv_nsmall, S->inv_wsmall, S->inv_nwide);
-        if (S->use_pairs)
-            for (const FrontDesc &F : P.fronts) launch_front_pair_inv(st, S->dp, F);
         HK_CHECK(hipStreamSynchronize(st));
         double tot = 0;
         for (size_t i = 0; i + 1 < evs.size(); i += 2) {

@@ -30,9 +30,6 @@ void launch_bwd_seg(hipStream_t st, const DevPlan &P, int seg, int item_begin, i
                     double *x, double *xout);
 void launch_front_fwd(hipStream_t st, const DevPlan &P, const FrontDesc &F, double *y, double *z);
 void launch_front_bwd(hipStream_t st, const DevPlan &P, const FrontDesc &F, const double *z, double *x, double *xout);
-void launch_front_pair_inv(hipStream_t st, const DevPlan &P, const FrontDesc &F);
-void launch_front_fwd2(hipStream_t st, const DevPlan &P, const FrontDesc &F, double *y, double *z);
-void launch_front_bwd2(hipStream_t st, const DevPlan &P, const FrontDesc &F, const double *z, double *x, double *xout);
 void launch_spmv_residual(hipStream_t st, const DevPlan &P, const double *b, const double *xi, double *e, int n,
                           unsigned long long *slot);
 void launch_norm_inf(hipStream_t st, const double *v, int n, unsigned long long *slot);

@@ -1170,10 +1170,10 @@ k_bwd_final(DevPlan P, int sn_begin, const double *__restrict__ z, double *__res
 // K5 over a FRONT (a chain of np panels cut from one wide supernode, e.g. the dense root of a random
 // sparse QP): ONE persistent launch per sweep instead of np dependent launches.  Workgroup b owns the
 // b-th row block of the front, accumulates  sum_q L[b,q] y_q  over the panels q in order while the
-// y_q are published by their owners (8-byte agent-scope stores + one flag per panel; consumers poll
-// the flag relaxed and read the payload with agent-scope loads: MI355X_MICROARCH.md "handoff-flag"),
-// then solves its own diagonal block and publishes.  The L blocks of step q+1 are prefetched while
-// the workgroup waits for y_q, so a hop costs one hand-off + two 64x64 GEMVs.
+// y_q are published by their owners through self-validating hand-off slots (below), then solves its
+// own diagonal block and publishes.  The L blocks of step q+1 are prefetched while the workgroup
+// waits for y_q, so a hop costs one hand-off + two 64x64 GEMVs (1.6 us measured; the sweep reads L
+// once, 126 MB on cfg 2a, i.e. it also runs at ~0.9 TB/s of HBM traffic).
 // Deadlock freedom: block indices are tickets taken in arrival order (a workgroup only ever waits for
 // lower tickets, whose owners are already running); every spin is bounded and aborts through the
 // front's error word, which makes the solve report a failure instead of hanging.
@@ -1187,27 +1187,6 @@ __device__ __forceinline__ double front_ld(const double *p) {
 }
 __device__ __forceinline__ void front_st(double *p, double v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// wave-uniform wait (all lanes read the same word); false = timed out / another workgroup failed
-__device__ __forceinline__ bool front_wait(int *flag, int *err, int *failflag) {
-    for (unsigned spins = 0;; spins++) {
-        if (front_ld_flag(flag) != 0) break;
-        if ((spins & 127u) == 127u) {
-            if (spins > (1u << 20)) {
-                __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                atomicOr(failflag, 1);
-                return false;
-            }
-            if (front_ld_flag(err) != 0) return false;
-        }
-        __builtin_amdgcn_s_sleep(1);
-    }
-    asm volatile("" ::: "memory");
-    return true;
-}
-__device__ __forceinline__ void front_publish(int *flag, int lane) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the payload stores of THIS wave have completed
-    if (lane == 0) __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Hand-off slots: the 64 values of a panel travel as 64 x 16 bytes {value, bits(value) ^ KEY}, written with ONE
@@ -1489,295 +1468,6 @@ k_front_bwd(DevPlan P, FrontDesc F, const double *__restrict__ z, double *__rest
             xout[perm_own] = v;
         }
     }
-}
-
-// ------------------------------------------------------------------------------------------
-// Paired front sweeps: the hop cost of k_front_fwd/bwd is ~2.3 us of publish/poll/visibility latency and
-// only ~0.5 us of arithmetic, so two panels are solved per hop.  The pair's 128 x 128 diagonal block
-// [L00 0; L10 L11] is applied through its explicit inverse [Linv0 0; W21 Linv1], W21 = -Linv1 L10 Linv0,
-// formed once per factorisation by k_front_pair_inv.  Workgroup = 512 threads = 8 wavefronts.
-// ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-k_front_pair_inv(DevPlan P, FrontDesc F) {
-    __shared__ double Bs[64 * 65], A0[64 * 65], T[64 * 65];
-    const int pr = blockIdx.x;
-    const FrontPanel *fps = P.front_panels + F.fp_off;
-    const int p0 = 2 * pr, p1 = 2 * pr + 1;
-    double *Wp = P.Wpair + F.wp_off + (int64_t)pr * 4096;
-    const int tid = threadIdx.x;
-    if (p1 >= F.np) {   // unpaired last panel: no coupling block
-        for (int q = tid; q < 4096; q += 256) Wp[q] = 0.0;
-        return;
-    }
-    const FrontPanel f0 = fps[p0], f1 = fps[p1];
-    const int w0 = f0.w, w1 = f1.w;
-    for (int q = tid; q < 64 * 64; q += 256) {
-        const int i = q & 63, k = q >> 6;
-        Bs[i * 65 + k] = (i < w1 && k < w0) ? P.Lx[f0.panel_off + (w0 + i) + (int64_t)k * f0.r] : 0.0;   // L10[i][k]
-        A0[i * 65 + k] = (i < w0 && k < w0 && k <= i) ? P.Linv[f0.diag_off + i + k * w0] : 0.0;          // Linv0[i][k]
-    }
-    __syncthreads();
-    const int i = tid & 63, jq = tid >> 6;
-    for (int t = 0; t < 16; t++) {   // T = L10 * Linv0
-        const int j = jq + 4 * t;
-        double a = 0.0;
-        for (int k = j; k < w0; k++) a = fma(Bs[i * 65 + k], A0[k * 65 + j], a);
-        T[i * 65 + j] = a;
-    }
-    __syncthreads();
-    for (int q = tid; q < 64 * 64; q += 256) {   // A0 <- Linv1
-        const int ii = q & 63, k = q >> 6;
-        A0[ii * 65 + k] = (ii < w1 && k < w1 && k <= ii) ? P.Linv[f1.diag_off + ii + k * w1] : 0.0;
-    }
-    __syncthreads();
-    for (int t = 0; t < 16; t++) {   // W21 = -Linv1 * T
-        const int j = jq + 4 * t;
-        double a = 0.0;
-        for (int m = 0; m <= i; m++) a = fma(A0[i * 65 + m], T[m * 65 + j], a);
-        Wp[i + j * 64] = -a;
-    }
-}
-
-__global__ void __launch_bounds__(512)
-k_front_fwd2(DevPlan P, FrontDesc F, double *__restrict__ y, double *__restrict__ z) {
-    __shared__ double red[4][128];
-    __shared__ double tv[128];
-    __shared__ int sb;
-    int *sync = P.front_sync + F.sync_off;
-    if (threadIdx.x == 0) sb = atomicAdd(sync, 1);
-    __syncthreads();
-    const int b = sb;
-    if (b >= F.nb2) return;
-    if (b == 0)   // re-arm the backward sweep's block (idle during this launch)
-        for (int q = threadIdx.x; q < F.sync_blk; q += blockDim.x) sync[F.sync_blk + q] = 0;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int ih = wv & 1, h = (wv >> 1) & 1, kq = wv >> 2;      // row half, source panel of a pair, k half
-    const int part = wv >> 1;                                      // 0..3: index of this wave among the 4 partial sums
-    const FrontPanel *fps = P.front_panels + F.fp_off;
-    const bool own = b < F.npair;
-    const int pme = own ? min(2 * b + ih, F.np - 1) : 0;
-    const FrontPanel me = fps[pme];
-    const bool have = own ? (2 * b + ih < F.np) : true;           // second panel of the last pair may be missing
-    const int i0 = own ? F.cw * (2 * b + ih) : F.W + 128 * (b - F.npair) + 64 * ih;
-    const int nrows = own ? (have ? me.w : 0) : max(0, min(64, F.rF - i0));
-    const int i = i0 + lane;
-    const bool valid = lane < nrows;
-    double base = 0.0, dinv_own = 0.0;
-    if (part == 0 && valid) {
-        double G = 0.0;
-        const int64_t g0 = P.front_gptr[F.gptr_off + i], g1 = P.front_gptr[F.gptr_off + i + 1];
-        for (int64_t g = g0; g < g1; g++) G += P.ubuf[P.front_gidx[g]];
-        base = own ? y[me.f + lane] - G : G;
-        if (own) dinv_own = P.Dinv[me.f + lane];
-    }
-    // explicit inverse of the pair's diagonal block, staged in LDS before the hops (registers are needed for the
-    // L blocks): Ms[0] = Linv0, Ms[1] = W21, Ms[2] = Linv1, each [row * 65 + col]
-    extern __shared__ __attribute__((aligned(16))) double Ms[];
-    if (own) {
-        const FrontPanel q0 = fps[2 * b], q1 = fps[min(2 * b + 1, F.np - 1)];
-        const bool two = 2 * b + 1 < F.np;
-        const double *Wp = P.Wpair + F.wp_off + (int64_t)b * 4096;
-        for (int q = tid; q < 4096; q += 512) {
-            const int r_ = q & 63, c_ = q >> 6;
-            Ms[r_ * 65 + c_] = (r_ < q0.w && c_ <= r_) ? P.Linv[q0.diag_off + r_ + c_ * q0.w] : 0.0;
-            Ms[4160 + r_ * 65 + c_] = two ? Wp[q] : 0.0;
-            Ms[8320 + r_ * 65 + c_] = (two && r_ < q1.w && c_ <= r_) ? P.Linv[q1.diag_off + r_ + c_ * q1.w] : 0.0;
-        }
-    }
-    const int nq = own ? b : F.npair;
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-    double lv[32];
-    auto load_L = [&](int q, double (&dst)[32]) {
-        const int ps = 2 * q + h;
-        const bool pok = ps < F.np;
-        const FrontPanel fp = fps[pok ? ps : 0];
-        const int jl = i - F.cw * ps;
-#pragma unroll
-        for (int t = 0; t < 32; t++) {
-            const int k = 32 * kq + t;
-            dst[t] = (pok && valid && k < fp.w) ? P.Lx[fp.panel_off + jl + (int64_t)k * fp.r] : 0.0;
-        }
-    };
-    if (nq > 0) load_L(0, lv);
-    bool ok = true;
-    for (int q = 0; q < nq; q++) {
-        // single L buffer: the block of hop q+1 is requested right after hop q's FMAs and is in flight while
-        // this workgroup waits for the next flag (a second buffer would spill: 512 threads x 256 VGPRs)
-        ok = front_wait(sync + 2 + q, sync + 1, P.flags + FL_FRONTFAIL);
-        if (!ok) break;
-        const int ps = 2 * q + h;
-        const FrontPanel fp = fps[ps < F.np ? ps : 0];
-        const int wsrc = ps < F.np ? fp.w : 0;
-#pragma unroll
-        for (int t = 0; t < 32; t += 4) {
-            const int k = 32 * kq + t;
-            a0 = fma(lv[t], front_ld(y + fp.f + (k < wsrc ? k : 0)), a0);
-            a1 = fma(lv[t + 1], front_ld(y + fp.f + (k + 1 < wsrc ? k + 1 : 0)), a1);
-            a2 = fma(lv[t + 2], front_ld(y + fp.f + (k + 2 < wsrc ? k + 2 : 0)), a2);
-            a3 = fma(lv[t + 3], front_ld(y + fp.f + (k + 3 < wsrc ? k + 3 : 0)), a3);
-        }
-        if (q + 1 < nq) load_L(q + 1, lv);
-    }
-    red[part][64 * ih + lane] = (a0 + a1) + (a2 + a3);
-    __syncthreads();
-    const int ri = 64 * ih + lane;
-    const double tot = ((red[0][ri] + red[1][ri]) + red[2][ri]) + red[3][ri];
-    if (!own) {
-        if (part == 0 && valid && ok) P.ubuf[F.ubelow_off + (i - F.W)] = base + tot;
-        return;
-    }
-    if (part == 0) tv[ri] = valid ? base - tot : 0.0;
-    __syncthreads();
-    {
-        double s0 = 0.0, s1 = 0.0;
-        const double *m0 = Ms + (ih ? 4160 : 0) + lane * 65;      // ih = 0: Linv0 row; ih = 1: W21 row (both against t0)
-        const double *m1 = Ms + 8320 + lane * 65;                 // ih = 1: Linv1 row (against t1)
-#pragma unroll
-        for (int t = 0; t < 16; t += 2) {
-            s0 = fma(m0[part + 4 * t], tv[part + 4 * t], s0);
-            s1 = fma(m0[part + 4 * t + 4], tv[part + 4 * t + 4], s1);
-            if (ih) {
-                s0 = fma(m1[part + 4 * t], tv[64 + part + 4 * t], s0);
-                s1 = fma(m1[part + 4 * t + 4], tv[64 + part + 4 * t + 4], s1);
-            }
-        }
-        red[part][ri] = s0 + s1;
-    }
-    __syncthreads();
-    if (part == 0) {
-        if (valid && ok) {
-            const double v = ((red[0][ri] + red[1][ri]) + red[2][ri]) + red[3][ri];
-            front_st(y + me.f + lane, v);
-            z[me.f + lane] = v * dinv_own;
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __syncthreads();     // both publishing waves have drained their stores
-    if (tid == 0 && ok) __hip_atomic_store(sync + 2 + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-__global__ void __launch_bounds__(512)
-k_front_bwd2(DevPlan P, FrontDesc F, const double *__restrict__ z, double *__restrict__ x, double *__restrict__ xout) {
-    __shared__ double red[4][128];
-    __shared__ double tv[128];
-    __shared__ int sb;
-    int *sync = P.front_sync + F.sync_off + F.sync_blk;
-    if (threadIdx.x == 0) sb = atomicAdd(sync, 1);
-    __syncthreads();
-    if (sb >= F.npair) return;
-    if (sb == 0)   // re-arm the forward sweep's block for the next solve (idle during this launch)
-        for (int q = threadIdx.x; q < F.sync_blk; q += blockDim.x) sync[q - F.sync_blk] = 0;
-    const int pr = F.npair - 1 - sb;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int pan = wv & 1, rq = wv >> 1;                          // which panel's columns, which row quarter
-    const FrontPanel *fps = P.front_panels + F.fp_off;
-    const int pp = 2 * pr + pan;
-    const bool have = pp < F.np;
-    const FrontPanel me = fps[have ? pp : F.np - 1];
-    const int w = have ? me.w : 0;
-    const bool cvalid = lane < w;
-    const double *lt = P.LT + me.lt_off;            // row-major: lt[(j - w) * w + k], j = local panel row
-    const int f0 = fps[0].f;
-    const int perm_own = (cvalid && rq == 0) ? P.perm[me.f + lane] : 0;
-    const double zin = (cvalid && rq == 0) ? z[me.f + lane] : 0.0;
-    // explicit inverse (transposed) of the pair's diagonal block in LDS: Ms[0][k*65+i] = Linv0[i][k],
-    // Ms[1][k*65+i] = W21[i][k], Ms[2][k*65+i] = Linv1[i][k]   (column k of the inverse contiguous in i)
-    extern __shared__ __attribute__((aligned(16))) double Ms[];
-    {
-        const FrontPanel q0 = fps[2 * pr], q1 = fps[min(2 * pr + 1, F.np - 1)];
-        const bool two = 2 * pr + 1 < F.np;
-        const double *Wp = P.Wpair + F.wp_off + (int64_t)pr * 4096;
-        for (int q = tid; q < 4096; q += 512) {
-            const int k_ = q & 63, i_ = q >> 6;     // LinvT is stored [k + i*w]
-            Ms[k_ * 65 + i_] = (k_ < q0.w && i_ < q0.w && i_ >= k_) ? P.LinvT[q0.diag_off + k_ + i_ * q0.w] : 0.0;
-            Ms[8320 + k_ * 65 + i_] = (two && k_ < q1.w && i_ < q1.w && i_ >= k_) ? P.LinvT[q1.diag_off + k_ + i_ * q1.w] : 0.0;
-            const int wi = q & 63, wk = q >> 6;     // Wp is stored [i + k*64]
-            Ms[4160 + wk * 65 + wi] = two ? Wp[q] : 0.0;
-        }
-    }
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-    // (A) rows below the front: x is final
-    {
-        const int *rows = P.sn_rows + F.rows_off;
-        for (int ib = F.W; ib < F.rF; ib += 128) {
-            const int lo = ib + 32 * rq;
-#pragma unroll 4
-            for (int t = 0; t < 32; t += 4) {
-                double xv[4], l[4];
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const int i = lo + t + u;
-                    const bool in = i < F.rF && i < ib + 128;
-                    xv[u] = in ? x[rows[in ? i : F.W]] : 0.0;
-                    l[u] = (in && cvalid) ? lt[(int64_t)(i - F.cw * pp - w) * w + lane] : 0.0;
-                }
-                a0 = fma(l[0], xv[0], a0);
-                a1 = fma(l[1], xv[1], a1);
-                a2 = fma(l[2], xv[2], a2);
-                a3 = fma(l[3], xv[3], a3);
-            }
-        }
-    }
-    // (B) later pairs, descending: the 128 rows of pair q are the front rows [2q*cw, 2q*cw + width(q))
-    auto pair_rows = [&](int q) { return min(F.W, (2 * q + 2) * F.cw) - 2 * q * F.cw; };
-    double lv[32];
-    auto load_L = [&](int q, double (&dst)[32]) {
-        const int nr = pair_rows(q);
-#pragma unroll
-        for (int t = 0; t < 32; t++) {
-            const int jr = 32 * rq + t;
-            const int frow = 2 * q * F.cw + jr;
-            dst[t] = (cvalid && jr < nr) ? lt[(int64_t)(frow - F.cw * pp - w) * w + lane] : 0.0;
-        }
-    };
-    bool ok = true;
-    if (F.npair - 1 > pr) load_L(F.npair - 1, lv);
-    for (int q = F.npair - 1; q > pr; q--) {
-        ok = front_wait(sync + 2 + q, sync + 1, P.flags + FL_FRONTFAIL);
-        if (!ok) break;
-        const int nr = pair_rows(q);
-        const double *xq = x + f0 + 2 * q * F.cw;
-#pragma unroll
-        for (int t = 0; t < 32; t += 4) {
-            const int jr = 32 * rq + t;
-            a0 = fma(lv[t], front_ld(xq + (jr < nr ? jr : 0)), a0);
-            a1 = fma(lv[t + 1], front_ld(xq + (jr + 1 < nr ? jr + 1 : 0)), a1);
-            a2 = fma(lv[t + 2], front_ld(xq + (jr + 2 < nr ? jr + 2 : 0)), a2);
-            a3 = fma(lv[t + 3], front_ld(xq + (jr + 3 < nr ? jr + 3 : 0)), a3);
-        }
-        if (q - 1 > pr) load_L(q - 1, lv);
-    }
-    const int ci = 64 * pan + lane;
-    red[rq][ci] = (a0 + a1) + (a2 + a3);
-    __syncthreads();
-    if (rq == 0) tv[ci] = cvalid ? zin - (((red[0][ci] + red[1][ci]) + red[2][ci]) + red[3][ci]) : 0.0;
-    __syncthreads();
-    {
-        double s0 = 0.0, s1 = 0.0;
-        const double *m0 = Ms + (pan ? 8320 : 0) + lane * 65;     // column `lane` of Linv_pan
-        const double *m1 = Ms + 4160 + lane * 65;                 // column `lane` of W21 (pan = 0: against t1)
-#pragma unroll
-        for (int t = 0; t < 16; t += 2) {
-            s0 = fma(m0[rq + 4 * t], tv[64 * pan + rq + 4 * t], s0);
-            s1 = fma(m0[rq + 4 * t + 4], tv[64 * pan + rq + 4 * t + 4], s1);
-            if (pan == 0) {
-                s0 = fma(m1[rq + 4 * t], tv[64 + rq + 4 * t], s0);
-                s1 = fma(m1[rq + 4 * t + 4], tv[64 + rq + 4 * t + 4], s1);
-            }
-        }
-        red[rq][ci] = s0 + s1;
-    }
-    __syncthreads();
-    if (rq == 0) {
-        if (cvalid && ok) {
-            const double v = ((red[0][ci] + red[1][ci]) + red[2][ci]) + red[3][ci];
-            front_st(x + me.f + lane, v);
-            xout[perm_own] = v;
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __syncthreads();
-    if (tid == 0 && ok) __hip_atomic_store(sync + 2 + pr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2223,15 +1913,6 @@ void launch_front_fwd(hipStream_t st, const DevPlan &P, const FrontDesc &F, doub
 }
 void launch_front_bwd(hipStream_t st, const DevPlan &P, const FrontDesc &F, const double *z, double *x, double *xout) {
     hipLaunchKernelGGL(k_front_bwd, dim3(F.np), dim3(256), 0, st, P, F, z, x, xout);
-}
-void launch_front_pair_inv(hipStream_t st, const DevPlan &P, const FrontDesc &F) {
-    hipLaunchKernelGGL(k_front_pair_inv, dim3(F.npair), dim3(256), 0, st, P, F);
-}
-void launch_front_fwd2(hipStream_t st, const DevPlan &P, const FrontDesc &F, double *y, double *z) {
-    hipLaunchKernelGGL(k_front_fwd2, dim3(F.nb2), dim3(512), 3 * 4160 * sizeof(double), st, P, F, y, z);
-}
-void launch_front_bwd2(hipStream_t st, const DevPlan &P, const FrontDesc &F, const double *z, double *x, double *xout) {
-    hipLaunchKernelGGL(k_front_bwd2, dim3(F.npair), dim3(512), 3 * 4160 * sizeof(double), st, P, F, z, x, xout);
 }
 void launch_spmv_residual(hipStream_t st, const DevPlan &P, const double *b, const double *xi, double *e, int n,
                           unsigned long long *slot) {

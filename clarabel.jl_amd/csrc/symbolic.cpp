@@ -660,10 +660,6 @@ std::string build_plan(int N, const int64_t *Ap, const int64_t *Ai, const int64_
             FrontDesc F{};
             F.s0 = s0; F.np = np; F.cw = cw; F.W = W; F.rF = rF;
             F.nb = np + (rF - W + 63) / 64;
-            F.npair = (np + 1) / 2;
-            F.nb2 = F.npair + (rF - W + 127) / 128;
-            F.wp_off = P.front_wpair_doubles;
-            P.front_wpair_doubles += (int64_t)F.npair * 4096;
             F.level_first = P.sn_level[s0]; F.level_last = P.sn_level[s0] + np - 1;
             F.gptr_off = (int64_t)P.front_gptr.size();
             F.fp_off = (int64_t)P.front_panels.size();

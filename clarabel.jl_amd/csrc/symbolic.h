@@ -91,8 +91,6 @@ struct FrontDesc {
     int64_t fp_off;               // front_panels[fp_off + p]
     int64_t ubelow_off;           // u_off of the last panel (its off-diagonal rows = the rows below the front)
     int64_t rows_off;             // sn_rowptr[s0]: global (permuted) index of every front row
-    int32_t npair, nb2;           // panels are solved in PAIRS (128-column hops): #pairs, #128-row blocks
-    int64_t wp_off;               // Wpair[wp_off + 4096 * pair]: the off-diagonal block of the pair's explicit inverse
     int32_t sync_off, sync_blk;   // sync area of this front: two blocks of sync_blk ints {ticket, error, flags[np], slots},
                                   // one per sweep; each sweep's kernel re-zeroes the OTHER block for the next solve
 };
@@ -170,7 +168,6 @@ struct HostPlan {
     std::vector<int> front_gidx;
     std::vector<int> sn_front;        // [nsuper] front index of a panel handled by the front kernels, else -1
     int front_sync_ints = 0;
-    int64_t front_wpair_doubles = 0;
 
     std::vector<int64_t> sym_rowptr;  // full symmetric CSR view of K (original ordering)
     std::vector<int> sym_col;
