@@ -9,6 +9,12 @@ namespace hipkkt {
 enum { SC_MAXDIAG = 0, SC_NORMB = 1, SC_NORME = 2, SC_COUNT = 8 };  // 64-bit scalar slots
 enum { FL_NONFINITE = 0, FL_NREG = 1, FL_FRONTFAIL = 2, FL_COUNT = 4 };                // int flags
 
+// hand-off slot of the persistent sweeps: a value and its self-validating tag (kernels.hip front_slot_* / seg_slot_*)
+struct __attribute__((aligned(16))) FrontSlot {
+    double v;
+    unsigned long long h;
+};
+
 struct DevPlan {
     // structure (read-only after setup)
     const int *sn_first;
@@ -67,6 +73,11 @@ struct DevPlan {
     double *D;
     double *Dinv;
     double *ubuf;    // forward-solve update vectors
+    // tagged hand-off of the backward segment sweep (kernels.hip seg_slot_*): 16-byte slots parallel to x / pbuf, the
+    // solve epoch, and the copy of sn_rows that marks the rows whose x is produced inside the same launch
+    FrontSlot *xseg, *pseg;
+    int *seg_epoch;
+    const int *rows_seg;         // sn_rows | kSegRowTag where the owning ancestor is solved inside the same launch
     double *pbuf;    // backward-solve partial dot products
     double *scal;    // SC_* slots (raw 64-bit)
     int *flags;      // FL_* slots

@@ -238,6 +238,7 @@ void setup_device(hipkkt_solver *S) {
     }
     // ---- persistent sweeps: segments, dependency lists, backward item order
     std::vector<int> dep_ptr(P.nsuper + 1, 0), dep_idx, sn_nitems(P.nsuper, 0), sn_bparent(P.nsuper, -1);
+    std::vector<int> rows_seg;
     {
         S->seg_of_level.assign(P.nlevels, 0);
         std::vector<char> boundary(P.nlevels + 1, 0);
@@ -276,6 +277,21 @@ void setup_device(hipkkt_solver *S) {
         for (int s = 0; s < P.nsuper; s++) {
             dep_ptr[s + 1] = dep_ptr[s] + (int)kids[s].size();
             dep_idx.insert(dep_idx.end(), kids[s].begin(), kids[s].end());
+        }
+        // tagged hand-off of the persistent backward sweep: mark the rows whose x is produced inside the same launch
+        {
+            auto in_seg_kernel = [&](int s) { return P.sn_front[s] < 0 && persistent(s); };
+            std::vector<int> col_sn(N, -1);
+            for (int c = 0; c < P.nsuper; c++)
+                for (int k = P.sn_first[c]; k < P.sn_first[c + 1]; k++) col_sn[k] = c;
+            rows_seg.assign(P.sn_rows.begin(), P.sn_rows.end());
+            for (int s = 0; s < P.nsuper; s++) {
+                if (!in_seg_kernel(s)) continue;
+                for (int64_t slot = P.sn_rowptr[s]; slot < P.sn_rowptr[s + 1]; slot++) {
+                    const int a = col_sn[P.sn_rows[slot]];
+                    if (a != s && a >= 0 && in_seg_kernel(a) && seg_of(a) == seg_of(s)) rows_seg[(size_t)slot] = P.sn_rows[slot] | 0x40000000;
+                }
+            }
         }
         // forward segments: slv_items is level-ordered, a segment is a level range
         S->fseg_ptr.assign(2 * S->nseg, 0);   // [2g] first persistent item, [2g+1] end, of segment g
@@ -413,6 +429,17 @@ void setup_device(hipkkt_solver *S) {
     D.Dinv = S->dalloc<double>(N);
     D.ubuf = S->dalloc<double>(P.ubuf_len);
     D.pbuf = S->dalloc<double>(S->p_off[P.nsuper]);
+    {
+        // slots start out all-zero = invalid in every epoch
+        const size_t nx = (size_t)std::max(N, 1), np_ = (size_t)std::max<int64_t>(S->p_off[P.nsuper], 1);
+        D.xseg = (FrontSlot *)S->dalloc<double>(2 * nx);
+        D.pseg = (FrontSlot *)S->dalloc<double>(2 * np_);
+        HK_CHECK(hipMemset(D.xseg, 0, 16 * nx));
+        HK_CHECK(hipMemset(D.pseg, 0, 16 * np_));
+        D.seg_epoch = S->dalloc<int>(4);
+        HK_CHECK(hipMemset(D.seg_epoch, 0, 4 * sizeof(int)));
+        D.rows_seg = S->upload(rows_seg);
+    }
     D.scal = S->dalloc<double>(SC_COUNT);
     D.flags = S->dalloc<int>(FL_COUNT);
     HK_CHECK(hipMemset(D.scal, 0, SC_COUNT * sizeof(double)));
@@ -533,7 +560,7 @@ void enqueue_factor(hipkkt_solver *S, int static_enable, double eps_const, doubl
 void enqueue_ldl_solve(hipkkt_solver *S) {
     const HostPlan &P = S->plan;
     hipStream_t st = S->stream;
-    launch_permute_in(st, S->d_sin, S->dp.perm, S->d_y, S->N);
+    launch_permute_in(st, S->d_sin, S->dp.perm, S->d_y, S->N, S->dp.seg_epoch);
     // one launch per level (wide bottom levels, and every level on the fallback path); levels of narrow supernodes
     // take the thread-per-supernode kernels
     auto fwd_level = [&](int l) {
@@ -643,6 +670,8 @@ bool recover_from_sweep_failure(hipkkt_solver *S) {
     if (!S->use_persist) return false;
     const HostPlan &P = S->plan;
     HK_CHECK(hipStreamSynchronize(S->stream));
+    fprintf(stderr, "hipkkt: a persistent sweep kernel timed out (flags 0x%x); this handle falls back to per-level solve kernels\n",
+            S->h_flags[FL_FRONTFAIL]);
     const size_t nsync = 2 * (size_t)S->nseg + 3 * (size_t)P.nsuper + 16;
     HK_CHECK(hipMemset(S->dp.seg_sync, 0, nsync * sizeof(int)));
     HK_CHECK(hipMemset(S->dp.front_sync, 0, (size_t)std::max(P.front_sync_ints, 16) * sizeof(int)));

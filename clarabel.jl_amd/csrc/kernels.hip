@@ -903,7 +903,9 @@ __global__ void k_mfma_probe(const double *__restrict__ A, const double *__restr
 //           (fixed summation order) + unit-upper solve with L11^T.
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-k_permute_in(const double *__restrict__ b, const int *__restrict__ perm, double *__restrict__ y, int n) {
+k_permute_in(const double *__restrict__ b, const int *__restrict__ perm, double *__restrict__ y, int n, int *epoch) {
+    // first kernel of every LDL solve: a new epoch invalidates the tagged hand-off values of the previous solve
+    if (blockIdx.x == 0 && threadIdx.x == 0 && epoch) epoch[0] = epoch[0] + 1;
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k < n) y[k] = b[perm[k]];
 }
@@ -1194,10 +1196,6 @@ __device__ __forceinline__ void front_st(double *p, double v) {
 // checks against its value, so no separate flag is needed (no "payload complete" wait before the flag, no second
 // round trip for the payload after it: 0.7 us per hop instead of 1.3 us in tools/ubench_chain.hip), a torn or
 // stale read can only fail the check, and a zeroed slot is invalid.
-struct __attribute__((aligned(16))) FrontSlot {
-    double v;
-    unsigned long long h;
-};
 constexpr unsigned long long kSlotKey = 0x5bd1e995a5a5a5a5ull;
 __device__ __forceinline__ FrontSlot front_slot_ld(const FrontSlot *p) {
     typedef unsigned v4u __attribute__((ext_vector_type(4)));
@@ -1212,7 +1210,9 @@ __device__ __forceinline__ void front_slot_st(FrontSlot *p, double v) {
     typedef unsigned v4u __attribute__((ext_vector_type(4)));
     const unsigned long long b = (unsigned long long)__double_as_longlong(v), h = b ^ kSlotKey;
     v4u r = {(unsigned)b, (unsigned)(b >> 32), (unsigned)h, (unsigned)(h >> 32)};
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(r) : "memory");
+    // s_nop: the data VGPRs of a store wider than 64 bits must not be overwritten in the next wait states (the
+    // compiler's hazard recogniser does not look inside inline asm)
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 2" : : "v"(p), "v"(r) : "memory");
 }
 // whole-wave wait for the 64 slots of one panel (lane = slot); false = timed out / another workgroup failed
 __device__ __forceinline__ bool front_slot_wait(const FrontSlot *p, double &v, int *err, int *failflag) {
@@ -1509,6 +1509,48 @@ __device__ __forceinline__ bool seg_wait(int *ctr, int want, int *err, int *fail
         __builtin_amdgcn_s_sleep(1);
     }
 }
+// Tagged hand-off inside a segment sweep: a value produced by one item and consumed by a later item of the SAME
+// launch travels as a self-validating 16-byte slot (see FrontSlot) next to its plain copy, keyed with the solve's
+// epoch so that the previous solve's slots are invalid without any re-arming.  The consumer polls the very values
+// it needs -- no dependency counter, no "stores complete" wait before an atomic, no second round trip.
+__device__ __forceinline__ unsigned long long seg_key(const DevPlan &P) {
+    return kSlotKey ^ ((unsigned long long)(unsigned)(P.seg_epoch[0] + 1) * 0x9E3779B97F4A7C15ull);
+}
+__device__ __forceinline__ void seg_slot_st(FrontSlot *p, double v, unsigned long long key) {
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v), h = b ^ key;
+    v4u r = {(unsigned)b, (unsigned)(b >> 32), (unsigned)h, (unsigned)(h >> 32)};
+    // s_nop: the data VGPRs of a store wider than 64 bits must not be overwritten in the next wait states (the
+    // compiler's hazard recogniser does not look inside inline asm and re-used them for an address right away)
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 2" : : "v"(p), "v"(r) : "memory");
+}
+// one lane waits for one slot; false = timed out / another workgroup failed (bounded like every other spin)
+__device__ __forceinline__ bool seg_slot_poll(const FrontSlot *p, unsigned long long key, double &v, int *err, int *failflag) {
+    for (unsigned spins = 0;; spins++) {
+        const FrontSlot s = front_slot_ld(p);
+        if (((unsigned long long)__double_as_longlong(s.v) ^ s.h) == key) { v = s.v; return true; }
+        if ((spins & 127u) == 127u) {
+            if (spins > (1u << 20)) {
+                __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                atomicOr(failflag, 1);
+                return false;
+            }
+            if (front_ld_flag(err) != 0) return false;
+        }
+    }
+}
+__device__ __forceinline__ bool seg_spin_check(unsigned &spins, int *err, int *failflag) {   // false = give up
+    if ((++spins & 127u) == 0u) {
+        if (spins > (1u << 20)) {
+            __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            atomicOr(failflag, 1);
+            return false;
+        }
+        if (front_ld_flag(err) != 0) return false;
+    }
+    return true;
+}
+constexpr int kSegRowTag = 0x40000000;   // rows_seg: the row's x comes from an item of the same launch
 
 __global__ void __launch_bounds__(256)
 k_fwd_seg(DevPlan P, int seg, int item_begin, int nitems, int nsuper, int first_launch, double *__restrict__ y,
@@ -1642,15 +1684,17 @@ k_bwd_seg(DevPlan P, int seg, int item_begin, int nitems, int nsuper, int first_
           double *__restrict__ x, double *__restrict__ xout) {
     __shared__ double red[4][kMaxSnWidth];
     __shared__ double tv[kMaxSnWidth];
-    __shared__ int sb;
+    __shared__ int bad;
     const SegSync Y = seg_sync(P, nsuper);
     const int tid = threadIdx.x;
     const int t = blockIdx.x;     // see k_fwd_seg
     if (t >= nitems) return;
-    if (first_launch && t == 0) {   // re-arm the forward sweep's state for the next solve
+    if (tid == 0) bad = 0;
+    if (first_launch && t == 0) {   // re-arm the forward sweep's counters for the next solve
         for (int q = tid; q < P.nseg; q += 256) Y.ftick[q] = 0;
         for (int q = tid; q < nsuper; q += 256) Y.fdone[q] = 0;
     }
+    const unsigned long long key = seg_key(P);
     const FacItem it = P.pbwd_items[item_begin + t];
     const int s = it.sn;
     const int f = P.sn_first[s];
@@ -1658,14 +1702,14 @@ k_bwd_seg(DevPlan P, int seg, int item_begin, int nitems, int nsuper, int first_
     const int r = (int)(P.sn_rowptr[s + 1] - P.sn_rowptr[s]);
     const int nblk = (r - w + kSlvRows - 1) / kSlvRows;
     const int lane = tid & 63, wave = tid >> 6;
-    const int *rows = P.sn_rows + P.sn_rowptr[s];
+    const int *rows = P.rows_seg + P.sn_rowptr[s];   // sn_rows with kSegRowTag on the rows solved inside this launch
     const double *lt = P.LT + P.lt_off[s];
-    // ---- static data first: the 16 rows x 1 column of L21^T this thread multiplies, their row indices,
-    //      the column of Linv^T and z (finaliser)
+    // ---- static data first: the 16 rows x 1 column of L21^T this thread multiplies, their row indices (and the x
+    //      values that were final before this launch), the column of Linv^T and z (finaliser)
     const bool dot_here = it.blk >= 0 || nblk == 1;
     const int blk = it.blk >= 0 ? it.blk : 0;
     const int lo = w + blk * kSlvRows + wave * 16;
-    double lv[16];
+    double lv[16], xv[16];
     int ri[16];
 #pragma unroll
     for (int t2 = 0; t2 < 16; t2++) {
@@ -1673,6 +1717,12 @@ k_bwd_seg(DevPlan P, int seg, int item_begin, int nitems, int nsuper, int first_
         const bool in = dot_here && i < r && i < w + (blk + 1) * kSlvRows;
         ri[t2] = in ? rows[i] : -1;
         lv[t2] = (in && lane < w) ? lt[(int64_t)(i - w) * w + lane] : 0.0;
+        xv[t2] = (ri[t2] >= 0 && !(ri[t2] & kSegRowTag)) ? x[ri[t2]] : 0.0;
+    }
+    int ri_lane = -1;   // row lo + (lane & 15) of this wave's 16 rows, for the tagged polls
+    {
+        const int i = lo + (lane & 15);
+        if (dot_here && i < r && i < w + (blk + 1) * kSlvRows) ri_lane = rows[i];
     }
     double litv[16];
     double zin = 0.0;
@@ -1690,23 +1740,33 @@ k_bwd_seg(DevPlan P, int seg, int item_begin, int nitems, int nsuper, int first_
 #pragma unroll
         for (int t2 = 0; t2 < 16; t2++) litv[t2] = 0.0;
     }
-    // ---- dependencies
-    if (tid == 0) {
-        bool ok = true;
-        const int par = P.sn_bparent[s];
-        if (par >= 0) ok = seg_wait(Y.bdone + par, 1, Y.err, P.flags + FL_FRONTFAIL);
-        if (ok && it.blk < 0 && nblk > 1) ok = seg_wait(Y.pdone + s, nblk, Y.err, P.flags + FL_FRONTFAIL);
-        sb = ok ? 1 : 0;
-        asm volatile("" ::: "memory");
-    }
-    __syncthreads();
-    if (!sb) return;
+    // ---- dependencies = the tagged x values (ancestors solved inside this launch) and partial sums themselves
+    bool ok = true;
     double dotv = 0.0;
     if (dot_here) {
         double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-        double xv[16];
+        {   // lane l < 16 polls the slot of row lo + l (ONE load instruction per round for the wave's 16 rows); the
+            // values are then broadcast to all lanes
+            const int rl = ri_lane;                       // this lane's row (tagged index) or -1
+            const bool mine = lane < 16 && rl >= 0 && (rl & kSegRowTag);
+            double myv = 0.0;
+            bool got = !mine;
+            unsigned spins = 0;
+            while (ok) {
+                if (!got) {
+                    const FrontSlot sl = front_slot_ld(P.xseg + (rl & ~kSegRowTag));
+                    if (((unsigned long long)__double_as_longlong(sl.v) ^ sl.h) == key) { myv = sl.v; got = true; }
+                }
+                if (__ballot(!got) == 0ull) break;
+                ok = seg_spin_check(spins, Y.err, P.flags + FL_FRONTFAIL);
+            }
 #pragma unroll
-        for (int t2 = 0; t2 < 16; t2++) xv[t2] = ri[t2] >= 0 ? front_ld(x + ri[t2]) : 0.0;
+            for (int t2 = 0; t2 < 16; t2++) {
+                const double bv = readlane_f64(myv, t2);
+                if (ri[t2] >= 0 && (ri[t2] & kSegRowTag)) xv[t2] = bv;
+            }
+        }
+        if (!ok) { bad = 1; atomicOr(P.flags + FL_FRONTFAIL, 4); }   // bit 2: the backward segment sweep gave up
 #pragma unroll
         for (int t2 = 0; t2 < 16; t2 += 4) {
             a0 = fma(lv[t2], xv[t2], a0);
@@ -1716,24 +1776,29 @@ k_bwd_seg(DevPlan P, int seg, int item_begin, int nitems, int nsuper, int first_
         }
         red[wave][lane] = (a0 + a1) + (a2 + a3);
         __syncthreads();
+        if (bad) return;
         dotv = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
         __syncthreads();
     }
-    if (it.blk >= 0) {
-        if (tid < w) front_st(P.pbuf + P.p_off[s] + (int64_t)it.blk * w + tid, dotv);
-        if (wave == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (tid == 0) atomicAdd(Y.pdone + s, 1);
+    if (it.blk >= 0) {   // partial item: its w sums travel to the finaliser as tagged slots
+        if (tid < w) seg_slot_st(P.pseg + P.p_off[s] + (int64_t)it.blk * w + tid, dotv, key);
         return;
     }
     double acc = dotv;
     if (nblk > 1) {
         double a = 0.0;
         if (lane < w) {
-            const double *pb = P.pbuf + P.p_off[s] + lane;
-            for (int b2 = wave; b2 < nblk; b2 += 4) a += front_ld(pb + (int64_t)b2 * w);
+            const FrontSlot *pb = P.pseg + P.p_off[s] + lane;
+            for (int b2 = wave; b2 < nblk && ok; b2 += 4) {
+                double v = 0.0;
+                ok = seg_slot_poll(pb + (int64_t)b2 * w, key, v, Y.err, P.flags + FL_FRONTFAIL);
+                a += v;
+            }
         }
+        if (!ok) { bad = 1; atomicOr(P.flags + FL_FRONTFAIL, 4); }   // bit 2: the backward segment sweep gave up
         red[wave][lane] = a;
         __syncthreads();
+        if (bad) return;
         acc = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
         __syncthreads();
     }
@@ -1749,13 +1814,12 @@ k_bwd_seg(DevPlan P, int seg, int item_begin, int nitems, int nsuper, int first_
         red[wave][lane] = s0 + s1;
     }
     __syncthreads();
-    if (tid < w) {
+    if (tid < w) {   // publish: tagged slot for the descendants solved in this launch, plain copy for everybody else
         const double v = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
-        front_st(x + f + tid, v);
+        seg_slot_st(P.xseg + f + tid, v, key);
+        x[f + tid] = v;
         xout[perm_own] = v;
     }
-    if (wave == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (tid == 0) atomicAdd(Y.bdone + s, 1);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1889,8 +1953,8 @@ void launch_invert_diag(hipStream_t st, const DevPlan &P, int n_small, int wmax_
 void launch_mfma_probe(hipStream_t st, const double *A, const double *B, double *out) {
     hipLaunchKernelGGL(k_mfma_probe, dim3(1), dim3(64), 0, st, A, B, out);
 }
-void launch_permute_in(hipStream_t st, const double *b, const int *perm, double *y, int n) {
-    if (n > 0) hipLaunchKernelGGL(k_permute_in, dim3(nblk(n)), dim3(256), 0, st, b, perm, y, n);
+void launch_permute_in(hipStream_t st, const double *b, const int *perm, double *y, int n, int *epoch) {
+    if (n > 0) hipLaunchKernelGGL(k_permute_in, dim3(nblk(n)), dim3(256), 0, st, b, perm, y, n, epoch);
 }
 void launch_fwd_level(hipStream_t st, const DevPlan &P, int item_begin, int nitems, double *y, double *z) {
     if (nitems > 0) hipLaunchKernelGGL(k_fwd_level, dim3(nitems), dim3(256), 0, st, P, item_begin, y, z);

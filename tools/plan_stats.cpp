@@ -66,6 +66,26 @@ int main(int argc, char **argv) {
         printf("%5d %7d %7d %7ld %9ld %12.3e %8d %8d   dense: %6d groups (far %5d) %10.3e flops; tasks %7d avgfill %.2f\n", l, P.lvl_ptr[l + 1] - P.lvl_ptr[l], maxw, (long)maxr, (long)srw, lf[l],
                P.upd_stage_ptr[l + 1] - P.upd_stage_ptr[l], P.fac_lvl_ptr[l + 1] - P.fac_lvl_ptr[l], P.upd_stage_ndense[l], P.upd_stage_nfar[l], lfd[l], ntk, ntk ? fills[l] / ntk : 0.0);
     }
+    if (argc > 6) {   // debug: who owns ubuf position argv[5], as seen from supernode argv[6]
+        const int64_t upos = atoll(argv[5]);
+        const int sn = atoi(argv[6]);
+        for (int c = 0; c < P.nsuper; c++) {
+            const int64_t r = P.sn_rowptr[c + 1] - P.sn_rowptr[c];
+            const int w = P.sn_first[c + 1] - P.sn_first[c];
+            if (upos >= P.u_off[c] && upos < P.u_off[c] + (r - w))
+                printf("ubuf %ld: owner sn %d (level %d, w %d, r %ld, front %d, parent %d) row %ld ; consumer sn %d level %d front %d parent %d\n", (long)upos, c,
+                       P.sn_level[c], w, (long)r, P.sn_front[c], P.sn_parent[c], (long)(upos - P.u_off[c]), sn, P.sn_level[sn], P.sn_front[sn], P.sn_parent[sn]);
+        }
+        for (int l = 0; l < P.nlevels; l++) {
+            int n = 0;
+            for (int q = P.lvl_ptr[l]; q < P.lvl_ptr[l + 1]; q++) {
+                const int s2 = P.lvl_sn[q];
+                if (P.sn_front[s2] >= 0) continue;
+                n += (int)std::max<int64_t>(1, (P.sn_rowptr[s2 + 1] - P.sn_rowptr[s2] - (P.sn_first[s2 + 1] - P.sn_first[s2]) + 63) / 64);
+            }
+            if (l < 12) printf("level %d: %d regular items\n", l, n);
+        }
+    }
     // K (source width) histogram of the dense tasks of the stage with the most dense tasks
     {
         int best = 0; int64_t bestn = -1;
