@@ -123,7 +123,7 @@ struct hipkkt_solver {
         hipError_t e = hipMalloc(&p, n * sizeof(T));
         if (e != hipSuccess) throw std::bad_alloc();
         allocs.push_back(p);
-        if (poison) hipMemset(p, 0xFF, n * sizeof(T));   // debugging aid (HIPKKT_POISON=1): NaNs in every fresh buffer
+        if (poison) (void)hipMemset(p, 0xFF, n * sizeof(T));   // debugging aid (HIPKKT_POISON=1): NaNs in every fresh buffer
         return (T *)p;
     }
     template <class T>
@@ -141,17 +141,17 @@ struct hipkkt_solver {
     }
     ~hipkkt_solver() {
         delete fallback;
-        hipSetDevice(device);
-        if (g_factor.exec) hipGraphExecDestroy(g_factor.exec);
-        if (g_solve.exec) hipGraphExecDestroy(g_solve.exec);
-        for (void *p : allocs) hipFree(p);
-        if (h_scal) hipHostFree(h_scal);
-        if (h_flags) hipHostFree(h_flags);
+        (void)hipSetDevice(device);
+        if (g_factor.exec) (void)hipGraphExecDestroy(g_factor.exec);
+        if (g_solve.exec) (void)hipGraphExecDestroy(g_solve.exec);
+        for (void *p : allocs) (void)hipFree(p);
+        if (h_scal) (void)hipHostFree(h_scal);
+        if (h_flags) (void)hipHostFree(h_flags);
         for (hipEvent_t e : {ev0, ev1, ev2, ev3})
-            if (e) hipEventDestroy(e);
-        for (hipEvent_t e : fork_events) hipEventDestroy(e);
-        if (side) hipStreamDestroy(side);
-        if (stream) hipStreamDestroy(stream);
+            if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t e : fork_events) (void)hipEventDestroy(e);
+        if (side) (void)hipStreamDestroy(side);
+        if (stream) (void)hipStreamDestroy(stream);
     }
 };
 
@@ -184,10 +184,10 @@ void init_runtime(hipkkt_solver *S) {
 void setup_device(hipkkt_solver *S) {
     HK_CHECK(hipSetDevice(S->device));
     for (GraphSlot *g : {&S->g_factor, &S->g_solve}) {
-        if (g->exec) hipGraphExecDestroy(g->exec);
+        if (g->exec) (void)hipGraphExecDestroy(g->exec);
         *g = GraphSlot();
     }
-    for (void *p : S->allocs) hipFree(p);
+    for (void *p : S->allocs) (void)hipFree(p);
     S->allocs.clear();
     S->slv_items.clear(); S->bwd_items.clear(); S->reg_lvl_sn.clear(); S->pbwd_items.clear();
     {
@@ -612,19 +612,19 @@ template <class F>
 void run_graphed(hipkkt_solver *S, GraphSlot &slot, bool reusable, F &&enqueue) {
     if (!S->use_graph) { enqueue(); return; }
     if (!(slot.valid && reusable)) {
-        if (slot.exec) { hipGraphExecDestroy(slot.exec); slot.exec = nullptr; slot.valid = false; }
+        if (slot.exec) { (void)hipGraphExecDestroy(slot.exec); slot.exec = nullptr; slot.valid = false; }
         hipGraph_t graph = nullptr;
         HK_CHECK(hipStreamBeginCapture(S->stream, hipStreamCaptureModeThreadLocal));
         try {
             enqueue();
         } catch (...) {
-            hipStreamEndCapture(S->stream, &graph);
-            if (graph) hipGraphDestroy(graph);
+            (void)hipStreamEndCapture(S->stream, &graph);
+            if (graph) (void)hipGraphDestroy(graph);
             throw;
         }
         HK_CHECK(hipStreamEndCapture(S->stream, &graph));
         hipError_t e = hipGraphInstantiate(&slot.exec, graph, nullptr, nullptr, 0);
-        hipGraphDestroy(graph);
+        (void)hipGraphDestroy(graph);
         if (e != hipSuccess) { slot.exec = nullptr; S->use_graph = false; enqueue(); return; }
         slot.valid = true;
     }
@@ -1227,19 +1227,19 @@ static int32_t refactor_once(hipkkt_handle h, int32_t static_reg_enable, double 
         double tot = 0;
         for (size_t i = 0; i + 1 < evs.size(); i += 2) {
             float ms = 0;
-            hipEventElapsedTime(&ms, evs[i], evs[i + 1]);
+            (void)hipEventElapsedTime(&ms, evs[i], evs[i + 1]);
             tot += ms;
         }
         S->prof_dense4_ms = 0; S->prof_dense4_flops = 0; S->prof_dense4_launches = 0;
         for (size_t i = 0; i + 1 < evd.size(); i += 2) {
             float ms = 0;
-            hipEventElapsedTime(&ms, evd[i], evd[i + 1]);
+            (void)hipEventElapsedTime(&ms, evd[i], evd[i + 1]);
             S->prof_dense4_ms += ms;
             S->prof_dense4_flops += P.upd_stage_flops_dense[evd_level[i / 2]];
             S->prof_dense4_launches++;
         }
-        for (size_t i = 1; i < evd.size(); i += 2) hipEventDestroy(evd[i]);
-        for (hipEvent_t e : evs) hipEventDestroy(e);
+        for (size_t i = 1; i < evd.size(); i += 2) (void)hipEventDestroy(evd[i]);
+        for (hipEvent_t e : evs) (void)hipEventDestroy(e);
         S->t_last_update = tot;
     } else {
         GraphSlot &g = S->g_factor;
@@ -1392,11 +1392,11 @@ int32_t hipkkt_selftest_mfma(int32_t device_id, double *max_err) {
     if (hipMalloc((void **)&dA, sizeof(A)) != hipSuccess || hipMalloc((void **)&dB, sizeof(B)) != hipSuccess ||
         hipMalloc((void **)&dD, sizeof(Dd)) != hipSuccess)
         return HIPKKT_ERR_ALLOC;
-    hipMemcpy(dA, A, sizeof(A), hipMemcpyHostToDevice);
-    hipMemcpy(dB, B, sizeof(B), hipMemcpyHostToDevice);
+    (void)hipMemcpy(dA, A, sizeof(A), hipMemcpyHostToDevice);
+    (void)hipMemcpy(dB, B, sizeof(B), hipMemcpyHostToDevice);
     launch_mfma_probe(nullptr, dA, dB, dD);
     hipError_t e = hipMemcpy(Dd, dD, sizeof(Dd), hipMemcpyDeviceToHost);
-    hipFree(dA); hipFree(dB); hipFree(dD);
+    (void)hipFree(dA); (void)hipFree(dB); (void)hipFree(dD);
     if (e != hipSuccess) return HIPKKT_ERR_DEVICE;
     double me = 0;
     for (int i = 0; i < 256; i++) me = std::max(me, std::fabs(Dd[i] - Dh[i]));

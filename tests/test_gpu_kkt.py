@@ -129,6 +129,42 @@ def test_plan_variants_agree(policy, maxw, oracle_factory):
     assert np.max(np.abs(xg - xc)) <= 1e-9 * max(1.0, np.max(np.abs(xc)))
 
 
+# Alternative code paths selected by developer switches (read when a handle is created): every one must give the same
+# answers as the default path.  cfg1-sized problem: a root front (persistent front sweeps, just-in-time updates),
+# thousands of narrow leaves, segment sweeps.
+@pytest.mark.parametrize("env", [
+    {"HIPKKT_NO_GRAPH": "1"},
+    {"HIPKKT_NO_PERSIST": "1"},
+    {"HIPKKT_NO_FRONT": "1"},
+    {"HIPKKT_NO_NARROW": "1"},
+    {"HIPKKT_FUSE_JIT": "1"},
+    {"HIPKKT_SIDE_STREAM": "1", "HIPKKT_FAR_WGS": "64"},
+    {"HIPKKT_ORDERING": "amd"},
+])
+def test_developer_switches_keep_parity(env, oracle_factory, monkeypatch):
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    rng = np.random.default_rng(5)
+    Pt, A, cones = _prep(problems.random_sparse_qp(1000, 2000, 1, 4, 2))
+    m, n = A.shape
+    st = cl.Settings()
+    hk = HipKKTSolver(Pt, A, cones, m, n, st)
+    ok_ = oracle_factory(Pt, A, cones, m, n, st, ordering=hk.h.perm())
+    for rep in range(2):
+        _scale_cones(cones, rng)
+        assert hk.kktsolver_update(cones) and ok_.kktsolver_update(cones)
+        b = rng.standard_normal(hk.h.N)
+        xg, xc = hk.h.ldl_solve(b), ok_.k.ldl_solve(b)
+        assert np.max(np.abs(xg - xc)) <= 1e-9 * max(1.0, np.max(np.abs(xc)))
+        rx, rz = rng.standard_normal(n), rng.standard_normal(m)
+        lx_g, lz_g, lx_c, lz_c = np.zeros(n), np.zeros(m), np.zeros(n), np.zeros(m)
+        hk.kktsolver_setrhs(rx, rz)
+        ok_.kktsolver_setrhs(rx, rz)
+        assert hk.kktsolver_solve(lx_g, lz_g) and ok_.kktsolver_solve(lx_c, lz_c)
+        scale = max(1.0, np.max(np.abs(lx_c)), np.max(np.abs(lz_c)))
+        assert np.max(np.abs(lx_g - lx_c)) <= 1e-10 * scale and np.max(np.abs(lz_g - lz_c)) <= 1e-10 * scale
+
+
 def test_l0_seam_matches_oracle(oracle_factory):
     """AbstractDirectLDLSolver seam: create from an assembled KKT, update_values / scale_values /
     refactor / solve (directldl_qdldl.jl call pattern)."""
