@@ -662,6 +662,9 @@ double refine_error(hipkkt_solver *S, const double *xi, bool also_normb, double 
     return slot_value(S, SC_NORME);
 }
 
+// bit 0: a front sweep / forward segment sweep gave up, bit 2: the backward segment sweep gave up
+static inline bool sweep_failed(const hipkkt_solver *S) { return (S->h_flags[FL_FRONTFAIL] & 7) != 0; }
+
 // A persistent sweep kernel gave up (bounded spin expired: the workgroups were not dispatched in the order the
 // fast path relies on, or a front hand-off stalled).  Re-arm every hand-off word, drop to the per-level kernels
 // for the rest of this handle's life and tell the caller to repeat the solve.  Returns false when there is
@@ -689,7 +692,7 @@ int32_t solve_core_once(hipkkt_solver *S, int ir_enable, double reltol, double a
 int32_t solve_core(hipkkt_solver *S, int ir_enable, double reltol, double abstol, int64_t max_iter,
                    double stop_ratio, int64_t *ir_steps) {
     int32_t rc = solve_core_once(S, ir_enable, reltol, abstol, max_iter, stop_ratio, ir_steps);
-    if (rc == HIPKKT_ERR_DEVICE && S->h_flags[FL_FRONTFAIL] && recover_from_sweep_failure(S))
+    if (rc == HIPKKT_ERR_DEVICE && sweep_failed(S) && recover_from_sweep_failure(S))
         rc = solve_core_once(S, ir_enable, reltol, abstol, max_iter, stop_ratio, ir_steps);
     return rc;
 }
@@ -737,7 +740,7 @@ int32_t solve_core_once(hipkkt_solver *S, int ir_enable, double reltol, double a
     S->t_acc_solve += ms;
     S->n_solvecalls++;
     if (ir_steps) *ir_steps = steps;
-    if (S->h_flags[FL_FRONTFAIL]) { S->err = "front solve kernel timed out"; return HIPKKT_ERR_DEVICE; }
+    if (sweep_failed(S)) { S->err = "front solve kernel timed out"; return HIPKKT_ERR_DEVICE; }
     return ok ? HIPKKT_OK : HIPKKT_NUMERICAL_FAILURE;
 }
 
@@ -1329,14 +1332,14 @@ int32_t hipkkt_ldl_solve(hipkkt_handle h, double *x, const double *b) {
     HK_CHECK(hipMemcpyAsync(x, S->d_sout, (size_t)S->N * sizeof(double), hipMemcpyDeviceToHost, S->stream));
     HK_CHECK(hipMemcpyAsync(S->h_flags, S->dp.flags, FL_COUNT * sizeof(int), hipMemcpyDeviceToHost, S->stream));
     HK_CHECK(hipStreamSynchronize(S->stream));
-    if (S->h_flags[FL_FRONTFAIL] && recover_from_sweep_failure(S)) {   // repeat once on the per-level kernels
+    if (sweep_failed(S) && recover_from_sweep_failure(S)) {   // repeat once on the per-level kernels
         HK_CHECK(hipMemcpyAsync(S->d_sin, b, (size_t)S->N * sizeof(double), hipMemcpyHostToDevice, S->stream));
         ldl_solve_dev(S, S->d_sin, S->d_sout);
         HK_CHECK(hipMemcpyAsync(x, S->d_sout, (size_t)S->N * sizeof(double), hipMemcpyDeviceToHost, S->stream));
         HK_CHECK(hipMemcpyAsync(S->h_flags, S->dp.flags, FL_COUNT * sizeof(int), hipMemcpyDeviceToHost, S->stream));
         HK_CHECK(hipStreamSynchronize(S->stream));
     }
-    if (S->h_flags[FL_FRONTFAIL]) { S->err = "front solve kernel timed out"; return HIPKKT_ERR_DEVICE; }
+    if (sweep_failed(S)) { S->err = "front solve kernel timed out"; return HIPKKT_ERR_DEVICE; }
     float ms = 0;
     HK_CHECK(hipEventElapsedTime(&ms, S->ev2, S->ev3));
     S->t_last_solve = ms;
