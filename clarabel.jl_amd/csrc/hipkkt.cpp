@@ -112,7 +112,7 @@ struct hipkkt_solver {
     double t_last_factor = 0, t_last_solve = 0, t_acc_factor = 0, t_acc_solve = 0, t_last_update = 0;
     int64_t n_factor = 0, n_solvecalls = 0, n_ldlsolves = 0;
     double last_eps = 0;
-    double prof_dense4_ms = 0, prof_dense4_flops = 0;   // last profiled refactorisation: k_update_dense<4> alone
+    double prof_dense4_ms = 0, prof_dense4_flops = 0;   // last profiled refactorisation: k_update_dense<4,4> alone
     int prof_dense4_launches = 0;
     int64_t last_nreg = 0;
 
@@ -518,8 +518,8 @@ void enqueue_updates(hipkkt_solver *S, int l, bool split_far = false) {
 void enqueue_factor(hipkkt_solver *S, int static_enable, double eps_const, double eps_prop) {
     const HostPlan &P = S->plan;
     hipStream_t st = S->stream;
-    HK_CHECK(hipMemsetAsync(S->dp.scal, 0, sizeof(double), st));  // SC_MAXDIAG
-    HK_CHECK(hipMemsetAsync(S->dp.flags, 0, FL_COUNT * sizeof(int), st));
+    launch_zero_words(st, S->dp.scal, 2);                 // SC_MAXDIAG  (kernels.hip: why not hipMemsetAsync)
+    launch_zero_words(st, S->dp.flags, FL_COUNT);
     launch_maxabs_gather(st, S->dp.kval, S->d_diag_full, S->N, (unsigned long long *)S->dp.scal + SC_MAXDIAG);
     HK_CHECK(hipMemsetAsync(S->dp.Lx, 0, (size_t)P.panel_doubles * sizeof(double), st));
     launch_init_panels(st, S->dp, S->nnzK, static_enable, eps_const, eps_prop);
@@ -654,7 +654,7 @@ void read_scalars(hipkkt_solver *S) {
 // e = b - K*xi, returns ||e||_inf (ref: _get_refine_error!, kktsolver_directldl.jl:455-466)
 double refine_error(hipkkt_solver *S, const double *xi, bool also_normb, double *normb) {
     hipStream_t st = S->stream;
-    HK_CHECK(hipMemsetAsync((char *)S->dp.scal + SC_NORMB * sizeof(double), 0, 2 * sizeof(double), st));
+    launch_zero_words(st, (char *)S->dp.scal + SC_NORMB * sizeof(double), 4);
     if (also_normb) launch_norm_inf(st, S->d_b, S->N, (unsigned long long *)S->dp.scal + SC_NORMB);
     launch_spmv_residual(st, S->dp, S->d_b, xi, S->d_e, S->N, (unsigned long long *)S->dp.scal + SC_NORME);
     read_scalars(S);
@@ -663,7 +663,20 @@ double refine_error(hipkkt_solver *S, const double *xi, bool also_normb, double 
 }
 
 // bit 0: a front sweep / forward segment sweep gave up, bit 2: the backward segment sweep gave up
-static inline bool sweep_failed(const hipkkt_solver *S) { return (S->h_flags[FL_FRONTFAIL] & 7) != 0; }
+static inline bool sweep_failed(const hipkkt_solver *S) {
+    if (S->h_flags[FL_FRONTFAIL] & ~7) {   // never written by this library (seen once: a small memset node of a
+                                            // captured graph wrote garbage under rocprofv3): report it, do not act on it
+        static bool told = false;
+        if (!told) {
+            int again[FL_COUNT] = {0, 0, 0, 0};
+            (void)hipMemcpy(again, S->dp.flags, sizeof(again), hipMemcpyDeviceToHost);
+            fprintf(stderr, "hipkkt: unexpected value in the flag words: pinned copy %x %x %x %x, fresh copy of the device words %x %x %x %x\n",
+                    S->h_flags[0], S->h_flags[1], S->h_flags[2], S->h_flags[3], again[0], again[1], again[2], again[3]);
+        }
+        told = true;
+    }
+    return (S->h_flags[FL_FRONTFAIL] & 7) != 0;
+}
 
 // A persistent sweep kernel gave up (bounded spin expired: the workgroups were not dispatched in the order the
 // fast path relies on, or a front hand-off stalled).  Re-arm every hand-off word, drop to the per-level kernels
@@ -724,7 +737,7 @@ int32_t solve_core_once(hipkkt_solver *S, int ir_enable, double reltol, double a
             std::swap(x, dx);
         }
     } else {
-        HK_CHECK(hipMemsetAsync(S->dp.flags, 0, sizeof(int), S->stream));
+        launch_zero_words(S->stream, S->dp.flags, 1);
         launch_check_finite(S->stream, x, S->N, S->dp.flags);
         HK_CHECK(hipMemcpyAsync(S->h_flags, S->dp.flags, FL_COUNT * sizeof(int), hipMemcpyDeviceToHost, S->stream));
         HK_CHECK(hipStreamSynchronize(S->stream));
@@ -1194,12 +1207,12 @@ static int32_t refactor_once(hipkkt_handle h, int32_t static_reg_enable, double 
         // eager, with the dense-update launches timed separately (adds event overhead)
         const HostPlan &P = S->plan;
         hipStream_t st = S->stream;
-        HK_CHECK(hipMemsetAsync(S->dp.scal, 0, sizeof(double), st));
-        HK_CHECK(hipMemsetAsync(S->dp.flags, 0, FL_COUNT * sizeof(int), st));
+        launch_zero_words(st, S->dp.scal, 2);
+        launch_zero_words(st, S->dp.flags, FL_COUNT);
         launch_maxabs_gather(st, S->dp.kval, S->d_diag_full, S->N, (unsigned long long *)S->dp.scal + SC_MAXDIAG);
         HK_CHECK(hipMemsetAsync(S->dp.Lx, 0, (size_t)P.panel_doubles * sizeof(double), st));
         launch_init_panels(st, S->dp, S->nnzK, static_reg_enable, eps_const, eps_prop);
-        std::vector<hipEvent_t> evs, evd;   // evs: all update kernels of a stage; evd: its k_update_dense<4> launch alone
+        std::vector<hipEvent_t> evs, evd;   // evs: all update kernels of a stage; evd: its k_update_dense<4,4> launch alone
         std::vector<int> evd_level;
         for (int l = 0; l < P.nlevels; l++) {
             enqueue_factor_level(S, l);

@@ -262,7 +262,7 @@ __device__ __forceinline__ void dense_tile_core(const DevPlan &P, double *tp, in
 
 // FUSED (experiment, off by default: symbolic.h PlanOptions::fuse_jit): the panel's pending just-in-time updates
 // (FacJit) are applied here first, on the matrix cores: waves 0-3 take the diagonal tile, waves 4-7 the workgroup's
-// row chunk, one 16-column strip each (the code of k_update_dense<1>), and hand the updated rows over through the
+// row chunk, one 16-column strip each (the code of k_update_dense<1,4>), and hand the updated rows over through the
 // staging buffer instead of through the panel.
 template <bool FUSED>
 __global__ void __launch_bounds__(512)
@@ -1939,6 +1939,17 @@ void launch_fwd_narrow(hipStream_t st, const DevPlan &P, int sn_begin, int n, do
 }
 void launch_bwd_narrow(hipStream_t st, const DevPlan &P, int sn_begin, int n, const double *z, double *x, double *xout) {
     if (n > 0) hipLaunchKernelGGL(k_bwd_narrow, dim3(nblk(n)), dim3(256), 0, st, P, sn_begin, n, z, x, xout);
+}
+// zero a few 32-bit words.  Small hipMemsetAsync nodes inside a captured hipGraph are not reliable in every ROCm
+// set-up (under rocprofv3 the 16-byte memset of the flag words was seen to write its own arguments instead of
+// zeros; under PyTorch's bundled runtime a 56-byte one was seen to do nothing), so the factor / solve graphs
+// clear their flag and scalar words with this kernel.
+__global__ void k_zero_words(int *p, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0;
+}
+void launch_zero_words(hipStream_t st, void *p, int nwords) {
+    if (nwords > 0) hipLaunchKernelGGL(k_zero_words, dim3(nblk(nwords, 64)), dim3(64), 0, st, (int *)p, nwords);
 }
 void launch_update_gather(hipStream_t st, const DevPlan &P, int64_t ebegin, int64_t n) {
     if (n > 0) hipLaunchKernelGGL(k_update_gather, dim3(nblk(n)), dim3(256), 0, st, P, ebegin, n);

@@ -489,7 +489,7 @@ std::string build_plan(int N, const int64_t *Ap, const int64_t *Ai, const int64_
             auto b = P.upd_groups.begin() + P.upd_stage_ptr[l], e = P.upd_groups.begin() + P.upd_stage_ptr[l + 1];
             auto mid = std::stable_partition(b, e, [](const UpdGroup &g) { return g.dense == 1; });
             if (opt.xcd_order && mid - b >= 256) {
-                // XCD-aware order (performance only): workgroup k of k_update_dense<4> takes 4 consecutive tiles and is
+                // XCD-aware order (performance only): workgroup k of k_update_dense<4,4> takes 4 consecutive tiles and is
                 // observed to run on XCD k % 8.  Tiles are bucketed by (global row block) % 8 and the buckets are
                 // interleaved 4 tiles at a time, so one XCD's L2 keeps re-using 1/8 of the source panels' rows (its A
                 // operands) while the 64-row column operands stream through.

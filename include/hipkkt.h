@@ -179,7 +179,7 @@ int32_t hipkkt_ldl_solve(hipkkt_handle h, double *x, const double *b);
 int32_t hipkkt_get_timing(hipkkt_handle h, double *out8);
 int32_t hipkkt_reset_timing(hipkkt_handle h);
 /* last refactorisation run with profiling enabled: out[0] = ms of all Schur-update kernels, out[1] = ms of the
- * k_update_dense<4> launches alone (one wavefront per 64x64 tile), out[2] = their algorithmic flops, out[3] = their
+ * k_update_dense<4,4> launches alone (one wavefront per 64x64 tile), out[2] = their algorithmic flops, out[3] = their
  * number; out[4..7] reserved */
 int32_t hipkkt_get_profile(hipkkt_handle h, double *out8);
 /* 1 = time the update (MFMA) kernels separately inside refactor (adds event overhead) */
