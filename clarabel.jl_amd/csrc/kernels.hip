@@ -905,7 +905,8 @@ __global__ void k_mfma_probe(const double *__restrict__ A, const double *__restr
 __global__ void __launch_bounds__(256)
 k_permute_in(const double *__restrict__ b, const int *__restrict__ perm, double *__restrict__ y, int n, int *epoch) {
     // first kernel of every LDL solve: a new epoch invalidates the tagged hand-off values of the previous solve
-    if (blockIdx.x == 0 && threadIdx.x == 0 && epoch) epoch[0] = epoch[0] + 1;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && epoch) ((unsigned *)epoch)[0] += 1u;   // wraps after 2^32 solves: any
+                                                                                        // two consecutive epochs differ
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k < n) y[k] = b[perm[k]];
 }
@@ -1514,7 +1515,7 @@ __device__ __forceinline__ bool seg_wait(int *ctr, int want, int *err, int *fail
 // epoch so that the previous solve's slots are invalid without any re-arming.  The consumer polls the very values
 // it needs -- no dependency counter, no "stores complete" wait before an atomic, no second round trip.
 __device__ __forceinline__ unsigned long long seg_key(const DevPlan &P) {
-    return kSlotKey ^ ((unsigned long long)(unsigned)(P.seg_epoch[0] + 1) * 0x9E3779B97F4A7C15ull);
+    return kSlotKey ^ ((unsigned long long)(((const unsigned *)P.seg_epoch)[0] + 1u) * 0x9E3779B97F4A7C15ull);
 }
 __device__ __forceinline__ void seg_slot_st(FrontSlot *p, double v, unsigned long long key) {
     typedef unsigned v4u __attribute__((ext_vector_type(4)));
