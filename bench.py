@@ -143,7 +143,11 @@ def main():
     class Recorder(HipKKTSolver):
         def kktsolver_update(self, cones_):
             ok = super().kktsolver_update(cones_)
-            trace.append(dict(hs=self.Hsblocks.copy(), u=self._u.copy(), v=self._v.copy(), eta2=self._eta2.copy(), rhs=[]))
+            hs = self.Hsblocks.copy()
+            for c, off in self._psd:      # PSD blocks are formed on the device during the solve; the replay needs them as data
+                nent = c.numel * (c.numel + 1) // 2
+                c.get_Hs(hs[off:off + nent])
+            trace.append(dict(hs=hs, u=self._u.copy(), v=self._v.copy(), eta2=self._eta2.copy(), rhs=[]))
             return ok
 
         def kktsolver_setrhs(self, rhsx, rhsz):

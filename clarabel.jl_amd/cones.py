@@ -403,6 +403,8 @@ class PSDTriangleCone:
         self.R = np.zeros((n, n))
         self.Rinv = np.zeros((n, n))
         self.Hs = np.zeros((self.numel, self.numel))
+        self.RRt = np.eye(n)          # W = R R^T of the current scaling (what skron! is applied to)
+        self._hs_valid = False        # Hs is formed lazily: the HIP path builds the block on the device from RRt
         # packed index helpers: element k <-> (row[k], col[k]), row <= col, column-major packed
         # (= row-major packed lower triangle with the roles of row/col swapped)
         il = np.tril_indices(n)
@@ -442,7 +444,9 @@ class PSDTriangleCone:
     def set_identity_scaling(self):  # :66-75
         self.R[:] = np.eye(self.n)
         self.Rinv[:] = np.eye(self.n)
+        self.RRt[:] = np.eye(self.n)
         self.Hs[:] = np.eye(self.numel)
+        self._hs_valid = True
 
     def update_scaling(self, s, z, mu):  # :78-143
         if s.size == 0:
@@ -459,8 +463,8 @@ class PSDTriangleCone:
         self.lisqrt[:] = 1.0 / np.sqrt(sv)
         self.R[:] = (L1 @ Vt.T) * self.lisqrt[None, :]
         self.Rinv[:] = self.lisqrt[:, None] * (U.T @ L2.T)
-        RRt = self.R @ self.R.T
-        self._skron(RRt)
+        self.RRt[:] = self.R @ self.R.T
+        self._hs_valid = False        # skron! (:153-161) is deferred until somebody asks for the block
         return True
 
     def _skron(self, A):
@@ -471,6 +475,9 @@ class PSDTriangleCone:
         self.Hs[:] = ff * (A[i, k] * A[j, l] + A[i, l] * A[j, k])
 
     def get_Hs(self, block):  # :153-161 -> pack_triu (mathutils.jl:402-412)
+        if not self._hs_valid:
+            self._skron(self.RRt)
+            self._hs_valid = True
         block[:] = self.Hs[self._hs_r, self._hs_c]
 
     def _mul_Wx_inner(self, transpose, x, Rx):  # :404-432
@@ -618,9 +625,10 @@ class CompositeCone:
                 return False
         return True
 
-    def get_Hs(self, hsblocks):  # :122-131
+    def get_Hs(self, hsblocks, skip=()):  # :122-131; `skip`: cones whose block the caller forms elsewhere
         for c, r in zip(self.cones, self.rng_blocks):
-            c.get_Hs(hsblocks[r])
+            if c not in skip:
+                c.get_Hs(hsblocks[r])
 
     def mul_Hs(self, y, x, work):
         for c, r in zip(self.cones, self.rng_cones):

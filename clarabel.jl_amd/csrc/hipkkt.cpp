@@ -1071,6 +1071,28 @@ int32_t hipkkt_set_hs(hipkkt_handle h, const double *hs, int64_t nHs) {
     HK_LEAVE
 }
 
+int32_t hipkkt_set_hs_psd(hipkkt_handle h, int64_t npsd, const int64_t *hs_off, const int64_t *dim, const double *w_all) {
+    HK_ENTER(h)
+    if (!S->l1 || npsd < 0 || (npsd && (!hs_off || !dim || !w_all))) { S->err = "set_hs_psd: bad arguments / not an L1 handle"; return HIPKKT_ERR_ARGUMENT; }
+    int64_t total = 0;
+    for (int64_t c = 0; c < npsd; c++) {
+        const int64_t n = dim[c], numel = n * (n + 1) / 2, nent = numel * (numel + 1) / 2;
+        if (n < 1 || n > 30000 || hs_off[c] < 0 || hs_off[c] + nent > S->img.nHs) { S->err = "set_hs_psd: block outside the Hs vector"; return HIPKKT_ERR_ARGUMENT; }
+        total += n * n;
+    }
+    if (npsd == 0) return HIPKKT_OK;
+    S->ensure_stage(total);
+    HK_CHECK(hipMemcpyAsync(S->d_stage, w_all, (size_t)total * sizeof(double), hipMemcpyHostToDevice, S->stream));
+    int64_t woff = 0;
+    for (int64_t c = 0; c < npsd; c++) {
+        launch_psd_hs(S->stream, S->dp.kval, S->d_mapHs, hs_off[c], S->d_stage + woff, (int)dim[c]);
+        woff += dim[c] * dim[c];
+    }
+    HK_CHECK(hipStreamSynchronize(S->stream));
+    return HIPKKT_OK;
+    HK_LEAVE
+}
+
 int32_t hipkkt_set_soc_batch(hipkkt_handle h, int64_t nsoc, const double *eta2, const double *u_all, const double *v_all,
                              int64_t total) {
     HK_ENTER(h)

@@ -1949,6 +1949,39 @@ __global__ void k_zero_words(int *p, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = 0;
 }
+// Hs block of one PSD triangle cone on the device: entry e of the packed (column-major) upper triangle of
+// W (x)_s W, e <-> (a <= b), a <-> (i <= j), b <-> (k <= l) in the svec ordering:
+//   Hs[a,b] = ((1/2 f_a) f_b) (W_ik W_jl + W_il W_jk),  f = 1 on the diagonal of the matrix, sqrt(2) off it
+// (coneops_psdtrianglecone.jl:502-540).  Explicitly rounded products and sums (no FMA contraction): bit-identical to
+// the host loop.  The value is negated and scattered through map.Hsblocks (kktsolver_directldl.jl:225-228).
+__device__ __forceinline__ long long tri_root(long long e) {   // largest t with t(t+1)/2 <= e
+    long long t = (long long)((sqrt(8.0 * (double)e + 1.0) - 1.0) * 0.5);
+    while (t * (t + 1) / 2 > e) t--;
+    while ((t + 1) * (t + 2) / 2 <= e) t++;
+    return t;
+}
+__global__ void __launch_bounds__(256)
+k_psd_hs(double *__restrict__ kval, const int64_t *__restrict__ map_hs, int64_t hs_off, const double *__restrict__ W, int n,
+         int64_t nent) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nent) return;
+    const long long b = tri_root(e), a = e - b * (b + 1) / 2;
+    const long long j = tri_root(a), i = a - j * (j + 1) / 2;
+    const long long l = tri_root(b), k = b - l * (l + 1) / 2;
+    const double sqrt2 = sqrt(2.0);
+    const double fa = i == j ? 1.0 : sqrt2, fb = k == l ? 1.0 : sqrt2;
+    const double ff = (0.5 * fa) * fb;
+    // products and the sum are rounded one by one like the host loop: HIP's __dmul_rn is a plain `*` that the compiler
+    // contracts into an FMA, so the products pass through an opaque asm before they are added
+    double p1 = W[i * n + k] * W[j * n + l];
+    double p2 = W[i * n + l] * W[j * n + k];
+    asm volatile("" : "+v"(p1), "+v"(p2));
+    kval[map_hs[hs_off + e]] = -(ff * (p1 + p2));
+}
+void launch_psd_hs(hipStream_t st, double *kval, const int64_t *map_hs, int64_t hs_off, const double *W, int n) {
+    const int64_t numel = (int64_t)n * (n + 1) / 2, nent = numel * (numel + 1) / 2;
+    if (nent > 0) hipLaunchKernelGGL(k_psd_hs, dim3(nblk(nent)), dim3(256), 0, st, kval, map_hs, hs_off, W, n, nent);
+}
 void launch_zero_words(hipStream_t st, void *p, int nwords) {
     if (nwords > 0) hipLaunchKernelGGL(k_zero_words, dim3(nblk(nwords, 64)), dim3(64), 0, st, (int *)p, nwords);
 }

@@ -21,7 +21,7 @@ SYMBOLS = [
     "hipkkt_default_opts", "hipkkt_is_available", "hipkkt_create", "hipkkt_create_from_parts", "hipkkt_destroy",
     "hipkkt_get_dims", "hipkkt_info", "hipkkt_get_cost_model", "hipkkt_get_kkt", "hipkkt_get_perm",
     "hipkkt_get_dsigns", "hipkkt_get_map", "hipkkt_get_sparse_map", "hipkkt_update_values", "hipkkt_scale_values",
-    "hipkkt_set_hs", "hipkkt_set_hs_dev", "hipkkt_set_soc", "hipkkt_set_soc_batch", "hipkkt_set_genpow",
+    "hipkkt_set_hs", "hipkkt_set_hs_dev", "hipkkt_set_hs_psd", "hipkkt_set_soc", "hipkkt_set_soc_batch", "hipkkt_set_genpow",
     "hipkkt_update_P", "hipkkt_update_A", "hipkkt_refactor", "hipkkt_setrhs", "hipkkt_setrhs_dev", "hipkkt_solve",
     "hipkkt_solve_dev", "hipkkt_ldl_solve", "hipkkt_get_timing", "hipkkt_reset_timing", "hipkkt_get_profile", "hipkkt_set_profiling",
     "hipkkt_selftest_mfma", "hipkkt_last_error",
@@ -74,6 +74,7 @@ def lib():
     L.hipkkt_scale_values.argtypes = [vp, _i64p, i64, f64]
     L.hipkkt_set_hs.argtypes = [vp, _f64p, i64]
     L.hipkkt_set_hs_dev.argtypes = [vp, vp, i64]
+    L.hipkkt_set_hs_psd.argtypes = [vp, i64, _i64p, _i64p, _f64p]
     L.hipkkt_set_soc.argtypes = [vp, i64, f64, _f64p, _f64p, i64]
     L.hipkkt_set_soc_batch.argtypes = [vp, i64, _f64p, _f64p, _f64p, i64]
     L.hipkkt_set_genpow.argtypes = [vp, i64, f64, _f64p, _f64p, _f64p]
@@ -229,6 +230,12 @@ class Handle:
 
     def set_hs(self, hs):
         self._chk(self.L.hipkkt_set_hs(self.h, np.ascontiguousarray(hs, dtype=np.float64), len(hs)), "set_hs")
+
+    def set_hs_psd(self, hs_off, dims, w_all):
+        """Hs blocks of PSD cones formed on the device from W = R R^T (include/hipkkt.h hipkkt_set_hs_psd)."""
+        hs_off = np.ascontiguousarray(hs_off, dtype=np.int64)
+        dims = np.ascontiguousarray(dims, dtype=np.int64)
+        self._chk(self.L.hipkkt_set_hs_psd(self.h, len(dims), hs_off, dims, np.ascontiguousarray(w_all, dtype=np.float64)), "set_hs_psd")
 
     def set_soc(self, i, eta2, u, v):
         self._chk(self.L.hipkkt_set_soc(self.h, i, eta2, np.ascontiguousarray(u), np.ascontiguousarray(v), len(u)), "set_soc")

@@ -36,6 +36,12 @@ class HipKKTSolver:
         self._u = np.zeros(self._soc_total)
         self._v = np.zeros(self._soc_total)
         self._eta2 = np.zeros(len(self._soc))
+        # PSD cones: the Hs block (packed triu of W (x)_s W, numel^2/2 values) is formed on the device from the
+        # n x n matrix W = R R^T (hipkkt_set_hs_psd): no host skron!, no upload of the block
+        self._psd = [(c, r.start) for c, r in zip(cones.cones, cones.rng_blocks) if hasattr(c, "RRt")]
+        self._psd_off = np.array([off for _, off in self._psd], dtype=np.int64)
+        self._psd_dim = np.array([c.n for c, _ in self._psd], dtype=np.int64)
+        self._psd_cones = tuple(c for c, _ in self._psd)
         self.diagonal_regularizer = 0.0
         self.last_ir_steps = 0
         self.total_ir_steps = 0
@@ -44,8 +50,14 @@ class HipKKTSolver:
 
     # ref: kktsolver_update!, kktsolver_directldl.jl:197-245
     def kktsolver_update(self, cones) -> bool:
-        cones.get_Hs(self.Hsblocks)                    # :223 (cone algebra stays on the host)
+        # PSD cones whose block is not formed yet (i.e. after update_scaling!; the identity scaling sets Hs = I exactly,
+        # :66-75, and goes the host way) get it from the device-side skron
+        dev = [k for k, c in enumerate(self._psd_cones) if not c._hs_valid]
+        cones.get_Hs(self.Hsblocks, skip=tuple(self._psd_cones[k] for k in dev))   # :223 (host cone algebra)
         self.h.set_hs(self.Hsblocks)                   # :225-228 negate + scatter, on the device
+        if dev:
+            self.h.set_hs_psd(self._psd_off[dev], self._psd_dim[dev],
+                              np.concatenate([self._psd_cones[k].RRt.ravel() for k in dev]))
         if self._soc:                                  # :235-241 sparse-cone expansion columns
             off = 0
             for i, c in enumerate(self._soc):

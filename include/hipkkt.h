@@ -131,6 +131,16 @@ int32_t hipkkt_scale_values(hipkkt_handle h, const int64_t *index, int64_t k, do
  * get_Hs!(cones,Hsblocks); negated and scattered through map.Hsblocks on the device. */
 int32_t hipkkt_set_hs(hipkkt_handle h, const double *hs, int64_t nHs);
 int32_t hipkkt_set_hs_dev(hipkkt_handle h, const double *hs_dev, int64_t nHs);
+
+/* SURVEY section 8(f) row N1 (first step): the Hs block of PSD triangle cones formed ON THE DEVICE.
+ * ref: get_Hs!(::PSDTriangleCone) = pack_triu(skron(R R^T)), coneops_psdtrianglecone.jl:153-161, 502-540.
+ * For cone c (c = 0..npsd-1): dim[c] = matrix side n, w_all holds its dense symmetric W = R R^T (n x n, row-major,
+ * cones concatenated), hs_off[c] = 0-based offset of the cone's block inside the Hs vector (as used by
+ * hipkkt_set_hs).  The packed upper triangle of  W (x)_s W  (numel(numel+1)/2 values, numel = n(n+1)/2) is computed,
+ * negated and scattered through map.Hsblocks like hipkkt_set_hs does -- with the same products, sums and rounding
+ * as the reference's skron! loop, so K is bit-identical to the host path.  Saves the O(numel^2) host loop and the
+ * upload of the block (813 450 doubles per 50 x 50 cone). */
+int32_t hipkkt_set_hs_psd(hipkkt_handle h, int64_t npsd, const int64_t *hs_off, const int64_t *dim, const double *w_all);
 /* ref: _csc_update_sparsecone(::SecondOrderCone,...), directldl_datamaps.jl:61-79 */
 int32_t hipkkt_set_soc(hipkkt_handle h, int64_t sparse_idx, double eta2, const double *u, const double *v,
                        int64_t dim);
