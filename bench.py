@@ -142,12 +142,11 @@ def main():
 
     class Recorder(HipKKTSolver):
         def kktsolver_update(self, cones_):
+            # PSD blocks are formed on the device during the solve (hipkkt_set_hs_psd); the replay wants the whole Hs
+            # vector as data, so W = R R^T is kept here and expanded on the host AFTER the timed end-to-end solve
+            psd_w = [(None if c._hs_valid else c.RRt.copy()) for c in self._psd_cones]
             ok = super().kktsolver_update(cones_)
-            hs = self.Hsblocks.copy()
-            for c, off in self._psd:      # PSD blocks are formed on the device during the solve; the replay needs them as data
-                nent = c.numel * (c.numel + 1) // 2
-                c.get_Hs(hs[off:off + nent])
-            trace.append(dict(hs=hs, u=self._u.copy(), v=self._v.copy(), eta2=self._eta2.copy(), rhs=[]))
+            trace.append(dict(hs=self.Hsblocks.copy(), psd_w=psd_w, u=self._u.copy(), v=self._v.copy(), eta2=self._eta2.copy(), rhs=[]))
             return ok
 
         def kktsolver_setrhs(self, rhsx, rhsz):
@@ -176,6 +175,12 @@ def main():
     units = [t for t in trace if len(t["rhs"]) == 3]
     if not units:
         raise SystemExit("no complete KKT iteration units recorded")
+    for t in units:                       # expand the PSD blocks of the recorded units (host skron, outside any timing)
+        for (c, off), w in zip(ks._psd, t["psd_w"]):
+            if w is not None:
+                c._skron(w)
+                c._hs_valid = True
+                c.get_Hs(t["hs"][off:off + c.numel * (c.numel + 1) // 2])
 
     # ---- 2. stage the trace in HBM
     dev = torch.device("cuda", local)
