@@ -1,0 +1,58 @@
+"""CPU check of the index arithmetic of k_psd_hs (clarabel.jl_amd/csrc/kernels.hip): entry e of the packed upper
+triangle of W (x)_s W  <->  (a <= b)  <->  ((i <= j), (k <= l)), evaluated with the kernel's formula and order of
+operations, must reproduce the host path (cones.PSDTriangleCone._skron + get_Hs = the reference's skron! + pack_triu,
+coneops_psdtrianglecone.jl:153-161, 502-540) bit for bit.  The GPU side of the same statement is
+tests/test_gpu_kkt.py::test_assembly_bit_exact_and_factor_solve_parity[sdp_*]."""
+import math
+
+import numpy as np
+import pytest
+
+from clarabel_jl_amd.cones import PSDTriangleCone
+
+
+def _tri_root(e):
+    t = int((math.sqrt(8.0 * e + 1.0) - 1.0) * 0.5)
+    while t * (t + 1) // 2 > e:
+        t -= 1
+    while (t + 1) * (t + 2) // 2 <= e:
+        t += 1
+    return t
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 8])
+def test_kernel_formula_matches_host_skron(n):
+    rng = np.random.default_rng(n)
+    c = PSDTriangleCone(n)
+    for _ in range(2):
+        M = rng.standard_normal((n, n))
+        S = M @ M.T + n * np.eye(n)
+        M = rng.standard_normal((n, n))
+        Z = M @ M.T + n * np.eye(n)
+        assert c.update_scaling(c.mat_to_svec(S), c.mat_to_svec(Z), 1.0)
+        nent = c.numel * (c.numel + 1) // 2
+        host = np.zeros(nent)
+        c.get_Hs(host)
+        W = c.RRt
+        s2 = math.sqrt(2.0)
+        dev = np.zeros(nent)
+        for e in range(nent):
+            b = _tri_root(e)
+            a = e - b * (b + 1) // 2
+            j = _tri_root(a)
+            i = a - j * (j + 1) // 2
+            l = _tri_root(b)
+            k = b - l * (l + 1) // 2
+            ff = (0.5 * (1.0 if i == j else s2)) * (1.0 if k == l else s2)
+            dev[e] = ff * (W[i, k] * W[j, l] + W[i, l] * W[j, k])
+        assert np.array_equal(dev, host)
+
+
+def test_identity_scaling_block_is_exact_identity():
+    c = PSDTriangleCone(4)
+    c.set_identity_scaling()
+    blk = np.zeros(c.numel * (c.numel + 1) // 2)
+    c.get_Hs(blk)
+    full = np.zeros((c.numel, c.numel))
+    full[c._hs_r, c._hs_c] = blk
+    assert np.array_equal(full, np.eye(c.numel))
