@@ -1071,6 +1071,23 @@ int32_t hipkkt_set_hs(hipkkt_handle h, const double *hs, int64_t nHs) {
     HK_LEAVE
 }
 
+int32_t hipkkt_block_products(hipkkt_handle h, const double *x, const double *z, double *Px, double *ATz, double *Ax) {
+    HK_ENTER(h)
+    const int64_t n = S->img.n, m = S->img.m;
+    if (!S->l1 || (n && !x) || (m && !z)) { S->err = "block_products: bad arguments / not an L1 handle"; return HIPKKT_ERR_ARGUMENT; }
+    S->ensure_stage(3 * n + 2 * m);     // x | z | Px | ATz | Ax
+    double *dx = S->d_stage, *dz = dx + n, *dPx = dz + m, *dATz = dPx + n, *dAx = dATz + n;
+    if (n) HK_CHECK(hipMemcpyAsync(dx, x, n * sizeof(double), hipMemcpyHostToDevice, S->stream));
+    if (m) HK_CHECK(hipMemcpyAsync(dz, z, m * sizeof(double), hipMemcpyHostToDevice, S->stream));
+    launch_block_products(S->stream, S->dp, dx, dz, dPx, dATz, dAx, (int)n, (int)m);
+    if (Px && n) HK_CHECK(hipMemcpyAsync(Px, dPx, n * sizeof(double), hipMemcpyDeviceToHost, S->stream));
+    if (ATz && n) HK_CHECK(hipMemcpyAsync(ATz, dATz, n * sizeof(double), hipMemcpyDeviceToHost, S->stream));
+    if (Ax && m) HK_CHECK(hipMemcpyAsync(Ax, dAx, m * sizeof(double), hipMemcpyDeviceToHost, S->stream));
+    HK_CHECK(hipStreamSynchronize(S->stream));
+    return HIPKKT_OK;
+    HK_LEAVE
+}
+
 int32_t hipkkt_set_hs_psd(hipkkt_handle h, int64_t npsd, const int64_t *hs_off, const int64_t *dim, const double *w_all) {
     HK_ENTER(h)
     if (!S->l1 || npsd < 0 || (npsd && (!hs_off || !dim || !w_all))) { S->err = "set_hs_psd: bad arguments / not an L1 handle"; return HIPKKT_ERR_ARGUMENT; }

@@ -19,6 +19,8 @@ void launch_update_dense(hipStream_t st, const DevPlan &P, int group_begin, int 
 void launch_fwd_narrow(hipStream_t st, const DevPlan &P, int sn_begin, int n, double *y, double *z);
 void launch_bwd_narrow(hipStream_t st, const DevPlan &P, int sn_begin, int n, const double *z, double *x, double *xout);
 void launch_psd_hs(hipStream_t st, double *kval, const int64_t *map_hs, int64_t hs_off, const double *W, int n);
+void launch_block_products(hipStream_t st, const DevPlan &P, const double *x, const double *z, double *Px, double *ATz,
+                           double *Ax, int n, int m);
 void launch_zero_words(hipStream_t st, void *p, int nwords);
 void launch_update_gather(hipStream_t st, const DevPlan &P, int64_t ebegin, int64_t n);
 void launch_invert_diag(hipStream_t st, const DevPlan &P, int n_small, int wmax_small, int n_wide);

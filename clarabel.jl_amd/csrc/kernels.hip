@@ -1849,6 +1849,36 @@ k_spmv_residual(const int64_t *__restrict__ rowptr, const int *__restrict__ col,
     block_atomic_max_abs(norm_slot, a);
 }
 
+// the three sparse products of residuals_update! (residuals.jl:12-25) from the RESIDENT KKT
+// values -- K = [P A'; A -Hs] in the original ordering, symmetric CSR view, 4 lanes per row:
+//   rows i < n:        Px_i  = sum_{c < n} K_ic x_c ,   ATz_i = sum_{n <= c < n+m} K_ic z_{c-n}
+//   rows n <= i < n+m: Ax_{i-n} = sum_{c < n} K_ic x_c          (the -Hs block and the expansion columns are skipped)
+__global__ void __launch_bounds__(256)
+k_block_products(const int64_t *__restrict__ rowptr, const int *__restrict__ col, const int64_t *__restrict__ qidx,
+                 const double *__restrict__ kval, const double *__restrict__ x, const double *__restrict__ z,
+                 double *__restrict__ Px, double *__restrict__ ATz, double *__restrict__ Ax, int n, int m) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int row = gid >> 2, sub = gid & 3;
+    double ax = 0.0, az = 0.0;
+    if (row < n + m) {
+        const int64_t p0 = rowptr[row], p1 = rowptr[row + 1];
+        for (int64_t p = p0 + sub; p < p1; p += 4) {
+            const int c = col[p];
+            const double v = kval[qidx[p]];
+            if (c < n) ax += v * x[c];
+            else if (row < n && c < n + m) az += v * z[c - n];
+        }
+    }
+    ax += __shfl_xor(ax, 1, 64);
+    ax += __shfl_xor(ax, 2, 64);
+    az += __shfl_xor(az, 1, 64);
+    az += __shfl_xor(az, 2, 64);
+    if (sub == 0 && row < n + m) {
+        if (row < n) { Px[row] = ax; ATz[row] = az; }
+        else Ax[row - n] = ax;
+    }
+}
+
 __global__ void __launch_bounds__(256)
 k_norm_inf(const double *__restrict__ v, int n, unsigned long long *__restrict__ slot) {
     double a = 0.0;
@@ -2028,6 +2058,12 @@ void launch_spmv_residual(hipStream_t st, const DevPlan &P, const double *b, con
     if (n > 0)
         hipLaunchKernelGGL(k_spmv_residual, dim3(nblk((int64_t)n * 4)), dim3(256), 0, st, P.sym_rowptr, P.sym_col, P.sym_q,
                            P.kval, b, xi, e, n, slot);
+}
+void launch_block_products(hipStream_t st, const DevPlan &P, const double *x, const double *z, double *Px, double *ATz,
+                           double *Ax, int n, int m) {
+    if (n + m > 0)
+        hipLaunchKernelGGL(k_block_products, dim3(nblk((int64_t)(n + m) * 4)), dim3(256), 0, st, P.sym_rowptr, P.sym_col, P.sym_q,
+                           P.kval, x, z, Px, ATz, Ax, n, m);
 }
 void launch_norm_inf(hipStream_t st, const double *v, int n, unsigned long long *slot) {
     if (n > 0) hipLaunchKernelGGL(k_norm_inf, dim3(min(nblk(n), 64u)), dim3(256), 0, st, v, n, slot);

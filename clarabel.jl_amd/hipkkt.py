@@ -21,7 +21,7 @@ SYMBOLS = [
     "hipkkt_default_opts", "hipkkt_is_available", "hipkkt_create", "hipkkt_create_from_parts", "hipkkt_destroy",
     "hipkkt_get_dims", "hipkkt_info", "hipkkt_get_cost_model", "hipkkt_get_kkt", "hipkkt_get_perm",
     "hipkkt_get_dsigns", "hipkkt_get_map", "hipkkt_get_sparse_map", "hipkkt_update_values", "hipkkt_scale_values",
-    "hipkkt_set_hs", "hipkkt_set_hs_dev", "hipkkt_set_hs_psd", "hipkkt_set_soc", "hipkkt_set_soc_batch", "hipkkt_set_genpow",
+    "hipkkt_set_hs", "hipkkt_set_hs_dev", "hipkkt_set_hs_psd", "hipkkt_block_products", "hipkkt_set_soc", "hipkkt_set_soc_batch", "hipkkt_set_genpow",
     "hipkkt_update_P", "hipkkt_update_A", "hipkkt_refactor", "hipkkt_setrhs", "hipkkt_setrhs_dev", "hipkkt_solve",
     "hipkkt_solve_dev", "hipkkt_ldl_solve", "hipkkt_get_timing", "hipkkt_reset_timing", "hipkkt_get_profile", "hipkkt_set_profiling",
     "hipkkt_selftest_mfma", "hipkkt_last_error",
@@ -75,6 +75,7 @@ def lib():
     L.hipkkt_set_hs.argtypes = [vp, _f64p, i64]
     L.hipkkt_set_hs_dev.argtypes = [vp, vp, i64]
     L.hipkkt_set_hs_psd.argtypes = [vp, i64, _i64p, _i64p, _f64p]
+    L.hipkkt_block_products.argtypes = [vp, _f64p, _f64p, _f64p, _f64p, _f64p]
     L.hipkkt_set_soc.argtypes = [vp, i64, f64, _f64p, _f64p, i64]
     L.hipkkt_set_soc_batch.argtypes = [vp, i64, _f64p, _f64p, _f64p, i64]
     L.hipkkt_set_genpow.argtypes = [vp, i64, f64, _f64p, _f64p, _f64p]
@@ -288,6 +289,13 @@ class Handle:
 
     def reset_timing(self):
         self.L.hipkkt_reset_timing(self.h)
+
+    def block_products(self, x, z):
+        """Px = Symmetric(P) x, ATz = A' z, Ax = A x from the resident values (include/hipkkt.h hipkkt_block_products)."""
+        Px, ATz, Ax = np.zeros(self.n), np.zeros(self.n), np.zeros(self.m)
+        self._chk(self.L.hipkkt_block_products(self.h, np.ascontiguousarray(x, dtype=np.float64),
+                                               np.ascontiguousarray(z, dtype=np.float64), Px, ATz, Ax), "block_products")
+        return Px, ATz, Ax
 
     def ldl_solve(self, b):
         x = np.zeros(self.N)

@@ -181,6 +181,11 @@ int32_t hipkkt_solve_dev(hipkkt_handle h, double *lhs_dev, int32_t ir_enable, do
  * no refinement (the Julia-side DirectLDLKKTSolver refines).  x and b must not alias. */
 int32_t hipkkt_ldl_solve(hipkkt_handle h, double *x, const double *b);
 
+/* SURVEY section 8(f) row N4 (building block): the sparse products of residuals_update!, residuals.jl:12-25, from the
+ * P and A values resident on the device (L1 handles): Px = Symmetric(P) x, ATz = A' z, Ax = A x.
+ * x[n], z[m] in; Px[n], ATz[n], Ax[m] out (host memory; any of the outputs may be NULL). */
+int32_t hipkkt_block_products(hipkkt_handle h, const double *x, const double *z, double *Px, double *ATz, double *Ax);
+
 /* ---- timing (device time on the handle's stream, HIP events) ------------------------------- */
 /* out[0] = ms of last refactor (value scatter + numeric LDL), out[1] = ms of last solve call
  * (all LDL solves + SpMVs of the refinement), out[2] = accumulated refactor ms, out[3] = accumulated

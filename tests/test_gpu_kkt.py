@@ -165,6 +165,27 @@ def test_developer_switches_keep_parity(env, oracle_factory, monkeypatch):
         assert np.max(np.abs(lx_g - lx_c)) <= 1e-10 * scale and np.max(np.abs(lz_g - lz_c)) <= 1e-10 * scale
 
 
+# SURVEY section 8(f) row N4 (building block): Px, A'z, Ax of residuals_update! from the resident values, also after
+# kktsolver_update_P! / update_A!
+@pytest.mark.parametrize("name", ["qp_fixture", "rand_uniform_300", "portfolio_small", "sdp_small"])
+def test_block_products_match_scipy(name):
+    rng = np.random.default_rng(3)
+    Pt, A, cones = _prep(PROBLEMS[name]())
+    m, n = A.shape
+    hk = HipKKTSolver(Pt, A, cones, m, n, cl.Settings())
+    for rep in range(2):
+        if rep == 1:   # new values on the same pattern
+            Pt = Pt.copy(); Pt.data = Pt.data * (1.0 + 0.1 * rng.random(Pt.nnz))
+            A = A.copy(); A.data = A.data * (1.0 + 0.1 * rng.random(A.nnz))
+            hk.kktsolver_update_P(Pt)
+            hk.kktsolver_update_A(A)
+        x, z = rng.standard_normal(n), rng.standard_normal(m)
+        Px, ATz, Ax = hk.h.block_products(x, z)
+        Pfull = Pt + sp.triu(Pt, 1).T
+        for got, ref in ((Px, Pfull @ x), (ATz, A.T @ z), (Ax, A @ x)):
+            assert np.max(np.abs(got - ref)) <= 1e-13 * max(1.0, np.max(np.abs(ref)))
+
+
 def test_l0_seam_matches_oracle(oracle_factory):
     """AbstractDirectLDLSolver seam: create from an assembled KKT, update_values / scale_values /
     refactor / solve (directldl_qdldl.jl call pattern)."""
