@@ -784,6 +784,8 @@ int32_t finish_create(hipkkt_solver *S, const hipkkt_opts *opts, hipkkt_handle *
     {
         const char *ns = getenv("HIPKKT_SIDE_STREAM");
         po.split_far = ns && ns[0] == '1';
+        const char *dc = getenv("HIPKKT_DENSE_COVER");   // A/B: threshold between the tile path and the gather lists
+        if (dc && atof(dc) > 0) po.dense_min_cover = atof(dc);
         const char *nf = getenv("HIPKKT_FUSE_JIT");    // experiment: just-in-time updates inside the panel kernel
         if (nf && nf[0] == '1') po.fuse_jit = true;
         const char *nx = getenv("HIPKKT_XCD_ORDER");   // measured: no effect on cfg 2a (L2 locality is not the limiter)

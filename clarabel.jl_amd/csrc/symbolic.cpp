@@ -461,7 +461,7 @@ std::string build_plan(int N, const int64_t *Ap, const int64_t *Ai, const int64_
             const double fill = covered / (ntasks * kUpdRows * kMaxSnWidth);
             // dense enough per contribution -> matrix-core path; otherwise the contributions are single
             // entries of tiny leaf supernodes -> per-entry gather
-            G.dense = ((all_contig && fill >= 0.4) || fill >= 0.3 || covered >= 64.0 * ntasks) ? 1 : 2;
+            G.dense = ((all_contig && fill >= 0.4) || fill >= 0.3 || covered >= opt.dense_min_cover * ntasks) ? 1 : 2;
             if (G.dense != 1) continue;
             P.flops_update_dense += flops;
             // contributions that do not land contiguously get explicit tile maps (tile row / column ->

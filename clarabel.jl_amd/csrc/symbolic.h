@@ -101,6 +101,8 @@ struct PlanOptions {
     int update_policy = 2;  // 0 right-looking, 1 left-looking, 2 batched right-looking
     int update_batch = 4;   // levels per batch for policy 2
     double amd_dense_scale = 1.5;
+    double dense_min_cover = 64.0;   // a target tile takes the matrix-core path when its sources cover at least this
+                                     // many entries each on average (else: per-entry gather lists)
     bool fuse_jit = false;     // apply the just-in-time updates of a front panel inside its panel kernel
                                // (measured slower on MI355X, DESIGN.md section 9: every workgroup repeats the diagonal tile)
     bool split_far = false;    // separate the far dense tiles of a stage (side-stream experiments)
