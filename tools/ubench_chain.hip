@@ -90,6 +90,9 @@ __global__ void k_chain_all(int *ticket, Slot *slots, long long *tstamp, int n) 
         if (lane == 0) tstamp[b] = wall_clock64();
     }
 }
+// NOTE on D: issue and wait are separate asm statements here, which is NOT safe in product code (the compiler may copy
+// an output register between them, i.e. before the data has landed: DESIGN.md section 9); a mis-read can only make a
+// poll round look invalid and repeat it, so the timing conclusion (more polls in flight are slower) stands.
 // D: as C, but the polling wave keeps FOUR polls in flight (a new one every s_sleep(GAP)) instead of one round trip
 //    at a time: the detection delay after the value becomes visible drops from up to a full round trip to ~GAP.
 typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
