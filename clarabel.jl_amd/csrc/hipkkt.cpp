@@ -845,7 +845,7 @@ void hipkkt_default_opts(hipkkt_opts *o) {
     o->supernode_max_width = kMaxSnWidth;
     o->relax_supernodes = 1;
     o->update_policy = 2;
-    o->update_batch = 4;
+    o->update_batch = 0;   // automatic
     o->front_min_panels = 0;
     o->dynamic_reg_eps = 1e-13;
     o->dynamic_reg_delta = 2e-7;

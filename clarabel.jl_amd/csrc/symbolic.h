@@ -99,7 +99,7 @@ struct PlanOptions {
     int max_width = kMaxSnWidth;
     bool relax = true;
     int update_policy = 2;  // 0 right-looking, 1 left-looking, 2 batched right-looking
-    int update_batch = 4;   // levels per batch for policy 2
+    int update_batch = 0;   // levels per batch for policy 2 (0 = automatic: 4, or 5 for fronts of >= 64 panels)
     double amd_dense_scale = 1.5;
     double dense_min_cover = 64.0;   // a target tile takes the matrix-core path when its sources cover at least this
                                      // many entries each on average (else: per-entry gather lists)
@@ -148,6 +148,7 @@ struct HostPlan {
     std::vector<int> upd_stage_nfar;    // [nlevels] the LAST nfar dense groups of a stage update targets more than
                                         // `update_batch` levels ahead: nothing needs them before the next batch end,
                                         // so they run on a side stream concurrently with the next panels' critical path
+    int update_batch_used = 4;          // the batch length the schedule was built with
     int lookahead = 0;                  // = update_batch when far groups were separated, else 0
     // per-entry gather lists (groups of kind 2): entries of one stage are contiguous
     std::vector<int64_t> gath_stage_ptr;   // [nlevels+1] into gath_tgt

@@ -52,7 +52,8 @@ typedef struct hipkkt_opts {
     int32_t supernode_max_width;   /* 0 = default (64) */
     int32_t relax_supernodes;      /* 1 = relaxed amalgamation (default), 0 = fundamental only */
     int32_t update_policy;         /* 0 = right-looking, 1 = left-looking, 2 = batched right-looking (default) */
-    int32_t update_batch;          /* policy 2: #levels whose updates are applied together (default 4) */
+    int32_t update_batch;          /* policy 2: #levels whose updates are applied together (0 = automatic: 4, or 5
+                                      when a front of >= 64 panels dominates the factorisation) */
     int32_t front_min_panels;      /* chains of >= this many panels of one wide supernode are solved by the
                                       persistent front kernels; 0 = default (4), < 0 = never */
     double dynamic_reg_eps;        /* ref: settings.jl:123, passed at directldl_qdldl.jl:21 */
