@@ -129,7 +129,8 @@ def main():
         dist = dist_
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
-    import clarabel_jl_amd as cl
+    import clarabel_jl_amd  # noqa: F401
+    import julia_standin as cl
     from clarabel_jl_amd.kktsolver import HipKKTSolver
 
     if args.config == "4":

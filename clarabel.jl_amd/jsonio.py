@@ -16,7 +16,7 @@ import sys
 import numpy as np
 import scipy.sparse as sp
 
-from .cones import NonnegativeConeT, PSDTriangleConeT, SecondOrderConeT, ZeroConeT
+from .cone_api import NonnegativeConeT, PSDTriangleConeT, SecondOrderConeT, ZeroConeT
 from .settings import Settings
 
 _FLOATMAX = sys.float_info.max

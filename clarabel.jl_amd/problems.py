@@ -7,7 +7,7 @@ from __future__ import annotations
 import numpy as np
 import scipy.sparse as sp
 
-from .cones import NonnegativeConeT, PSDTriangleConeT, SecondOrderConeT, ZeroConeT, triangular_number
+from .cone_api import NonnegativeConeT, PSDTriangleConeT, SecondOrderConeT, ZeroConeT, triangular_number
 
 
 def _sparse_rows(rng, nrows, ncols, k, window=None, centers=None):

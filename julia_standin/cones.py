@@ -14,7 +14,6 @@ All vectors are numpy float64; indices 0-based.
 from __future__ import annotations
 
 import math
-from dataclasses import dataclass
 
 import numpy as np
 
@@ -22,71 +21,8 @@ FLOATMAX = float(np.finfo(np.float64).max)
 SOC_NO_EXPANSION_MAX_SIZE = 4  # cone_types.jl:101
 
 
-# ------------------------------------------------------------------ user-facing cone specs
-@dataclass(frozen=True)
-class ZeroConeT:
-    dim: int
-
-
-@dataclass(frozen=True)
-class NonnegativeConeT:
-    dim: int
-
-
-@dataclass(frozen=True)
-class SecondOrderConeT:
-    dim: int
-
-
-@dataclass(frozen=True)
-class PSDTriangleConeT:
-    dim: int  # matrix side dimension
-
-
-def triangular_number(k: int) -> int:
-    return (k * (k + 1)) >> 1
-
-
-def nvars(spec) -> int:
-    """cone_api.jl: number of rows a cone spec occupies."""
-    if isinstance(spec, PSDTriangleConeT):
-        return triangular_number(spec.dim)
-    return spec.dim
-
-
-def cones_new_collapsed(specs):
-    """cone_api.jl:96-153: merge runs of NN / 1-dim SOC / 1-dim PSD into one NN cone, drop empties."""
-    out = []
-    i = 0
-    n = len(specs)
-
-    def collapsible(c):
-        return (
-            isinstance(c, NonnegativeConeT)
-            or (isinstance(c, SecondOrderConeT) and c.dim == 1)
-            or (isinstance(c, PSDTriangleConeT) and c.dim == 1)
-        )
-
-    while i < n:
-        c = specs[i]
-        i += 1
-        if nvars(c) == 0:
-            continue
-        if collapsible(c):
-            total = nvars(c)
-            while i < n:
-                d = specs[i]
-                if nvars(d) == 0:
-                    pass
-                elif collapsible(d):
-                    total += nvars(d)
-                else:
-                    break
-                i += 1
-            out.append(NonnegativeConeT(total))
-        else:
-            out.append(c)
-    return out
+from clarabel_jl_amd.cone_api import (NonnegativeConeT, PSDTriangleConeT, SecondOrderConeT, ZeroConeT,  # noqa: F401
+                                       cones_new_collapsed, nvars, triangular_number)
 
 
 # ------------------------------------------------------------------ concrete cones

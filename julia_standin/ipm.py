@@ -25,7 +25,7 @@ import numpy as np
 import scipy.sparse as sp
 
 from .cones import CompositeCone, cones_new_collapsed
-from .settings import Settings
+from clarabel_jl_amd.settings import Settings
 
 INFINITY = 1e20  # Clarabel.jl:15
 _EPS = float(np.finfo(np.float64).eps)
@@ -336,7 +336,7 @@ class Solver:
         self.variables = Variables.zeros(n, m)
         self.residuals = Residuals(np.zeros(n), np.zeros(m), 1.0, np.zeros(n), np.zeros(m), np.zeros(n))
         if kktsolver_factory is None:
-            from .kktsolver import HipKKTSolver
+            from clarabel_jl_amd.kktsolver import HipKKTSolver
 
             kktsolver_factory = HipKKTSolver
         t1 = time.perf_counter()

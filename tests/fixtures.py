@@ -3,7 +3,8 @@ Each returns (P, q, A, b, cone_specs) in scipy/numpy form."""
 import numpy as np
 import scipy.sparse as sp
 
-import clarabel_jl_amd as cl
+import clarabel_jl_amd  # noqa: F401  (registers the dotted package directory)
+import julia_standin as cl
 
 
 def basic_qp():  # basic_qp.jl:6-19

@@ -33,13 +33,16 @@ def test_default_opts_match_reference_settings():
     assert o.supernode_max_width == 64 and o.index_base == 0
 
 
-def test_product_never_imports_oracle():
-    """the product path must not reach into oracle/ (parity would be void)"""
+def test_product_never_imports_oracle_or_the_caller_standin():
+    """the product path must not reach into oracle/ (parity would be void) nor into julia_standin/ (the numpy
+    stand-in of the Julia caller is test / bench infrastructure, not product)"""
     pkg = os.path.join(ROOT, "clarabel.jl_amd")
     for dp, _, files in os.walk(pkg):
         for f in files:
             if f.endswith((".py", ".cpp", ".h", ".hip", ".sh")):
                 src = open(os.path.join(dp, f)).read()
-                assert "oracle" not in src.lower() or f in ("ipm.py", "__init__.py", "hipkkt.py", "kktsolver.py", "cones.py"), f
                 if f.endswith(".py"):
-                    assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), f
+                    assert not re.search(r"^\s*(from|import)\s+(oracle|julia_standin)", src, flags=re.M), f
+                else:
+                    assert "oracle" not in src.lower() and "julia_standin" not in src, f
+    assert not os.path.exists(os.path.join(pkg, "ipm.py")) and not os.path.exists(os.path.join(pkg, "cones.py"))

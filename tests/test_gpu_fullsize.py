@@ -10,7 +10,8 @@ import numpy as np
 import pytest
 import scipy.sparse as sp
 
-import clarabel_jl_amd as cl
+import clarabel_jl_amd  # noqa: F401  (registers the dotted package directory)
+import julia_standin as cl
 from clarabel_jl_amd import problems
 from clarabel_jl_amd.kktsolver import HipKKTSolver
 from tests.fixtures import scale_cones

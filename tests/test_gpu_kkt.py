@@ -17,7 +17,8 @@ import numpy as np
 import pytest
 import scipy.sparse as sp
 
-import clarabel_jl_amd as cl
+import clarabel_jl_amd  # noqa: F401  (registers the dotted package directory)
+import julia_standin as cl
 from clarabel_jl_amd import hipkkt, problems
 from clarabel_jl_amd.kktsolver import HipKKTSolver
 from tests import fixtures as fx

@@ -11,7 +11,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-import clarabel_jl_amd as cl
+import clarabel_jl_amd  # noqa: F401  (registers the dotted package directory)
+import julia_standin as cl
 from clarabel_jl_amd import batch, problems
 
 

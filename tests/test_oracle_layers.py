@@ -4,7 +4,8 @@ construction, LDL factor/solve vs dense numpy, dynamic regularisation, IR stoppi
 import numpy as np
 import scipy.sparse as sp
 
-import clarabel_jl_amd as cl
+import clarabel_jl_amd  # noqa: F401  (registers the dotted package directory)
+import julia_standin as cl
 from oracle.kkt_oracle import OracleKKT, OracleKKTSolver, mmd_order
 from tests import fixtures as fx
 

@@ -8,7 +8,8 @@ import math
 import numpy as np
 import pytest
 
-from clarabel_jl_amd.cones import PSDTriangleCone
+import clarabel_jl_amd  # noqa: F401
+from julia_standin.cones import PSDTriangleCone
 
 
 def _tri_root(e):

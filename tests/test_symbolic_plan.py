@@ -4,7 +4,8 @@ import numpy as np
 import pytest
 import scipy.sparse as sp
 
-import clarabel_jl_amd as cl
+import clarabel_jl_amd  # noqa: F401  (registers the dotted package directory)
+import julia_standin as cl
 from clarabel_jl_amd import problems
 from oracle.kkt_oracle import OracleKKT
 from tests import fixtures as fx

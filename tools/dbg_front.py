@@ -1,7 +1,8 @@
 import os, sys
 import numpy as np, scipy.sparse as sp
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import clarabel_jl_amd as cl
+import clarabel_jl_amd  # noqa: F401  (registers the dotted package directory)
+import julia_standin as cl
 from clarabel_jl_amd import problems
 from clarabel_jl_amd.kktsolver import HipKKTSolver
 from oracle.kkt_oracle import OracleKKTSolver

@@ -3,7 +3,8 @@
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
-import clarabel_jl_amd as cl
+import clarabel_jl_amd  # noqa: F401  (registers the dotted package directory)
+import julia_standin as cl
 (P, q, A, b, cones), name = bench.make_problem(sys.argv[1])
 t0 = time.time()
 s = cl.Solver(P, q, A, b, cones, cl.Settings(verbose=True))

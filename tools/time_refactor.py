@@ -5,7 +5,8 @@ import os, sys
 import numpy as np, scipy.sparse as sp
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
-import clarabel_jl_amd as cl
+import clarabel_jl_amd  # noqa: F401  (registers the dotted package directory)
+import julia_standin as cl
 from clarabel_jl_amd.kktsolver import HipKKTSolver
 (P, q, A, b, specs), name = bench.make_problem(sys.argv[1])
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
