@@ -62,6 +62,8 @@ struct DevPlan {
     const int *sn_nitems;        // forward items (64-row blocks) of a supernode
     const int *sn_bparent;       // same-segment regular parent, or -1
     int *seg_sync;               // [0,nseg) forward tickets, [nseg,2nseg) backward tickets, then per-supernode counters:
+    int seg_ticket;              // 1: segment-sweep items are atomic tickets (default), 0: blockIdx (A/B timing only)
+    unsigned spin_limit;         // bound of every spin loop of the persistent sweeps (default 2^20; HIPKKT_SPIN_LIMIT)
     int nseg;                    //   fdone[nsuper], bdone[nsuper], pdone[nsuper]; error word last   // per front: {ticket, error, flags[np]} (zeroed before every front kernel)
     // numeric state
     double *kval;    // resident, UNREGULARISED triu KKT values (original nz order)

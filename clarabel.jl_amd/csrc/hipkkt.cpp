@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <new>
 #include <string>
 #include <vector>
@@ -69,6 +70,11 @@ struct hipkkt_solver {
     std::vector<char> lvl_narrow;                // [nlevels] every regular supernode is narrow (k_fwd_narrow / k_bwd_narrow)
     // persistent sweeps over the regular supernodes: segments = level ranges between front kernels
     bool use_persist = true;
+    bool persist_allowed = true;         // false: HIPKKT_NO_PERSIST (never tried)
+    int64_t persist_retry_at = -1;       // after a sweep time-out: the LDL-solve count at which the persistent kernels are tried again
+    int64_t persist_backoff = 0;         // doubles with every time-out (64, 128, ...); HIPKKT_PERSIST_RETRY=0 disables the retry
+    int64_t n_sweep_timeouts = 0;
+    int64_t n_twin_refactors = 0;        // factorisations repeated on the robust-order twin
     int nseg = 0;
     std::vector<int> seg_of_level;               // [nlevels]
     std::vector<int> fseg_ptr, bseg_ptr;         // [nseg+1] into slv_items / pbwd_items
@@ -193,6 +199,8 @@ void setup_device(hipkkt_solver *S) {
     {
         const char *np_ = getenv("HIPKKT_NO_PERSIST");
         S->use_persist = !(np_ && np_[0] == '1');
+        S->persist_allowed = S->use_persist;
+        S->persist_retry_at = -1;
     }
     S->soc_off.clear(); S->soc_of_sparse.clear();
     S->nsoc = 0; S->soc_total = 0; S->wmax_all = 1;
@@ -412,6 +420,12 @@ void setup_device(hipkkt_solver *S) {
     D.sn_nitems = S->upload(sn_nitems);
     D.sn_bparent = S->upload(sn_bparent);
     D.nseg = S->nseg;
+    {
+        const char *tk = getenv("HIPKKT_SEG_TICKET");      // 0: item = blockIdx (A/B timing of the ticket's cost)
+        D.seg_ticket = !(tk && tk[0] == '0');
+        const char *sl = getenv("HIPKKT_SPIN_LIMIT");      // tests force a sweep time-out with a tiny bound
+        D.spin_limit = sl ? (unsigned)strtoul(sl, nullptr, 10) : (1u << 20);
+    }
     {
         const size_t nsync = 2 * (size_t)S->nseg + 3 * (size_t)P.nsuper + 16;
         D.seg_sync = S->dalloc<int>(nsync);
@@ -633,6 +647,11 @@ void run_graphed(hipkkt_solver *S, GraphSlot &slot, bool reusable, F &&enqueue) 
 
 void ldl_solve_dev(hipkkt_solver *S, const double *in, double *out) {
     size_t nb = (size_t)S->N * sizeof(double);
+    if (!S->use_persist && S->persist_allowed && S->persist_retry_at >= 0 && S->n_ldlsolves >= S->persist_retry_at) {
+        S->use_persist = true;          // the downgrade after a sweep time-out is temporary
+        S->persist_retry_at = -1;
+        S->g_solve.valid = false;
+    }
     if (in != S->d_sin) HK_CHECK(hipMemcpyAsync(S->d_sin, in, nb, hipMemcpyDeviceToDevice, S->stream));
     run_graphed(S, S->g_solve, true, [&] { enqueue_ldl_solve(S); });
     if (out != S->d_sout) HK_CHECK(hipMemcpyAsync(out, S->d_sout, nb, hipMemcpyDeviceToDevice, S->stream));
@@ -679,15 +698,23 @@ static inline bool sweep_failed(const hipkkt_solver *S) {
 }
 
 // A persistent sweep kernel gave up (bounded spin expired: the workgroups were not dispatched in the order the
-// fast path relies on, or a front hand-off stalled).  Re-arm every hand-off word, drop to the per-level kernels
-// for the rest of this handle's life and tell the caller to repeat the solve.  Returns false when there is
-// nothing left to fall back to.
+// hardware was shared with something that starved a hand-off).  Re-arm every hand-off word, drop to the per-level
+// kernels and tell the caller to repeat the solve.  The downgrade is temporary: after 64 further LDL solves (doubling
+// with every time-out; HIPKKT_PERSIST_RETRY=<n> sets the first interval, 0 = never) the persistent kernels are tried
+// again.  Returns false when there is nothing left to fall back to.
 bool recover_from_sweep_failure(hipkkt_solver *S) {
     if (!S->use_persist) return false;
     const HostPlan &P = S->plan;
     HK_CHECK(hipStreamSynchronize(S->stream));
-    fprintf(stderr, "hipkkt: a persistent sweep kernel timed out (flags 0x%x); this handle falls back to per-level solve kernels\n",
-            S->h_flags[FL_FRONTFAIL]);
+    S->n_sweep_timeouts++;
+    {
+        const char *rt = getenv("HIPKKT_PERSIST_RETRY");
+        const int64_t first = rt ? atoll(rt) : 64;
+        S->persist_backoff = S->persist_backoff > 0 ? 2 * S->persist_backoff : first;
+        S->persist_retry_at = first > 0 ? S->n_ldlsolves + S->persist_backoff : -1;
+    }
+    fprintf(stderr, "hipkkt: a persistent sweep kernel timed out (flags 0x%x); per-level solve kernels for the next %lld LDL solves\n",
+            S->h_flags[FL_FRONTFAIL], (long long)(S->persist_retry_at >= 0 ? S->persist_backoff : -1));
     const size_t nsync = 2 * (size_t)S->nseg + 3 * (size_t)P.nsuper + 16;
     HK_CHECK(hipMemset(S->dp.seg_sync, 0, nsync * sizeof(int)));
     HK_CHECK(hipMemset(S->dp.front_sync, 0, (size_t)std::max(P.front_sync_ints, 16) * sizeof(int)));
@@ -1212,8 +1239,9 @@ int32_t hipkkt_refactor(hipkkt_handle h, int32_t static_reg_enable, double eps_c
     try {
         if (hipSetDevice(S->device) != hipSuccess) return rc;
         if (!S->fallback) {
-            hipkkt_solver *T = new hipkkt_solver();
-            S->fallback = T;
+            // built in a local owner: a set-up that throws half-way (e.g. device OOM) must not leave a twin with null
+            // streams / device pointers behind -- the next failing factorisation then simply tries again
+            std::unique_ptr<hipkkt_solver> T(new hipkkt_solver());
             T->device = S->device;
             T->opts = S->opts;
             T->l1 = S->l1;
@@ -1221,10 +1249,11 @@ int32_t hipkkt_refactor(hipkkt_handle h, int32_t static_reg_enable, double eps_c
             PlanOptions po = S->plan_opts;
             po.n_hold = 0;
             std::string err = build_plan((int)T->img.N, T->img.colptr.data(), T->img.rowval.data(), nullptr, po, T->plan);
-            if (!err.empty()) { delete T; S->fallback = nullptr; return rc; }
+            if (!err.empty()) return rc;
             T->plan_opts = po;
-            init_runtime(T);
-            setup_device(T);
+            init_runtime(T.get());
+            setup_device(T.get());
+            S->fallback = T.release();
         }
         HK_CHECK(hipMemcpy(S->fallback->dp.kval, S->dp.kval, (size_t)S->nnzK * sizeof(double), hipMemcpyDeviceToDevice));
     } catch (...) {
@@ -1233,6 +1262,7 @@ int32_t hipkkt_refactor(hipkkt_handle h, int32_t static_reg_enable, double eps_c
     }
     rc = refactor_once(S->fallback, static_reg_enable, eps_const, eps_prop, eps_used, n_dynamic_reg);
     S->using_fallback = true;
+    S->n_twin_refactors++;
     S->last_eps = S->fallback->last_eps;
     S->last_nreg = S->fallback->last_nreg;
     S->t_last_factor += S->fallback->t_last_factor;      // the failed attempt + the repeated one
@@ -1414,6 +1444,13 @@ int32_t hipkkt_get_profile(hipkkt_handle h, double *o) {
     if (!h || !o) return HIPKKT_ERR_ARGUMENT;
     o[0] = h->t_last_update; o[1] = h->prof_dense4_ms; o[2] = h->prof_dense4_flops; o[3] = (double)h->prof_dense4_launches;
     o[4] = o[5] = o[6] = o[7] = 0;
+    return HIPKKT_OK;
+}
+
+int32_t hipkkt_get_counters(hipkkt_handle h, int64_t *o) {
+    if (!h || !o) return HIPKKT_ERR_ARGUMENT;
+    o[0] = h->n_sweep_timeouts; o[1] = h->use_persist ? 1 : 0; o[2] = h->n_twin_refactors; o[3] = h->fallback ? 1 : 0;
+    o[4] = h->using_fallback ? 1 : 0; o[5] = h->plan.ordering_used; o[6] = (int64_t)h->plan.fronts.size(); o[7] = h->nseg;
     return HIPKKT_OK;
 }
 

@@ -1216,13 +1216,13 @@ __device__ __forceinline__ void front_slot_st(FrontSlot *p, double v) {
     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 2" : : "v"(p), "v"(r) : "memory");
 }
 // whole-wave wait for the 64 slots of one panel (lane = slot); false = timed out / another workgroup failed
-__device__ __forceinline__ bool front_slot_wait(const FrontSlot *p, double &v, int *err, int *failflag) {
+__device__ __forceinline__ bool front_slot_wait(const FrontSlot *p, double &v, int *err, int *failflag, unsigned lim) {
     for (unsigned spins = 0;; spins++) {
         const FrontSlot s = front_slot_ld(p);
         const bool okl = ((unsigned long long)__double_as_longlong(s.v) ^ s.h) == kSlotKey;
         if (__ballot(okl) == ~0ull) { v = s.v; return true; }
-        if ((spins & 127u) == 127u) {
-            if (spins > (1u << 20)) {
+        if ((spins & 127u) == 127u || lim < 128u) {
+            if (spins > lim) {
                 __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 atomicOr(failflag, 1);
                 return false;
@@ -1303,7 +1303,7 @@ k_front_fwd(DevPlan P, FrontDesc F, double *__restrict__ y, double *__restrict__
         double *yb = ybuf[q & 1];
         if (wv == 0) {
             double yv = 0.0;
-            ok = front_slot_wait(slots + q * 64 + lane, yv, sync + 1, P.flags + FL_FRONTFAIL);
+            ok = front_slot_wait(slots + q * 64 + lane, yv, sync + 1, P.flags + FL_FRONTFAIL, P.spin_limit);
             yb[lane] = ok ? yv : 0.0;
             if (lane == 0) okflag = ok ? 1 : 0;
         }
@@ -1431,7 +1431,7 @@ k_front_bwd(DevPlan P, FrontDesc F, const double *__restrict__ z, double *__rest
         double *xb = xbuf[q & 1];
         if (wv == 0) {   // one polling wave, broadcast through LDS (see k_front_fwd)
             double xv = 0.0;
-            ok = front_slot_wait(slots + q * 64 + lane, xv, sync + 1, P.flags + FL_FRONTFAIL);
+            ok = front_slot_wait(slots + q * 64 + lane, xv, sync + 1, P.flags + FL_FRONTFAIL, P.spin_limit);
             xb[lane] = ok ? xv : 0.0;
             if (lane == 0) okflag = ok ? 1 : 0;
         }
@@ -1496,11 +1496,11 @@ __device__ __forceinline__ SegSync seg_sync(const DevPlan &P, int nsuper) {
     return s;
 }
 // thread 0 waits until *ctr >= want (relaxed polls); false on time-out / foreign failure
-__device__ __forceinline__ bool seg_wait(int *ctr, int want, int *err, int *failflag) {
+__device__ __forceinline__ bool seg_wait(int *ctr, int want, int *err, int *failflag, unsigned lim) {
     for (unsigned spins = 0;; spins++) {
         if (front_ld_flag(ctr) >= want) return true;
-        if ((spins & 127u) == 127u) {
-            if (spins > (1u << 20)) {
+        if ((spins & 127u) == 127u || lim < 128u) {
+            if (spins > lim) {
                 __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 atomicOr(failflag, 1);
                 return false;
@@ -1526,12 +1526,12 @@ __device__ __forceinline__ void seg_slot_st(FrontSlot *p, double v, unsigned lon
     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 2" : : "v"(p), "v"(r) : "memory");
 }
 // one lane waits for one slot; false = timed out / another workgroup failed (bounded like every other spin)
-__device__ __forceinline__ bool seg_slot_poll(const FrontSlot *p, unsigned long long key, double &v, int *err, int *failflag) {
+__device__ __forceinline__ bool seg_slot_poll(const FrontSlot *p, unsigned long long key, double &v, int *err, int *failflag, unsigned lim) {
     for (unsigned spins = 0;; spins++) {
         const FrontSlot s = front_slot_ld(p);
         if (((unsigned long long)__double_as_longlong(s.v) ^ s.h) == key) { v = s.v; return true; }
-        if ((spins & 127u) == 127u) {
-            if (spins > (1u << 20)) {
+        if ((spins & 127u) == 127u || lim < 128u) {
+            if (spins > lim) {
                 __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 atomicOr(failflag, 1);
                 return false;
@@ -1540,9 +1540,9 @@ __device__ __forceinline__ bool seg_slot_poll(const FrontSlot *p, unsigned long 
         }
     }
 }
-__device__ __forceinline__ bool seg_spin_check(unsigned &spins, int *err, int *failflag) {   // false = give up
-    if ((++spins & 127u) == 0u) {
-        if (spins > (1u << 20)) {
+__device__ __forceinline__ bool seg_spin_check(unsigned &spins, int *err, int *failflag, unsigned lim) {   // false = give up
+    if ((++spins & 127u) == 0u || lim < 128u) {
+        if (spins > lim) {
             __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             atomicOr(failflag, 1);
             return false;
@@ -1562,10 +1562,17 @@ k_fwd_seg(DevPlan P, int seg, int item_begin, int nitems, int nsuper, int first_
     __shared__ int sb;
     const SegSync Y = seg_sync(P, nsuper);
     const int tid = threadIdx.x;
-    // item = blockIdx (level order).  A shared ticket word would serialise the ~2*10^4 leaf items of a random
-    // sparse QP at ~88 tickets/us, so the in-order dispatch of workgroups is relied upon for SPEED only: every
-    // spin is bounded, a time-out fails the solve and the host then falls back to the per-level kernels.
-    const int t = blockIdx.x;
+    // item = a ticket taken in arrival order (level order): an item only ever waits for items with lower tickets, whose
+    // owners are therefore already running -- forward progress does not depend on the order in which the hardware
+    // dispatches workgroups.  One atomic per workgroup (~11 ns each on one word); the wide bottom levels, where that
+    // would add up, are not part of the persistent launches (hipkkt.cpp kPersistMaxItems).  seg_ticket == 0 selects
+    // item = blockIdx (in-order dispatch assumed; kept for A/B timing only: HIPKKT_SEG_TICKET=0).
+    if (P.seg_ticket) {
+        if (tid == 0) sb = atomicAdd(Y.ftick + seg, 1);
+        __syncthreads();
+    }
+    const int t = P.seg_ticket ? sb : (int)blockIdx.x;
+    if (P.seg_ticket) __syncthreads();   // sb is reused below
     if (t >= nitems) return;
     if (first_launch && t == 0) {   // re-arm the backward sweep's state (idle during the forward sweep)
         for (int q = tid; q < P.nseg; q += 256) Y.btick[q] = 0;
@@ -1613,7 +1620,7 @@ k_fwd_seg(DevPlan P, int seg, int item_begin, int nitems, int nsuper, int first_
     //      themselves into THIS supernode's counter, so the wait is one poll loop on one word
     const int want = P.dep_total[s], fpar = P.sn_bparent[s];
     if (tid == 0) {
-        sb = (want == 0 || seg_wait(Y.fdone + s, want, Y.err, P.flags + FL_FRONTFAIL)) ? 1 : 0;
+        sb = (want == 0 || seg_wait(Y.fdone + s, want, Y.err, P.flags + FL_FRONTFAIL, P.spin_limit)) ? 1 : 0;
         asm volatile("" ::: "memory");
     }
     __syncthreads();
@@ -1688,9 +1695,11 @@ k_bwd_seg(DevPlan P, int seg, int item_begin, int nitems, int nsuper, int first_
     __shared__ int bad;
     const SegSync Y = seg_sync(P, nsuper);
     const int tid = threadIdx.x;
-    const int t = blockIdx.x;     // see k_fwd_seg
+    __shared__ int tick;
+    if (tid == 0) { bad = 0; tick = P.seg_ticket ? atomicAdd(Y.btick + seg, 1) : (int)blockIdx.x; }   // see k_fwd_seg
+    __syncthreads();                // `bad` may be set by any wave from here on
+    const int t = tick;
     if (t >= nitems) return;
-    if (tid == 0) bad = 0;
     if (first_launch && t == 0) {   // re-arm the forward sweep's counters for the next solve
         for (int q = tid; q < P.nseg; q += 256) Y.ftick[q] = 0;
         for (int q = tid; q < nsuper; q += 256) Y.fdone[q] = 0;
@@ -1759,7 +1768,7 @@ k_bwd_seg(DevPlan P, int seg, int item_begin, int nitems, int nsuper, int first_
                     if (((unsigned long long)__double_as_longlong(sl.v) ^ sl.h) == key) { myv = sl.v; got = true; }
                 }
                 if (__ballot(!got) == 0ull) break;
-                ok = seg_spin_check(spins, Y.err, P.flags + FL_FRONTFAIL);
+                ok = seg_spin_check(spins, Y.err, P.flags + FL_FRONTFAIL, P.spin_limit);
             }
 #pragma unroll
             for (int t2 = 0; t2 < 16; t2++) {
@@ -1792,7 +1801,7 @@ k_bwd_seg(DevPlan P, int seg, int item_begin, int nitems, int nsuper, int first_
             const FrontSlot *pb = P.pseg + P.p_off[s] + lane;
             for (int b2 = wave; b2 < nblk && ok; b2 += 4) {
                 double v = 0.0;
-                ok = seg_slot_poll(pb + (int64_t)b2 * w, key, v, Y.err, P.flags + FL_FRONTFAIL);
+                ok = seg_slot_poll(pb + (int64_t)b2 * w, key, v, Y.err, P.flags + FL_FRONTFAIL, P.spin_limit);
                 a += v;
             }
         }
@@ -1980,10 +1989,12 @@ __global__ void k_zero_words(int *p, int n) {
     if (i < n) p[i] = 0;
 }
 // Hs block of one PSD triangle cone on the device: entry e of the packed (column-major) upper triangle of
-// W (x)_s W, e <-> (a <= b), a <-> (i <= j), b <-> (k <= l) in the svec ordering:
-//   Hs[a,b] = ((1/2 f_a) f_b) (W_ik W_jl + W_il W_jk),  f = 1 on the diagonal of the matrix, sqrt(2) off it
-// (coneops_psdtrianglecone.jl:502-540).  Explicitly rounded products and sums (no FMA contraction): bit-identical to
-// the host loop.  The value is negated and scattered through map.Hsblocks (kktsolver_directldl.jl:225-228).
+// W (x)_s W, e <-> (a <= b), a <-> (i <= j), b <-> (k <= l) in the svec ordering.  The four cases of the reference's
+// skron! (coneops_psdtrianglecone.jl:502-540), with its products, association and rounding:
+//   i != j, k != l :  W_ik W_jl + W_il W_jk          i == j, k != l :  (sqrt2 W_jl) W_jk
+//   i != j, k == l :  (sqrt2 W_il) W_jk               i == j, k == l :  W_jl W_jl
+// Explicitly rounded products and sums (no FMA contraction).  The value is negated and scattered through
+// map.Hsblocks (kktsolver_directldl.jl:225-228).
 __device__ __forceinline__ long long tri_root(long long e) {   // largest t with t(t+1)/2 <= e
     long long t = (long long)((sqrt(8.0 * (double)e + 1.0) - 1.0) * 0.5);
     while (t * (t + 1) / 2 > e) t--;
@@ -1999,14 +2010,22 @@ k_psd_hs(double *__restrict__ kval, const int64_t *__restrict__ map_hs, int64_t 
     const long long j = tri_root(a), i = a - j * (j + 1) / 2;
     const long long l = tri_root(b), k = b - l * (l + 1) / 2;
     const double sqrt2 = sqrt(2.0);
-    const double fa = i == j ? 1.0 : sqrt2, fb = k == l ? 1.0 : sqrt2;
-    const double ff = (0.5 * fa) * fb;
-    // products and the sum are rounded one by one like the host loop: HIP's __dmul_rn is a plain `*` that the compiler
-    // contracts into an FMA, so the products pass through an opaque asm before they are added
-    double p1 = W[i * n + k] * W[j * n + l];
-    double p2 = W[i * n + l] * W[j * n + k];
-    asm volatile("" : "+v"(p1), "+v"(p2));
-    kval[map_hs[hs_off + e]] = -(ff * (p1 + p2));
+    double v;
+    if (i != j && k != l) {
+        // products and the sum are rounded one by one like the reference's loop: HIP's `*` followed by `+` is contracted
+        // into an FMA by the compiler, so the products pass through an opaque asm before they are added
+        double p1 = W[i * n + k] * W[j * n + l];
+        double p2 = W[i * n + l] * W[j * n + k];
+        asm volatile("" : "+v"(p1), "+v"(p2));
+        v = p1 + p2;
+    } else if (i == j && k != l) {
+        v = (sqrt2 * W[j * n + l]) * W[j * n + k];
+    } else if (i != j) {
+        v = (sqrt2 * W[i * n + l]) * W[j * n + k];
+    } else {
+        v = W[j * n + l] * W[j * n + l];
+    }
+    kval[map_hs[hs_off + e]] = -v;
 }
 void launch_psd_hs(hipStream_t st, double *kval, const int64_t *map_hs, int64_t hs_off, const double *W, int n) {
     const int64_t numel = (int64_t)n * (n + 1) / 2, nent = numel * (numel + 1) / 2;

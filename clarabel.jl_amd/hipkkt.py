@@ -24,6 +24,7 @@ SYMBOLS = [
     "hipkkt_set_hs", "hipkkt_set_hs_dev", "hipkkt_set_hs_psd", "hipkkt_block_products", "hipkkt_set_soc", "hipkkt_set_soc_batch", "hipkkt_set_genpow",
     "hipkkt_update_P", "hipkkt_update_A", "hipkkt_refactor", "hipkkt_setrhs", "hipkkt_setrhs_dev", "hipkkt_solve",
     "hipkkt_solve_dev", "hipkkt_ldl_solve", "hipkkt_get_timing", "hipkkt_reset_timing", "hipkkt_get_profile", "hipkkt_set_profiling",
+    "hipkkt_get_counters",
     "hipkkt_selftest_mfma", "hipkkt_last_error",
 ]
 
@@ -91,6 +92,7 @@ def lib():
     L.hipkkt_reset_timing.argtypes = [vp]
     L.hipkkt_get_profile.argtypes = [vp, _f64p]
     L.hipkkt_set_profiling.argtypes = [vp, i32]
+    L.hipkkt_get_counters.argtypes = [vp, _i64p]
     L.hipkkt_selftest_mfma.argtypes = [i32, C.POINTER(f64)]
     L.hipkkt_last_error.argtypes = [vp]
     L.hipkkt_last_error.restype = C.c_char_p
@@ -172,6 +174,16 @@ class Handle:
             raise HipKKTError(f"{what} failed ({rc}): {self.L.hipkkt_last_error(self.h).decode()}")
         return rc
 
+    @staticmethod
+    def _out_ptr(a, need, what):
+        """raw pointer of an OUTPUT array the library writes `need` doubles into (None = Julia `nothing`)"""
+        if a is None:
+            return None
+        if not (isinstance(a, np.ndarray) and a.dtype == np.float64 and a.flags.c_contiguous and a.flags.writeable
+                and a.size >= need):
+            raise HipKKTError(f"{what}: need a writeable C-contiguous float64 ndarray of at least {need} elements")
+        return a.ctypes.data
+
     # ---- introspection
     def kkt(self):
         colptr = np.zeros(self.N + 1, dtype=np.int64)
@@ -214,6 +226,12 @@ class Handle:
         self.L.hipkkt_get_timing(self.h, o)
         return dict(last_factor_ms=o[0], last_solve_ms=o[1], acc_factor_ms=o[2], acc_solve_ms=o[3], n_factor=int(o[4]),
                     n_solve_calls=int(o[5]), n_ldl_solves=int(o[6]), last_update_ms=o[7])
+
+    def counters(self):
+        o = np.zeros(8, dtype=np.int64)
+        self.L.hipkkt_get_counters(self.h, o)
+        return dict(sweep_timeouts=int(o[0]), persistent=bool(o[1]), twin_refactors=int(o[2]), twin_exists=bool(o[3]),
+                    in_twin=bool(o[4]), ordering=int(o[5]), fronts=int(o[6]), segments=int(o[7]))
 
     def profile(self):
         o = np.zeros(8)
@@ -265,8 +283,8 @@ class Handle:
 
     def solve(self, lhsx, lhsz, ir_enable=True, reltol=1e-13, abstol=1e-12, max_iter=10, stop_ratio=5.0):
         steps = C.c_int64(0)
-        px = lhsx.ctypes.data if lhsx is not None else None
-        pz = lhsz.ctypes.data if lhsz is not None else None
+        px = self._out_ptr(lhsx, self.n, "lhsx")
+        pz = self._out_ptr(lhsz, self.m, "lhsz")
         rc = self._chk(self.L.hipkkt_solve(self.h, px, pz, int(ir_enable), reltol, abstol, max_iter, stop_ratio,
                                            C.byref(steps)), "solve")
         return rc == 0, steps.value

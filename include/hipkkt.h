@@ -201,6 +201,13 @@ int32_t hipkkt_get_profile(hipkkt_handle h, double *out8);
 /* 1 = time the update (MFMA) kernels separately inside refactor (adds event overhead) */
 int32_t hipkkt_set_profiling(hipkkt_handle h, int32_t enable);
 
+/* robustness counters: out[0] = persistent sweep time-outs seen so far (each one repeats the solve on the per-level
+ * kernels and suspends the persistent kernels for a while), out[1] = persistent sweeps currently enabled (0/1),
+ * out[2] = factorisations repeated on the robust-order twin, out[3] = twin exists, out[4] = the current factorisation
+ * lives in the twin, out[5] = ordering in use (0 minimum degree on K, 1 cone rows first, 2 user), out[6] = #fronts,
+ * out[7] = #segments */
+int32_t hipkkt_get_counters(hipkkt_handle h, int64_t *out8);
+
 /* diagnostic: checks the FP64 matrix-core operand/result lane maps used by the update kernel
  * against a host product with an asymmetric B (returns 0 when they agree to 1e-12) */
 int32_t hipkkt_selftest_mfma(int32_t device_id, double *max_err);

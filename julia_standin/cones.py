@@ -404,11 +404,17 @@ class PSDTriangleCone:
         return True
 
     def _skron(self, A):
-        """triu(A (x)_s A), :502-540, vectorised: out[(i,j),(k,l)] = f_ij f_kl (A_ik A_jl + A_il A_jk)/2."""
+        """triu(A (x)_s A), :502-540, vectorised with the reference's four cases and association:
+        i != j, k != l: A_ik A_jl + A_il A_jk;  i == j, k != l: (sqrt2 A_jl) A_jk;
+        i != j, k == l: (sqrt2 A_il) A_jk;      i == j, k == l: A_jl A_jl.
+        Only row <= col is meaningful (the reference fills only the upper triangle); get_Hs packs that part."""
         i, j = self._r[:, None], self._c[:, None]
         k, l = self._r[None, :], self._c[None, :]
-        ff = 0.5 * self._f[:, None] * self._f[None, :]
-        self.Hs[:] = ff * (A[i, k] * A[j, l] + A[i, l] * A[j, k])
+        ij_eq, kl_eq = self._isdiag[:, None], self._isdiag[None, :]
+        sqrt2 = math.sqrt(2.0)
+        Ajl, Ajk, Ail, Aik = A[j, l], A[j, k], A[i, l], A[i, k]
+        self.Hs[:] = np.where(ij_eq, np.where(kl_eq, Ajl * Ajl, (sqrt2 * Ajl) * Ajk),
+                              np.where(kl_eq, (sqrt2 * Ail) * Ajk, Aik * Ajl + Ail * Ajk))
 
     def get_Hs(self, block):  # :153-161 -> pack_triu (mathutils.jl:402-412)
         if not self._hs_valid:

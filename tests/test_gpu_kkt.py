@@ -13,6 +13,8 @@ Tolerances (Float64, stated by north_star: residuals/objective to 1e-10):
     (observed 4e-9 on the reference's SOCP fixture while objective and residuals agree to 1e-12).
 """
 X_TOL = 1e-6
+import zlib
+
 import numpy as np
 import pytest
 import scipy.sparse as sp
@@ -65,7 +67,7 @@ PROBLEMS = {
 
 @pytest.mark.parametrize("name", list(PROBLEMS))
 def test_assembly_bit_exact_and_factor_solve_parity(name, oracle_factory):
-    rng = np.random.default_rng(abs(hash(name)) % (1 << 31))
+    rng = np.random.default_rng(zlib.crc32(name.encode()))   # a fixed seed per case (str hashes vary per process)
     Pt, A, cones = _prep(PROBLEMS[name]())
     m, n = A.shape
     st = cl.Settings()

@@ -1,7 +1,7 @@
 """CPU check of the index arithmetic of k_psd_hs (clarabel.jl_amd/csrc/kernels.hip): entry e of the packed upper
-triangle of W (x)_s W  <->  (a <= b)  <->  ((i <= j), (k <= l)), evaluated with the kernel's formula and order of
-operations, must reproduce the host path (cones.PSDTriangleCone._skron + get_Hs = the reference's skron! + pack_triu,
-coneops_psdtrianglecone.jl:153-161, 502-540) bit for bit.  The GPU side of the same statement is
+triangle of W (x)_s W  <->  (a <= b)  <->  ((i <= j), (k <= l)), evaluated with the kernel's four cases and order of
+operations, must reproduce a literal restatement of the reference's skron! loop + pack_triu
+(coneops_psdtrianglecone.jl:153-161, 502-540) bit for bit, and so must the vectorised host stand-in.  The GPU side of the same statement is
 tests/test_gpu_kkt.py::test_assembly_bit_exact_and_factor_solve_parity[sdp_*]."""
 import math
 
@@ -21,8 +21,38 @@ def _tri_root(e):
     return t
 
 
+def _reference_skron_loop(A):
+    """literal restatement of skron!(out, A), coneops_psdtrianglecone.jl:502-540 (1-based loops kept)"""
+    n = A.shape[0]
+    numel = n * (n + 1) // 2
+    out = np.zeros((numel, numel))
+    sqrt2 = math.sqrt(2.0)
+    col = 1
+    for l in range(1, n + 1):
+        for k in range(1, l + 1):
+            row = 1
+            kl_eq = k == l
+            for j in range(1, n + 1):
+                Ajl, Ajk = A[j - 1, l - 1], A[j - 1, k - 1]
+                for i in range(1, j + 1):
+                    if row > col:
+                        break
+                    ij_eq = i == j
+                    if not ij_eq and not kl_eq:
+                        out[row - 1, col - 1] = A[i - 1, k - 1] * Ajl + A[i - 1, l - 1] * Ajk
+                    elif ij_eq and not kl_eq:
+                        out[row - 1, col - 1] = sqrt2 * Ajl * Ajk
+                    elif not ij_eq and kl_eq:
+                        out[row - 1, col - 1] = sqrt2 * A[i - 1, l - 1] * Ajk
+                    else:
+                        out[row - 1, col - 1] = Ajl * Ajl
+                    row += 1
+            col += 1
+    return out
+
+
 @pytest.mark.parametrize("n", [1, 2, 3, 5, 8])
-def test_kernel_formula_matches_host_skron(n):
+def test_kernel_formula_matches_reference_skron(n):
     rng = np.random.default_rng(n)
     c = PSDTriangleCone(n)
     for _ in range(2):
@@ -35,18 +65,26 @@ def test_kernel_formula_matches_host_skron(n):
         host = np.zeros(nent)
         c.get_Hs(host)
         W = c.RRt
+        ref = _reference_skron_loop(W)[c._hs_r, c._hs_c]          # pack_triu (mathutils.jl:402-412)
+        assert np.array_equal(host, ref)                          # vectorised stand-in == the reference's loop
         s2 = math.sqrt(2.0)
         dev = np.zeros(nent)
-        for e in range(nent):
+        for e in range(nent):                                     # k_psd_hs: same index arithmetic and case split
             b = _tri_root(e)
             a = e - b * (b + 1) // 2
             j = _tri_root(a)
             i = a - j * (j + 1) // 2
             l = _tri_root(b)
             k = b - l * (l + 1) // 2
-            ff = (0.5 * (1.0 if i == j else s2)) * (1.0 if k == l else s2)
-            dev[e] = ff * (W[i, k] * W[j, l] + W[i, l] * W[j, k])
-        assert np.array_equal(dev, host)
+            if i != j and k != l:
+                dev[e] = W[i, k] * W[j, l] + W[i, l] * W[j, k]
+            elif i == j and k != l:
+                dev[e] = (s2 * W[j, l]) * W[j, k]
+            elif i != j:
+                dev[e] = (s2 * W[i, l]) * W[j, k]
+            else:
+                dev[e] = W[j, l] * W[j, l]
+        assert np.array_equal(dev, ref)
 
 
 def test_identity_scaling_block_is_exact_identity():
