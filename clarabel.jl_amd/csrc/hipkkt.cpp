@@ -68,6 +68,10 @@ struct hipkkt_solver {
     std::vector<int> slv_lvl_ptr, bwd_lvl_ptr;
     std::vector<int> reg_lvl_sn, reg_lvl_ptr;   // supernodes of every level that are NOT front panels
     std::vector<char> lvl_narrow;                // [nlevels] every regular supernode is narrow (k_fwd_narrow / k_bwd_narrow)
+    // the same level lists over ALL supernodes (front panels included), appended to the same item arrays: the path without
+    // any persistent kernel, taken after a sweep time-out
+    std::vector<int> all_slv_lvl_ptr, all_bwd_lvl_ptr, all_reg_lvl_ptr;
+    std::vector<char> all_lvl_narrow;
     // persistent sweeps over the regular supernodes: segments = level ranges between front kernels
     bool use_persist = true;
     bool persist_allowed = true;         // false: HIPKKT_NO_PERSIST (never tried)
@@ -224,26 +228,39 @@ void setup_device(hipkkt_solver *S) {
     S->lvl_narrow.assign(P.nlevels, 0);
     const char *nn = getenv("HIPKKT_NO_NARROW");
     const bool allow_narrow = !(nn && nn[0] == '1');
-    for (int l = 0; l < P.nlevels; l++) {
-        bool narrow = allow_narrow;
-        for (int q = P.lvl_ptr[l]; q < P.lvl_ptr[l + 1]; q++) {
-            int s = P.lvl_sn[q];
-            int w = P.sn_first[s + 1] - P.sn_first[s];
-            S->wmax_all = std::max(S->wmax_all, w);
-            if (P.sn_front[s] >= 0) continue;      // solved by the persistent front kernels
-            int64_t r = P.sn_rowptr[s + 1] - P.sn_rowptr[s];
-            if (w > kNarrowW || r - w > kNarrowR) narrow = false;
-            int nb = (int)std::max<int64_t>(1, (r - w + 63) / 64);
-            for (int b = 0; b < nb; b++) S->slv_items.push_back({s, b});
-            if (nb > 1)
-                for (int b = 0; b < nb; b++) S->bwd_items.push_back({s, b});
-            S->reg_lvl_sn.push_back(s);
+    // Level lists of the per-level solve kernels, appended to slv_items / bwd_items / reg_lvl_sn.  Variant 0 leaves out the
+    // panels of the fronts (the persistent front kernels solve those); variant 1 holds EVERY supernode and is what a
+    // handle falls back to after a persistent sweep timed out (front kernels included: no persistent kernel at all).
+    auto build_level_lists = [&](bool with_fronts, std::vector<int> &slv_ptr, std::vector<int> &bwd_ptr, std::vector<int> &reg_ptr,
+                                 std::vector<char> &narrow_lvl) {
+        slv_ptr.assign(P.nlevels + 1, (int)S->slv_items.size());
+        bwd_ptr.assign(P.nlevels + 1, (int)S->bwd_items.size());
+        reg_ptr.assign(P.nlevels + 1, (int)S->reg_lvl_sn.size());
+        narrow_lvl.assign(P.nlevels, 0);
+        for (int l = 0; l < P.nlevels; l++) {
+            bool narrow = allow_narrow;
+            for (int q = P.lvl_ptr[l]; q < P.lvl_ptr[l + 1]; q++) {
+                int s = P.lvl_sn[q];
+                int w = P.sn_first[s + 1] - P.sn_first[s];
+                S->wmax_all = std::max(S->wmax_all, w);
+                if (!with_fronts && P.sn_front[s] >= 0) continue;      // solved by the persistent front kernels
+                int64_t r = P.sn_rowptr[s + 1] - P.sn_rowptr[s];
+                if (w > kNarrowW || r - w > kNarrowR) narrow = false;
+                int nb = (int)std::max<int64_t>(1, (r - w + 63) / 64);
+                for (int b = 0; b < nb; b++) S->slv_items.push_back({s, b});
+                if (nb > 1)
+                    for (int b = 0; b < nb; b++) S->bwd_items.push_back({s, b});
+                S->reg_lvl_sn.push_back(s);
+            }
+            slv_ptr[l + 1] = (int)S->slv_items.size();
+            bwd_ptr[l + 1] = (int)S->bwd_items.size();
+            reg_ptr[l + 1] = (int)S->reg_lvl_sn.size();
+            narrow_lvl[l] = narrow && reg_ptr[l + 1] - reg_ptr[l] >= 256;
         }
-        S->slv_lvl_ptr[l + 1] = (int)S->slv_items.size();
-        S->bwd_lvl_ptr[l + 1] = (int)S->bwd_items.size();
-        S->reg_lvl_ptr[l + 1] = (int)S->reg_lvl_sn.size();
-        S->lvl_narrow[l] = narrow && S->reg_lvl_ptr[l + 1] - S->reg_lvl_ptr[l] >= 256;
-    }
+    };
+    build_level_lists(false, S->slv_lvl_ptr, S->bwd_lvl_ptr, S->reg_lvl_ptr, S->lvl_narrow);
+    if (!P.fronts.empty()) build_level_lists(true, S->all_slv_lvl_ptr, S->all_bwd_lvl_ptr, S->all_reg_lvl_ptr, S->all_lvl_narrow);
+    else { S->all_slv_lvl_ptr = S->slv_lvl_ptr; S->all_bwd_lvl_ptr = S->bwd_lvl_ptr; S->all_reg_lvl_ptr = S->reg_lvl_ptr; S->all_lvl_narrow = S->lvl_narrow; }
     // ---- persistent sweeps: segments, dependency lists, backward item order
     std::vector<int> dep_ptr(P.nsuper + 1, 0), dep_idx, sn_nitems(P.nsuper, 0), sn_bparent(P.nsuper, -1);
     std::vector<int> rows_seg;
@@ -577,17 +594,21 @@ void enqueue_ldl_solve(hipkkt_solver *S) {
     launch_permute_in(st, S->d_sin, S->dp.perm, S->d_y, S->N, S->dp.seg_epoch);
     // one launch per level (wide bottom levels, and every level on the fallback path); levels of narrow supernodes
     // take the thread-per-supernode kernels
+    const bool all = !S->use_persist;   // no persistent kernel at all: level lists over every supernode
+    const std::vector<int> &slvp = all ? S->all_slv_lvl_ptr : S->slv_lvl_ptr, &bwdp = all ? S->all_bwd_lvl_ptr : S->bwd_lvl_ptr,
+                           &regp = all ? S->all_reg_lvl_ptr : S->reg_lvl_ptr;
+    const std::vector<char> &narrow = all ? S->all_lvl_narrow : S->lvl_narrow;
     auto fwd_level = [&](int l) {
-        if (S->lvl_narrow[l]) launch_fwd_narrow(st, S->dp, S->reg_lvl_ptr[l], S->reg_lvl_ptr[l + 1] - S->reg_lvl_ptr[l], S->d_y, S->d_z);
-        else launch_fwd_level(st, S->dp, S->slv_lvl_ptr[l], S->slv_lvl_ptr[l + 1] - S->slv_lvl_ptr[l], S->d_y, S->d_z);
+        if (narrow[l]) launch_fwd_narrow(st, S->dp, regp[l], regp[l + 1] - regp[l], S->d_y, S->d_z);
+        else launch_fwd_level(st, S->dp, slvp[l], slvp[l + 1] - slvp[l], S->d_y, S->d_z);
     };
     auto bwd_level = [&](int l) {
-        if (S->lvl_narrow[l]) {
-            launch_bwd_narrow(st, S->dp, S->reg_lvl_ptr[l], S->reg_lvl_ptr[l + 1] - S->reg_lvl_ptr[l], S->d_z, S->d_xp, S->d_sout);
+        if (narrow[l]) {
+            launch_bwd_narrow(st, S->dp, regp[l], regp[l + 1] - regp[l], S->d_z, S->d_xp, S->d_sout);
             return;
         }
-        launch_bwd_partial(st, S->dp, S->bwd_lvl_ptr[l], S->bwd_lvl_ptr[l + 1] - S->bwd_lvl_ptr[l], S->d_xp);
-        launch_bwd_final(st, S->dp, S->reg_lvl_ptr[l], S->reg_lvl_ptr[l + 1] - S->reg_lvl_ptr[l], S->d_z, S->d_xp, S->d_sout);
+        launch_bwd_partial(st, S->dp, bwdp[l], bwdp[l + 1] - bwdp[l], S->d_xp);
+        launch_bwd_final(st, S->dp, regp[l], regp[l + 1] - regp[l], S->d_z, S->d_xp, S->d_sout);
     };
     if (S->use_persist) {
         // one persistent launch per segment of regular levels, front kernels in between
@@ -610,16 +631,8 @@ void enqueue_ldl_solve(hipkkt_solver *S) {
         }
         return;
     }
-    for (int l = 0; l < P.nlevels; l++) {
-        fwd_level(l);
-        for (const FrontDesc &F : P.fronts)
-            if (F.level_last == l) launch_front_fwd(st, S->dp, F, S->d_y, S->d_z);
-    }
-    for (int l = P.nlevels - 1; l >= 0; l--) {
-        for (const FrontDesc &F : P.fronts)
-            if (F.level_last == l) launch_front_bwd(st, S->dp, F, S->d_z, S->d_xp, S->d_sout);
-        bwd_level(l);
-    }
+    for (int l = 0; l < P.nlevels; l++) fwd_level(l);
+    for (int l = P.nlevels - 1; l >= 0; l--) bwd_level(l);
 }
 
 template <class F>

@@ -264,6 +264,10 @@ class Handle:
                                               np.ascontiguousarray(u_all, dtype=np.float64),
                                               np.ascontiguousarray(v_all, dtype=np.float64), len(u_all)), "set_soc_batch")
 
+    def set_genpow(self, i, sqrtmu, p, q, r):
+        f = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+        self._chk(self.L.hipkkt_set_genpow(self.h, i, sqrtmu, f(p), f(q), f(r)), "set_genpow")
+
     def update_P(self, vals):
         self._chk(self.L.hipkkt_update_P(self.h, np.ascontiguousarray(vals, dtype=np.float64), len(vals)), "update_P")
 

@@ -53,6 +53,7 @@ def lib():
     L.oracle_kkt_sparse_map.argtypes = [vp, C.c_int64, C.c_int, C.POINTER(C.c_int64)]
     L.oracle_kkt_update_Hs.argtypes = [vp, _f64p]
     L.oracle_kkt_update_soc.argtypes = [vp, C.c_int64, C.c_double, _f64p, _f64p]
+    L.oracle_kkt_update_genpow.argtypes = [vp, C.c_int64, C.c_double, _f64p, _f64p, _f64p]
     L.oracle_kkt_update_values.argtypes = [vp, _i64p, _f64p, C.c_int64]
     L.oracle_kkt_scale_values.argtypes = [vp, _i64p, C.c_int64, C.c_double]
     L.oracle_kkt_update_P.argtypes = [vp, _f64p]

@@ -1,5 +1,5 @@
-"""BASELINE.json's configs at FULL size on the GPU, checked through size-independent properties (the oracle
-needs minutes per factorisation at these sizes, so it is not run here):
+"""BASELINE.json's configs at FULL size on the GPU: against the CPU oracle on the same permutation
+(test_full_size_matches_oracle) and through size-independent properties:
   * the refined solve satisfies the reference's own stopping rule against the TRUE (unregularised) K,
     recomputed on the host with scipy from the library's resident image;
   * linearity of the factorisation's solve operator;
@@ -75,6 +75,40 @@ def test_full_size_solve_properties(name):
     # determinism
     assert hk.kktsolver_update(cones)
     assert np.array_equal(hk.h.ldl_solve(b1), x1)
+
+
+@pytest.mark.parametrize("name", list(FULL))
+def test_full_size_matches_oracle(name, oracle_factory):
+    """BASELINE.json's configs at FULL size against the CPU oracle on the same permutation (one scalar QDLDL
+    factorisation each: ~0.1 s cfg 2b, ~7 s cfg 3, ~20 s cfg 5, ~25 s cfg 2a on one host core): resident K bit for bit,
+    regulariser and the number of dynamically regularised pivots equal, unrefined LDL solve to 1e-9, refined solve
+    (kktsolver_solve!) to 1e-10."""
+    rng = np.random.default_rng(23)
+    Pt, A, cones = _prep(FULL[name]())
+    m, n = A.shape
+    st = cl.Settings()
+    hk = HipKKTSolver(Pt, A, cones, m, n, st)
+    ok_ = oracle_factory(Pt, A, cones, m, n, st, ordering=hk.h.perm())
+    o = ok_.k
+    assert hk.h.nnzL == o.nnzL
+    scale_cones(cones, rng)
+    assert hk.kktsolver_update(cones) and ok_.kktsolver_update(cones)
+    assert np.array_equal(hk.h.kkt()[2], o.nzval)
+    assert abs(hk.diagonal_regularizer - ok_.diagonal_regularizer) <= 1e-16 * max(1.0, ok_.diagonal_regularizer)
+    in_twin = hk.h.counters()["in_twin"]      # cfg 5: a factorisation that broke down in the cheap order was repeated in
+    if not in_twin:                           # the robust one -- then only the refined results are comparable
+        assert hk.last_nreg == o.L.oracle_kkt_nreg(o.h)
+        b = rng.standard_normal(o.N)
+        xg, xc = hk.h.ldl_solve(b), o.ldl_solve(b)
+        assert np.max(np.abs(xg - xc)) <= 1e-9 * max(1.0, np.max(np.abs(xc)))
+    for rep in range(2):
+        rx, rz = rng.standard_normal(n), rng.standard_normal(m)
+        lx_g, lz_g, lx_c, lz_c = np.zeros(n), np.zeros(m), np.zeros(n), np.zeros(m)
+        hk.kktsolver_setrhs(rx, rz)
+        ok_.kktsolver_setrhs(rx, rz)
+        assert hk.kktsolver_solve(lx_g, lz_g) and ok_.kktsolver_solve(lx_c, lz_c)
+        scale = max(1.0, np.max(np.abs(lx_c)), np.max(np.abs(lz_c)))
+        assert np.max(np.abs(lx_g - lx_c)) <= 1e-10 * scale and np.max(np.abs(lz_g - lz_c)) <= 1e-10 * scale
 
 
 @pytest.mark.parametrize("name", ["cfg2a", "cfg3", "cfg5"])

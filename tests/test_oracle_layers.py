@@ -35,6 +35,32 @@ def test_appendix_b_layout():
     assert list(rows) == [1, 1, 2, 1, 2, 3, 1, 4, 2, 5, 1, 2, 6, 1, 7, 2, 8]
 
 
+def test_genpow_expansion_layout_hand_derived():
+    """GenPowExpansionMap (directldl_datamaps.jl:81-144) on a 2-variable problem with cones [NN(1), GenPow(dim1=2,
+    dim2=1)]: the :triu image gets three extra columns -- q over the cone's first dim1 rows, r over its last dim2
+    rows, p over all of them -- each closed by its diagonal entry D, with Dsigns (-1,-1,+1) (:98).  Layout derived
+    by hand from _csc_colcount_sparsecone / _csc_fill_sparsecone (:101-144); 0-based here."""
+    P = sp.csc_matrix(np.diag([1.0, 2.0]))
+    A = sp.csc_matrix(np.array([[1.0, 2.0], [3.0, 0.0], [0.0, 4.0], [5.0, 6.0]]))
+    numel = np.array([1, 3])
+    k = OracleKKT(P, A, numel, np.array([0, 0], dtype=np.int32), np.array([0, 2], dtype=np.int32), np.array([0, 2]))
+    assert (k.N, k.n, k.m, k.p, k.nnzK, k.nsparse) == (9, 2, 4, 3, 21, 1)
+    assert list(k.colptr) == [0, 1, 2, 5, 7, 9, 12, 15, 17, 21]
+    assert list(k.rowval) == [0, 1, 0, 1, 2, 0, 3, 1, 4, 0, 1, 5, 3, 4, 6, 5, 7, 3, 4, 5, 8]
+    assert list(k.map("map_Hs")) == [4, 6, 8, 11]
+    assert list(k.sparse_map(0, 0)) == [12, 13]          # q
+    assert list(k.sparse_map(0, 1)) == [15]              # r
+    assert list(k.sparse_map(0, 2)) == [17, 18, 19]      # p
+    assert list(k.sparse_map(0, 3)) == [14, 16, 20]      # D
+    assert list(k.map("dsigns")) == [1, 1, -1, -1, -1, -1, -1, -1, 1]
+    # _csc_update_sparsecone(::GenPowerCone), :146-167: K[q] = q*(-sqrt(mu)) etc., D = (-1,-1,+1)
+    pv, qv, rv = np.array([0.1, 0.2, 0.3]), np.array([1.5, -2.5]), np.array([4.0])
+    k.L.oracle_kkt_update_genpow(k.h, 0, 3.0, pv, qv, rv)
+    nz = k.nzval
+    assert list(nz[[12, 13]]) == [-4.5, 7.5] and list(nz[[15]]) == [-12.0]
+    assert np.array_equal(nz[[17, 18, 19]], pv * -3.0) and list(nz[[14, 16, 20]]) == [-1.0, -1.0, 1.0]
+
+
 def _random_problem(rng, n, m_nn, soc_dims=(), psd_dims=(), zero=0, pdiag=True):
     specs = []
     if zero:
