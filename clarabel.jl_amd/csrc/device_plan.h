@@ -62,7 +62,7 @@ struct DevPlan {
     const int *sn_nitems;        // forward items (64-row blocks) of a supernode
     const int *sn_bparent;       // same-segment regular parent, or -1
     int *seg_sync;               // [0,nseg) forward tickets, [nseg,2nseg) backward tickets, then per-supernode counters:
-    int seg_ticket;              // 1: segment-sweep items are atomic tickets (default), 0: blockIdx (A/B timing only)
+    int seg_ticket;              // bit 0 / bit 1: forward / backward segment-sweep items are atomic tickets (default 3); 0: blockIdx
     unsigned spin_limit;         // bound of every spin loop of the persistent sweeps (default 2^20; HIPKKT_SPIN_LIMIT)
     int nseg;                    //   fdone[nsuper], bdone[nsuper], pdone[nsuper]; error word last   // per front: {ticket, error, flags[np]} (zeroed before every front kernel)
     // numeric state

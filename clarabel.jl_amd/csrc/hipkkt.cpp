@@ -167,6 +167,10 @@ struct hipkkt_solver {
 
 namespace {
 
+// seg_sync = [forward tickets | backward tickets] padded to whole 128-byte lines, then fdone / bdone / pdone [nsuper each],
+// then the error word (kernels.hip seg_sync())
+static size_t seg_sync_ints(int nseg, int nsuper) { return (size_t)((2 * nseg + 31) & ~31) + 3 * (size_t)nsuper + 16; }
+
 void init_runtime(hipkkt_solver *S) {
     { const char *pz = getenv("HIPKKT_POISON"); S->poison = pz && pz[0] == '1'; }
     HK_CHECK(hipSetDevice(S->device));
@@ -439,12 +443,12 @@ void setup_device(hipkkt_solver *S) {
     D.nseg = S->nseg;
     {
         const char *tk = getenv("HIPKKT_SEG_TICKET");      // 0: item = blockIdx (A/B timing of the ticket's cost)
-        D.seg_ticket = !(tk && tk[0] == '0');
+        D.seg_ticket = tk ? atoi(tk) : 3;                  // bit 0: forward sweep, bit 1: backward sweep
         const char *sl = getenv("HIPKKT_SPIN_LIMIT");      // tests force a sweep time-out with a tiny bound
         D.spin_limit = sl ? (unsigned)strtoul(sl, nullptr, 10) : (1u << 20);
     }
     {
-        const size_t nsync = 2 * (size_t)S->nseg + 3 * (size_t)P.nsuper + 16;
+        const size_t nsync = seg_sync_ints(S->nseg, P.nsuper);
         D.seg_sync = S->dalloc<int>(nsync);
         HK_CHECK(hipMemset(D.seg_sync, 0, nsync * sizeof(int)));
     }
@@ -591,7 +595,7 @@ void enqueue_factor(hipkkt_solver *S, int static_enable, double eps_const, doubl
 void enqueue_ldl_solve(hipkkt_solver *S) {
     const HostPlan &P = S->plan;
     hipStream_t st = S->stream;
-    launch_permute_in(st, S->d_sin, S->dp.perm, S->d_y, S->N, S->dp.seg_epoch);
+    launch_permute_in(st, S->d_sin, S->dp.perm, S->d_y, S->N, S->dp.seg_epoch, S->dp.seg_sync, 2 * S->nseg);
     // one launch per level (wide bottom levels, and every level on the fallback path); levels of narrow supernodes
     // take the thread-per-supernode kernels
     const bool all = !S->use_persist;   // no persistent kernel at all: level lists over every supernode
@@ -728,7 +732,7 @@ bool recover_from_sweep_failure(hipkkt_solver *S) {
     }
     fprintf(stderr, "hipkkt: a persistent sweep kernel timed out (flags 0x%x); per-level solve kernels for the next %lld LDL solves\n",
             S->h_flags[FL_FRONTFAIL], (long long)(S->persist_retry_at >= 0 ? S->persist_backoff : -1));
-    const size_t nsync = 2 * (size_t)S->nseg + 3 * (size_t)P.nsuper + 16;
+    const size_t nsync = seg_sync_ints(S->nseg, P.nsuper);
     HK_CHECK(hipMemset(S->dp.seg_sync, 0, nsync * sizeof(int)));
     HK_CHECK(hipMemset(S->dp.front_sync, 0, (size_t)std::max(P.front_sync_ints, 16) * sizeof(int)));
     HK_CHECK(hipMemset(S->dp.flags + FL_FRONTFAIL, 0, sizeof(int)));
@@ -1465,6 +1469,36 @@ int32_t hipkkt_get_counters(hipkkt_handle h, int64_t *o) {
     o[0] = h->n_sweep_timeouts; o[1] = h->use_persist ? 1 : 0; o[2] = h->n_twin_refactors; o[3] = h->fallback ? 1 : 0;
     o[4] = h->using_fallback ? 1 : 0; o[5] = h->plan.ordering_used; o[6] = (int64_t)h->plan.fronts.size(); o[7] = h->nseg;
     return HIPKKT_OK;
+}
+
+// developer diagnostic (not part of the plugin contract): internal vectors of the last LDL solve / plan tables as doubles.
+// what: 0 = the permuted right-hand side, 1 = z (forward result / D), 2 = x (permuted), 3 = ubuf, 10 = sn_first, 11 = sn_level,
+// 12 = rows per supernode, 13 = sn_parent, 14 = persistent-sweep membership (1 = item of a segment launch)
+int32_t hipkkt_debug_dump(hipkkt_handle h, int32_t what, double *out, int64_t cap, int64_t *len) {
+    HK_ENTER(h)
+    const HostPlan &P = S->plan;
+    auto dev = [&](const double *p, int64_t n) {
+        if (len) *len = n;
+        if (out && cap >= n) HK_CHECK(hipMemcpy(out, p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+    };
+    auto host = [&](int64_t n, auto f) {
+        if (len) *len = n;
+        if (out && cap >= n) for (int64_t i = 0; i < n; i++) out[i] = (double)f(i);
+    };
+    switch (what) {
+        case 0: dev(S->d_y, S->N); break;
+        case 1: dev(S->d_z, S->N); break;
+        case 2: dev(S->d_xp, S->N); break;
+        case 3: dev(S->dp.ubuf, P.ubuf_len); break;
+        case 10: host(P.nsuper + 1, [&](int64_t i) { return P.sn_first[i]; }); break;
+        case 11: host(P.nsuper, [&](int64_t i) { return P.sn_level[i]; }); break;
+        case 12: host(P.nsuper, [&](int64_t i) { return P.sn_rowptr[i + 1] - P.sn_rowptr[i]; }); break;
+        case 13: host(P.nsuper, [&](int64_t i) { return P.sn_parent[i]; }); break;
+        case 14: host(P.nsuper, [&](int64_t i) { return P.sn_front[i] < 0 && P.sn_level[i] >= S->seg_lstar[S->seg_of_level[P.sn_level[i]]] ? 1 : 0; }); break;
+        default: return HIPKKT_ERR_ARGUMENT;
+    }
+    return HIPKKT_OK;
+    HK_LEAVE
 }
 
 int32_t hipkkt_reset_timing(hipkkt_handle h) {

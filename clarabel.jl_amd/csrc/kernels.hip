@@ -903,10 +903,17 @@ __global__ void k_mfma_probe(const double *__restrict__ A, const double *__restr
 //           (fixed summation order) + unit-upper solve with L11^T.
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-k_permute_in(const double *__restrict__ b, const int *__restrict__ perm, double *__restrict__ y, int n, int *epoch) {
+k_permute_in(const double *__restrict__ b, const int *__restrict__ perm, double *__restrict__ y, int n, int *epoch,
+             int *ticks, int nticks) {
     // first kernel of every LDL solve: a new epoch invalidates the tagged hand-off values of the previous solve
     if (blockIdx.x == 0 && threadIdx.x == 0 && epoch) ((unsigned *)epoch)[0] += 1u;   // wraps after 2^32 solves: any
                                                                                         // two consecutive epochs differ
+    // ... and the ticket words of the segment sweeps start from zero.  They are cleared HERE, by a kernel that runs
+    // no atomics, and live in cache lines of their own (seg_sync layout): a plain store next to a word that other
+    // workgroups are incrementing atomically can lose increments when the writer's L2 writes the line back (seen on
+    // MI355X: duplicate tickets => the last items of a launch silently never ran).
+    if (blockIdx.x == 0)
+        for (int q = threadIdx.x; q < nticks; q += blockDim.x) ticks[q] = 0;
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k < n) y[k] = b[perm[k]];
 }
@@ -972,10 +979,8 @@ k_fwd_level(DevPlan P, int item_begin, double *__restrict__ y, double *__restric
     if (tid < w) {
         const double v = ((part[0][tid] + part[1][tid]) + part[2][tid]) + part[3][tid];
         yv[tid] = v;
-        if (it.blk == 0) {
-            y[f + tid] = v;
-            z[f + tid] = v * P.Dinv[f + tid];
-        }
+        if (it.blk == 0) z[f + tid] = v * P.Dinv[f + tid];   // y keeps the right-hand side: the other block items of
+                                                              // this supernode (same launch) may still have to read it
     } else if (tid < kMaxSnWidth) {
         yv[tid] = 0.0;   // padded columns multiply prefetched zeros: keep them finite
     }
@@ -1057,10 +1062,7 @@ k_fwd_narrow(DevPlan P, int sn_begin, int n, double *__restrict__ y, double *__r
         for (int k = 0; k <= i; k++)
             if (i < w) v += li[i + k * w] * rhs[k];
         yv[i] = v;
-        if (i < w) {
-            y[f + i] = v;
-            z[f + i] = v * P.Dinv[f + i];
-        }
+        if (i < w) z[f + i] = v * P.Dinv[f + i];
     }
     double *u = P.ubuf + P.u_off[s];
     for (int row = w; row < r; row++) {
@@ -1232,7 +1234,7 @@ __device__ __forceinline__ bool front_slot_wait(const FrontSlot *p, double &v, i
     }
 }
 __device__ __forceinline__ FrontSlot *front_slots(int *sync_block, int np) {
-    return (FrontSlot *)(sync_block + ((2 + np + 15) & ~15));
+    return (FrontSlot *)(sync_block + ((2 + np + 31) & ~31));   // header = whole 128-byte lines (symbolic.cpp sync_blk)
 }
 
 __global__ void __launch_bounds__(256)
@@ -1342,10 +1344,7 @@ k_front_fwd(DevPlan P, FrontDesc F, double *__restrict__ y, double *__restrict__
     if (wv == 0) {
         const double v = valid ? ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane] : 0.0;
         if (ok) front_slot_st(slots + b * 64 + lane, v);     // first: the next panel's owner is waiting for it
-        if (valid && ok) {
-            y[me.f + lane] = v;
-            z[me.f + lane] = v * dinv_own;
-        }
+        if (valid && ok) z[me.f + lane] = v * dinv_own;
     }
 }
 
@@ -1487,9 +1486,9 @@ struct SegSync {
 };
 __device__ __forceinline__ SegSync seg_sync(const DevPlan &P, int nsuper) {
     SegSync s;
-    s.ftick = P.seg_sync;
+    s.ftick = P.seg_sync;                                 // ticket words: [0, 2 nseg), padded to whole 128-byte lines
     s.btick = P.seg_sync + P.nseg;
-    s.fdone = P.seg_sync + 2 * P.nseg;
+    s.fdone = P.seg_sync + ((2 * P.nseg + 31) & ~31);     // (mirrored by seg_sync_ints() in hipkkt.cpp)
     s.bdone = s.fdone + nsuper;
     s.pdone = s.bdone + nsuper;
     s.err = s.pdone + nsuper;
@@ -1565,17 +1564,16 @@ k_fwd_seg(DevPlan P, int seg, int item_begin, int nitems, int nsuper, int first_
     // item = a ticket taken in arrival order (level order): an item only ever waits for items with lower tickets, whose
     // owners are therefore already running -- forward progress does not depend on the order in which the hardware
     // dispatches workgroups.  One atomic per workgroup (~11 ns each on one word); the wide bottom levels, where that
-    // would add up, are not part of the persistent launches (hipkkt.cpp kPersistMaxItems).  seg_ticket == 0 selects
-    // item = blockIdx (in-order dispatch assumed; kept for A/B timing only: HIPKKT_SEG_TICKET=0).
-    if (P.seg_ticket) {
+    // would add up, are not part of the persistent launches (hipkkt.cpp kPersistMaxItems).  seg_ticket bit 0 clear selects
+    // item = blockIdx (in-order dispatch assumed; kept for A/B timing only: HIPKKT_SEG_TICKET=0; bit 1 = backward sweep).
+    if (P.seg_ticket & 1) {
         if (tid == 0) sb = atomicAdd(Y.ftick + seg, 1);
         __syncthreads();
     }
-    const int t = P.seg_ticket ? sb : (int)blockIdx.x;
-    if (P.seg_ticket) __syncthreads();   // sb is reused below
+    const int t = (P.seg_ticket & 1) ? sb : (int)blockIdx.x;
+    if (P.seg_ticket & 1) __syncthreads();   // sb is reused below
     if (t >= nitems) return;
     if (first_launch && t == 0) {   // re-arm the backward sweep's state (idle during the forward sweep)
-        for (int q = tid; q < P.nseg; q += 256) Y.btick[q] = 0;
         for (int q = tid; q < 2 * nsuper; q += 256) Y.bdone[q] = 0;   // bdone and pdone are adjacent
     }
     const FacItem it = P.slv_items[item_begin + t];
@@ -1657,10 +1655,7 @@ k_fwd_seg(DevPlan P, int seg, int item_begin, int nitems, int nsuper, int first_
     if (tid < w) {
         const double v = ((part[0][tid] + part[1][tid]) + part[2][tid]) + part[3][tid];
         yv[tid] = v;
-        if (it.blk == 0) {
-            y[f + tid] = v;
-            z[f + tid] = v * dinv_own;
-        }
+        if (it.blk == 0) z[f + tid] = v * dinv_own;   // y is never overwritten (see k_fwd_level)
     } else if (tid < kMaxSnWidth) {
         yv[tid] = 0.0;
     }
@@ -1696,12 +1691,11 @@ k_bwd_seg(DevPlan P, int seg, int item_begin, int nitems, int nsuper, int first_
     const SegSync Y = seg_sync(P, nsuper);
     const int tid = threadIdx.x;
     __shared__ int tick;
-    if (tid == 0) { bad = 0; tick = P.seg_ticket ? atomicAdd(Y.btick + seg, 1) : (int)blockIdx.x; }   // see k_fwd_seg
+    if (tid == 0) { bad = 0; tick = (P.seg_ticket & 2) ? atomicAdd(Y.btick + seg, 1) : (int)blockIdx.x; }   // see k_fwd_seg
     __syncthreads();                // `bad` may be set by any wave from here on
     const int t = tick;
     if (t >= nitems) return;
     if (first_launch && t == 0) {   // re-arm the forward sweep's counters for the next solve
-        for (int q = tid; q < P.nseg; q += 256) Y.ftick[q] = 0;
         for (int q = tid; q < nsuper; q += 256) Y.fdone[q] = 0;
     }
     const unsigned long long key = seg_key(P);
@@ -2047,8 +2041,8 @@ void launch_invert_diag(hipStream_t st, const DevPlan &P, int n_small, int wmax_
 void launch_mfma_probe(hipStream_t st, const double *A, const double *B, double *out) {
     hipLaunchKernelGGL(k_mfma_probe, dim3(1), dim3(64), 0, st, A, B, out);
 }
-void launch_permute_in(hipStream_t st, const double *b, const int *perm, double *y, int n, int *epoch) {
-    if (n > 0) hipLaunchKernelGGL(k_permute_in, dim3(nblk(n)), dim3(256), 0, st, b, perm, y, n, epoch);
+void launch_permute_in(hipStream_t st, const double *b, const int *perm, double *y, int n, int *epoch, int *ticks, int nticks) {
+    if (n > 0) hipLaunchKernelGGL(k_permute_in, dim3(nblk(n)), dim3(256), 0, st, b, perm, y, n, epoch, ticks, nticks);
 }
 void launch_fwd_level(hipStream_t st, const DevPlan &P, int item_begin, int nitems, double *y, double *z) {
     if (nitems > 0) hipLaunchKernelGGL(k_fwd_level, dim3(nitems), dim3(256), 0, st, P, item_begin, y, z);

@@ -677,9 +677,9 @@ std::string build_plan(int N, const int64_t *Ap, const int64_t *Ai, const int64_
             F.ubelow_off = P.u_off[s0 + np - 1];
             F.rows_off = P.sn_rowptr[s0];
             F.sync_off = sync_ints;
-            // two blocks (forward sweep, backward sweep): {ticket, error, flags[np]} padded to 16 ints, then np x 64
+            // two blocks (forward sweep, backward sweep): {ticket, error, flags[np]} padded to 32 ints (128 B), then np x 64
             // hand-off slots of 16 bytes (value, self-validating tag: kernels.hip front_slot_*)
-            F.sync_blk = ((2 + np + 15) & ~15) + np * 64 * 4;
+            F.sync_blk = ((2 + np + 31) & ~31) + np * 64 * 4;   // multiple of 32 ints: the two blocks share no cache line
             sync_ints += 2 * F.sync_blk;
             for (int p = 0; p < np; p++) {
                 const int s = s0 + p;

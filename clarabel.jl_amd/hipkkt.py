@@ -24,7 +24,7 @@ SYMBOLS = [
     "hipkkt_set_hs", "hipkkt_set_hs_dev", "hipkkt_set_hs_psd", "hipkkt_block_products", "hipkkt_set_soc", "hipkkt_set_soc_batch", "hipkkt_set_genpow",
     "hipkkt_update_P", "hipkkt_update_A", "hipkkt_refactor", "hipkkt_setrhs", "hipkkt_setrhs_dev", "hipkkt_solve",
     "hipkkt_solve_dev", "hipkkt_ldl_solve", "hipkkt_get_timing", "hipkkt_reset_timing", "hipkkt_get_profile", "hipkkt_set_profiling",
-    "hipkkt_get_counters",
+    "hipkkt_get_counters", "hipkkt_debug_dump",
     "hipkkt_selftest_mfma", "hipkkt_last_error",
 ]
 
@@ -93,6 +93,7 @@ def lib():
     L.hipkkt_get_profile.argtypes = [vp, _f64p]
     L.hipkkt_set_profiling.argtypes = [vp, i32]
     L.hipkkt_get_counters.argtypes = [vp, _i64p]
+    L.hipkkt_debug_dump.argtypes = [vp, i32, vp, i64, C.POINTER(i64)]
     L.hipkkt_selftest_mfma.argtypes = [i32, C.POINTER(f64)]
     L.hipkkt_last_error.argtypes = [vp]
     L.hipkkt_last_error.restype = C.c_char_p
@@ -232,6 +233,13 @@ class Handle:
         self.L.hipkkt_get_counters(self.h, o)
         return dict(sweep_timeouts=int(o[0]), persistent=bool(o[1]), twin_refactors=int(o[2]), twin_exists=bool(o[3]),
                     in_twin=bool(o[4]), ordering=int(o[5]), fronts=int(o[6]), segments=int(o[7]))
+
+    def debug_dump(self, what):
+        ln = C.c_int64(0)
+        self._chk(self.L.hipkkt_debug_dump(self.h, what, None, 0, C.byref(ln)), "debug_dump")
+        out = np.zeros(max(ln.value, 1))
+        self._chk(self.L.hipkkt_debug_dump(self.h, what, out.ctypes.data, ln.value, C.byref(ln)), "debug_dump")
+        return out[: ln.value]
 
     def profile(self):
         o = np.zeros(8)

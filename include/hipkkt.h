@@ -208,6 +208,12 @@ int32_t hipkkt_set_profiling(hipkkt_handle h, int32_t enable);
  * out[7] = #segments */
 int32_t hipkkt_get_counters(hipkkt_handle h, int64_t *out8);
 
+/* developer diagnostic, not part of the plugin contract: copies an internal vector of the last LDL solve (what = 0 the
+ * permuted right-hand side, 1 z = D^-1 L^-1 b, 2 x in permuted order, 3 the forward update vectors) or a plan table converted to doubles (10 supernode first
+ * columns, 11 levels, 12 rows per supernode, 13 parents, 14 membership in the persistent sweeps); *len receives the
+ * length, nothing is copied when cap is too small */
+int32_t hipkkt_debug_dump(hipkkt_handle h, int32_t what, double *out, int64_t cap, int64_t *len);
+
 /* diagnostic: checks the FP64 matrix-core operand/result lane maps used by the update kernel
  * against a host product with an asymmetric B (returns 0 when they agree to 1e-12) */
 int32_t hipkkt_selftest_mfma(int32_t device_id, double *max_err);
