@@ -249,4 +249,191 @@ void amd_order(int n, const int64_t *Ap, const int64_t *Ai, double dense_scale, 
     perm.swap(out);
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// Nested dissection by breadth-first level structures (George's automatic nested dissection), minimum degree on the
+// leaves.  Why it exists: on the GPU a factorisation / triangular solve costs (levels of the supernodal elimination
+// tree) x (a few microseconds of dependency latency) + flops / throughput.  Minimum degree minimises the second
+// term only; on banded / grid-like KKT systems (cfg 2b, the Maros-Meszaros-like batch) it produces a CHAIN of ~150
+// dependent supernodes where dissection gives a balanced tree of depth ~log2(N / leaf) with separators of the size
+// of the bandwidth.  build_plan() evaluates both orders with a latency + throughput model and keeps the cheaper one,
+// so problems without small separators (cfg 2a: uniform random pattern) keep the minimum-degree order.
+// Host code, once per problem; any order only changes rounding.
+// ------------------------------------------------------------------------------------------------------------
+namespace {
+
+struct NDGraph {
+    int n;
+    std::vector<int64_t> xadj;
+    std::vector<int> adj;
+    std::vector<int> region;     // current region id of every node (-1 = already ordered / separator)
+    std::vector<int> lvl;        // scratch: BFS level
+    std::vector<int> queue;
+    double dense_scale;
+    int leaf_size;
+    int next_region = 1;
+};
+
+// BFS over the nodes of region `rid` from `root`; fills G.queue (visit order) and G.lvl; returns the number of levels
+int nd_bfs(NDGraph &G, int rid, int root, std::vector<int> &lvl_ptr) {
+    G.queue.clear();
+    lvl_ptr.clear();
+    G.queue.push_back(root);
+    G.lvl[root] = 0;
+    lvl_ptr.push_back(0);
+    size_t head = 0;
+    int cur = 0;
+    while (head < G.queue.size()) {
+        const int v = G.queue[head];
+        if (G.lvl[v] != cur) { cur = G.lvl[v]; lvl_ptr.push_back((int)head); }
+        head++;
+        for (int64_t p = G.xadj[v]; p < G.xadj[v + 1]; p++) {
+            const int u = G.adj[p];
+            if (G.region[u] == rid && G.lvl[u] < 0) { G.lvl[u] = cur + 1; G.queue.push_back(u); }
+        }
+    }
+    lvl_ptr.push_back((int)G.queue.size());
+    return (int)lvl_ptr.size() - 1;
+}
+
+void nd_leaf(NDGraph &G, const std::vector<int> &nodes, std::vector<int> &out) {
+    // minimum degree on the induced subgraph (upper-triangular CSC in local numbering)
+    const int nl = (int)nodes.size();
+    if (nl <= 2) { out.insert(out.end(), nodes.begin(), nodes.end()); return; }
+    std::vector<int> &loc = G.lvl;       // scratch reuse: local index of a node, restored to -1 below
+    for (int i = 0; i < nl; i++) loc[nodes[i]] = i;
+    std::vector<int64_t> cp(nl + 1, 0);
+    std::vector<int64_t> ci;
+    for (int j = 0; j < nl; j++) {
+        const int v = nodes[j];
+        for (int64_t p = G.xadj[v]; p < G.xadj[v + 1]; p++) {
+            const int u = G.adj[p];
+            if (loc[u] >= 0 && loc[u] < j && nodes[loc[u]] == u) ci.push_back(loc[u]);
+        }
+        ci.push_back(j);
+        cp[j + 1] = (int64_t)ci.size();
+    }
+    for (int i = 0; i < nl; i++) loc[nodes[i]] = -1;
+    std::vector<int> lp;
+    amd_order(nl, cp.data(), ci.data(), G.dense_scale, lp, nullptr);
+    for (int k : lp) out.push_back(nodes[k]);
+}
+
+void nd_dissect(NDGraph &G, std::vector<int> nodes, std::vector<int> &out, int depth) {
+    const int nn = (int)nodes.size();
+    if (nn <= G.leaf_size || depth > 40) { nd_leaf(G, nodes, out); return; }
+    const int rid = G.next_region++;
+    for (int v : nodes) { G.region[v] = rid; G.lvl[v] = -1; }
+    // connected components first: independent subtrees
+    std::vector<int> lvl_ptr;
+    {
+        int nlev = nd_bfs(G, rid, nodes[0], lvl_ptr);
+        (void)nlev;
+        if ((int)G.queue.size() < nn) {
+            std::vector<std::vector<int>> comps;
+            comps.emplace_back(G.queue);
+            for (int v : nodes)
+                if (G.lvl[v] < 0) { nd_bfs(G, rid, v, lvl_ptr); comps.emplace_back(G.queue); }
+            for (int v : nodes) G.lvl[v] = -1;
+            for (auto &c : comps) nd_dissect(G, std::move(c), out, depth + 1);
+            return;
+        }
+    }
+    // pseudo-peripheral root: repeat BFS from a minimum-degree node of the last level while the depth grows
+    int root = nodes[0], nlev = (int)lvl_ptr.size() - 1;
+    for (int it = 0; it < 4; it++) {
+        int best = -1;
+        int64_t bestdeg = INT64_MAX;
+        for (int q = lvl_ptr[nlev - 1]; q < lvl_ptr[nlev]; q++) {
+            const int v = G.queue[q];
+            const int64_t d = G.xadj[v + 1] - G.xadj[v];
+            if (d < bestdeg) { bestdeg = d; best = v; }
+        }
+        for (int v : nodes) G.lvl[v] = -1;
+        std::vector<int> lp2;
+        const int nl2 = nd_bfs(G, rid, best, lp2);
+        const bool better = nl2 > nlev;
+        root = best; nlev = nl2; lvl_ptr.swap(lp2);
+        if (!better) break;
+    }
+    (void)root;
+    if (nlev < 5) { for (int v : nodes) G.lvl[v] = -1; nd_leaf(G, nodes, out); return; }   // no usable level structure
+    // separator level: the smallest level among those that leave 30..70 % of the nodes on the near side
+    int m = -1;
+    int64_t msize = INT64_MAX;
+    for (int l = 1; l + 1 < nlev; l++) {
+        const int before = lvl_ptr[l], size = lvl_ptr[l + 1] - lvl_ptr[l];
+        if (before < 0.3 * nn || before + size > 0.7 * nn) continue;
+        if (size < msize) { msize = size; m = l; }
+    }
+    if (m < 0) {   // one huge level around the middle: take the level that contains the median node
+        for (int l = 1; l + 1 < nlev; l++)
+            if (lvl_ptr[l + 1] > nn / 2) { m = l; break; }
+        if (m < 0) m = nlev / 2;
+        msize = lvl_ptr[m + 1] - lvl_ptr[m];
+    }
+    if (msize > 0.2 * nn) { for (int v : nodes) G.lvl[v] = -1; nd_leaf(G, nodes, out); return; }   // separators too fat: minimum degree does better
+    std::vector<int> A, B, S;
+    A.reserve(lvl_ptr[m + 1]); B.reserve(nn - lvl_ptr[m + 1]);
+    for (int q = 0; q < lvl_ptr[m]; q++) A.push_back(G.queue[q]);
+    for (int q = lvl_ptr[m]; q < lvl_ptr[m + 1]; q++) {      // thin the level: only nodes that touch the far side separate
+        const int v = G.queue[q];
+        bool touches = false;
+        for (int64_t p = G.xadj[v]; p < G.xadj[v + 1] && !touches; p++) {
+            const int u = G.adj[p];
+            touches = G.region[u] == rid && G.lvl[u] == m + 1;
+        }
+        (touches ? S : A).push_back(v);
+    }
+    for (int q = lvl_ptr[m + 1]; q < nn; q++) B.push_back(G.queue[q]);
+    for (int v : nodes) G.lvl[v] = -1;
+    for (int v : S) G.region[v] = -1;
+    nd_dissect(G, std::move(A), out, depth + 1);
+    nd_dissect(G, std::move(B), out, depth + 1);
+    out.insert(out.end(), S.begin(), S.end());
+}
+
+}  // namespace
+
+void nd_order(int n, const int64_t *Ap, const int64_t *Ai, double dense_scale, int leaf_size, std::vector<int> &perm) {
+    perm.clear();
+    perm.reserve(n);
+    if (n == 0) return;
+    NDGraph G;
+    G.n = n;
+    G.dense_scale = dense_scale;
+    G.leaf_size = std::max(8, leaf_size);
+    G.xadj.assign(n + 1, 0);
+    for (int j = 0; j < n; j++)
+        for (int64_t p = Ap[j]; p < Ap[j + 1]; p++) {
+            const int i = (int)Ai[p];
+            if (i != j) { G.xadj[i + 1]++; G.xadj[j + 1]++; }
+        }
+    for (int i = 0; i < n; i++) G.xadj[i + 1] += G.xadj[i];
+    G.adj.resize(G.xadj[n]);
+    {
+        std::vector<int64_t> nxt(G.xadj.begin(), G.xadj.end() - 1);
+        for (int j = 0; j < n; j++)
+            for (int64_t p = Ap[j]; p < Ap[j + 1]; p++) {
+                const int i = (int)Ai[p];
+                if (i != j) { G.adj[nxt[i]++] = j; G.adj[nxt[j]++] = i; }
+            }
+    }
+    G.region.assign(n, 0);
+    G.lvl.assign(n, -1);
+    // very dense rows would glue every level structure together: ordered last, like amd_order does
+    std::vector<int> nodes, dense;
+    const double thresh = std::max(16.0, dense_scale * 10.0 * std::sqrt((double)n));
+    for (int i = 0; i < n; i++) {
+        if ((double)(G.xadj[i + 1] - G.xadj[i]) > thresh) { dense.push_back(i); G.region[i] = -1; }
+        else nodes.push_back(i);
+    }
+    nd_dissect(G, std::move(nodes), perm, 0);
+    std::sort(dense.begin(), dense.end(), [&](int a, int b) {
+        const int64_t da = G.xadj[a + 1] - G.xadj[a], db = G.xadj[b + 1] - G.xadj[b];
+        return da != db ? da < db : a < b;
+    });
+    perm.insert(perm.end(), dense.begin(), dense.end());
+}
+
 }  // namespace hipkkt

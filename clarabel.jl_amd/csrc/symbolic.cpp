@@ -70,6 +70,53 @@ void postorder(int N, const std::vector<int> &parent, std::vector<int> &post) {
     }
 }
 
+// Cost of one KKT iteration unit (1 factorisation + ~6 triangular solve pairs) predicted for an elimination order, in
+// seconds: dependency latency per level of the (fundamental, width-capped) supernodal elimination tree + factor flops
+// at the rate the dense kernels sustain + the solves' traffic.  Constants measured on MI355X (DESIGN.md section 7:
+// cfg 2b 4.3 ms / 150 levels per factorisation, 6 us per level and solve; cfg 2a 11.7 TFLOP/s over the whole
+// factorisation).  Only used to choose between candidate orders.
+struct OrderCost {
+    double flops = 0, nnzL = 0, seconds = 0;
+    int levels = 0;
+};
+OrderCost order_cost(int N, const int64_t *Ap, const int64_t *Ai, const std::vector<int> &perm, int maxw) {
+    std::vector<int> ip(N);
+    for (int k = 0; k < N; k++) ip[perm[k]] = k;
+    std::vector<int64_t> up;
+    std::vector<int> ui, parent, cnt, post;
+    permuted_upper(N, Ap, Ai, ip, up, ui);
+    etree_counts(N, up, ui, parent, cnt);
+    postorder(N, parent, post);
+    std::vector<int> newlab(N), par2(N), cnt2(N);
+    for (int k = 0; k < N; k++) newlab[post[k]] = k;
+    for (int k = 0; k < N; k++) {
+        const int o = post[k];
+        par2[k] = parent[o] < 0 ? -1 : newlab[parent[o]];
+        cnt2[k] = cnt[o];
+    }
+    OrderCost c;
+    // supernodes: fundamental, cut at maxw columns; level = longest chain of supernodes below
+    std::vector<int> sn_of(N), sn_last;
+    int ns = 0, width = 0;
+    for (int j = 0; j < N; j++) {
+        const bool cont = j > 0 && par2[j - 1] == j && cnt2[j - 1] == cnt2[j] + 1 && width < maxw;
+        if (!cont) { ns++; width = 0; sn_last.push_back(j); }
+        else sn_last.back() = j;
+        width++;
+        sn_of[j] = ns - 1;
+        c.flops += (double)cnt2[j] * cnt2[j] + 3.0 * cnt2[j];
+        c.nnzL += cnt2[j];
+    }
+    std::vector<int> level(ns, 0);
+    for (int s = 0; s < ns; s++) {
+        const int pj = par2[sn_last[s]];
+        if (pj >= 0) level[sn_of[pj]] = std::max(level[sn_of[pj]], level[s] + 1);
+        c.levels = std::max(c.levels, level[s] + 1);
+    }
+    c.seconds = c.levels * 64e-6 + c.flops / 12e12 + 6.0 * 24.0 * c.nnzL / 1.5e12;
+    return c;
+}
+
 struct TaskKey {
     int32_t stage, tgt, rb, src;
     int32_t task;
@@ -122,6 +169,17 @@ std::string build_plan(int N, const int64_t *Ap, const int64_t *Ai, const int64_
                 // only worth a different elimination order when the factorisation is expensive at all
                 if (cost[0] > 1e9 && cost[1] < 0.7 * cost[0]) { perm0.swap(perm1); P.ordering_used = 1; }
             }
+        }
+    }
+    if (!user_perm && opt.nd_mode > 0 && N >= 64) {
+        // third candidate: nested dissection (ordering.cpp) -- far fewer dependent levels on banded / grid-like systems
+        std::vector<int> permN;
+        nd_order(N, Ap, Ai, opt.amd_dense_scale, opt.nd_leaf, permN);
+        if ((int)permN.size() == N) {
+            const OrderCost c0 = order_cost(N, Ap, Ai, perm0, maxw), c1 = order_cost(N, Ap, Ai, permN, maxw);
+            P.cost_md_seconds = c0.seconds; P.cost_nd_seconds = c1.seconds;
+            P.cost_md_levels = c0.levels; P.cost_nd_levels = c1.levels;
+            if (opt.nd_mode >= 2 || c1.seconds < 0.8 * c0.seconds) { perm0.swap(permN); P.ordering_used = 3; }
         }
     }
     std::vector<int> iperm0(N);

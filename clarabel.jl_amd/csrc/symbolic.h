@@ -110,6 +110,9 @@ struct PlanOptions {
     int n_hold = 0;            // > 0: also try the "variables last" order (nodes < n_hold held back) and keep
                                // whichever order predicts fewer factor flops
     int front_min_panels = 4;  // chains at least this long are solved by the persistent front kernels (0 = never)
+    int nd_mode = 1;           // nested dissection candidate: 0 never, 1 when the latency + throughput model predicts a
+                               // >= 20 % cheaper KKT iteration than minimum degree, 2 always
+    int nd_leaf = 256;         // subgraphs of at most this many nodes are ordered by minimum degree
 };
 
 struct HostPlan {
@@ -182,7 +185,9 @@ struct HostPlan {
     int64_t diag_doubles = 0;
     int64_t ubuf_len = 0;
     int etree_height = 0;
-    int ordering_used = 0;       // 0 = minimum degree on K, 1 = cone rows first / variables last, 2 = user
+    int ordering_used = 0;       // 0 = minimum degree on K, 1 = cone rows first / variables last, 2 = user, 3 = nested dissection
+    double cost_md_seconds = 0, cost_nd_seconds = 0;   // predicted seconds per KKT iteration unit of the two candidates
+    int cost_md_levels = 0, cost_nd_levels = 0;
     double flops_colcount = 0;   // sum_j c_j^2 + 3 c_j
     double flops_update = 0;     // executed flops of the dense update tasks (2*rows*cols*k)
     double flops_exec = 0;       // update + diagonal-block + TRSM flops actually executed
@@ -195,5 +200,7 @@ std::string build_plan(int N, const int64_t *Ap, const int64_t *Ai, const int64_
 
 void amd_order(int n, const int64_t *Ap, const int64_t *Ai, double dense_scale, std::vector<int> &perm,
                const char *hold = nullptr);
+// nested dissection by BFS level structures, minimum degree on leaves of <= leaf_size nodes (ordering.cpp)
+void nd_order(int n, const int64_t *Ap, const int64_t *Ai, double dense_scale, int leaf_size, std::vector<int> &perm);
 
 }  // namespace hipkkt

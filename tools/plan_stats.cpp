@@ -19,6 +19,8 @@ int main(int argc, char **argv) {
     if (argc > 2) opt.max_width = atoi(argv[2]);
     if (argc > 3) opt.update_policy = atoi(argv[3]);
     if (argc > 4) opt.n_hold = atoi(argv[4]);
+    if (argc > 5) opt.nd_mode = atoi(argv[5]);
+    if (argc > 6) opt.nd_leaf = atoi(argv[6]);
     HostPlan P;
     auto t0 = std::chrono::steady_clock::now();
     std::string err = build_plan((int)N, Ap.data(), Ai.data(), nullptr, opt, P);
@@ -27,7 +29,7 @@ int main(int argc, char **argv) {
     printf("N %d nnzK %ld nnzL %ld nsuper %d nlevels %d panel_doubles %ld flops_colcount %.3e flops_update %.3e flops_exec %.3e plan_s %.3f\n",
            P.N, (long)P.nnzK, (long)P.nnzL, P.nsuper, P.nlevels, (long)P.panel_doubles, P.flops_colcount, P.flops_update, P.flops_exec,
            std::chrono::duration<double>(t1 - t0).count());
-    printf("ntasks %zu ngroups %zu ordering_used %d fronts %zu\n", P.upd_tasks.size(), P.upd_groups.size(), P.ordering_used, P.fronts.size());
+    printf("ntasks %zu ngroups %zu ordering_used %d fronts %zu | model: md %.3f ms (%d levels)  nd %.3f ms (%d levels)\n", P.upd_tasks.size(), P.upd_groups.size(), P.ordering_used, P.fronts.size(), 1e3 * P.cost_md_seconds, P.cost_md_levels, 1e3 * P.cost_nd_seconds, P.cost_nd_levels);
     printf("%5s %7s %7s %7s %9s %12s %8s %8s\n", "lvl", "nsn", "maxw", "maxr", "sum_rw", "upd_flops", "groups", "facitems");
     std::vector<double> lf(P.nlevels, 0.0), lfd(P.nlevels, 0.0), fills(P.nlevels, 0.0);
     for (int l = 0; l < P.nlevels; l++)
