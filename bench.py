@@ -264,7 +264,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": workload, "N": h.N, "nnzK": h.nnzK, "nnzL": h.nnzL, "supernodes": h.nsuper,
-                   "levels": h.nlevels, "parallelism": f"{world} independent problem(s), one per GPU"},
+                   "levels": h.nlevels, "ordering": ["minimum degree", "cone rows first, variables last", "user", "nested dissection"][h.ordering], "parallelism": f"{world} independent problem(s), one per GPU"},
         "ipm_iterations_per_s_end_to_end": round(e2e_iters / e2e_time, 4),
         "value_is": "replayed KKT iteration units per second with every input resident in HBM (tier rule for `value`); "
                     "`ipm_iterations_per_s_end_to_end` is SURVEY section 8(d)'s rate: iterations / wall time of the whole IPM loop "

@@ -6,6 +6,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -67,11 +68,12 @@ struct hipkkt_solver {
     std::vector<FacItem> slv_items, bwd_items;
     std::vector<int> slv_lvl_ptr, bwd_lvl_ptr;
     std::vector<int> reg_lvl_sn, reg_lvl_ptr;   // supernodes of every level that are NOT front panels
-    std::vector<char> lvl_narrow;                // [nlevels] every regular supernode is narrow (k_fwd_narrow / k_bwd_narrow)
+    std::vector<int> lvl_wnarrow, all_lvl_wnarrow;   // [nlevels] widest narrow supernode of the level
+    std::vector<int> lvl_nnarrow;                // [nlevels] the first lvl_nnarrow[l] supernodes of a level's list are narrow (one thread each)
     // the same level lists over ALL supernodes (front panels included), appended to the same item arrays: the path without
     // any persistent kernel, taken after a sweep time-out
     std::vector<int> all_slv_lvl_ptr, all_bwd_lvl_ptr, all_reg_lvl_ptr;
-    std::vector<char> all_lvl_narrow;
+    std::vector<int> all_lvl_nnarrow;
     // persistent sweeps over the regular supernodes: segments = level ranges between front kernels
     bool use_persist = true;
     bool persist_allowed = true;         // false: HIPKKT_NO_PERSIST (never tried)
@@ -229,43 +231,11 @@ void setup_device(hipkkt_solver *S) {
         S->p_off[s + 1] = S->p_off[s] + nb * w;
     }
     S->reg_lvl_ptr.assign(P.nlevels + 1, 0);
-    S->lvl_narrow.assign(P.nlevels, 0);
     const char *nn = getenv("HIPKKT_NO_NARROW");
     const bool allow_narrow = !(nn && nn[0] == '1');
-    // Level lists of the per-level solve kernels, appended to slv_items / bwd_items / reg_lvl_sn.  Variant 0 leaves out the
-    // panels of the fronts (the persistent front kernels solve those); variant 1 holds EVERY supernode and is what a
-    // handle falls back to after a persistent sweep timed out (front kernels included: no persistent kernel at all).
-    auto build_level_lists = [&](bool with_fronts, std::vector<int> &slv_ptr, std::vector<int> &bwd_ptr, std::vector<int> &reg_ptr,
-                                 std::vector<char> &narrow_lvl) {
-        slv_ptr.assign(P.nlevels + 1, (int)S->slv_items.size());
-        bwd_ptr.assign(P.nlevels + 1, (int)S->bwd_items.size());
-        reg_ptr.assign(P.nlevels + 1, (int)S->reg_lvl_sn.size());
-        narrow_lvl.assign(P.nlevels, 0);
-        for (int l = 0; l < P.nlevels; l++) {
-            bool narrow = allow_narrow;
-            for (int q = P.lvl_ptr[l]; q < P.lvl_ptr[l + 1]; q++) {
-                int s = P.lvl_sn[q];
-                int w = P.sn_first[s + 1] - P.sn_first[s];
-                S->wmax_all = std::max(S->wmax_all, w);
-                if (!with_fronts && P.sn_front[s] >= 0) continue;      // solved by the persistent front kernels
-                int64_t r = P.sn_rowptr[s + 1] - P.sn_rowptr[s];
-                if (w > kNarrowW || r - w > kNarrowR) narrow = false;
-                int nb = (int)std::max<int64_t>(1, (r - w + 63) / 64);
-                for (int b = 0; b < nb; b++) S->slv_items.push_back({s, b});
-                if (nb > 1)
-                    for (int b = 0; b < nb; b++) S->bwd_items.push_back({s, b});
-                S->reg_lvl_sn.push_back(s);
-            }
-            slv_ptr[l + 1] = (int)S->slv_items.size();
-            bwd_ptr[l + 1] = (int)S->bwd_items.size();
-            reg_ptr[l + 1] = (int)S->reg_lvl_sn.size();
-            narrow_lvl[l] = narrow && reg_ptr[l + 1] - reg_ptr[l] >= 256;
-        }
-    };
-    build_level_lists(false, S->slv_lvl_ptr, S->bwd_lvl_ptr, S->reg_lvl_ptr, S->lvl_narrow);
-    if (!P.fronts.empty()) build_level_lists(true, S->all_slv_lvl_ptr, S->all_bwd_lvl_ptr, S->all_reg_lvl_ptr, S->all_lvl_narrow);
-    else { S->all_slv_lvl_ptr = S->slv_lvl_ptr; S->all_bwd_lvl_ptr = S->bwd_lvl_ptr; S->all_reg_lvl_ptr = S->reg_lvl_ptr; S->all_lvl_narrow = S->lvl_narrow; }
-    // ---- persistent sweeps: segments, dependency lists, backward item order
+    // ---- segments of the persistent sweeps = level ranges between two front kernels; inside a segment the wide bottom
+    //      levels (thousands of leaf supernodes) are cheaper as one launch per level, the persistent kernels take over
+    //      from the first level with fewer than kPersistMaxItems items (seg_lstar)
     std::vector<int> dep_ptr(P.nsuper + 1, 0), dep_idx, sn_nitems(P.nsuper, 0), sn_bparent(P.nsuper, -1);
     std::vector<int> rows_seg;
     {
@@ -275,9 +245,13 @@ void setup_device(hipkkt_solver *S) {
         int sg = 0;
         for (int l = 0; l < P.nlevels; l++) { S->seg_of_level[l] = sg; if (boundary[l]) sg++; }
         S->nseg = sg + 1;
-        auto seg_of = [&](int s) { return S->seg_of_level[P.sn_level[s]]; };
-        // wide bottom levels (thousands of leaf supernodes) are cheaper as one launch per level; the persistent
-        // kernels take over from the first level with fewer than kPersistMaxItems items
+        std::vector<int> lvl_items(P.nlevels, 0);      // forward items of the regular (non-front) supernodes of a level
+        for (int s = 0; s < P.nsuper; s++) {
+            if (P.sn_front[s] >= 0) continue;
+            const int64_t r = P.sn_rowptr[s + 1] - P.sn_rowptr[s];
+            const int w = P.sn_first[s + 1] - P.sn_first[s];
+            lvl_items[P.sn_level[s]] += (int)std::max<int64_t>(1, (r - w + 63) / 64);
+        }
         const int kPersistMaxItems = 1024;
         S->seg_lo.assign(S->nseg, P.nlevels); S->seg_hi.assign(S->nseg, -1); S->seg_lstar.assign(S->nseg, 0);
         for (int l = 0; l < P.nlevels; l++) {
@@ -287,9 +261,72 @@ void setup_device(hipkkt_solver *S) {
         }
         for (int g = 0; g < S->nseg; g++) {
             int ls = S->seg_lo[g];
-            while (ls <= S->seg_hi[g] && S->slv_lvl_ptr[ls + 1] - S->slv_lvl_ptr[ls] >= kPersistMaxItems) ls++;
+            while (ls <= S->seg_hi[g] && lvl_items[ls] >= kPersistMaxItems) ls++;
             S->seg_lstar[g] = ls;
         }
+    }
+    // Level lists of the per-level solve kernels, appended to slv_items / bwd_items / reg_lvl_sn.  Variant 0 leaves out the
+    // panels of the fronts (the persistent front kernels solve those); variant 1 holds EVERY supernode and is what a
+    // handle falls back to after a persistent sweep timed out (front kernels included: no persistent kernel at all).
+    // On a level that gets its own launches the NARROW supernodes (<= kNarrowW columns, <= kNarrowR rows below the
+    // block: the leaves) are listed first and solved one THREAD each (k_fwd_narrow / k_bwd_narrow); they have no items.
+    std::vector<char> has_child(P.nsuper, 0);
+    for (int c = 0; c < P.nsuper; c++)
+        if (P.sn_parent[c] >= 0) has_child[P.sn_parent[c]] = 1;
+    auto build_level_lists = [&](bool with_fronts, std::vector<int> &slv_ptr, std::vector<int> &bwd_ptr, std::vector<int> &reg_ptr,
+                                 std::vector<int> &nnarrow, std::vector<int> &wnarrow) {
+        slv_ptr.assign(P.nlevels + 1, (int)S->slv_items.size());
+        bwd_ptr.assign(P.nlevels + 1, (int)S->bwd_items.size());
+        reg_ptr.assign(P.nlevels + 1, (int)S->reg_lvl_sn.size());
+        nnarrow.assign(P.nlevels, 0);
+        wnarrow.assign(P.nlevels, 1);
+        std::vector<int> nar, reg;
+        for (int l = 0; l < P.nlevels; l++) {
+            const bool own_launches = with_fronts || l < S->seg_lstar[S->seg_of_level[l]];
+            nar.clear(); reg.clear();
+            bool all_tiny = true;    // every supernode of the level has <= 4 columns and <= 16 rows below the block
+            for (int q = P.lvl_ptr[l]; q < P.lvl_ptr[l + 1]; q++) {
+                int s = P.lvl_sn[q];
+                int w = P.sn_first[s + 1] - P.sn_first[s];
+                S->wmax_all = std::max(S->wmax_all, w);
+                if (!with_fronts && P.sn_front[s] >= 0) continue;      // solved by the persistent front kernels
+                int64_t r = P.sn_rowptr[s + 1] - P.sn_rowptr[s];
+                all_tiny = all_tiny && w <= 4 && r - w <= 16;
+            }
+            for (int q = P.lvl_ptr[l]; q < P.lvl_ptr[l + 1]; q++) {
+                int s = P.lvl_sn[q];
+                int w = P.sn_first[s + 1] - P.sn_first[s];
+                if (!with_fronts && P.sn_front[s] >= 0) continue;
+                int64_t r = P.sn_rowptr[s + 1] - P.sn_rowptr[s];
+                // one thread per supernode pays for every gather of a child's update vector with a serial memory round trip:
+                // a level goes to the thread kernels as a whole when all of it is tiny; otherwise only its childless
+                // supernodes (leaves: nothing to gather) do, up to kNarrowW x kNarrowR
+                const bool thr = all_tiny || (!has_child[s] && w <= kNarrowW && r - w <= kNarrowR);
+                (allow_narrow && own_launches && thr ? nar : reg).push_back(s);
+            }
+            if (nar.size() < (all_tiny ? 256u : 64u)) { reg.insert(reg.end(), nar.begin(), nar.end()); std::sort(reg.begin(), reg.end()); nar.clear(); }
+            nnarrow[l] = (int)nar.size();
+            for (int s : nar) wnarrow[l] = std::max(wnarrow[l], P.sn_first[s + 1] - P.sn_first[s]);
+            S->reg_lvl_sn.insert(S->reg_lvl_sn.end(), nar.begin(), nar.end());
+            for (int s : reg) {
+                int w = P.sn_first[s + 1] - P.sn_first[s];
+                int64_t r = P.sn_rowptr[s + 1] - P.sn_rowptr[s];
+                int nb = (int)std::max<int64_t>(1, (r - w + 63) / 64);
+                for (int b = 0; b < nb; b++) S->slv_items.push_back({s, b});
+                if (nb > 1)
+                    for (int b = 0; b < nb; b++) S->bwd_items.push_back({s, b});
+                S->reg_lvl_sn.push_back(s);
+            }
+            slv_ptr[l + 1] = (int)S->slv_items.size();
+            bwd_ptr[l + 1] = (int)S->bwd_items.size();
+            reg_ptr[l + 1] = (int)S->reg_lvl_sn.size();
+        }
+    };
+    build_level_lists(false, S->slv_lvl_ptr, S->bwd_lvl_ptr, S->reg_lvl_ptr, S->lvl_nnarrow, S->lvl_wnarrow);
+    if (!P.fronts.empty() || S->nseg > 0) build_level_lists(true, S->all_slv_lvl_ptr, S->all_bwd_lvl_ptr, S->all_reg_lvl_ptr, S->all_lvl_nnarrow, S->all_lvl_wnarrow);
+    // ---- persistent sweeps: dependency lists, backward item order
+    {
+        auto seg_of = [&](int s) { return S->seg_of_level[P.sn_level[s]]; };
         auto persistent = [&](int s) { return P.sn_level[s] >= S->seg_lstar[seg_of(s)]; };
         std::vector<std::vector<int>> kids(P.nsuper);
         for (int c = 0; c < P.nsuper; c++) {
@@ -601,18 +638,15 @@ void enqueue_ldl_solve(hipkkt_solver *S) {
     const bool all = !S->use_persist;   // no persistent kernel at all: level lists over every supernode
     const std::vector<int> &slvp = all ? S->all_slv_lvl_ptr : S->slv_lvl_ptr, &bwdp = all ? S->all_bwd_lvl_ptr : S->bwd_lvl_ptr,
                            &regp = all ? S->all_reg_lvl_ptr : S->reg_lvl_ptr;
-    const std::vector<char> &narrow = all ? S->all_lvl_narrow : S->lvl_narrow;
+    const std::vector<int> &nnar = all ? S->all_lvl_nnarrow : S->lvl_nnarrow, &wnar = all ? S->all_lvl_wnarrow : S->lvl_wnarrow;
     auto fwd_level = [&](int l) {
-        if (narrow[l]) launch_fwd_narrow(st, S->dp, regp[l], regp[l + 1] - regp[l], S->d_y, S->d_z);
-        else launch_fwd_level(st, S->dp, slvp[l], slvp[l + 1] - slvp[l], S->d_y, S->d_z);
+        launch_fwd_narrow(st, S->dp, regp[l], nnar[l], wnar[l], S->d_y, S->d_z);
+        launch_fwd_level(st, S->dp, slvp[l], slvp[l + 1] - slvp[l], S->d_y, S->d_z);
     };
     auto bwd_level = [&](int l) {
-        if (narrow[l]) {
-            launch_bwd_narrow(st, S->dp, regp[l], regp[l + 1] - regp[l], S->d_z, S->d_xp, S->d_sout);
-            return;
-        }
         launch_bwd_partial(st, S->dp, bwdp[l], bwdp[l + 1] - bwdp[l], S->d_xp);
-        launch_bwd_final(st, S->dp, regp[l], regp[l + 1] - regp[l], S->d_z, S->d_xp, S->d_sout);
+        launch_bwd_final(st, S->dp, regp[l] + nnar[l], regp[l + 1] - regp[l] - nnar[l], S->d_z, S->d_xp, S->d_sout);
+        launch_bwd_narrow(st, S->dp, regp[l], nnar[l], wnar[l], S->d_z, S->d_xp, S->d_sout);
     };
     if (S->use_persist) {
         // one persistent launch per segment of regular levels, front kernels in between
@@ -982,7 +1016,7 @@ int32_t hipkkt_get_dims(hipkkt_handle h, int64_t *o) {
     const HostPlan &P = h->plan;
     o[0] = K.N; o[1] = K.n; o[2] = K.m; o[3] = K.p; o[4] = h->nnzK; o[5] = K.nHs; o[6] = (int64_t)K.smaps.size();
     o[7] = K.nnzP; o[8] = K.nnzA; o[9] = P.nnzL; o[10] = P.nsuper; o[11] = P.nlevels; o[12] = P.panel_doubles;
-    o[13] = (int64_t)P.upd_tasks.size(); o[14] = P.etree_height; o[15] = 0;
+    o[13] = (int64_t)P.upd_tasks.size(); o[14] = P.etree_height; o[15] = P.ordering_used;
     return HIPKKT_OK;
 }
 

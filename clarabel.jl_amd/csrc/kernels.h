@@ -16,8 +16,8 @@ void launch_factor_panel(hipStream_t st, const DevPlan &P, int item_begin, int n
                          bool fused = false);
 void launch_update_stage(hipStream_t st, const DevPlan &P, int group_begin, int ngroups);
 void launch_update_dense(hipStream_t st, const DevPlan &P, int group_begin, int ngroups, int max_wgs = 0);
-void launch_fwd_narrow(hipStream_t st, const DevPlan &P, int sn_begin, int n, double *y, double *z);
-void launch_bwd_narrow(hipStream_t st, const DevPlan &P, int sn_begin, int n, const double *z, double *x, double *xout);
+void launch_fwd_narrow(hipStream_t st, const DevPlan &P, int sn_begin, int n, int wmax, double *y, double *z);
+void launch_bwd_narrow(hipStream_t st, const DevPlan &P, int sn_begin, int n, int wmax, const double *z, double *x, double *xout);
 void launch_psd_hs(hipStream_t st, double *kval, const int64_t *map_hs, int64_t hs_off, const double *W, int n);
 void launch_block_products(hipStream_t st, const DevPlan &P, const double *x, const double *z, double *Px, double *ATz,
                            double *Ax, int n, int m);

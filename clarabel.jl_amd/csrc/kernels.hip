@@ -1034,6 +1034,7 @@ __device__ __forceinline__ double bwd_block_dot(const DevPlan &P, int s, int w, 
 // thousands of 1-2 column leaves of a sparse QP): one THREAD per supernode instead of one 256-thread workgroup --
 // a level-0 launch of cfg 2a drops from 17884 workgroups (39 us) to 70.  Same arithmetic as k_fwd_level /
 // k_bwd_final, sums taken in index order.
+template <int NW>   // NW >= widest supernode of the launch (register arrays)
 __global__ void __launch_bounds__(256)
 k_fwd_narrow(DevPlan P, int sn_begin, int n, double *__restrict__ y, double *__restrict__ z) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1045,9 +1046,9 @@ k_fwd_narrow(DevPlan P, int sn_begin, int n, double *__restrict__ y, double *__r
     const int r = (int)(P.sn_rowptr[s + 1] - slot0);
     const double *pan = P.Lx + P.sn_panel[s];
     const double *li = P.Linv + P.sn_diag[s];
-    double rhs[kNarrowW], yv[kNarrowW];
+    double rhs[NW], yv[NW];
 #pragma unroll
-    for (int k = 0; k < kNarrowW; k++) {
+    for (int k = 0; k < NW; k++) {
         rhs[k] = 0.0;
         if (k < w) {
             double acc = 0.0;
@@ -1056,7 +1057,7 @@ k_fwd_narrow(DevPlan P, int sn_begin, int n, double *__restrict__ y, double *__r
         }
     }
 #pragma unroll
-    for (int i = 0; i < kNarrowW; i++) {
+    for (int i = 0; i < NW; i++) {
         double v = 0.0;
 #pragma unroll
         for (int k = 0; k <= i; k++)
@@ -1069,12 +1070,13 @@ k_fwd_narrow(DevPlan P, int sn_begin, int n, double *__restrict__ y, double *__r
         double a = 0.0;
         for (int64_t g = P.g_ptr[slot0 + row]; g < P.g_ptr[slot0 + row + 1]; g++) a += P.ubuf[P.g_idx[g]];
 #pragma unroll
-        for (int k = 0; k < kNarrowW; k++)
+        for (int k = 0; k < NW; k++)
             if (k < w) a += pan[row + (int64_t)k * r] * yv[k];
         u[row - w] = a;
     }
 }
 
+template <int NW>
 __global__ void __launch_bounds__(256)
 k_bwd_narrow(DevPlan P, int sn_begin, int n, const double *__restrict__ z, double *__restrict__ x, double *__restrict__ xout) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1087,20 +1089,20 @@ k_bwd_narrow(DevPlan P, int sn_begin, int n, const double *__restrict__ z, doubl
     const int *rows = P.sn_rows + slot0;
     const double *lt = P.LT + P.lt_off[s];          // row-major: lt[(i - w) * w + k]
     const double *lit = P.LinvT + P.sn_diag[s];     // Linv[i][k] at [k + i * w]
-    double tv[kNarrowW];
+    double tv[NW];
 #pragma unroll
-    for (int k = 0; k < kNarrowW; k++) tv[k] = k < w ? z[f + k] : 0.0;
+    for (int k = 0; k < NW; k++) tv[k] = k < w ? z[f + k] : 0.0;
     for (int i = w; i < r; i++) {
         const double xi = x[rows[i]];
 #pragma unroll
-        for (int k = 0; k < kNarrowW; k++)
+        for (int k = 0; k < NW; k++)
             if (k < w) tv[k] -= lt[(int64_t)(i - w) * w + k] * xi;
     }
 #pragma unroll
-    for (int k = 0; k < kNarrowW; k++) {
+    for (int k = 0; k < NW; k++) {
         double v = 0.0;
 #pragma unroll
-        for (int i = k; i < kNarrowW; i++)
+        for (int i = k; i < NW; i++)
             if (i < w) v += lit[k + i * w] * tv[i];
         if (k < w) {
             x[f + k] = v;
@@ -1968,11 +1970,15 @@ void launch_update_dense(hipStream_t st, const DevPlan &P, int group_begin, int 
         default: hipLaunchKernelGGL((k_update_dense<1, 4>), dim3(ngroups), dim3(256), 0, st, P, group_begin, ngroups);
         }
 }
-void launch_fwd_narrow(hipStream_t st, const DevPlan &P, int sn_begin, int n, double *y, double *z) {
-    if (n > 0) hipLaunchKernelGGL(k_fwd_narrow, dim3(nblk(n)), dim3(256), 0, st, P, sn_begin, n, y, z);
+void launch_fwd_narrow(hipStream_t st, const DevPlan &P, int sn_begin, int n, int wmax, double *y, double *z) {
+    if (n <= 0) return;
+    if (wmax <= 4) hipLaunchKernelGGL(k_fwd_narrow<4>, dim3(nblk(n)), dim3(256), 0, st, P, sn_begin, n, y, z);
+    else hipLaunchKernelGGL(k_fwd_narrow<kNarrowW>, dim3(nblk(n)), dim3(256), 0, st, P, sn_begin, n, y, z);
 }
-void launch_bwd_narrow(hipStream_t st, const DevPlan &P, int sn_begin, int n, const double *z, double *x, double *xout) {
-    if (n > 0) hipLaunchKernelGGL(k_bwd_narrow, dim3(nblk(n)), dim3(256), 0, st, P, sn_begin, n, z, x, xout);
+void launch_bwd_narrow(hipStream_t st, const DevPlan &P, int sn_begin, int n, int wmax, const double *z, double *x, double *xout) {
+    if (n <= 0) return;
+    if (wmax <= 4) hipLaunchKernelGGL(k_bwd_narrow<4>, dim3(nblk(n)), dim3(256), 0, st, P, sn_begin, n, z, x, xout);
+    else hipLaunchKernelGGL(k_bwd_narrow<kNarrowW>, dim3(nblk(n)), dim3(256), 0, st, P, sn_begin, n, z, x, xout);
 }
 // zero a few 32-bit words.  Small hipMemsetAsync nodes inside a captured hipGraph are not reliable in every ROCm
 // set-up (under rocprofv3 the 16-byte memset of the flag words was seen to write its own arguments instead of

@@ -171,7 +171,7 @@ std::string build_plan(int N, const int64_t *Ap, const int64_t *Ai, const int64_
             }
         }
     }
-    if (!user_perm && opt.nd_mode > 0 && N >= 64) {
+    if (!user_perm && opt.nd_mode > 0 && N >= 64 && (opt.nd_mode >= 2 || Ap[N] <= (int64_t)64 * N)) {   // (dense blocks: no separators)
         // third candidate: nested dissection (ordering.cpp) -- far fewer dependent levels on banded / grid-like systems
         std::vector<int> permN;
         nd_order(N, Ap, Ai, opt.amd_dense_scale, opt.nd_leaf, permN);

@@ -12,8 +12,8 @@ namespace hipkkt {
 
 constexpr int kMaxSnWidth = 64;   // supernode (panel) width cap = LDS-resident diagonal block
 constexpr int kUpdRows = 64;      // target row-block owned by one workgroup in the update kernel
-constexpr int kNarrowW = 4;       // solve levels made only of supernodes this narrow ...
-constexpr int kNarrowR = 16;      // ... and with at most this many rows below the diagonal block: one thread per supernode
+constexpr int kNarrowW = 8;       // solve: supernodes this narrow ...
+constexpr int kNarrowR = 32;      // ... and with at most this many rows below the diagonal block: one thread per supernode
 constexpr int kFacRows = 64;      // panel rows handled per workgroup in the TRSM part
 
 // one contribution of a factored source panel to a target row-block (gather-GEMM-scatter)

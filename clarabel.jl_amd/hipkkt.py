@@ -127,7 +127,7 @@ class Handle:
         d = np.zeros(16, dtype=np.int64)
         self.L.hipkkt_get_dims(self.h, d)
         (self.N, self.n, self.m, self.p, self.nnzK, self.nHs, self.nsparse, self.nnzP, self.nnzA, self.nnzL,
-         self.nsuper, self.nlevels, self.panel_doubles, self.ntasks, self.etree_height, _) = (int(v) for v in d)
+         self.nsuper, self.nlevels, self.panel_doubles, self.ntasks, self.etree_height, self.ordering) = (int(v) for v in d)
 
     @classmethod
     def from_kkt(cls, colptr, rowval, nzval, dsigns, device=0, **optkw):

@@ -98,7 +98,8 @@ void hipkkt_destroy(hipkkt_handle h);
 
 /* out[0..15] = N, n, m, p, nnzK, nHs, nsparse, nnzP, nnzA, nnzL (strictly-lower entries of L,
  * structural), n_supernodes, n_levels, panel_doubles (supernodal storage incl. padding zeros),
- * n_update_tasks, etree_height (columns), reserved.  (n,m,p,nHs,nnzP,nnzA are 0 for L0 handles.) */
+ * n_update_tasks, etree_height (columns), ordering in use (0 minimum degree on K, 1 cone rows first /
+ * variables last, 2 user, 3 nested dissection).  (n,m,p,nHs,nnzP,nnzA are 0 for L0 handles.) */
 int32_t hipkkt_get_dims(hipkkt_handle h, int64_t *out16);
 
 /* ref: linear_solver_info(ldlsolver) -> LinearSolverInfo(name,threads,direct,nnzA,nnzL),

@@ -8,7 +8,8 @@ import bench
 
 def kkt_pattern_oracle(cfg):
     """exact KKT pattern (incl. dense PSD / SOC expansion blocks) from the oracle's assembly"""
-    import clarabel_jl_amd as cl
+    import clarabel_jl_amd  # noqa: F401
+    import julia_standin as cl
     from oracle.kkt_oracle import OracleKKTSolver
     (P, q, A, b, specs), _ = bench.make_problem(cfg)
     cones = cl.CompositeCone(cl.cones_new_collapsed(specs))
