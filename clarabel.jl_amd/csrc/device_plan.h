@@ -15,6 +15,18 @@ struct __attribute__((aligned(16))) FrontSlot {
     unsigned long long h;
 };
 
+// Device-resident state of one refined solve (kernels.hip k_refine_*): the control flow of the reference's
+// _iterative_refinement (kktsolver_directldl.jl:389-449) is decided ON THE DEVICE, so a refined solve needs one host
+// synchronisation (at its end) instead of one per refinement step.  The current iterate is xbuf[cur], the candidate
+// xbuf[1 - cur] (the reference swaps x and dx).
+struct RefineState {
+    int32_t cur;        // index of the buffer holding the accepted iterate
+    int32_t steps;      // refinement steps taken (LDL solves beyond the first)
+    int32_t active;     // 1: the loop of :421-446 would go round again
+    int32_t fail;       // 1: non-finite residual norm (solve reports a numerical failure)
+    double lastnorme, normb, norme;
+};
+
 struct DevPlan {
     // structure (read-only after setup)
     const int *sn_first;

@@ -47,8 +47,33 @@ struct GraphSlot {
 
 }  // namespace
 
+// One solve context = everything a refined KKT solve mutates: its stream, work vectors, the hand-off / counter words
+// of the persistent sweeps (a private copy of those DevPlan pointers), the device-side refinement state and its
+// captured graphs.  Two contexts let two right-hand sides be solved CONCURRENTLY on one factorisation (SURVEY
+// section 8(f) row N2: the constant-rhs solve and the affine solve of an IPM iteration): the sweeps are bound by
+// dependency latency, not by throughput, so two of them overlap almost perfectly.
+constexpr int kNumCtx = 2;
+struct SolveCtx {
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    DevPlan dp{};                 // S->dp with this context's ubuf / pbuf / slots / sync words / scal / flags
+    double *d_b = nullptr, *d_x0 = nullptr, *d_x1 = nullptr, *d_e = nullptr, *d_corr = nullptr;
+    double *d_y = nullptr, *d_z = nullptr, *d_xp = nullptr;
+    RefineState *d_rs = nullptr, *h_rs = nullptr;   // device state, pinned host copy
+    int *h_flags = nullptr;                         // pinned copy of dp.flags
+    GraphSlot g_ldl, g_first, g_step;               // plain LDL solve (d_b -> d_x0) / refined solve incl. its first step / one more step
+    double g_reltol = -1, g_abstol = -1, g_stop = -1;   // parameters baked into g_first / g_step
+    int64_t g_maxit = -1;
+    hipEvent_t ev_a = nullptr, ev_b = nullptr;
+    double last_ms = 0;
+    int64_t last_steps = 0;
+    bool ir_used = false;
+    const double *result() const { return (ir_used && h_rs->cur) ? d_x1 : d_x0; }
+};
+
 struct hipkkt_solver {
     int device = 0;
+    SolveCtx ctx[kNumCtx];
     hipStream_t stream = nullptr;
     hipStream_t side = nullptr;          // far Schur updates run here, overlapped with the critical path
     std::vector<hipEvent_t> fork_events;
@@ -111,7 +136,7 @@ struct hipkkt_solver {
     double *h_scal = nullptr;    // pinned read-back area
     int *h_flags = nullptr;
 
-    GraphSlot g_factor, g_solve;
+    GraphSlot g_factor;
     bool use_graph = true;
     bool poison = false;
     PlanOptions plan_opts;       // as used for the current plan
@@ -122,7 +147,7 @@ struct hipkkt_solver {
     bool profiling = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
     double t_last_factor = 0, t_last_solve = 0, t_acc_factor = 0, t_acc_solve = 0, t_last_update = 0;
-    int64_t n_factor = 0, n_solvecalls = 0, n_ldlsolves = 0;
+    int64_t n_factor = 0, n_solvecalls = 0, n_ldlsolves = 0, n_rhs_solved = 0;
     double last_eps = 0;
     double prof_dense4_ms = 0, prof_dense4_flops = 0;   // last profiled refactorisation: k_update_dense<4,4> alone
     int prof_dense4_launches = 0;
@@ -155,7 +180,15 @@ struct hipkkt_solver {
         delete fallback;
         (void)hipSetDevice(device);
         if (g_factor.exec) (void)hipGraphExecDestroy(g_factor.exec);
-        if (g_solve.exec) (void)hipGraphExecDestroy(g_solve.exec);
+        for (SolveCtx &C : ctx) {
+            for (GraphSlot *g : {&C.g_ldl, &C.g_first, &C.g_step})
+                if (g->exec) (void)hipGraphExecDestroy(g->exec);
+            if (C.h_rs) (void)hipHostFree(C.h_rs);
+            if (C.h_flags) (void)hipHostFree(C.h_flags);
+            for (hipEvent_t e : {C.ev_a, C.ev_b})
+                if (e) (void)hipEventDestroy(e);
+            if (C.own_stream && C.stream) (void)hipStreamDestroy(C.stream);
+        }
         for (void *p : allocs) (void)hipFree(p);
         if (h_scal) (void)hipHostFree(h_scal);
         if (h_flags) (void)hipHostFree(h_flags);
@@ -194,12 +227,24 @@ void init_runtime(hipkkt_solver *S) {
     HK_CHECK(hipHostMalloc((void **)&S->h_flags, FL_COUNT * sizeof(int), hipHostMallocDefault));
     const char *ng = getenv("HIPKKT_NO_GRAPH");
     if (ng && ng[0] == '1') S->use_graph = false;
+    for (int c = 0; c < kNumCtx; c++) {
+        SolveCtx &C = S->ctx[c];
+        if (c == 0) C.stream = S->stream;
+        else { HK_CHECK(hipStreamCreateWithFlags(&C.stream, hipStreamNonBlocking)); C.own_stream = true; }
+        HK_CHECK(hipEventCreate(&C.ev_a));
+        HK_CHECK(hipEventCreate(&C.ev_b));
+        HK_CHECK(hipHostMalloc((void **)&C.h_rs, sizeof(RefineState), hipHostMallocDefault));
+        HK_CHECK(hipHostMalloc((void **)&C.h_flags, FL_COUNT * sizeof(int), hipHostMallocDefault));
+        memset(C.h_rs, 0, sizeof(RefineState));
+        memset(C.h_flags, 0, FL_COUNT * sizeof(int));
+    }
 }
 
 // (re)builds every device-resident structure from S->plan and S->img (values included)
 void setup_device(hipkkt_solver *S) {
     HK_CHECK(hipSetDevice(S->device));
-    for (GraphSlot *g : {&S->g_factor, &S->g_solve}) {
+    for (GraphSlot *g : {&S->g_factor, &S->ctx[0].g_ldl, &S->ctx[0].g_first, &S->ctx[0].g_step, &S->ctx[1].g_ldl, &S->ctx[1].g_first,
+                         &S->ctx[1].g_step}) {
         if (g->exec) (void)hipGraphExecDestroy(g->exec);
         *g = GraphSlot();
     }
@@ -552,10 +597,41 @@ void setup_device(hipkkt_solver *S) {
         S->d_soc_v = S->dalloc<double>(S->soc_total);
         S->d_soc_eta2 = S->dalloc<double>(S->nsoc);
     }
-    for (double **v : {&S->d_b, &S->d_x, &S->d_dx, &S->d_e, &S->d_sin, &S->d_sout, &S->d_y, &S->d_z, &S->d_xp}) {
-        *v = S->dalloc<double>(N);
-        HK_CHECK(hipMemset(*v, 0, (size_t)std::max(N, 1) * sizeof(double)));
+    for (int c = 0; c < kNumCtx; c++) {
+        SolveCtx &C = S->ctx[c];
+        for (double **v : {&C.d_b, &C.d_x0, &C.d_x1, &C.d_e, &C.d_corr, &C.d_y, &C.d_z, &C.d_xp}) {
+            *v = S->dalloc<double>(N);
+            HK_CHECK(hipMemset(*v, 0, (size_t)std::max(N, 1) * sizeof(double)));
+        }
+        C.d_rs = (RefineState *)S->dalloc<double>(sizeof(RefineState) / sizeof(double) + 1);
+        HK_CHECK(hipMemset(C.d_rs, 0, sizeof(RefineState)));
+        C.dp = D;
+        if (c > 0) {   // private copies of everything a solve writes besides its vectors
+            const size_t nx = (size_t)std::max(N, 1), np_ = (size_t)std::max<int64_t>(S->p_off[P.nsuper], 1);
+            const size_t nsync = seg_sync_ints(S->nseg, P.nsuper), nfs = (size_t)std::max(P.front_sync_ints, 16);
+            C.dp.ubuf = S->dalloc<double>(P.ubuf_len);
+            C.dp.pbuf = S->dalloc<double>(S->p_off[P.nsuper]);
+            C.dp.xseg = (FrontSlot *)S->dalloc<double>(2 * nx);
+            C.dp.pseg = (FrontSlot *)S->dalloc<double>(2 * np_);
+            HK_CHECK(hipMemset(C.dp.xseg, 0, 16 * nx));
+            HK_CHECK(hipMemset(C.dp.pseg, 0, 16 * np_));
+            C.dp.seg_epoch = S->dalloc<int>(4);
+            HK_CHECK(hipMemset(C.dp.seg_epoch, 0, 4 * sizeof(int)));
+            C.dp.seg_sync = S->dalloc<int>(nsync);
+            HK_CHECK(hipMemset(C.dp.seg_sync, 0, nsync * sizeof(int)));
+            C.dp.front_sync = S->dalloc<int>(nfs);
+            HK_CHECK(hipMemset(C.dp.front_sync, 0, nfs * sizeof(int)));
+            C.dp.scal = S->dalloc<double>(SC_COUNT);
+            C.dp.flags = S->dalloc<int>(FL_COUNT);
+            HK_CHECK(hipMemset(C.dp.scal, 0, SC_COUNT * sizeof(double)));
+            HK_CHECK(hipMemset(C.dp.flags, 0, FL_COUNT * sizeof(int)));
+        }
+        C.ir_used = false;
+        C.h_rs->cur = 0;
     }
+    // legacy names = context 0
+    S->d_b = S->ctx[0].d_b; S->d_x = S->ctx[0].d_x0; S->d_dx = S->ctx[0].d_x1; S->d_e = S->ctx[0].d_e;
+    S->d_sin = S->ctx[0].d_b; S->d_sout = S->ctx[0].d_corr; S->d_y = S->ctx[0].d_y; S->d_z = S->ctx[0].d_z; S->d_xp = S->ctx[0].d_xp;
     S->ensure_stage(std::max<int64_t>(1024, std::max<int64_t>(S->img.nHs, N)));
     HK_CHECK(hipDeviceSynchronize());
 }
@@ -628,25 +704,26 @@ void enqueue_factor(hipkkt_solver *S, int static_enable, double eps_const, doubl
     launch_invert_diag(st, S->dp, S->inv_nsmall, S->inv_wsmall, S->inv_nwide);
 }
 
-// d_sin -> d_sout (original ordering on both sides)
-void enqueue_ldl_solve(hipkkt_solver *S) {
+// in -> out (original ordering on both sides) on context C
+void enqueue_ldl_solve(hipkkt_solver *S, SolveCtx &C, const double *in, double *out) {
     const HostPlan &P = S->plan;
-    hipStream_t st = S->stream;
-    launch_permute_in(st, S->d_sin, S->dp.perm, S->d_y, S->N, S->dp.seg_epoch, S->dp.seg_sync, 2 * S->nseg);
-    // one launch per level (wide bottom levels, and every level on the fallback path); levels of narrow supernodes
+    hipStream_t st = C.stream;
+    const DevPlan &D = C.dp;
+    launch_permute_in(st, in, D.perm, C.d_y, S->N, D.seg_epoch, D.seg_sync, 2 * S->nseg);
+    // one launch per level (wide bottom levels, and every level on the fallback path); the leaves of such a level
     // take the thread-per-supernode kernels
     const bool all = !S->use_persist;   // no persistent kernel at all: level lists over every supernode
     const std::vector<int> &slvp = all ? S->all_slv_lvl_ptr : S->slv_lvl_ptr, &bwdp = all ? S->all_bwd_lvl_ptr : S->bwd_lvl_ptr,
                            &regp = all ? S->all_reg_lvl_ptr : S->reg_lvl_ptr;
     const std::vector<int> &nnar = all ? S->all_lvl_nnarrow : S->lvl_nnarrow, &wnar = all ? S->all_lvl_wnarrow : S->lvl_wnarrow;
     auto fwd_level = [&](int l) {
-        launch_fwd_narrow(st, S->dp, regp[l], nnar[l], wnar[l], S->d_y, S->d_z);
-        launch_fwd_level(st, S->dp, slvp[l], slvp[l + 1] - slvp[l], S->d_y, S->d_z);
+        launch_fwd_narrow(st, D, regp[l], nnar[l], wnar[l], C.d_y, C.d_z);
+        launch_fwd_level(st, D, slvp[l], slvp[l + 1] - slvp[l], C.d_y, C.d_z);
     };
     auto bwd_level = [&](int l) {
-        launch_bwd_partial(st, S->dp, bwdp[l], bwdp[l + 1] - bwdp[l], S->d_xp);
-        launch_bwd_final(st, S->dp, regp[l] + nnar[l], regp[l + 1] - regp[l] - nnar[l], S->d_z, S->d_xp, S->d_sout);
-        launch_bwd_narrow(st, S->dp, regp[l], nnar[l], wnar[l], S->d_z, S->d_xp, S->d_sout);
+        launch_bwd_partial(st, D, bwdp[l], bwdp[l + 1] - bwdp[l], C.d_xp);
+        launch_bwd_final(st, D, regp[l] + nnar[l], regp[l + 1] - regp[l] - nnar[l], C.d_z, C.d_xp, out);
+        launch_bwd_narrow(st, D, regp[l], nnar[l], wnar[l], C.d_z, C.d_xp, out);
     };
     if (S->use_persist) {
         // one persistent launch per segment of regular levels, front kernels in between
@@ -654,17 +731,17 @@ void enqueue_ldl_solve(hipkkt_solver *S) {
         for (int g = 0; g < S->nseg; g++) {
             for (int l = S->seg_lo[g]; l < std::min(S->seg_lstar[g], S->seg_hi[g] + 1); l++) fwd_level(l);   // wide bottom levels
             const int n = S->fseg_ptr[2 * g + 1] - S->fseg_ptr[2 * g];
-            if (n > 0) { launch_fwd_seg(st, S->dp, g, S->fseg_ptr[2 * g], n, P.nsuper, first ? 1 : 0, S->d_y, S->d_z); first = false; }
+            if (n > 0) { launch_fwd_seg(st, D, g, S->fseg_ptr[2 * g], n, P.nsuper, first ? 1 : 0, C.d_y, C.d_z); first = false; }
             for (const FrontDesc &F : P.fronts)
-                if (S->seg_of_level[F.level_last] == g) launch_front_fwd(st, S->dp, F, S->d_y, S->d_z);
+                if (S->seg_of_level[F.level_last] == g) launch_front_fwd(st, D, F, C.d_y, C.d_z);
         }
         first = true;
         for (int g = S->nseg - 1; g >= 0; g--) {
             for (const FrontDesc &F : P.fronts)
-                if (S->seg_of_level[F.level_last] == g) launch_front_bwd(st, S->dp, F, S->d_z, S->d_xp, S->d_sout);
+                if (S->seg_of_level[F.level_last] == g) launch_front_bwd(st, D, F, C.d_z, C.d_xp, out);
             const int k = S->nseg - 1 - g;     // launch order index
             const int n = S->bseg_ptr[k + 1] - S->bseg_ptr[k];
-            if (n > 0) { launch_bwd_seg(st, S->dp, g, S->bseg_ptr[k], n, P.nsuper, first ? 1 : 0, S->d_z, S->d_xp, S->d_sout); first = false; }
+            if (n > 0) { launch_bwd_seg(st, D, g, S->bseg_ptr[k], n, P.nsuper, first ? 1 : 0, C.d_z, C.d_xp, out); first = false; }
             for (int l = std::min(S->seg_lstar[g], S->seg_hi[g] + 1) - 1; l >= S->seg_lo[g]; l--) bwd_level(l);
         }
         return;
@@ -674,39 +751,35 @@ void enqueue_ldl_solve(hipkkt_solver *S) {
 }
 
 template <class F>
-void run_graphed(hipkkt_solver *S, GraphSlot &slot, bool reusable, F &&enqueue) {
+void run_graphed(hipkkt_solver *S, hipStream_t stream, GraphSlot &slot, bool reusable, F &&enqueue) {
     if (!S->use_graph) { enqueue(); return; }
     if (!(slot.valid && reusable)) {
         if (slot.exec) { (void)hipGraphExecDestroy(slot.exec); slot.exec = nullptr; slot.valid = false; }
         hipGraph_t graph = nullptr;
-        HK_CHECK(hipStreamBeginCapture(S->stream, hipStreamCaptureModeThreadLocal));
+        HK_CHECK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
         try {
             enqueue();
         } catch (...) {
-            (void)hipStreamEndCapture(S->stream, &graph);
+            (void)hipStreamEndCapture(stream, &graph);
             if (graph) (void)hipGraphDestroy(graph);
             throw;
         }
-        HK_CHECK(hipStreamEndCapture(S->stream, &graph));
+        HK_CHECK(hipStreamEndCapture(stream, &graph));
         hipError_t e = hipGraphInstantiate(&slot.exec, graph, nullptr, nullptr, 0);
         (void)hipGraphDestroy(graph);
         if (e != hipSuccess) { slot.exec = nullptr; S->use_graph = false; enqueue(); return; }
         slot.valid = true;
     }
-    HK_CHECK(hipGraphLaunch(slot.exec, S->stream));
+    HK_CHECK(hipGraphLaunch(slot.exec, stream));
 }
 
-void ldl_solve_dev(hipkkt_solver *S, const double *in, double *out) {
-    size_t nb = (size_t)S->N * sizeof(double);
+// the downgrade to per-level kernels after a sweep time-out is temporary
+void maybe_retry_persistent(hipkkt_solver *S) {
     if (!S->use_persist && S->persist_allowed && S->persist_retry_at >= 0 && S->n_ldlsolves >= S->persist_retry_at) {
-        S->use_persist = true;          // the downgrade after a sweep time-out is temporary
+        S->use_persist = true;
         S->persist_retry_at = -1;
-        S->g_solve.valid = false;
+        for (SolveCtx &C : S->ctx) C.g_ldl.valid = C.g_first.valid = C.g_step.valid = false;
     }
-    if (in != S->d_sin) HK_CHECK(hipMemcpyAsync(S->d_sin, in, nb, hipMemcpyDeviceToDevice, S->stream));
-    run_graphed(S, S->g_solve, true, [&] { enqueue_ldl_solve(S); });
-    if (out != S->d_sout) HK_CHECK(hipMemcpyAsync(out, S->d_sout, nb, hipMemcpyDeviceToDevice, S->stream));
-    S->n_ldlsolves++;
 }
 
 double slot_value(const hipkkt_solver *S, int slot) {
@@ -721,31 +794,26 @@ void read_scalars(hipkkt_solver *S) {
     HK_CHECK(hipStreamSynchronize(S->stream));
 }
 
-// e = b - K*xi, returns ||e||_inf (ref: _get_refine_error!, kktsolver_directldl.jl:455-466)
-double refine_error(hipkkt_solver *S, const double *xi, bool also_normb, double *normb) {
-    hipStream_t st = S->stream;
-    launch_zero_words(st, (char *)S->dp.scal + SC_NORMB * sizeof(double), 4);
-    if (also_normb) launch_norm_inf(st, S->d_b, S->N, (unsigned long long *)S->dp.scal + SC_NORMB);
-    launch_spmv_residual(st, S->dp, S->d_b, xi, S->d_e, S->N, (unsigned long long *)S->dp.scal + SC_NORME);
-    read_scalars(S);
-    if (also_normb && normb) *normb = slot_value(S, SC_NORMB);
-    return slot_value(S, SC_NORME);
+// one refinement step on the device: correction solve, candidate = iterate + correction, its residual, the decision
+void enqueue_refine_step(hipkkt_solver *S, SolveCtx &C, double reltol, double abstol, int64_t max_iter, double stop_ratio) {
+    hipStream_t st = C.stream;
+    enqueue_ldl_solve(S, C, C.d_e, C.d_corr);
+    launch_refine_add(st, C.d_rs, C.d_x0, C.d_x1, C.d_corr, S->N);
+    launch_zero_words(st, (char *)C.dp.scal + SC_NORME * sizeof(double), 2);
+    launch_spmv_residual_cand(st, C.dp, C.d_b, C.d_rs, C.d_x0, C.d_x1, C.d_e, S->N, (unsigned long long *)C.dp.scal + SC_NORME);
+    launch_refine_decide(st, C.d_rs, C.dp.scal, 1, reltol, abstol, (int)std::min<int64_t>(max_iter, 1 << 30), stop_ratio);
 }
 
 // bit 0: a front sweep / forward segment sweep gave up, bit 2: the backward segment sweep gave up
-static inline bool sweep_failed(const hipkkt_solver *S) {
-    if (S->h_flags[FL_FRONTFAIL] & ~7) {   // never written by this library (seen once: a small memset node of a
-                                            // captured graph wrote garbage under rocprofv3): report it, do not act on it
+static inline bool sweep_failed(const SolveCtx &C) {
+    if (C.h_flags[FL_FRONTFAIL] & ~7) {   // never written by this library (seen once: a small memset node of a captured
+                                           // graph wrote garbage under rocprofv3): report it, do not act on it
         static bool told = false;
-        if (!told) {
-            int again[FL_COUNT] = {0, 0, 0, 0};
-            (void)hipMemcpy(again, S->dp.flags, sizeof(again), hipMemcpyDeviceToHost);
-            fprintf(stderr, "hipkkt: unexpected value in the flag words: pinned copy %x %x %x %x, fresh copy of the device words %x %x %x %x\n",
-                    S->h_flags[0], S->h_flags[1], S->h_flags[2], S->h_flags[3], again[0], again[1], again[2], again[3]);
-        }
+        if (!told)
+            fprintf(stderr, "hipkkt: unexpected value in the flag words: %x %x %x %x\n", C.h_flags[0], C.h_flags[1], C.h_flags[2], C.h_flags[3]);
         told = true;
     }
-    return (S->h_flags[FL_FRONTFAIL] & 7) != 0;
+    return (C.h_flags[FL_FRONTFAIL] & 7) != 0;
 }
 
 // A persistent sweep kernel gave up (bounded spin expired: the workgroups were not dispatched in the order the
@@ -756,7 +824,7 @@ static inline bool sweep_failed(const hipkkt_solver *S) {
 bool recover_from_sweep_failure(hipkkt_solver *S) {
     if (!S->use_persist) return false;
     const HostPlan &P = S->plan;
-    HK_CHECK(hipStreamSynchronize(S->stream));
+    for (SolveCtx &C : S->ctx) HK_CHECK(hipStreamSynchronize(C.stream));
     S->n_sweep_timeouts++;
     {
         const char *rt = getenv("HIPKKT_PERSIST_RETRY");
@@ -764,90 +832,125 @@ bool recover_from_sweep_failure(hipkkt_solver *S) {
         S->persist_backoff = S->persist_backoff > 0 ? 2 * S->persist_backoff : first;
         S->persist_retry_at = first > 0 ? S->n_ldlsolves + S->persist_backoff : -1;
     }
-    fprintf(stderr, "hipkkt: a persistent sweep kernel timed out (flags 0x%x); per-level solve kernels for the next %lld LDL solves\n",
-            S->h_flags[FL_FRONTFAIL], (long long)(S->persist_retry_at >= 0 ? S->persist_backoff : -1));
+    fprintf(stderr, "hipkkt: a persistent sweep kernel timed out (flags 0x%x 0x%x); per-level solve kernels for the next %lld LDL solves\n",
+            S->ctx[0].h_flags[FL_FRONTFAIL], S->ctx[1].h_flags[FL_FRONTFAIL], (long long)(S->persist_retry_at >= 0 ? S->persist_backoff : -1));
     const size_t nsync = seg_sync_ints(S->nseg, P.nsuper);
-    HK_CHECK(hipMemset(S->dp.seg_sync, 0, nsync * sizeof(int)));
-    HK_CHECK(hipMemset(S->dp.front_sync, 0, (size_t)std::max(P.front_sync_ints, 16) * sizeof(int)));
-    HK_CHECK(hipMemset(S->dp.flags + FL_FRONTFAIL, 0, sizeof(int)));
-    S->h_flags[FL_FRONTFAIL] = 0;
+    for (SolveCtx &C : S->ctx) {
+        HK_CHECK(hipMemset(C.dp.seg_sync, 0, nsync * sizeof(int)));
+        HK_CHECK(hipMemset(C.dp.front_sync, 0, (size_t)std::max(P.front_sync_ints, 16) * sizeof(int)));
+        HK_CHECK(hipMemset(C.dp.flags + FL_FRONTFAIL, 0, sizeof(int)));
+        C.h_flags[FL_FRONTFAIL] = 0;
+        C.g_ldl.valid = C.g_first.valid = C.g_step.valid = false;
+    }
     S->use_persist = false;
-    S->g_solve.valid = false;
     return true;
 }
 
-int32_t solve_core_once(hipkkt_solver *S, int ir_enable, double reltol, double abstol, int64_t max_iter,
-                        double stop_ratio, int64_t *ir_steps);
-
-// ref: kktsolver_solve! + _iterative_refinement (kktsolver_directldl.jl:346-449); d_b holds b
-int32_t solve_core(hipkkt_solver *S, int ir_enable, double reltol, double abstol, int64_t max_iter,
-                   double stop_ratio, int64_t *ir_steps) {
-    int32_t rc = solve_core_once(S, ir_enable, reltol, abstol, max_iter, stop_ratio, ir_steps);
-    if (rc == HIPKKT_ERR_DEVICE && sweep_failed(S) && recover_from_sweep_failure(S))
-        rc = solve_core_once(S, ir_enable, reltol, abstol, max_iter, stop_ratio, ir_steps);
-    return rc;
+// ref: kktsolver_solve! + _iterative_refinement (kktsolver_directldl.jl:346-449); C.d_b holds b.  Enqueues the first
+// solve, its residual, the device-side decision and ONE refinement step (decided on the device whether it counts), then
+// the read-back of the state -- no synchronisation: several contexts can be started before any is finished.
+void solve_begin(hipkkt_solver *S, SolveCtx &C, int ir_enable, double reltol, double abstol, int64_t max_iter, double stop_ratio) {
+    hipStream_t st = C.stream;
+    HK_CHECK(hipEventRecord(C.ev_a, st));
+    C.ir_used = ir_enable != 0;
+    if (ir_enable) {
+        const bool same = C.g_reltol == reltol && C.g_abstol == abstol && C.g_maxit == max_iter && C.g_stop == stop_ratio;
+        run_graphed(S, st, C.g_first, same, [&] {
+            enqueue_ldl_solve(S, C, C.d_b, C.d_x0);
+            launch_zero_words(st, (char *)C.dp.scal + SC_NORMB * sizeof(double), 4);
+            launch_norm_inf(st, C.d_b, S->N, (unsigned long long *)C.dp.scal + SC_NORMB);
+            launch_spmv_residual(st, C.dp, C.d_b, C.d_x0, C.d_e, S->N, (unsigned long long *)C.dp.scal + SC_NORME);
+            launch_refine_decide(st, C.d_rs, C.dp.scal, 0, reltol, abstol, (int)std::min<int64_t>(max_iter, 1 << 30), stop_ratio);
+            if (max_iter > 0) enqueue_refine_step(S, C, reltol, abstol, max_iter, stop_ratio);
+        });
+        if (!same) { C.g_step.valid = false; C.g_reltol = reltol; C.g_abstol = abstol; C.g_maxit = max_iter; C.g_stop = stop_ratio; }
+        S->n_ldlsolves += max_iter > 0 ? 2 : 1;
+    } else {
+        run_graphed(S, st, C.g_ldl, true, [&] {
+            enqueue_ldl_solve(S, C, C.d_b, C.d_x0);
+            launch_zero_words(st, C.dp.flags, 1);
+            launch_check_finite(st, C.d_x0, S->N, C.dp.flags);
+        });
+        S->n_ldlsolves += 1;
+    }
 }
 
-int32_t solve_core_once(hipkkt_solver *S, int ir_enable, double reltol, double abstol, int64_t max_iter,
-                        double stop_ratio, int64_t *ir_steps) {
-    HK_CHECK(hipEventRecord(S->ev2, S->stream));
-    int64_t steps = 0;
-    bool ok = true;
-    double *x = S->d_x, *dx = S->d_dx;
-    ldl_solve_dev(S, S->d_b, x);
-    if (ir_enable) {
-        double normb = 0;
-        double norme = refine_error(S, x, true, &normb);
-        if (!std::isfinite(norme)) ok = false;
-        for (int64_t i = 0; ok && i < max_iter; i++) {
-            if (norme <= abstol + reltol * normb) break;
-            const double lastnorme = norme;
-            ldl_solve_dev(S, S->d_e, dx);
-            steps++;
-            launch_add(S->stream, dx, x, S->N);
-            norme = refine_error(S, dx, false, nullptr);
-            if (!std::isfinite(norme)) { ok = false; break; }
-            const double improved = lastnorme / norme;
-            if (improved < stop_ratio) {
-                if (improved > 1.0) std::swap(x, dx);
-                break;
-            }
-            std::swap(x, dx);
-        }
-    } else {
-        launch_zero_words(S->stream, S->dp.flags, 1);
-        launch_check_finite(S->stream, x, S->N, S->dp.flags);
-        HK_CHECK(hipMemcpyAsync(S->h_flags, S->dp.flags, FL_COUNT * sizeof(int), hipMemcpyDeviceToHost, S->stream));
-        HK_CHECK(hipStreamSynchronize(S->stream));
-        ok = S->h_flags[FL_NONFINITE] == 0;
+// copy the accepted iterate of a started solve to a device buffer (first nm entries), still without synchronising
+void solve_copy_out_dev(hipkkt_solver *S, SolveCtx &C, double *out_dev, int nm) {
+    if (!out_dev) return;
+    if (C.ir_used) launch_refine_copy_out(C.stream, C.d_rs, C.d_x0, C.d_x1, out_dev, nm);
+    else HK_CHECK(hipMemcpyAsync(out_dev, C.d_x0, (size_t)nm * sizeof(double), hipMemcpyDeviceToDevice, C.stream));
+}
+
+// waits for a started solve, runs further refinement steps while the device says so, reports like the reference
+int32_t solve_finish(hipkkt_solver *S, SolveCtx &C, int64_t *ir_steps, double *out_dev, int nm) {
+    hipStream_t st = C.stream;
+    auto readback = [&] {
+        if (C.ir_used) HK_CHECK(hipMemcpyAsync(C.h_rs, C.d_rs, sizeof(RefineState), hipMemcpyDeviceToHost, st));
+        HK_CHECK(hipMemcpyAsync(C.h_flags, C.dp.flags, FL_COUNT * sizeof(int), hipMemcpyDeviceToHost, st));
+        HK_CHECK(hipEventRecord(C.ev_b, st));
+        HK_CHECK(hipStreamSynchronize(st));
+    };
+    readback();
+    bool more = false;
+    while (C.ir_used && C.h_rs->active && !sweep_failed(C)) {   // rare: more than one step needed
+        run_graphed(S, st, C.g_step, true, [&] { enqueue_refine_step(S, C, C.g_reltol, C.g_abstol, C.g_maxit, C.g_stop); });
+        S->n_ldlsolves += 1;
+        more = true;
+        readback();
     }
-    S->d_x = x;
-    S->d_dx = dx;
-    HK_CHECK(hipEventRecord(S->ev3, S->stream));
-    HK_CHECK(hipStreamSynchronize(S->stream));
+    if (more && out_dev) {   // the accepted iterate changed after the copy that solve_copy_out_dev enqueued
+        solve_copy_out_dev(S, C, out_dev, nm);
+        HK_CHECK(hipEventRecord(C.ev_b, st));
+        HK_CHECK(hipStreamSynchronize(st));
+    }
     float ms = 0;
-    HK_CHECK(hipEventElapsedTime(&ms, S->ev2, S->ev3));
-    S->t_last_solve = ms;
-    S->t_acc_solve += ms;
-    S->n_solvecalls++;
-    if (ir_steps) *ir_steps = steps;
-    if (sweep_failed(S)) { S->err = "front solve kernel timed out"; return HIPKKT_ERR_DEVICE; }
+    HK_CHECK(hipEventElapsedTime(&ms, C.ev_a, C.ev_b));
+    C.last_ms = ms;
+    C.last_steps = C.ir_used ? C.h_rs->steps : 0;
+    if (ir_steps) *ir_steps = C.last_steps;
+    if (sweep_failed(C)) { S->err = "persistent solve kernel timed out"; return HIPKKT_ERR_DEVICE; }
+    const bool ok = C.ir_used ? C.h_rs->fail == 0 : C.h_flags[FL_NONFINITE] == 0;
     return ok ? HIPKKT_OK : HIPKKT_NUMERICAL_FAILURE;
 }
 
-// the solver that holds the current factorisation (the robust-order twin after a fallback); its right-hand side
-// is refreshed from the primary's
-hipkkt_solver *solve_target(hipkkt_solver *S) {
-    if (!(S->using_fallback && S->fallback)) return S;
-    hipkkt_solver *T = S->fallback;
-    HK_CHECK(hipMemcpy(T->d_b, S->d_b, (size_t)S->N * sizeof(double), hipMemcpyDeviceToDevice));
-    return T;
+// nrhs (<= kNumCtx) right-hand sides already in ctx[c].d_b: solved concurrently, results optionally copied to out_dev[c]
+int32_t solve_many(hipkkt_solver *S, int nrhs, int ir_enable, double reltol, double abstol, int64_t max_iter, double stop_ratio,
+                   int64_t *ir_steps, double *const *out_dev, int nm) {
+    for (int attempt = 0; attempt < 2; attempt++) {
+        maybe_retry_persistent(S);
+        for (int c = 0; c < nrhs; c++) {
+            solve_begin(S, S->ctx[c], ir_enable, reltol, abstol, max_iter, stop_ratio);
+            solve_copy_out_dev(S, S->ctx[c], out_dev ? out_dev[c] : nullptr, nm);
+        }
+        int32_t rc = HIPKKT_OK;
+        double ms = 0;
+        for (int c = 0; c < nrhs; c++) {
+            const int32_t r = solve_finish(S, S->ctx[c], ir_steps ? ir_steps + c : nullptr, out_dev ? out_dev[c] : nullptr, nm);
+            if (r < 0 || (r > 0 && rc == HIPKKT_OK)) rc = r < 0 ? r : (rc < 0 ? rc : r);
+            ms = std::max(ms, S->ctx[c].last_ms);
+        }
+        bool timed_out = false;
+        for (int c = 0; c < nrhs; c++) timed_out = timed_out || sweep_failed(S->ctx[c]);
+        if (timed_out && recover_from_sweep_failure(S)) continue;   // repeat everything on the per-level kernels
+        S->t_last_solve = ms;
+        S->t_acc_solve += ms;
+        S->n_solvecalls++;
+        S->n_rhs_solved += nrhs;
+        S->d_x = const_cast<double *>(S->ctx[0].result());
+        return rc;
+    }
+    return HIPKKT_ERR_DEVICE;
 }
+
+// the solver that holds the current factorisation (the robust-order twin after a fallback)
+hipkkt_solver *solve_target(hipkkt_solver *S) { return (S->using_fallback && S->fallback) ? S->fallback : S; }
 void account_fallback_solve(hipkkt_solver *S, hipkkt_solver *T) {
     if (T == S) return;
     S->t_last_solve = T->t_last_solve;
     S->t_acc_solve += T->t_last_solve;
     S->n_solvecalls++;
+    S->n_rhs_solved += 1;
 }
 
 int32_t finish_create(hipkkt_solver *S, const hipkkt_opts *opts, hipkkt_handle *out) {
@@ -1382,7 +1485,7 @@ static int32_t refactor_once(hipkkt_handle h, int32_t static_reg_enable, double 
     } else {
         GraphSlot &g = S->g_factor;
         const bool same = g.static_enable == static_reg_enable && g.eps_const == eps_const && g.eps_prop == eps_prop;
-        run_graphed(S, g, same, [&] { enqueue_factor(S, static_reg_enable, eps_const, eps_prop); });
+        run_graphed(S, S->stream, g, same, [&] { enqueue_factor(S, static_reg_enable, eps_const, eps_prop); });
         g.static_enable = static_reg_enable; g.eps_const = eps_const; g.eps_prop = eps_prop;
     }
     HK_CHECK(hipEventRecord(S->ev1, S->stream));
@@ -1430,12 +1533,14 @@ int32_t hipkkt_solve(hipkkt_handle h, double *lhsx, double *lhsz, int32_t ir_ena
     HK_ENTER(h)
     if (!S->l1) return HIPKKT_ERR_ARGUMENT;
     hipkkt_solver *T = solve_target(S);
-    int32_t rc = solve_core(T, ir_enable, reltol, abstol, max_iter, stop_ratio, ir_steps);
+    if (T != S) HK_CHECK(hipMemcpy(T->ctx[0].d_b, S->ctx[0].d_b, (size_t)S->N * sizeof(double), hipMemcpyDeviceToDevice));
+    int32_t rc = solve_many(T, 1, ir_enable, reltol, abstol, max_iter, stop_ratio, ir_steps, nullptr, 0);
     account_fallback_solve(S, T);
     if (rc == HIPKKT_OK) {  // ref: kktsolver_getlhs! only on success
         const int64_t n = S->img.n, m = S->img.m;
-        if (lhsx && n) HK_CHECK(hipMemcpy(lhsx, T->d_x, n * sizeof(double), hipMemcpyDeviceToHost));
-        if (lhsz && m) HK_CHECK(hipMemcpy(lhsz, T->d_x + n, m * sizeof(double), hipMemcpyDeviceToHost));
+        const double *x = T->ctx[0].result();
+        if (lhsx && n) HK_CHECK(hipMemcpy(lhsx, x, n * sizeof(double), hipMemcpyDeviceToHost));
+        if (lhsz && m) HK_CHECK(hipMemcpy(lhsz, x + n, m * sizeof(double), hipMemcpyDeviceToHost));
     }
     return rc;
     HK_LEAVE
@@ -1446,13 +1551,65 @@ int32_t hipkkt_solve_dev(hipkkt_handle h, double *lhs_dev, int32_t ir_enable, do
     HK_ENTER(h)
     if (!S->l1) return HIPKKT_ERR_ARGUMENT;
     hipkkt_solver *T = solve_target(S);
-    int32_t rc = solve_core(T, ir_enable, reltol, abstol, max_iter, stop_ratio, ir_steps);
+    if (T != S) HK_CHECK(hipMemcpy(T->ctx[0].d_b, S->ctx[0].d_b, (size_t)S->N * sizeof(double), hipMemcpyDeviceToDevice));
+    double *outs[1] = {lhs_dev};
+    int32_t rc = solve_many(T, 1, ir_enable, reltol, abstol, max_iter, stop_ratio, ir_steps, outs, (int)(S->img.n + S->img.m));
     account_fallback_solve(S, T);
-    if (rc == HIPKKT_OK && lhs_dev) {
-        HK_CHECK(hipMemcpyAsync(lhs_dev, T->d_x, (S->img.n + S->img.m) * sizeof(double), hipMemcpyDeviceToDevice, T->stream));
-        HK_CHECK(hipStreamSynchronize(T->stream));
-    }
     return rc;
+    HK_LEAVE
+}
+
+// several right-hand sides on one factorisation, two at a time on concurrent solve contexts
+static int32_t solve_multi_impl(hipkkt_solver *S, int64_t nrhs, const double *rhsx, const double *rhsz, const double *rhs_dev,
+                                double *lhsx, double *lhsz, double *lhs_dev, int32_t ir_enable, double reltol, double abstol,
+                                int64_t max_iter, double stop_ratio, int64_t *ir_steps) {
+    const int64_t n = S->img.n, m = S->img.m, p = S->img.p;
+    hipkkt_solver *T = solve_target(S);
+    int32_t rc_all = HIPKKT_OK;
+    for (int64_t r0 = 0; r0 < nrhs; r0 += kNumCtx) {
+        const int k = (int)std::min<int64_t>(kNumCtx, nrhs - r0);
+        double *outs[kNumCtx] = {nullptr, nullptr};
+        for (int c = 0; c < k; c++) {
+            SolveCtx &C = T->ctx[c];
+            const int64_t r = r0 + c;
+            if (rhs_dev) {
+                launch_set_rhs(C.stream, C.d_b, rhs_dev + r * (n + m), (int)(n + m), T->N);
+            } else {
+                if (n) HK_CHECK(hipMemcpyAsync(C.d_b, rhsx + r * n, n * sizeof(double), hipMemcpyHostToDevice, C.stream));
+                if (m) HK_CHECK(hipMemcpyAsync(C.d_b + n, rhsz + r * m, m * sizeof(double), hipMemcpyHostToDevice, C.stream));
+                if (p) HK_CHECK(hipMemsetAsync(C.d_b + n + m, 0, p * sizeof(double), C.stream));
+            }
+            if (lhs_dev) outs[c] = lhs_dev + r * (n + m);
+        }
+        const int32_t rc = solve_many(T, k, ir_enable, reltol, abstol, max_iter, stop_ratio, ir_steps ? ir_steps + r0 : nullptr,
+                                      lhs_dev ? outs : nullptr, (int)(n + m));
+        if (T != S) { S->t_last_solve = T->t_last_solve; S->t_acc_solve += T->t_last_solve; S->n_solvecalls++; S->n_rhs_solved += k; }
+        if (rc < 0) return rc;
+        if (rc > 0) rc_all = rc;
+        if (rc == HIPKKT_OK && (lhsx || lhsz))
+            for (int c = 0; c < k; c++) {
+                const double *x = T->ctx[c].result();
+                const int64_t r = r0 + c;
+                if (lhsx && n) HK_CHECK(hipMemcpy(lhsx + r * n, x, n * sizeof(double), hipMemcpyDeviceToHost));
+                if (lhsz && m) HK_CHECK(hipMemcpy(lhsz + r * m, x + n, m * sizeof(double), hipMemcpyDeviceToHost));
+            }
+    }
+    return rc_all;
+}
+
+int32_t hipkkt_solve_multi(hipkkt_handle h, int64_t nrhs, const double *rhsx, const double *rhsz, double *lhsx, double *lhsz,
+                           int32_t ir_enable, double reltol, double abstol, int64_t max_iter, double stop_ratio, int64_t *ir_steps) {
+    HK_ENTER(h)
+    if (!S->l1 || nrhs < 0 || (nrhs && ((S->img.n && !rhsx) || (S->img.m && !rhsz)))) return HIPKKT_ERR_ARGUMENT;
+    return solve_multi_impl(S, nrhs, rhsx, rhsz, nullptr, lhsx, lhsz, nullptr, ir_enable, reltol, abstol, max_iter, stop_ratio, ir_steps);
+    HK_LEAVE
+}
+
+int32_t hipkkt_solve_multi_dev(hipkkt_handle h, int64_t nrhs, const double *rhs_dev, double *lhs_dev, int32_t ir_enable, double reltol,
+                               double abstol, int64_t max_iter, double stop_ratio, int64_t *ir_steps) {
+    HK_ENTER(h)
+    if (!S->l1 || nrhs < 0 || (nrhs && !rhs_dev)) return HIPKKT_ERR_ARGUMENT;
+    return solve_multi_impl(S, nrhs, nullptr, nullptr, rhs_dev, nullptr, nullptr, lhs_dev, ir_enable, reltol, abstol, max_iter, stop_ratio, ir_steps);
     HK_LEAVE
 }
 
@@ -1460,26 +1617,12 @@ int32_t hipkkt_ldl_solve(hipkkt_handle h, double *x, const double *b) {
     if (h && h->using_fallback && h->fallback) return hipkkt_ldl_solve(h->fallback, x, b);
     HK_ENTER(h)
     if (!x || !b) return HIPKKT_ERR_ARGUMENT;
-    HK_CHECK(hipEventRecord(S->ev2, S->stream));
-    HK_CHECK(hipMemcpyAsync(S->d_sin, b, (size_t)S->N * sizeof(double), hipMemcpyHostToDevice, S->stream));
-    ldl_solve_dev(S, S->d_sin, S->d_sout);
-    HK_CHECK(hipEventRecord(S->ev3, S->stream));
-    HK_CHECK(hipMemcpyAsync(x, S->d_sout, (size_t)S->N * sizeof(double), hipMemcpyDeviceToHost, S->stream));
-    HK_CHECK(hipMemcpyAsync(S->h_flags, S->dp.flags, FL_COUNT * sizeof(int), hipMemcpyDeviceToHost, S->stream));
-    HK_CHECK(hipStreamSynchronize(S->stream));
-    if (sweep_failed(S) && recover_from_sweep_failure(S)) {   // repeat once on the per-level kernels
-        HK_CHECK(hipMemcpyAsync(S->d_sin, b, (size_t)S->N * sizeof(double), hipMemcpyHostToDevice, S->stream));
-        ldl_solve_dev(S, S->d_sin, S->d_sout);
-        HK_CHECK(hipMemcpyAsync(x, S->d_sout, (size_t)S->N * sizeof(double), hipMemcpyDeviceToHost, S->stream));
-        HK_CHECK(hipMemcpyAsync(S->h_flags, S->dp.flags, FL_COUNT * sizeof(int), hipMemcpyDeviceToHost, S->stream));
-        HK_CHECK(hipStreamSynchronize(S->stream));
-    }
-    if (sweep_failed(S)) { S->err = "front solve kernel timed out"; return HIPKKT_ERR_DEVICE; }
-    float ms = 0;
-    HK_CHECK(hipEventElapsedTime(&ms, S->ev2, S->ev3));
-    S->t_last_solve = ms;
-    S->t_acc_solve += ms;
-    S->n_solvecalls++;
+    SolveCtx &C = S->ctx[0];
+    HK_CHECK(hipMemcpyAsync(C.d_b, b, (size_t)S->N * sizeof(double), hipMemcpyHostToDevice, C.stream));
+    int32_t rc = solve_many(S, 1, 0, 0.0, 0.0, 0, 0.0, nullptr, nullptr, 0);
+    if (rc < 0) return rc;
+    // ref: solve!(ldlsolver,K,x,b) returns whatever the triangular solves produce; a non-finite result is the caller's to detect
+    HK_CHECK(hipMemcpy(x, C.d_x0, (size_t)S->N * sizeof(double), hipMemcpyDeviceToHost));
     return HIPKKT_OK;
     HK_LEAVE
 }

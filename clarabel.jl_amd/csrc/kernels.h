@@ -36,6 +36,12 @@ void launch_front_fwd(hipStream_t st, const DevPlan &P, const FrontDesc &F, doub
 void launch_front_bwd(hipStream_t st, const DevPlan &P, const FrontDesc &F, const double *z, double *x, double *xout);
 void launch_spmv_residual(hipStream_t st, const DevPlan &P, const double *b, const double *xi, double *e, int n,
                           unsigned long long *slot);
+void launch_refine_decide(hipStream_t st, RefineState *rs, const double *scal, int phase, double reltol, double abstol, int max_iter,
+                          double stop_ratio);
+void launch_refine_add(hipStream_t st, const RefineState *rs, double *x0, double *x1, const double *corr, int n);
+void launch_refine_copy_out(hipStream_t st, const RefineState *rs, const double *x0, const double *x1, double *out, int nm);
+void launch_spmv_residual_cand(hipStream_t st, const DevPlan &P, const double *b, const RefineState *rs, const double *x0,
+                               const double *x1, double *e, int n, unsigned long long *slot);
 void launch_norm_inf(hipStream_t st, const double *v, int n, unsigned long long *slot);
 void launch_add(hipStream_t st, double *dst, const double *a, int n);
 void launch_set_rhs(hipStream_t st, double *b, const double *rhs, int nm, int n);

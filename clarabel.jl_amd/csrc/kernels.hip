@@ -1894,6 +1894,80 @@ k_norm_inf(const double *__restrict__ v, int n, unsigned long long *__restrict__
     block_atomic_max_abs(slot, a);
 }
 
+// ---- refinement decided on the device (one host synchronisation per refined solve instead of one per step).
+// k_refine_decide<phase 0> runs after the first solve and its residual, <phase 1> after every refinement step; both are
+// single-thread kernels that replay the branches of kktsolver_directldl.jl:418-446 on the RefineState.
+__global__ void k_refine_decide(RefineState *st, const unsigned long long *scal, int phase, double reltol, double abstol,
+                                int max_iter, double stop_ratio) {
+    if (blockIdx.x || threadIdx.x) return;
+    const double norme = __longlong_as_double((long long)scal[SC_NORME]);
+    if (phase == 0) {
+        const double normb = __longlong_as_double((long long)scal[SC_NORMB]);
+        st->cur = 0;
+        st->steps = 0;
+        st->normb = normb;
+        st->norme = norme;
+        st->lastnorme = norme;
+        st->fail = isfinite(norme) ? 0 : 1;                                        // :414-416
+        st->active = (!st->fail && max_iter > 0 && !(norme <= abstol + reltol * normb)) ? 1 : 0;   // :421-426
+        return;
+    }
+    if (!st->active) return;
+    st->steps += 1;
+    st->norme = norme;
+    if (!isfinite(norme)) { st->fail = 1; st->active = 0; return; }               // :433-435
+    const double improved = st->lastnorme / norme;                                // :437
+    if (improved < stop_ratio) {                                                  // :438-444: insufficient improvement
+        if (improved > 1.0) st->cur ^= 1;                                         //           (keep the better of the two)
+        st->active = 0;
+        return;
+    }
+    st->cur ^= 1;                                                                 // :445 swap x, dx
+    st->lastnorme = norme;
+    st->active = (st->steps < max_iter && !(norme <= abstol + reltol * st->normb)) ? 1 : 0;
+}
+// candidate = iterate + correction  (:430-431: dx = K \ e, dx += x); inactive states leave the candidate alone
+__global__ void k_refine_add(const RefineState *st, double *__restrict__ x0, double *__restrict__ x1,
+                             const double *__restrict__ corr, int n) {
+    if (!st->active) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const double *src = st->cur ? x1 : x0;
+    double *dst = st->cur ? x0 : x1;
+    if (i < n) dst[i] = src[i] + corr[i];
+}
+// out = the accepted iterate (first nm entries)
+__global__ void k_refine_copy_out(const RefineState *st, const double *__restrict__ x0, const double *__restrict__ x1,
+                                  double *__restrict__ out, int nm) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const double *src = st->cur ? x1 : x0;
+    if (i < nm) out[i] = src[i];
+}
+// e = b - K * (candidate), ||e||_inf; the candidate is xbuf[1 - cur] (after a step) -- see k_spmv_residual
+__global__ void __launch_bounds__(256)
+k_spmv_residual_cand(const int64_t *__restrict__ rowptr, const int *__restrict__ col, const int64_t *__restrict__ qidx,
+                     const double *__restrict__ kval, const double *__restrict__ b, const RefineState *st,
+                     const double *__restrict__ x0, const double *__restrict__ x1, double *__restrict__ e, int n,
+                     unsigned long long *__restrict__ norm_slot) {
+    if (!st->active) return;           // the norm slot keeps its previous value; k_refine_decide ignores it when inactive
+    const double *xi = st->cur ? x0 : x1;
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int row = gid >> 2, sub = gid & 3;
+    double acc = 0.0;
+    if (row < n) {
+        const int64_t p0 = rowptr[row], p1 = rowptr[row + 1];
+        for (int64_t p = p0 + sub; p < p1; p += 4) acc += kval[qidx[p]] * xi[col[p]];
+    }
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    double a = 0.0;
+    if (row < n && sub == 0) {
+        const double ev = b[row] - acc;
+        e[row] = ev;
+        a = fabs(ev);
+    }
+    block_atomic_max_abs(norm_slot, a);
+}
+
 __global__ void k_add(double *__restrict__ dst, const double *__restrict__ a, int n) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] += a[i];
@@ -2083,6 +2157,23 @@ void launch_block_products(hipStream_t st, const DevPlan &P, const double *x, co
     if (n + m > 0)
         hipLaunchKernelGGL(k_block_products, dim3(nblk((int64_t)(n + m) * 4)), dim3(256), 0, st, P.sym_rowptr, P.sym_col, P.sym_q,
                            P.kval, x, z, Px, ATz, Ax, n, m);
+}
+void launch_refine_decide(hipStream_t st, RefineState *rs, const double *scal, int phase, double reltol, double abstol, int max_iter,
+                          double stop_ratio) {
+    hipLaunchKernelGGL(k_refine_decide, dim3(1), dim3(64), 0, st, rs, (const unsigned long long *)scal, phase, reltol, abstol, max_iter,
+                       stop_ratio);
+}
+void launch_refine_add(hipStream_t st, const RefineState *rs, double *x0, double *x1, const double *corr, int n) {
+    if (n > 0) hipLaunchKernelGGL(k_refine_add, dim3(nblk(n)), dim3(256), 0, st, rs, x0, x1, corr, n);
+}
+void launch_refine_copy_out(hipStream_t st, const RefineState *rs, const double *x0, const double *x1, double *out, int nm) {
+    if (nm > 0) hipLaunchKernelGGL(k_refine_copy_out, dim3(nblk(nm)), dim3(256), 0, st, rs, x0, x1, out, nm);
+}
+void launch_spmv_residual_cand(hipStream_t st, const DevPlan &P, const double *b, const RefineState *rs, const double *x0,
+                               const double *x1, double *e, int n, unsigned long long *slot) {
+    if (n > 0)
+        hipLaunchKernelGGL(k_spmv_residual_cand, dim3(nblk((int64_t)n * 4)), dim3(256), 0, st, P.sym_rowptr, P.sym_col, P.sym_q,
+                           P.kval, b, rs, x0, x1, e, n, slot);
 }
 void launch_norm_inf(hipStream_t st, const double *v, int n, unsigned long long *slot) {
     if (n > 0) hipLaunchKernelGGL(k_norm_inf, dim3(min(nblk(n), 64u)), dim3(256), 0, st, v, n, slot);

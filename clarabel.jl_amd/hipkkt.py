@@ -23,7 +23,7 @@ SYMBOLS = [
     "hipkkt_get_dsigns", "hipkkt_get_map", "hipkkt_get_sparse_map", "hipkkt_update_values", "hipkkt_scale_values",
     "hipkkt_set_hs", "hipkkt_set_hs_dev", "hipkkt_set_hs_psd", "hipkkt_block_products", "hipkkt_set_soc", "hipkkt_set_soc_batch", "hipkkt_set_genpow",
     "hipkkt_update_P", "hipkkt_update_A", "hipkkt_refactor", "hipkkt_setrhs", "hipkkt_setrhs_dev", "hipkkt_solve",
-    "hipkkt_solve_dev", "hipkkt_ldl_solve", "hipkkt_get_timing", "hipkkt_reset_timing", "hipkkt_get_profile", "hipkkt_set_profiling",
+    "hipkkt_solve_dev", "hipkkt_solve_multi", "hipkkt_solve_multi_dev", "hipkkt_ldl_solve", "hipkkt_get_timing", "hipkkt_reset_timing", "hipkkt_get_profile", "hipkkt_set_profiling",
     "hipkkt_get_counters", "hipkkt_debug_dump",
     "hipkkt_selftest_mfma", "hipkkt_last_error",
 ]
@@ -88,6 +88,8 @@ def lib():
     L.hipkkt_solve.argtypes = [vp, vp, vp, i32, f64, f64, i64, f64, C.POINTER(i64)]
     L.hipkkt_solve_dev.argtypes = [vp, vp, i32, f64, f64, i64, f64, C.POINTER(i64)]
     L.hipkkt_ldl_solve.argtypes = [vp, _f64p, _f64p]
+    L.hipkkt_solve_multi.argtypes = [vp, i64, _f64p, _f64p, vp, vp, i32, f64, f64, i64, f64, vp]
+    L.hipkkt_solve_multi_dev.argtypes = [vp, i64, vp, vp, i32, f64, f64, i64, f64, vp]
     L.hipkkt_get_timing.argtypes = [vp, _f64p]
     L.hipkkt_reset_timing.argtypes = [vp]
     L.hipkkt_get_profile.argtypes = [vp, _f64p]
@@ -300,6 +302,25 @@ class Handle:
         rc = self._chk(self.L.hipkkt_solve(self.h, px, pz, int(ir_enable), reltol, abstol, max_iter, stop_ratio,
                                            C.byref(steps)), "solve")
         return rc == 0, steps.value
+
+    def solve_multi(self, rhsx, rhsz, lhsx, lhsz, ir_enable=True, reltol=1e-13, abstol=1e-12, max_iter=10, stop_ratio=5.0):
+        """nrhs right-hand sides on one factorisation (include/hipkkt.h hipkkt_solve_multi): rhsx [nrhs, n], rhsz [nrhs, m];
+        lhsx / lhsz = writeable arrays of the same shapes (or None).  Returns (ok, steps[nrhs])."""
+        rhsx = np.ascontiguousarray(rhsx, dtype=np.float64).reshape(-1, self.n) if self.n else np.zeros((len(rhsz), 0))
+        rhsz = np.ascontiguousarray(rhsz, dtype=np.float64).reshape(-1, self.m) if self.m else np.zeros((len(rhsx), 0))
+        nrhs = max(rhsx.shape[0], rhsz.shape[0])
+        steps = np.zeros(max(nrhs, 1), dtype=np.int64)
+        px = self._out_ptr(lhsx, nrhs * self.n, "lhsx")
+        pz = self._out_ptr(lhsz, nrhs * self.m, "lhsz")
+        rc = self._chk(self.L.hipkkt_solve_multi(self.h, nrhs, rhsx, rhsz, px, pz, int(ir_enable), reltol, abstol, max_iter,
+                                                 stop_ratio, steps.ctypes.data), "solve_multi")
+        return rc == 0, steps[:nrhs]
+
+    def solve_multi_dev(self, nrhs, rhs_ptr, out_ptr, ir_enable=True, reltol=1e-13, abstol=1e-12, max_iter=10, stop_ratio=5.0):
+        steps = np.zeros(max(nrhs, 1), dtype=np.int64)
+        rc = self._chk(self.L.hipkkt_solve_multi_dev(self.h, nrhs, rhs_ptr, out_ptr, int(ir_enable), reltol, abstol, max_iter,
+                                                     stop_ratio, steps.ctypes.data), "solve_multi_dev")
+        return rc == 0, steps[:nrhs]
 
     # device-pointer variants (inputs already resident in HBM, e.g. torch tensors' data_ptr())
     def set_hs_dev(self, ptr, n):

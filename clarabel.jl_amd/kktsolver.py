@@ -92,6 +92,20 @@ class HipKKTSolver:
             print(f"[hipkkt] solve ok={ok} ir_steps={steps}")
         return ok
 
+    # several right-hand sides on the current factorisation (rhsx [k, n], rhsz [k, m]), refined
+    # like kktsolver_solve! refines one, two at a time on concurrent device contexts
+    def kktsolver_solve_multi(self, rhsx, rhsz, lhsx, lhsz) -> bool:
+        st = self.settings
+        ok, steps = self.h.solve_multi(rhsx, rhsz, lhsx, lhsz, st.iterative_refinement_enable, st.iterative_refinement_reltol,
+                                       st.iterative_refinement_abstol, st.iterative_refinement_max_iter,
+                                       st.iterative_refinement_stop_ratio)
+        self.last_ir_steps = int(steps[-1]) if len(steps) else 0
+        self.total_ir_steps += int(np.sum(steps))
+        self.nsolves += len(steps)
+        if _DEBUG:
+            print(f"[hipkkt] solve_multi ok={ok} ir_steps={list(steps)}")
+        return ok
+
     # ref: kktsolver_update_P!/A!, :374-386
     def kktsolver_update_P(self, P):
         self.h.update_P(P.data)

@@ -179,6 +179,18 @@ int32_t hipkkt_solve(hipkkt_handle h, double *lhsx, double *lhsz, int32_t ir_ena
 /* same, result left on the device: lhs_dev receives n+m doubles (may be NULL to discard) */
 int32_t hipkkt_solve_dev(hipkkt_handle h, double *lhs_dev, int32_t ir_enable, double reltol,
                          double abstol, int64_t max_iter, double stop_ratio, int64_t *ir_steps);
+/* SURVEY section 8(f) row N2.  nrhs right-hand sides on ONE factorisation, each refined exactly like hipkkt_solve does,
+ * two at a time on concurrent solve contexts (the triangular sweeps are bound by dependency latency, so two of them
+ * overlap almost completely).  The caller this serves: kkt_update! leaves the constant-rhs solve of kktsystem.jl:80-92
+ * pending and the first kkt_solve! of the iteration (:135-215, affine step) solves [-q; b] and its own right-hand side
+ * together.  rhsx = nrhs x n, rhsz = nrhs x m, lhsx / lhsz likewise (row-major, one right-hand side after the other;
+ * lhs pointers may be NULL); ir_steps[nrhs] may be NULL.  Returns 0, or HIPKKT_NUMERICAL_FAILURE if any solve failed. */
+int32_t hipkkt_solve_multi(hipkkt_handle h, int64_t nrhs, const double *rhsx, const double *rhsz, double *lhsx, double *lhsz,
+                           int32_t ir_enable, double reltol, double abstol, int64_t max_iter, double stop_ratio,
+                           int64_t *ir_steps);
+/* same with everything resident: rhs_dev / lhs_dev = nrhs x (n+m) doubles on the device */
+int32_t hipkkt_solve_multi_dev(hipkkt_handle h, int64_t nrhs, const double *rhs_dev, double *lhs_dev, int32_t ir_enable,
+                               double reltol, double abstol, int64_t max_iter, double stop_ratio, int64_t *ir_steps);
 /* seam L0.  ref: solve!(ldlsolver,K,x,b), directldl_qdldl.jl:85-96: x = K_fact^{-1} b, length N,
  * no refinement (the Julia-side DirectLDLKKTSolver refines).  x and b must not alias. */
 int32_t hipkkt_ldl_solve(hipkkt_handle h, double *x, const double *b);

@@ -251,10 +251,19 @@ class KKTSystem:
         self.workx = np.zeros(n)
         self.workz = np.zeros(m)
         self.work_conic = np.zeros(m)
+        self._multi = hasattr(kktsolver, "kktsolver_solve_multi") and getattr(kktsolver, "batch_constant_rhs", True)
+        self._const_pending = False
+        self._rx2, self._rz2 = np.zeros((2, n)), np.zeros((2, m))
+        self._lx2, self._lz2 = np.zeros((2, n)), np.zeros((2, m))
 
     def kkt_update(self, data, cones):  # :62-78
         if not self.kktsolver.kktsolver_update(cones):
             return False
+        if self._multi:
+            # the constant-rhs solve of :80-92 is left pending and batched with the first
+            # kkt_solve of the iteration (both right-hand sides are known by then; INTEGRATION.md shows the Julia side)
+            self._const_pending = True
+            return True
         return self._solve_constant_rhs(data)
 
     def _solve_constant_rhs(self, data):  # :80-92
@@ -294,9 +303,18 @@ class KKTSystem:
         else:
             cones.ds_from_dz_offset(ds_const, rhs.s, lhs.z, variables.z)
         workz[:] = ds_const - rhs.z
-        self.kktsolver.kktsolver_setrhs(workx, workz)
-        if not self.kktsolver.kktsolver_solve(x1, z1):
-            return False
+        if self._const_pending:      # [-q; b] and this step's right-hand side on one factorisation, concurrently
+            self._rx2[0], self._rz2[0] = -data.q, data.b
+            self._rx2[1], self._rz2[1] = workx, workz
+            if not self.kktsolver.kktsolver_solve_multi(self._rx2, self._rz2, self._lx2, self._lz2):
+                return False
+            x2[:], z2[:] = self._lx2[0], self._lz2[0]
+            x1[:], z1[:] = self._lx2[1], self._lz2[1]
+            self._const_pending = False
+        else:
+            self.kktsolver.kktsolver_setrhs(workx, workz)
+            if not self.kktsolver.kktsolver_solve(x1, z1):
+                return False
         xi = workx
         xi[:] = variables.x / variables.tau
         P = data.P

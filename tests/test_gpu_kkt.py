@@ -486,3 +486,59 @@ def test_output_arrays_are_validated():
     for bad in (np.zeros(n, dtype=np.float32), np.zeros(2 * n)[::2], np.zeros(max(n - 1, 0))):
         with pytest.raises(hipkkt.HipKKTError):
             hk.h.solve(bad, np.zeros(m))
+
+
+@pytest.mark.parametrize("name", ["cfg1", "portfolio_small", "sdp_small", "rand_window_2000"])
+def test_solve_multi_matches_separate_solves(name, oracle_factory):
+    """hipkkt_solve_multi solves its right-hand sides on concurrent device contexts; every one must
+    be BIT-IDENTICAL to what a separate kktsolver_setrhs! / kktsolver_solve! pair returns (same kernels, same order of
+    operations, private work areas) and match the oracle's separate solves to 1e-10.  Three right-hand sides = two rounds
+    (2 concurrent + 1)."""
+    rng = np.random.default_rng(zlib.crc32(name.encode()) + 1)
+    Pt, A, cones = _prep(PROBLEMS[name]())
+    m, n = A.shape
+    st = cl.Settings()
+    hk = HipKKTSolver(Pt, A, cones, m, n, st)
+    ok_ = oracle_factory(Pt, A, cones, m, n, st, ordering=hk.h.perm())
+    for rep in range(2):
+        _scale_cones(cones, rng)
+        assert hk.kktsolver_update(cones) and ok_.kktsolver_update(cones)
+        rx, rz = rng.standard_normal((3, n)), rng.standard_normal((3, m))
+        lx, lz = np.zeros((3, n)), np.zeros((3, m))
+        assert hk.kktsolver_solve_multi(rx, rz, lx, lz)
+        for k in range(3):
+            sx, sz, cx, cz = np.zeros(n), np.zeros(m), np.zeros(n), np.zeros(m)
+            hk.kktsolver_setrhs(rx[k], rz[k])
+            assert hk.kktsolver_solve(sx, sz)
+            assert np.array_equal(sx, lx[k]) and np.array_equal(sz, lz[k])
+            ok_.kktsolver_setrhs(rx[k], rz[k])
+            assert ok_.kktsolver_solve(cx, cz)
+            scale = max(1.0, np.max(np.abs(cx)), np.max(np.abs(cz)))
+            assert np.max(np.abs(lx[k] - cx)) <= 1e-10 * scale and np.max(np.abs(lz[k] - cz)) <= 1e-10 * scale
+
+
+def test_refinement_steps_match_oracle_on_a_hard_system(oracle_factory):
+    """the device-side replay of _iterative_refinement's branches (kktsolver_directldl.jl:418-446): on a badly scaled
+    system the number of refinement steps and the accepted iterate must be the oracle's"""
+    rng = np.random.default_rng(31)
+    Pt, A, cones = _prep(problems.random_sparse_qp(400, 700, 21, 3, 1))
+    m, n = A.shape
+    st = cl.Settings()
+    hk = HipKKTSolver(Pt, A, cones, m, n, st)
+    ok_ = oracle_factory(Pt, A, cones, m, n, st, ordering=hk.h.perm())
+    s, z = rng.random(m) * 1e-7 + 1e-9, rng.random(m) + 0.1        # late-IPM scaling: Hs = s/z spans many decades
+    s[::3] = rng.random(len(s[::3])) * 1e3
+    assert cones.update_scaling(s, z, 1.0)
+    assert hk.kktsolver_update(cones) and ok_.kktsolver_update(cones)
+    seen = set()
+    for rep in range(6):
+        rx, rz = rng.standard_normal(n) * 10.0 ** rng.integers(-3, 4), rng.standard_normal(m) * 10.0 ** rng.integers(-3, 4)
+        lx_g, lz_g, lx_c, lz_c = np.zeros(n), np.zeros(m), np.zeros(n), np.zeros(m)
+        hk.kktsolver_setrhs(rx, rz)
+        ok_.kktsolver_setrhs(rx, rz)
+        assert hk.kktsolver_solve(lx_g, lz_g) and ok_.kktsolver_solve(lx_c, lz_c)
+        seen.add(ok_.last_ir_steps)
+        assert abs(hk.last_ir_steps - ok_.last_ir_steps) <= 1      # a stopping test decided by the last digits of a norm may differ
+        scale = max(1.0, np.max(np.abs(lx_c)), np.max(np.abs(lz_c)))
+        assert np.max(np.abs(lx_g - lx_c)) <= 1e-9 * scale and np.max(np.abs(lz_g - lz_c)) <= 1e-9 * scale
+    print("refinement steps seen on the oracle:", sorted(seen))
