@@ -62,31 +62,113 @@ def pmc_traffic(cfg):
     return None
 
 
+def _cpu_batch_worker(seed):
+    """all-cores CPU baseline of cfg 4: one problem per core, the oracle (reference :qdldl restatement) as KKT solver"""
+    import time as _t
+
+    import clarabel_jl_amd  # noqa: F401
+    import julia_standin as cl_
+    from clarabel_jl_amd import problems as pr_
+    from oracle.kkt_oracle import OracleKKTSolver
+
+    t0 = _t.perf_counter()
+    P, q, A, b, cones = pr_.batch_problem(seed)
+    sol = cl_.Solver(P, q, A, b, cones, cl_.Settings(), kktsolver_factory=lambda *a: OracleKKTSolver(*a, ordering="mmd")).solve()
+    return sol.iterations, sol.status, _t.perf_counter() - t0
+
+
+def _gpu_batch_init(device):
+    """worker process of the cfg-4 batch driver: one HIP context of its own on the rank's GPU, warmed up"""
+    import clarabel_jl_amd  # noqa: F401
+    import julia_standin as cl_
+    from clarabel_jl_amd import problems as pr_
+
+    global _W
+    _W = (cl_, pr_, device)
+    P, q, A, b, cones = pr_.batch_problem(100)
+    cl_.Solver(P, q, A, b, cones, cl_.Settings(device_id=device)).solve()
+
+
+def _gpu_batch_chunk(arg):
+    seeds, in_flight = arg
+    from clarabel_jl_amd import batch as b_
+
+    cl_, pr_, device = _W
+
+    def one(seed):
+        P, q, A, b, cones = pr_.batch_problem(seed)
+        sol = cl_.Solver(P, q, A, b, cones, cl_.Settings(device_id=device)).solve()
+        return seed, sol.iterations, sol.status
+
+    return b_.run_concurrent(one, seeds, in_flight)
+
+
 def bench_batch(args, cl, torch, dist, rank, world, local):
     """cfg 4: the 256 seeded Maros-Meszaros-like QPs (problems.batch_problem, seeds 100..355) sharded round-robin
     over the ranks; a step = one problem solved end-to-end on the HIP path (symbolic set-up + IPM loop with the
-    numpy stand-in caller).  value = IPM iterations / s over the whole job."""
+    numpy stand-in caller), `--in-flight` problems at a time per GPU (one host thread + handle each).
+    value = IPM iterations / s over the whole job."""
     from clarabel_jl_amd import batch, problems
 
     dev = torch.device("cuda", local)
     mine = batch.shard(256, rank, world)
     steps = min(args.steps, len(mine)) if args.steps > 0 else len(mine)
-    iters = [0]
-    stats = {"solved": 0}
 
-    def step(i):
-        P, q, A, b, cones = problems.batch_problem(100 + mine[i % len(mine)])
+    def solve_one(k):
+        P, q, A, b, cones = problems.batch_problem(100 + mine[k % len(mine)])
         sol = cl.Solver(P, q, A, b, cones, cl.Settings(device_id=local)).solve()
-        iters[0] += sol.iterations
-        stats["solved"] += sol.status == "SOLVED"
+        return 100 + mine[k % len(mine)], sol.iterations, sol.status
 
-    batch.timed_steps(step, 0, args.warmup)
-    iters[0] = 0
-    stats["solved"] = 0
-    elapsed = batch.timed_steps(lambda i: step(i + args.warmup), steps, 0, dist=dist, device_sync=torch.cuda.synchronize, reduce_device=dev)
-    total_iters = batch.gather_counts(iters[0], dist, dev)
-    total_solved = batch.gather_counts(stats["solved"], dist, dev)
+    res = []
+    pool = None
+    if args.workers > 1:
+        # several host processes per GPU (each its own HIP context, `--in-flight` threads inside each): the per-problem work is
+        # mostly host-side (symbolic analysis, the numpy caller, call latencies), and Python threads alone stop scaling at ~2
+        import multiprocessing as mp
+
+        pool = mp.get_context("spawn").Pool(args.workers, initializer=_gpu_batch_init, initargs=(local,))
+        pool.map(_gpu_batch_chunk, [([100 + mine[k % len(mine)]], 1) for k in range(args.workers)])      # warm-up: every worker once
+        seeds = [100 + mine[(args.warmup + i) % len(mine)] for i in range(steps)]
+        chunks = [(seeds[w::args.workers], args.in_flight) for w in range(args.workers)]
+
+        def timed(_):
+            for part in pool.map(_gpu_batch_chunk, chunks):
+                res.extend(part)
+    else:
+        batch.run_concurrent(solve_one, list(range(min(args.warmup, len(mine)))), args.in_flight)      # warm-up
+
+        def timed(_):
+            res.extend(batch.run_concurrent(solve_one, [args.warmup + i for i in range(steps)], args.in_flight))
+
+    elapsed = batch.timed_steps(timed, 1, 0, dist=dist, device_sync=torch.cuda.synchronize, reduce_device=dev)
+    if pool is not None:
+        pool.close()
+        pool.join()
+    total_iters = batch.gather_counts(sum(r[1] for r in res), dist, dev)
+    total_solved = batch.gather_counts(sum(r[2] == "SOLVED" for r in res), dist, dev)
     total_probs = batch.gather_counts(steps, dist, dev)
+    not_solved = [(r[0], r[2]) for r in res if r[2] != "SOLVED"]
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # all-cores CPU baseline (BASELINE.md section 2): the same problems, one per core, oracle KKT solver, bounded sample
+        import multiprocessing as mp
+
+        ncores = min(os.cpu_count() or 1, 64)
+        seeds = [r[0] for r in res][: max(ncores, min(len(res), 2 * ncores))]
+        t0 = time.perf_counter()
+        with mp.get_context("spawn").Pool(ncores) as pool:
+            t_spawn = time.perf_counter() - t0
+            pool.map(_cpu_batch_worker, seeds[: min(len(seeds), ncores)])          # warm the workers (imports, oracle build)
+            t1 = time.perf_counter()
+            out = pool.map(_cpu_batch_worker, seeds)
+            t_cpu = time.perf_counter() - t1
+        cpu_baseline = {"value": round(sum(o[0] for o in out) / t_cpu, 2), "unit": "IPM-iterations/s (whole solves incl. set-up)",
+                        "cores": ncores, "kind": "port",
+                        "sample": f"{len(seeds)} of the same problems, one per core on {ncores} worker processes, oracle/ C restatement "
+                                  "of the :qdldl path inside the same numpy caller", "problems": len(seeds),
+                        "wall_s": round(t_cpu, 3), "sum_of_per_problem_s": round(sum(o[2] for o in out), 3),
+                        "one_core_iterations_per_s": round(sum(o[0] for o in out) / sum(o[2] for o in out), 2),
+                        "host_cores_available": os.cpu_count(), "pool_start_s": round(t_spawn, 2)}
     if rank == 0:
         print(json.dumps({
             "metric": "IPM iterations/sec + KKT factor+solve ms, 10k-var sparse QP, 1/2/4/8 GPU",
@@ -94,9 +176,11 @@ def bench_batch(args, cl, torch, dist, rank, world, local):
             "n_gpus": world, "steps": steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / max(1, steps), 3),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "batch of 256 Maros-Meszaros-like QPs (cfg 4), seeds 100..355, sharded round-robin",
-                       "problems_solved": total_probs, "status_solved": total_solved,
+                       "problems_solved": total_probs, "status_solved": total_solved, "not_solved": not_solved,
+                       "in_flight_per_gpu": args.in_flight * max(1, args.workers), "host_processes_per_gpu": max(1, args.workers),
+                       "threads_per_process": args.in_flight,
                        "parallelism": f"{world} rank(s), {len(mine)} problems on rank 0"},
-            "problems_per_s": round(total_probs / elapsed, 3), "roofline": None, "cpu_baseline": None}))
+            "problems_per_s": round(total_probs / elapsed, 3), "roofline": None, "cpu_baseline": cpu_baseline}))
     if dist is not None:
         dist.destroy_process_group()
 
@@ -110,6 +194,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=30.0, help="seconds of CPU-oracle work allowed for cpu_baseline/parity")
     ap.add_argument("--update-policy", type=int, default=None)
+    ap.add_argument("--in-flight", type=int, default=1, help="cfg 4: problems solved concurrently per host process (threads)")
+    ap.add_argument("--workers", type=int, default=6, help="cfg 4: host processes per GPU, each with its own HIP context")
     ap.add_argument("--sequential-solves", action="store_true", help="three separate solve calls per unit instead of 2 concurrent + 1")
     args = ap.parse_args()
 

@@ -47,3 +47,15 @@ def gather_counts(local_count: int, dist=None, reduce_device=None) -> int:
     tt = torch.tensor([local_count], dtype=torch.int64, device=reduce_device or "cpu")
     dist.all_reduce(tt, op=dist.ReduceOp.SUM)
     return int(tt.item())
+
+
+def run_concurrent(solve_one, items, in_flight: int):
+    """several independent problems in flight on ONE GPU -- one host thread and one handle each (the
+    C ABI is per-handle thread-safe and releases the GIL while a call runs), so that one problem's host-side work (symbolic
+    analysis, cone algebra, PCIe) overlaps the others' device work.  Returns the results in item order."""
+    if in_flight <= 1:
+        return [solve_one(it) for it in items]
+    from concurrent.futures import ThreadPoolExecutor
+
+    with ThreadPoolExecutor(max_workers=in_flight) as ex:
+        return list(ex.map(solve_one, items))

@@ -37,6 +37,18 @@ struct DeviceError {
             throw DeviceError{std::string(#expr) + ": " + hipGetErrorString(e_)};                 \
     } while (0)
 
+// Synchronous copy / fill on a handle's OWN stream.  The legacy (NULL) stream is never used: an operation on it from
+// one host thread fails while another thread captures a hipGraph ("would make the legacy stream depend on a capturing
+// stream"), and handles are meant to be driven concurrently from several threads.
+inline void copy_sync(hipStream_t st, void *dst, const void *src, size_t bytes, hipMemcpyKind kind) {
+    if (!bytes) return;
+    HK_CHECK(hipMemcpyAsync(dst, src, bytes, kind, st));
+    HK_CHECK(hipStreamSynchronize(st));
+}
+inline void fill_async(hipStream_t st, void *dst, int value, size_t bytes) {
+    if (bytes) HK_CHECK(hipMemsetAsync(dst, value, bytes, st));
+}
+
 struct GraphSlot {
     hipGraphExec_t exec = nullptr;
     bool valid = false;
@@ -153,20 +165,33 @@ struct hipkkt_solver {
     int prof_dense4_launches = 0;
     int64_t last_nreg = 0;
 
+    // Device memory comes from a few slabs (bump allocation, 256-byte aligned) instead of one hipMalloc per array:
+    // a handle owns ~80 arrays, and on the small problems of a batch the ~160 hipMalloc / hipFree calls were a
+    // third of the set-up + tear-down time.
+    char *slab_cur = nullptr;
+    size_t slab_left = 0;
     template <class T>
     T *dalloc(size_t n) {
-        void *p = nullptr;
         if (n == 0) n = 1;
-        hipError_t e = hipMalloc(&p, n * sizeof(T));
-        if (e != hipSuccess) throw std::bad_alloc();
-        allocs.push_back(p);
-        if (poison) (void)hipMemset(p, 0xFF, n * sizeof(T));   // debugging aid (HIPKKT_POISON=1): NaNs in every fresh buffer
+        const size_t bytes = (n * sizeof(T) + 255) & ~(size_t)255;
+        if (bytes > slab_left) {
+            const size_t slab = std::max<size_t>(bytes, (size_t)8 << 20);
+            void *p = nullptr;
+            if (hipMalloc(&p, slab) != hipSuccess) throw std::bad_alloc();
+            allocs.push_back(p);
+            slab_cur = (char *)p;
+            slab_left = slab;
+        }
+        void *p = slab_cur;
+        slab_cur += bytes;
+        slab_left -= bytes;
+        if (poison) (void)hipMemsetAsync(p, 0xFF, n * sizeof(T), stream);   // debugging aid (HIPKKT_POISON=1): NaNs in every fresh buffer
         return (T *)p;
     }
     template <class T>
     T *upload(const std::vector<T> &v) {
         T *p = dalloc<T>(v.size());
-        if (!v.empty()) HK_CHECK(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+        if (!v.empty()) copy_sync(stream, p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
         return p;
     }
     void ensure_stage(int64_t n) {
@@ -250,6 +275,8 @@ void setup_device(hipkkt_solver *S) {
     }
     for (void *p : S->allocs) (void)hipFree(p);
     S->allocs.clear();
+    S->slab_cur = nullptr;
+    S->slab_left = 0;
     S->slv_items.clear(); S->bwd_items.clear(); S->reg_lvl_sn.clear(); S->pbwd_items.clear();
     {
         const char *np_ = getenv("HIPKKT_NO_PERSIST");
@@ -532,10 +559,10 @@ void setup_device(hipkkt_solver *S) {
     {
         const size_t nsync = seg_sync_ints(S->nseg, P.nsuper);
         D.seg_sync = S->dalloc<int>(nsync);
-        HK_CHECK(hipMemset(D.seg_sync, 0, nsync * sizeof(int)));
+        fill_async(S->stream, D.seg_sync, 0, nsync * sizeof(int));
     }
     D.front_sync = S->dalloc<int>(std::max(P.front_sync_ints, 16));
-    HK_CHECK(hipMemset(D.front_sync, 0, (size_t)std::max(P.front_sync_ints, 16) * sizeof(int)));
+    fill_async(S->stream, D.front_sync, 0, (size_t)std::max(P.front_sync_ints, 16) * sizeof(int));
     D.kval = S->upload(S->img.nzval);
     D.Lx = S->dalloc<double>(P.panel_doubles);
     D.Ldiag = S->dalloc<double>(P.diag_doubles);
@@ -551,18 +578,18 @@ void setup_device(hipkkt_solver *S) {
         const size_t nx = (size_t)std::max(N, 1), np_ = (size_t)std::max<int64_t>(S->p_off[P.nsuper], 1);
         D.xseg = (FrontSlot *)S->dalloc<double>(2 * nx);
         D.pseg = (FrontSlot *)S->dalloc<double>(2 * np_);
-        HK_CHECK(hipMemset(D.xseg, 0, 16 * nx));
-        HK_CHECK(hipMemset(D.pseg, 0, 16 * np_));
+        fill_async(S->stream, D.xseg, 0, 16 * nx);
+        fill_async(S->stream, D.pseg, 0, 16 * np_);
         D.seg_epoch = S->dalloc<int>(4);
-        HK_CHECK(hipMemset(D.seg_epoch, 0, 4 * sizeof(int)));
+        fill_async(S->stream, D.seg_epoch, 0, 4 * sizeof(int));
         D.rows_seg = S->upload(rows_seg);
     }
     D.scal = S->dalloc<double>(SC_COUNT);
     D.flags = S->dalloc<int>(FL_COUNT);
-    HK_CHECK(hipMemset(D.scal, 0, SC_COUNT * sizeof(double)));
-    HK_CHECK(hipMemset(D.flags, 0, FL_COUNT * sizeof(int)));
-    HK_CHECK(hipMemset(D.Dinv, 0, (size_t)std::max(N, 1) * sizeof(double)));
-    HK_CHECK(hipMemset(D.Ldiag, 0, (size_t)std::max<int64_t>(P.diag_doubles, 1) * sizeof(double)));
+    fill_async(S->stream, D.scal, 0, SC_COUNT * sizeof(double));
+    fill_async(S->stream, D.flags, 0, FL_COUNT * sizeof(int));
+    fill_async(S->stream, D.Dinv, 0, (size_t)std::max(N, 1) * sizeof(double));
+    fill_async(S->stream, D.Ldiag, 0, (size_t)std::max<int64_t>(P.diag_doubles, 1) * sizeof(double));
 
     S->d_diag_full = S->upload(S->img.diag_full);
     if (S->l1) {
@@ -601,10 +628,10 @@ void setup_device(hipkkt_solver *S) {
         SolveCtx &C = S->ctx[c];
         for (double **v : {&C.d_b, &C.d_x0, &C.d_x1, &C.d_e, &C.d_corr, &C.d_y, &C.d_z, &C.d_xp}) {
             *v = S->dalloc<double>(N);
-            HK_CHECK(hipMemset(*v, 0, (size_t)std::max(N, 1) * sizeof(double)));
+            fill_async(S->stream, *v, 0, (size_t)std::max(N, 1) * sizeof(double));
         }
         C.d_rs = (RefineState *)S->dalloc<double>(sizeof(RefineState) / sizeof(double) + 1);
-        HK_CHECK(hipMemset(C.d_rs, 0, sizeof(RefineState)));
+        fill_async(S->stream, C.d_rs, 0, sizeof(RefineState));
         C.dp = D;
         if (c > 0) {   // private copies of everything a solve writes besides its vectors
             const size_t nx = (size_t)std::max(N, 1), np_ = (size_t)std::max<int64_t>(S->p_off[P.nsuper], 1);
@@ -613,18 +640,18 @@ void setup_device(hipkkt_solver *S) {
             C.dp.pbuf = S->dalloc<double>(S->p_off[P.nsuper]);
             C.dp.xseg = (FrontSlot *)S->dalloc<double>(2 * nx);
             C.dp.pseg = (FrontSlot *)S->dalloc<double>(2 * np_);
-            HK_CHECK(hipMemset(C.dp.xseg, 0, 16 * nx));
-            HK_CHECK(hipMemset(C.dp.pseg, 0, 16 * np_));
+            fill_async(S->stream, C.dp.xseg, 0, 16 * nx);
+            fill_async(S->stream, C.dp.pseg, 0, 16 * np_);
             C.dp.seg_epoch = S->dalloc<int>(4);
-            HK_CHECK(hipMemset(C.dp.seg_epoch, 0, 4 * sizeof(int)));
+            fill_async(S->stream, C.dp.seg_epoch, 0, 4 * sizeof(int));
             C.dp.seg_sync = S->dalloc<int>(nsync);
-            HK_CHECK(hipMemset(C.dp.seg_sync, 0, nsync * sizeof(int)));
+            fill_async(S->stream, C.dp.seg_sync, 0, nsync * sizeof(int));
             C.dp.front_sync = S->dalloc<int>(nfs);
-            HK_CHECK(hipMemset(C.dp.front_sync, 0, nfs * sizeof(int)));
+            fill_async(S->stream, C.dp.front_sync, 0, nfs * sizeof(int));
             C.dp.scal = S->dalloc<double>(SC_COUNT);
             C.dp.flags = S->dalloc<int>(FL_COUNT);
-            HK_CHECK(hipMemset(C.dp.scal, 0, SC_COUNT * sizeof(double)));
-            HK_CHECK(hipMemset(C.dp.flags, 0, FL_COUNT * sizeof(int)));
+            fill_async(S->stream, C.dp.scal, 0, SC_COUNT * sizeof(double));
+            fill_async(S->stream, C.dp.flags, 0, FL_COUNT * sizeof(int));
         }
         C.ir_used = false;
         C.h_rs->cur = 0;
@@ -633,7 +660,7 @@ void setup_device(hipkkt_solver *S) {
     S->d_b = S->ctx[0].d_b; S->d_x = S->ctx[0].d_x0; S->d_dx = S->ctx[0].d_x1; S->d_e = S->ctx[0].d_e;
     S->d_sin = S->ctx[0].d_b; S->d_sout = S->ctx[0].d_corr; S->d_y = S->ctx[0].d_y; S->d_z = S->ctx[0].d_z; S->d_xp = S->ctx[0].d_xp;
     S->ensure_stage(std::max<int64_t>(1024, std::max<int64_t>(S->img.nHs, N)));
-    HK_CHECK(hipDeviceSynchronize());
+    HK_CHECK(hipStreamSynchronize(S->stream));
 }
 
 // ---- enqueue helpers (no synchronisation inside; capturable) ---------------------------------
@@ -756,7 +783,7 @@ void run_graphed(hipkkt_solver *S, hipStream_t stream, GraphSlot &slot, bool reu
     if (!(slot.valid && reusable)) {
         if (slot.exec) { (void)hipGraphExecDestroy(slot.exec); slot.exec = nullptr; slot.valid = false; }
         hipGraph_t graph = nullptr;
-        HK_CHECK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+        HK_CHECK(hipStreamBeginCapture(stream, hipStreamCaptureModeRelaxed));
         try {
             enqueue();
         } catch (...) {
@@ -836,12 +863,13 @@ bool recover_from_sweep_failure(hipkkt_solver *S) {
             S->ctx[0].h_flags[FL_FRONTFAIL], S->ctx[1].h_flags[FL_FRONTFAIL], (long long)(S->persist_retry_at >= 0 ? S->persist_backoff : -1));
     const size_t nsync = seg_sync_ints(S->nseg, P.nsuper);
     for (SolveCtx &C : S->ctx) {
-        HK_CHECK(hipMemset(C.dp.seg_sync, 0, nsync * sizeof(int)));
-        HK_CHECK(hipMemset(C.dp.front_sync, 0, (size_t)std::max(P.front_sync_ints, 16) * sizeof(int)));
-        HK_CHECK(hipMemset(C.dp.flags + FL_FRONTFAIL, 0, sizeof(int)));
+        fill_async(S->stream, C.dp.seg_sync, 0, nsync * sizeof(int));
+        fill_async(S->stream, C.dp.front_sync, 0, (size_t)std::max(P.front_sync_ints, 16) * sizeof(int));
+        fill_async(S->stream, C.dp.flags + FL_FRONTFAIL, 0, sizeof(int));
         C.h_flags[FL_FRONTFAIL] = 0;
         C.g_ldl.valid = C.g_first.valid = C.g_step.valid = false;
     }
+    HK_CHECK(hipStreamSynchronize(S->stream));
     S->use_persist = false;
     return true;
 }
@@ -1151,7 +1179,7 @@ int32_t hipkkt_get_kkt(hipkkt_handle h, int64_t *colptr, int64_t *rowval, double
     const int64_t base = S->opts.index_base;
     if (colptr) for (int64_t j = 0; j <= K.N; j++) colptr[j] = K.colptr[j] + base;
     if (rowval) for (int64_t q = 0; q < S->nnzK; q++) rowval[q] = K.rowval[q] + base;
-    if (nzval) HK_CHECK(hipMemcpy(nzval, S->dp.kval, (size_t)S->nnzK * sizeof(double), hipMemcpyDeviceToHost));
+    if (nzval) copy_sync(S->stream, nzval, S->dp.kval, (size_t)S->nnzK * sizeof(double), hipMemcpyDeviceToHost);
     return HIPKKT_OK;
     HK_LEAVE
 }
@@ -1409,7 +1437,7 @@ int32_t hipkkt_refactor(hipkkt_handle h, int32_t static_reg_enable, double eps_c
             setup_device(T.get());
             S->fallback = T.release();
         }
-        HK_CHECK(hipMemcpy(S->fallback->dp.kval, S->dp.kval, (size_t)S->nnzK * sizeof(double), hipMemcpyDeviceToDevice));
+        copy_sync(S->stream, S->fallback->dp.kval, S->dp.kval, (size_t)S->nnzK * sizeof(double), hipMemcpyDeviceToDevice);
     } catch (...) {
         S->err = "building the fallback (minimum-degree) factorisation failed";
         return HIPKKT_ERR_DEVICE;
@@ -1533,14 +1561,14 @@ int32_t hipkkt_solve(hipkkt_handle h, double *lhsx, double *lhsz, int32_t ir_ena
     HK_ENTER(h)
     if (!S->l1) return HIPKKT_ERR_ARGUMENT;
     hipkkt_solver *T = solve_target(S);
-    if (T != S) HK_CHECK(hipMemcpy(T->ctx[0].d_b, S->ctx[0].d_b, (size_t)S->N * sizeof(double), hipMemcpyDeviceToDevice));
+    if (T != S) copy_sync(S->stream, T->ctx[0].d_b, S->ctx[0].d_b, (size_t)S->N * sizeof(double), hipMemcpyDeviceToDevice);
     int32_t rc = solve_many(T, 1, ir_enable, reltol, abstol, max_iter, stop_ratio, ir_steps, nullptr, 0);
     account_fallback_solve(S, T);
     if (rc == HIPKKT_OK) {  // ref: kktsolver_getlhs! only on success
         const int64_t n = S->img.n, m = S->img.m;
         const double *x = T->ctx[0].result();
-        if (lhsx && n) HK_CHECK(hipMemcpy(lhsx, x, n * sizeof(double), hipMemcpyDeviceToHost));
-        if (lhsz && m) HK_CHECK(hipMemcpy(lhsz, x + n, m * sizeof(double), hipMemcpyDeviceToHost));
+        if (lhsx && n) copy_sync(S->stream, lhsx, x, n * sizeof(double), hipMemcpyDeviceToHost);
+        if (lhsz && m) copy_sync(S->stream, lhsz, x + n, m * sizeof(double), hipMemcpyDeviceToHost);
     }
     return rc;
     HK_LEAVE
@@ -1551,7 +1579,7 @@ int32_t hipkkt_solve_dev(hipkkt_handle h, double *lhs_dev, int32_t ir_enable, do
     HK_ENTER(h)
     if (!S->l1) return HIPKKT_ERR_ARGUMENT;
     hipkkt_solver *T = solve_target(S);
-    if (T != S) HK_CHECK(hipMemcpy(T->ctx[0].d_b, S->ctx[0].d_b, (size_t)S->N * sizeof(double), hipMemcpyDeviceToDevice));
+    if (T != S) copy_sync(S->stream, T->ctx[0].d_b, S->ctx[0].d_b, (size_t)S->N * sizeof(double), hipMemcpyDeviceToDevice);
     double *outs[1] = {lhs_dev};
     int32_t rc = solve_many(T, 1, ir_enable, reltol, abstol, max_iter, stop_ratio, ir_steps, outs, (int)(S->img.n + S->img.m));
     account_fallback_solve(S, T);
@@ -1590,8 +1618,8 @@ static int32_t solve_multi_impl(hipkkt_solver *S, int64_t nrhs, const double *rh
             for (int c = 0; c < k; c++) {
                 const double *x = T->ctx[c].result();
                 const int64_t r = r0 + c;
-                if (lhsx && n) HK_CHECK(hipMemcpy(lhsx + r * n, x, n * sizeof(double), hipMemcpyDeviceToHost));
-                if (lhsz && m) HK_CHECK(hipMemcpy(lhsz + r * m, x + n, m * sizeof(double), hipMemcpyDeviceToHost));
+                if (lhsx && n) copy_sync(S->stream, lhsx + r * n, x, n * sizeof(double), hipMemcpyDeviceToHost);
+                if (lhsz && m) copy_sync(S->stream, lhsz + r * m, x + n, m * sizeof(double), hipMemcpyDeviceToHost);
             }
     }
     return rc_all;
@@ -1622,7 +1650,7 @@ int32_t hipkkt_ldl_solve(hipkkt_handle h, double *x, const double *b) {
     int32_t rc = solve_many(S, 1, 0, 0.0, 0.0, 0, 0.0, nullptr, nullptr, 0);
     if (rc < 0) return rc;
     // ref: solve!(ldlsolver,K,x,b) returns whatever the triangular solves produce; a non-finite result is the caller's to detect
-    HK_CHECK(hipMemcpy(x, C.d_x0, (size_t)S->N * sizeof(double), hipMemcpyDeviceToHost));
+    copy_sync(S->stream, x, C.d_x0, (size_t)S->N * sizeof(double), hipMemcpyDeviceToHost);
     return HIPKKT_OK;
     HK_LEAVE
 }
@@ -1656,7 +1684,7 @@ int32_t hipkkt_debug_dump(hipkkt_handle h, int32_t what, double *out, int64_t ca
     const HostPlan &P = S->plan;
     auto dev = [&](const double *p, int64_t n) {
         if (len) *len = n;
-        if (out && cap >= n) HK_CHECK(hipMemcpy(out, p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+        if (out && cap >= n) copy_sync(S->stream, out, p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost);
     };
     auto host = [&](int64_t n, auto f) {
         if (len) *len = n;

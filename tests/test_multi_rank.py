@@ -39,7 +39,17 @@ def _worker(rank, world, port, nprob, out):
         sol = s.solve()
         sols[k] = (sol.status, sol.iterations, float(sol.obj_val))
 
-    elapsed = batch.timed_steps(step, steps=len(mine), warmup=1, dist=dist)
+    if rank == 0:   # rank 0 also exercises the several-problems-in-flight driver (host threads, one solver each)
+        step(0)     # warm-up, like timed_steps does
+        done = []
+
+        def timed(_):
+            done.extend(batch.run_concurrent(lambda i: step(i), list(range(len(mine))), in_flight=2))
+
+        elapsed = batch.timed_steps(timed, steps=1, warmup=0, dist=dist)
+        assert len(done) == len(mine)
+    else:
+        elapsed = batch.timed_steps(step, steps=len(mine), warmup=1, dist=dist)
     total = batch.gather_counts(len(mine), dist)
     gathered = [None] * world
     dist.all_gather_object(gathered, (rank, mine, sols, elapsed, total))
@@ -84,3 +94,17 @@ def test_shard_partition_properties():
             parts = [batch.shard(n, r, w) for r in range(w)]
             assert sorted(sum(parts, [])) == list(range(n))
             assert max(map(len, parts)) - min(map(len, parts)) <= 1
+
+
+def test_run_concurrent_keeps_order_and_results():
+    """several problems in flight on one device (bench.py cfg 4): results come back in item order and equal the sequential ones"""
+    from oracle.kkt_oracle import OracleKKTSolver
+
+    def solve(k):
+        P, q, A, b, cones = problems.random_sparse_qp(30 + 4 * k, 50 + 6 * k, seed=200 + k, kA=3, kP=1)
+        sol = cl.Solver(P, q, A, b, cones, cl.Settings(), kktsolver_factory=lambda *a: OracleKKTSolver(*a)).solve()
+        return k, sol.status, sol.iterations, float(sol.obj_val)
+
+    seq = batch.run_concurrent(solve, list(range(6)), 1)
+    par = batch.run_concurrent(solve, list(range(6)), 3)
+    assert seq == par and [r[0] for r in par] == list(range(6)) and all(r[1] == "SOLVED" for r in par)
