@@ -142,6 +142,7 @@ struct hipkkt_solver {
     // vectors
     double *d_b = nullptr, *d_x = nullptr, *d_dx = nullptr, *d_e = nullptr;
     double *d_sin = nullptr, *d_sout = nullptr, *d_y = nullptr, *d_z = nullptr, *d_xp = nullptr;
+    double *d_qb = nullptr, *d_res_in = nullptr, *d_res_out = nullptr, *d_res_part = nullptr;   // residuals_update! on the device (N4)
     double *d_stage = nullptr;   // staging for host-supplied values
     int64_t *d_stage_idx = nullptr;
     int64_t stage_cap = 0;
@@ -287,6 +288,7 @@ void setup_device(hipkkt_solver *S) {
     S->soc_off.clear(); S->soc_of_sparse.clear();
     S->nsoc = 0; S->soc_total = 0; S->wmax_all = 1;
     S->stage_cap = 0; S->d_stage = nullptr; S->d_stage_idx = nullptr;
+    S->d_qb = S->d_res_in = S->d_res_out = S->d_res_part = nullptr;
 
     HostPlan &P = S->plan;
     const int N = P.N;
@@ -1296,6 +1298,57 @@ int32_t hipkkt_block_products(hipkkt_handle h, const double *x, const double *z,
     if (Ax && m) HK_CHECK(hipMemcpyAsync(Ax, dAx, m * sizeof(double), hipMemcpyDeviceToHost, S->stream));
     HK_CHECK(hipStreamSynchronize(S->stream));
     return HIPKKT_OK;
+    HK_LEAVE
+}
+
+// residuals_update! on the device.  q and b become resident with hipkkt_set_qb.
+int32_t hipkkt_set_qb(hipkkt_handle h, const double *q, const double *b) {
+    HK_ENTER(h)
+    const int64_t n = S->img.n, m = S->img.m;
+    if (!S->l1 || (n && !q) || (m && !b)) { S->err = "set_qb: bad arguments / not an L1 handle"; return HIPKKT_ERR_ARGUMENT; }
+    if (!S->d_qb) {
+        S->d_qb = S->dalloc<double>(n + m);
+        S->d_res_in = S->dalloc<double>(n + 2 * m);                  // x | z | s
+        S->d_res_out = S->dalloc<double>(3 * n + 2 * m + 8);         // rx | rz | rx_inf | rz_inf | Px | 5 scalars
+        S->d_res_part = S->dalloc<double>(4 * (size_t)residual_blocks((int)n, (int)m) + 4);
+    }
+    if (n) HK_CHECK(hipMemcpyAsync(S->d_qb, q, n * sizeof(double), hipMemcpyHostToDevice, S->stream));
+    if (m) HK_CHECK(hipMemcpyAsync(S->d_qb + n, b, m * sizeof(double), hipMemcpyHostToDevice, S->stream));
+    HK_CHECK(hipStreamSynchronize(S->stream));
+    return HIPKKT_OK;
+    HK_LEAVE
+}
+
+static int32_t residuals_impl(hipkkt_solver *S, const double *xzs_dev, double tau, double kappa, double *out_dev, double *scal5) {
+    const int64_t n = S->img.n, m = S->img.m;
+    launch_residuals(S->stream, S->dp, xzs_dev, xzs_dev + n, xzs_dev + n + m, S->d_qb, S->d_qb + n, tau, kappa, out_dev, S->d_res_part,
+                     S->d_res_out + 3 * n + 2 * m, (int)n, (int)m);
+    copy_sync(S->stream, scal5, S->d_res_out + 3 * n + 2 * m, 5 * sizeof(double), hipMemcpyDeviceToHost);
+    return HIPKKT_OK;
+}
+
+int32_t hipkkt_residuals(hipkkt_handle h, const double *x, const double *z, const double *s, double tau, double kappa, double *rx,
+                         double *rz, double *rx_inf, double *rz_inf, double *Px, double *scal5) {
+    HK_ENTER(h)
+    const int64_t n = S->img.n, m = S->img.m;
+    if (!S->l1 || !S->d_qb || !scal5 || (n && !x) || (m && (!z || !s))) { S->err = "residuals: call hipkkt_set_qb first / bad arguments"; return HIPKKT_ERR_ARGUMENT; }
+    if (n) HK_CHECK(hipMemcpyAsync(S->d_res_in, x, n * sizeof(double), hipMemcpyHostToDevice, S->stream));
+    if (m) HK_CHECK(hipMemcpyAsync(S->d_res_in + n, z, m * sizeof(double), hipMemcpyHostToDevice, S->stream));
+    if (m) HK_CHECK(hipMemcpyAsync(S->d_res_in + n + m, s, m * sizeof(double), hipMemcpyHostToDevice, S->stream));
+    const int32_t rc = residuals_impl(S, S->d_res_in, tau, kappa, S->d_res_out, scal5);
+    double *o = S->d_res_out;
+    struct { double *dst; const double *src; int64_t len; } cp[5] = {{rx, o, n}, {rz, o + n, m}, {rx_inf, o + n + m, n}, {rz_inf, o + 2 * n + m, m}, {Px, o + 2 * n + 2 * m, n}};
+    for (auto &c : cp)
+        if (c.dst && c.len) HK_CHECK(hipMemcpyAsync(c.dst, c.src, c.len * sizeof(double), hipMemcpyDeviceToHost, S->stream));
+    HK_CHECK(hipStreamSynchronize(S->stream));
+    return rc;
+    HK_LEAVE
+}
+
+int32_t hipkkt_residuals_dev(hipkkt_handle h, const double *xzs_dev, double tau, double kappa, double *out_dev, double *scal5) {
+    HK_ENTER(h)
+    if (!S->l1 || !S->d_qb || !xzs_dev || !out_dev || !scal5) { S->err = "residuals_dev: call hipkkt_set_qb first / bad arguments"; return HIPKKT_ERR_ARGUMENT; }
+    return residuals_impl(S, xzs_dev, tau, kappa, out_dev, scal5);
     HK_LEAVE
 }
 

@@ -42,6 +42,9 @@ void launch_refine_add(hipStream_t st, const RefineState *rs, double *x0, double
 void launch_refine_copy_out(hipStream_t st, const RefineState *rs, const double *x0, const double *x1, double *out, int nm);
 void launch_spmv_residual_cand(hipStream_t st, const DevPlan &P, const double *b, const RefineState *rs, const double *x0,
                                const double *x1, double *e, int n, unsigned long long *slot);
+int residual_blocks(int n, int m);
+void launch_residuals(hipStream_t st, const DevPlan &P, const double *x, const double *z, const double *s, const double *q,
+                      const double *b, double tau, double kappa, double *out, double *part, double *scal, int n, int m);
 void launch_norm_inf(hipStream_t st, const double *v, int n, unsigned long long *slot);
 void launch_add(hipStream_t st, double *dst, const double *a, int n);
 void launch_set_rhs(hipStream_t st, double *b, const double *rhs, int nm, int n);

@@ -1884,6 +1884,88 @@ k_block_products(const int64_t *__restrict__ rowptr, const int *__restrict__ col
     }
 }
 
+// residuals_update! (residuals.jl:1-37) from the RESIDENT P and A values -- rows of the symmetric
+// CSR view of K, 4 lanes per row (see k_block_products):
+//   rows i < n :  Px_i = (P x)_i, rx_inf_i = -(A' z)_i, rx_i = rx_inf_i - Px_i - q_i tau,  partial sums of q.x and x.Px
+//   rows n+j   :  rz_inf_j = s_j + (A x)_j,             rz_j = rz_inf_j - b_j tau,         partial sums of b.z and s.z
+// The four dot products are reduced per workgroup into part[blockIdx][4] and summed in block order by k_residuals_finish
+// (deterministic).  out = [rx | rz | rx_inf | rz_inf | Px]  (n + m + n + m + n doubles).
+__global__ void __launch_bounds__(256)
+k_residuals(const int64_t *__restrict__ rowptr, const int *__restrict__ col, const int64_t *__restrict__ qidx,
+            const double *__restrict__ kval, const double *__restrict__ x, const double *__restrict__ z,
+            const double *__restrict__ sv, const double *__restrict__ q, const double *__restrict__ b, double tau,
+            double *__restrict__ out, double *__restrict__ part, int n, int m) {
+    __shared__ double red[4][4];
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int row = gid >> 2, sub = gid & 3;
+    double ax = 0.0, az = 0.0;
+    if (row < n + m) {
+        const int64_t p0 = rowptr[row], p1 = rowptr[row + 1];
+        for (int64_t p = p0 + sub; p < p1; p += 4) {
+            const int c = col[p];
+            const double v = kval[qidx[p]];
+            if (c < n) ax += v * x[c];
+            else if (row < n && c < n + m) az += v * z[c - n];
+        }
+    }
+    ax += __shfl_xor(ax, 1, 64);
+    ax += __shfl_xor(ax, 2, 64);
+    az += __shfl_xor(az, 1, 64);
+    az += __shfl_xor(az, 2, 64);
+    double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0;      // q.x, b.z, s.z, x.Px contributions of this row
+    if (sub == 0 && row < n + m) {
+        double *rx = out, *rz = out + n, *rxi = rz + m, *rzi = rxi + n, *Px = rzi + m;
+        if (row < n) {
+            const double xi = x[row], rinf = -az;
+            Px[row] = ax;
+            rxi[row] = rinf;
+            rx[row] = (rinf - ax) - q[row] * tau;
+            d0 = q[row] * xi;
+            d3 = xi * ax;
+        } else {
+            const int j = row - n;
+            const double rinf = sv[j] + ax;
+            rzi[j] = rinf;
+            rz[j] = rinf - b[j] * tau;
+            d1 = b[j] * z[j];
+            d2 = sv[j] * z[j];
+        }
+    }
+    // workgroup reduction in a fixed order
+    for (int off = 32; off > 0; off >>= 1) {
+        d0 += __shfl_down(d0, off, 64);
+        d1 += __shfl_down(d1, off, 64);
+        d2 += __shfl_down(d2, off, 64);
+        d3 += __shfl_down(d3, off, 64);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { red[wave][0] = d0; red[wave][1] = d1; red[wave][2] = d2; red[wave][3] = d3; }
+    __syncthreads();
+    if (threadIdx.x < 4)
+        part[(int64_t)blockIdx.x * 4 + threadIdx.x] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+}
+// scal = [q.x, b.z, s.z, x.Px, r_tau = q.x + b.z + kappa + x.Px / tau]   (residuals.jl:27-34)
+__global__ void __launch_bounds__(256)
+k_residuals_finish(const double *__restrict__ part, int nblocks, double tau, double kappa, double *__restrict__ scal) {
+    __shared__ double buf[4][64];
+    const int which = threadIdx.x & 3, slot = threadIdx.x >> 2;      // 64 partial sums per dot product, fixed order
+    double a = 0.0;
+    for (int bq = slot; bq < nblocks; bq += 64) a += part[(int64_t)bq * 4 + which];
+    buf[which][slot] = a;
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        double t = 0.0;
+        for (int i = 0; i < 64; i++) t += buf[threadIdx.x][i];
+        buf[threadIdx.x][0] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double qx = buf[0][0], bz = buf[1][0], sz = buf[2][0], xPx = buf[3][0];
+        scal[0] = qx; scal[1] = bz; scal[2] = sz; scal[3] = xPx;
+        scal[4] = qx + bz + kappa + xPx / tau;
+    }
+}
+
 __global__ void __launch_bounds__(256)
 k_norm_inf(const double *__restrict__ v, int n, unsigned long long *__restrict__ slot) {
     double a = 0.0;
@@ -2174,6 +2256,14 @@ void launch_spmv_residual_cand(hipStream_t st, const DevPlan &P, const double *b
     if (n > 0)
         hipLaunchKernelGGL(k_spmv_residual_cand, dim3(nblk((int64_t)n * 4)), dim3(256), 0, st, P.sym_rowptr, P.sym_col, P.sym_q,
                            P.kval, b, rs, x0, x1, e, n, slot);
+}
+int residual_blocks(int n, int m) { return (int)nblk((int64_t)(n + m) * 4); }
+void launch_residuals(hipStream_t st, const DevPlan &P, const double *x, const double *z, const double *s, const double *q,
+                      const double *b, double tau, double kappa, double *out, double *part, double *scal, int n, int m) {
+    if (n + m <= 0) return;
+    const int nb = residual_blocks(n, m);
+    hipLaunchKernelGGL(k_residuals, dim3(nb), dim3(256), 0, st, P.sym_rowptr, P.sym_col, P.sym_q, P.kval, x, z, s, q, b, tau, out, part, n, m);
+    hipLaunchKernelGGL(k_residuals_finish, dim3(1), dim3(256), 0, st, part, nb, tau, kappa, scal);
 }
 void launch_norm_inf(hipStream_t st, const double *v, int n, unsigned long long *slot) {
     if (n > 0) hipLaunchKernelGGL(k_norm_inf, dim3(min(nblk(n), 64u)), dim3(256), 0, st, v, n, slot);

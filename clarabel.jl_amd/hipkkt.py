@@ -24,7 +24,7 @@ SYMBOLS = [
     "hipkkt_set_hs", "hipkkt_set_hs_dev", "hipkkt_set_hs_psd", "hipkkt_block_products", "hipkkt_set_soc", "hipkkt_set_soc_batch", "hipkkt_set_genpow",
     "hipkkt_update_P", "hipkkt_update_A", "hipkkt_refactor", "hipkkt_setrhs", "hipkkt_setrhs_dev", "hipkkt_solve",
     "hipkkt_solve_dev", "hipkkt_solve_multi", "hipkkt_solve_multi_dev", "hipkkt_ldl_solve", "hipkkt_get_timing", "hipkkt_reset_timing", "hipkkt_get_profile", "hipkkt_set_profiling",
-    "hipkkt_get_counters", "hipkkt_debug_dump",
+    "hipkkt_get_counters", "hipkkt_debug_dump", "hipkkt_set_qb", "hipkkt_residuals", "hipkkt_residuals_dev",
     "hipkkt_selftest_mfma", "hipkkt_last_error",
 ]
 
@@ -95,6 +95,9 @@ def lib():
     L.hipkkt_get_profile.argtypes = [vp, _f64p]
     L.hipkkt_set_profiling.argtypes = [vp, i32]
     L.hipkkt_get_counters.argtypes = [vp, _i64p]
+    L.hipkkt_set_qb.argtypes = [vp, _f64p, _f64p]
+    L.hipkkt_residuals.argtypes = [vp, _f64p, _f64p, _f64p, f64, f64, vp, vp, vp, vp, vp, _f64p]
+    L.hipkkt_residuals_dev.argtypes = [vp, vp, f64, f64, vp, _f64p]
     L.hipkkt_debug_dump.argtypes = [vp, i32, vp, i64, C.POINTER(i64)]
     L.hipkkt_selftest_mfma.argtypes = [i32, C.POINTER(f64)]
     L.hipkkt_last_error.argtypes = [vp]
@@ -347,6 +350,18 @@ class Handle:
         self._chk(self.L.hipkkt_block_products(self.h, np.ascontiguousarray(x, dtype=np.float64),
                                                np.ascontiguousarray(z, dtype=np.float64), Px, ATz, Ax), "block_products")
         return Px, ATz, Ax
+
+    def set_qb(self, q, b):
+        self._chk(self.L.hipkkt_set_qb(self.h, np.ascontiguousarray(q, dtype=np.float64), np.ascontiguousarray(b, dtype=np.float64)), "set_qb")
+
+    def residuals(self, x, z, s, tau, kappa, rx, rz, rx_inf, rz_inf, Px):
+        """residuals_update! on the device (include/hipkkt.h hipkkt_residuals); returns (dot_qx, dot_bz, dot_sz, dot_xPx, r_tau)"""
+        f = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+        scal = np.zeros(5)
+        ptrs = [self._out_ptr(a, k, nm) for a, k, nm in ((rx, self.n, "rx"), (rz, self.m, "rz"), (rx_inf, self.n, "rx_inf"),
+                                                          (rz_inf, self.m, "rz_inf"), (Px, self.n, "Px"))]
+        self._chk(self.L.hipkkt_residuals(self.h, f(x), f(z), f(s), float(tau), float(kappa), *ptrs, scal), "residuals")
+        return tuple(float(v) for v in scal)
 
     def ldl_solve(self, b):
         x = np.zeros(self.N)

@@ -106,6 +106,16 @@ class HipKKTSolver:
             print(f"[hipkkt] solve_multi ok={ok} ir_steps={list(steps)}")
         return ok
 
+    # residuals_update!(residuals, variables, data) (residuals.jl:1-37) from the resident P, A
+    def set_problem_vectors(self, q, b):
+        self.h.set_qb(q, b)
+        self._has_qb = True
+
+    def residuals_update(self, r, v):
+        """fills the residual object `r` (rx, rz, rx_inf, rz_inf, Px, rtau, dot_*) from the variables `v` (x, z, s, tau, kappa)"""
+        r.dot_qx, r.dot_bz, r.dot_sz, r.dot_xPx, r.rtau = self.h.residuals(v.x, v.z, v.s, v.tau, v.kappa, r.rx, r.rz, r.rx_inf,
+                                                                          r.rz_inf, r.Px)
+
     # ref: kktsolver_update_P!/A!, :374-386
     def kktsolver_update_P(self, P):
         self.h.update_P(P.data)

@@ -49,4 +49,6 @@ class Settings:
     chordal_decomposition_enable: bool = False  # :139 (out of scope here; configs run with it off)
     # device selection for the :hip KKT solver (not in the reference)
     device_id: int = 0
+    # SURVEY section 8(f) rows widened beyond the reference's plugin seam (all off by default = the reference's call pattern)
+    device_residuals: bool = False            # N4: residuals_update! computed by the plugin from the resident P, A
     extra: dict = field(default_factory=dict)

@@ -200,6 +200,17 @@ int32_t hipkkt_ldl_solve(hipkkt_handle h, double *x, const double *b);
  * x[n], z[m] in; Px[n], ATz[n], Ax[m] out (host memory; any of the outputs may be NULL). */
 int32_t hipkkt_block_products(hipkkt_handle h, const double *x, const double *z, double *Px, double *ATz, double *Ax);
 
+/* residuals_update!(residuals, variables, data), residuals.jl:1-37, computed on the device from
+ * the resident P and A values (L1 handles).  hipkkt_set_qb makes q[n] and b[m] resident (once per problem, again after
+ * update_q!/update_b!).  hipkkt_residuals: x[n], z[m], s[m], tau, kappa in; rx[n], rz[m], rx_inf[n], rz_inf[m], Px[n] out
+ * (host memory, any may be NULL); scal5 = {dot_qx, dot_bz, dot_sz, dot_xPx, r_tau} (host, required).  The dot products
+ * are summed in a fixed order (deterministic).  The _dev form takes xzs_dev = [x | z | s] and writes
+ * out_dev = [rx | rz | rx_inf | rz_inf | Px] (3n + 2m doubles) without touching PCIe except for the five scalars. */
+int32_t hipkkt_set_qb(hipkkt_handle h, const double *q, const double *b);
+int32_t hipkkt_residuals(hipkkt_handle h, const double *x, const double *z, const double *s, double tau, double kappa,
+                         double *rx, double *rz, double *rx_inf, double *rz_inf, double *Px, double *scal5);
+int32_t hipkkt_residuals_dev(hipkkt_handle h, const double *xzs_dev, double tau, double kappa, double *out_dev, double *scal5);
+
 /* ---- timing (device time on the handle's stream, HIP events) ------------------------------- */
 /* out[0] = ms of last refactor (value scatter + numeric LDL), out[1] = ms of last solve call
  * (all LDL solves + SpMVs of the refinement), out[2] = accumulated refactor ms, out[3] = accumulated

@@ -359,6 +359,10 @@ class Solver:
             kktsolver_factory = HipKKTSolver
         t1 = time.perf_counter()
         self.kktsystem = KKTSystem(kktsolver_factory(data.P, data.A, self.cones, m, n, st), m, n)
+        ks = self.kktsystem.kktsolver
+        self._device_residuals = bool(getattr(st, "device_residuals", False)) and hasattr(ks, "residuals_update")
+        if self._device_residuals:
+            ks.set_problem_vectors(data.q, data.b)
         self.info = Info()
         self.info.timers["kkt init"] = time.perf_counter() - t1
         self.step_lhs = Variables.zeros(n, m)
@@ -387,15 +391,22 @@ class Solver:
         data = self.data
         data.q[:] = np.asarray(q, dtype=np.float64) * data.d * data.c
         data.normq = None
+        if self._device_residuals:
+            self.kktsystem.kktsolver.set_problem_vectors(data.q, data.b)
 
     def update_b(self, b):
         data = self.data
         data.b[:] = np.minimum(np.asarray(b, dtype=np.float64), INFINITY) * data.e
         data.normb = None
+        if self._device_residuals:
+            self.kktsystem.kktsolver.set_problem_vectors(data.q, data.b)
 
     # ------------------------------------------------------------- residuals.jl:1-37
     def _residuals_update(self):
         r, v, d = self.residuals, self.variables, self.data
+        if self._device_residuals:       # the SpMVs and dots of residuals.jl on the device
+            self.kktsystem.kktsolver.residuals_update(r, v)
+            return
         qx = float(np.dot(d.q, v.x))
         bz = float(np.dot(d.b, v.z))
         sz = float(np.dot(v.s, v.z))

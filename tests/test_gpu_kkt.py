@@ -542,3 +542,38 @@ def test_refinement_steps_match_oracle_on_a_hard_system(oracle_factory):
         scale = max(1.0, np.max(np.abs(lx_c)), np.max(np.abs(lz_c)))
         assert np.max(np.abs(lx_g - lx_c)) <= 1e-9 * scale and np.max(np.abs(lz_g - lz_c)) <= 1e-9 * scale
     print("refinement steps seen on the oracle:", sorted(seen))
+
+
+@pytest.mark.parametrize("name", ["qp_fixture", "cfg1", "portfolio_small", "sdp_small"])
+def test_residuals_update_on_device(name):
+    """residuals_update! (residuals.jl:1-37) from the resident P, A against the numpy caller's own
+    (1e-13 relative; the dot products are summed in a different but fixed order), also after update_P!/update_A!, and the
+    whole IPM driven with device residuals reaches the same answer as with host residuals."""
+    rng = np.random.default_rng(17)
+    P, q, A, b, cones = PROBLEMS[name]()
+    ref = cl.Solver(P, q, A, b, cones, cl.Settings())
+    dev = cl.Solver(P, q, A, b, cones, cl.Settings(device_residuals=True))
+    assert dev._device_residuals
+    for rep in range(2):
+        for S in (ref, dev):
+            v = S.variables
+            v.x[:], v.z[:], v.s[:] = rng.standard_normal(v.x.size), rng.random(v.z.size), rng.random(v.s.size)
+            v.tau, v.kappa = 0.7 + rep, 0.3
+        dev.variables.x[:], dev.variables.z[:], dev.variables.s[:] = ref.variables.x, ref.variables.z, ref.variables.s
+        ref._residuals_update()
+        dev._residuals_update()
+        for nm in ("rx", "rz", "rx_inf", "rz_inf", "Px"):
+            a, c = getattr(dev.residuals, nm), getattr(ref.residuals, nm)
+            assert np.max(np.abs(a - c)) <= 1e-13 * max(1.0, np.max(np.abs(c))), nm
+        for nm in ("dot_qx", "dot_bz", "dot_sz", "dot_xPx", "rtau"):
+            a, c = getattr(dev.residuals, nm), getattr(ref.residuals, nm)
+            assert abs(a - c) <= 1e-12 * max(1.0, abs(c)), nm
+        if rep == 0:      # new values on the same pattern: the device products follow kktsolver_update_P!/A!
+            Pt = sp.triu(sp.csc_matrix(P), format="csc")
+            for S in (ref, dev):
+                S.update_P(Pt.data * 1.25)
+                S.update_A(sp.csc_matrix(A).data * 0.75)
+    solr = cl.Solver(P, q, A, b, cones, cl.Settings()).solve()
+    sold = cl.Solver(P, q, A, b, cones, cl.Settings(device_residuals=True)).solve()
+    assert solr.status == sold.status == "SOLVED" and abs(solr.iterations - sold.iterations) <= 1
+    assert abs(solr.obj_val - sold.obj_val) <= 1e-7 * max(1.0, abs(solr.obj_val))
