@@ -30,6 +30,38 @@ int main(int argc, char **argv) {
            P.N, (long)P.nnzK, (long)P.nnzL, P.nsuper, P.nlevels, (long)P.panel_doubles, P.flops_colcount, P.flops_update, P.flops_exec,
            std::chrono::duration<double>(t1 - t0).count());
     printf("ntasks %zu ngroups %zu ordering_used %d fronts %zu | model: md %.3f ms (%d levels)  nd %.3f ms (%d levels)\n", P.upd_tasks.size(), P.upd_groups.size(), P.ordering_used, P.fronts.size(), 1e3 * P.cost_md_seconds, P.cost_md_levels, 1e3 * P.cost_nd_seconds, P.cost_nd_levels);
+    {
+        size_t n3 = 0, n1 = 0, pairs = 0;
+        for (auto &g : P.upd_groups) { n3 += g.dense == 3; n1 += g.dense == 1; }
+        for (auto &st : P.subtiles) pairs += st.list_end - st.list_begin;
+        printf("dense tiles %zu, low-fill (sub-block) tiles %zu with %zu sub-blocks and %zu (task, sub-block) pairs\n", n1, n3, P.subtiles.size(), pairs);
+        for (int l = 0; l < P.nlevels; l++) if (P.upd_stage_nsub[l]) printf("  stage %d: %d low-fill tiles, %d sub-blocks\n", l, P.upd_stage_nsub[l], P.sub_stage_ptr[l + 1] - P.sub_stage_ptr[l]);
+    }
+    for (int l = 0; l < P.nlevels; l++) {   // per stage: dense tiles by average coverage per task, and sub-blocks touched per task
+        double cov = 0, nt = 0, sb = 0, kk = 0; int ng = 0;
+        int hist[6] = {0, 0, 0, 0, 0, 0};
+        for (int g = P.upd_stage_ptr[l]; g < P.upd_stage_ptr[l] + P.upd_stage_ndense[l]; g++) {
+            const UpdGroup &G = P.upd_groups[g];
+            const int ft = P.sn_first[G.tgt];
+            double c = 0;
+            for (int q = G.task_begin; q < G.task_end; q++) {
+                const UpdTask &T = P.upd_tasks[q];
+                c += (double)T.nrows * T.ncols;
+                unsigned rb = 0, cb = 0;
+                const int *srows = &P.sn_rows[P.sn_rowptr[T.src]];
+                const int *rel = &P.rel[T.rel_off];
+                for (int i = 0; i < T.nrows; i++) rb |= 1u << ((rel[T.row_lo + i - T.col_lo] - G.row_base) >> 4);
+                for (int j = 0; j < T.ncols; j++) cb |= 1u << ((srows[T.col_lo + j] - ft) >> 4);
+                sb += __builtin_popcount(rb) * __builtin_popcount(cb);
+                kk += P.sn_first[T.src + 1] - P.sn_first[T.src];
+            }
+            const double per = c / (G.task_end - G.task_begin);
+            hist[per < 100 ? 0 : per < 200 ? 1 : per < 400 ? 2 : per < 800 ? 3 : per < 1600 ? 4 : 5]++;
+            cov += c; nt += G.task_end - G.task_begin; ng++;
+        }
+        if (ng > 50) printf("  stage %d: %d dense tiles, %.0f tasks/tile, %.0f entries/task, %.1f sub-blocks/task, K %.1f; tiles by entries/task <100:%d <200:%d <400:%d <800:%d <1600:%d more:%d\n",
+                            l, ng, nt / ng, cov / nt, sb / nt, kk / nt, hist[0], hist[1], hist[2], hist[3], hist[4], hist[5]);
+    }
     printf("%5s %7s %7s %7s %9s %12s %8s %8s\n", "lvl", "nsn", "maxw", "maxr", "sum_rw", "upd_flops", "groups", "facitems");
     std::vector<double> lf(P.nlevels, 0.0), lfd(P.nlevels, 0.0), fills(P.nlevels, 0.0);
     for (int l = 0; l < P.nlevels; l++)
