@@ -30,13 +30,6 @@ int main(int argc, char **argv) {
            P.N, (long)P.nnzK, (long)P.nnzL, P.nsuper, P.nlevels, (long)P.panel_doubles, P.flops_colcount, P.flops_update, P.flops_exec,
            std::chrono::duration<double>(t1 - t0).count());
     printf("ntasks %zu ngroups %zu ordering_used %d fronts %zu | model: md %.3f ms (%d levels)  nd %.3f ms (%d levels)\n", P.upd_tasks.size(), P.upd_groups.size(), P.ordering_used, P.fronts.size(), 1e3 * P.cost_md_seconds, P.cost_md_levels, 1e3 * P.cost_nd_seconds, P.cost_nd_levels);
-    {
-        size_t n3 = 0, n1 = 0, pairs = 0;
-        for (auto &g : P.upd_groups) { n3 += g.dense == 3; n1 += g.dense == 1; }
-        for (auto &st : P.subtiles) pairs += st.list_end - st.list_begin;
-        printf("dense tiles %zu, low-fill (sub-block) tiles %zu with %zu sub-blocks and %zu (task, sub-block) pairs\n", n1, n3, P.subtiles.size(), pairs);
-        for (int l = 0; l < P.nlevels; l++) if (P.upd_stage_nsub[l]) printf("  stage %d: %d low-fill tiles, %d sub-blocks\n", l, P.upd_stage_nsub[l], P.sub_stage_ptr[l + 1] - P.sub_stage_ptr[l]);
-    }
     for (int l = 0; l < P.nlevels; l++) {   // per stage: dense tiles by average coverage per task, and sub-blocks touched per task
         double cov = 0, nt = 0, sb = 0, kk = 0; int ng = 0;
         int hist[6] = {0, 0, 0, 0, 0, 0};
