@@ -31,4 +31,9 @@ std::string assemble_kkt(int64_t n, int64_t m, const int64_t *Pp, const int64_t 
                          const int64_t *numel, const int32_t *hs_dense, const int32_t *sparse_kind,
                          const int64_t *dim1, KKTImage &K);
 
+// the same image built by count -> scan -> fill kernels on the current device (assemble_dev.hip); `stream` is a hipStream_t
+std::string assemble_kkt_device(void *stream, int64_t n, int64_t m, const int64_t *Pp, const int64_t *Pi, const double *Px,
+                                const int64_t *Ap, const int64_t *Ai, const double *Ax, int64_t ncones, const int64_t *numel,
+                                const int32_t *hs_dense, const int32_t *sparse_kind, const int64_t *dim1, KKTImage &K);
+
 }  // namespace hipkkt

@@ -12,6 +12,7 @@ for f in hipkkt.cpp symbolic.cpp ordering.cpp assemble.cpp; do
   $HIPCC $FLAGS -x c++ -I/opt/rocm/include -D__HIP_PLATFORM_AMD__ -c $f -o $OBJ/${f%.cpp}.o & pids+=($!)
 done
 $HIPCC $FLAGS -c kernels.hip -o $OBJ/kernels.o & pids+=($!)
+$HIPCC $FLAGS -c assemble_dev.hip -o $OBJ/assemble_dev.o & pids+=($!)
 for p in "${pids[@]}"; do wait $p; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT $OBJ/hipkkt.o $OBJ/symbolic.o $OBJ/ordering.o $OBJ/assemble.o $OBJ/kernels.o
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT $OBJ/hipkkt.o $OBJ/symbolic.o $OBJ/ordering.o $OBJ/assemble.o $OBJ/assemble_dev.o $OBJ/kernels.o
 echo "built $(readlink -f $OUT)"

@@ -151,6 +151,7 @@ struct hipkkt_solver {
 
     GraphSlot g_factor;
     bool use_graph = true;
+    bool runtime_ready = false;   // init_runtime done (streams, events, pinned areas)
     bool poison = false;
     PlanOptions plan_opts;       // as used for the current plan
     // robust-order twin (minimum degree on K), created on the first factorisation that fails in the
@@ -1022,7 +1023,8 @@ int32_t finish_create(hipkkt_solver *S, const hipkkt_opts *opts, hipkkt_handle *
     if (!err.empty()) { g_create_error = err; delete S; return HIPKKT_ERR_ARGUMENT; }
     S->plan_opts = po;
     try {
-        init_runtime(S);
+        if (!S->runtime_ready) init_runtime(S);
+        S->runtime_ready = true;
         setup_device(S);
     } catch (const DeviceError &e) {
         g_create_error = e.msg; delete S; return HIPKKT_ERR_DEVICE;
@@ -1130,8 +1132,23 @@ int32_t hipkkt_create_from_parts(int32_t device_id, int64_t n, int64_t m, const 
         for (int64_t q = 0; q < Ap[n]; q++) Ai[q] = Arowval[q] - base;
         std::vector<int64_t> dim1(ncones, 0);
         if (cone_dim1) for (int64_t c = 0; c < ncones; c++) dim1[c] = cone_dim1[c];
-        std::string err = assemble_kkt(n, m, Pp.data(), Pi.data(), Pnzval, Ap.data(), Ai.data(), Anzval, ncones,
-                                       cone_numel, cone_hs_dense, cone_sparse_kind, dim1.data(), S->img);
+        // the image is assembled by count -> scan -> fill kernels on the device (assemble_dev.hip); HIPKKT_HOST_ASSEMBLY=1
+        // selects the host twin (assemble.cpp), which the GPU tests compare the device image with
+        const char *ha = getenv("HIPKKT_HOST_ASSEMBLY");
+        std::string err;
+        if (ha && ha[0] == '1') {
+            err = assemble_kkt(n, m, Pp.data(), Pi.data(), Pnzval, Ap.data(), Ai.data(), Anzval, ncones, cone_numel, cone_hs_dense,
+                               cone_sparse_kind, dim1.data(), S->img);
+        } else {
+            try {
+                init_runtime(S);
+                S->runtime_ready = true;
+            } catch (const DeviceError &e) {
+                g_create_error = e.msg; delete S; return HIPKKT_ERR_DEVICE;
+            }
+            err = assemble_kkt_device((void *)S->stream, n, m, Pp.data(), Pi.data(), Pnzval, Ap.data(), Ai.data(), Anzval, ncones, cone_numel,
+                                      cone_hs_dense, cone_sparse_kind, dim1.data(), S->img);
+        }
         if (!err.empty()) { g_create_error = err; delete S; return HIPKKT_ERR_ARGUMENT; }
     } catch (const std::bad_alloc &) {
         delete S;

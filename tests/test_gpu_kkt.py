@@ -577,3 +577,57 @@ def test_residuals_update_on_device(name):
     sold = cl.Solver(P, q, A, b, cones, cl.Settings(device_residuals=True)).solve()
     assert solr.status == sold.status == "SOLVED" and abs(solr.iterations - sold.iterations) <= 1
     assert abs(solr.obj_val - sold.obj_val) <= 1e-7 * max(1.0, abs(solr.obj_val))
+
+
+def _image(h):
+    colptr, rowval, nzval = h.kkt()
+    maps = [h.map(w) for w in range(5)]
+    smaps = [[h.sparse_map(i, w) for w in range(4)] for i in range(h.nsparse)]
+    return colptr, rowval, nzval, maps, smaps, h.dsigns()
+
+
+@pytest.mark.parametrize("name", ["qp_fixture", "socp_fixture", "sdp_fixture", "lasso_sparse_soc", "cfg1", "portfolio_small",
+                                  "sdp_small", "genpow_mix", "p_without_diagonal"])
+def test_device_assembly_equals_host_assembly(name, monkeypatch):
+    """J1: the count -> scan -> fill kernels of assemble_dev.hip (the default of hipkkt_create_from_parts) against the host
+    twin assemble.cpp (HIPKKT_HOST_ASSEMBLY=1), which tests/test_gpu_kkt.py::test_assembly_bit_exact_... and the hand-derived
+    layouts pin on the oracle: colptr / rowval / nzval, every LDLDataMap vector, the expansion maps and Dsigns, bit for bit."""
+    if name == "genpow_mix":
+        n = 30
+        numel, hs_dense = np.array([5, 5, 0, 6, 6, 4]), np.array([0, 0, 0, 0, 0, 1], dtype=np.int32)
+        sparse_kind, dim1 = np.array([0, 2, 0, 1, 2, 0], dtype=np.int32), np.array([0, 3, 0, 0, 2, 0])
+        S = sp.random(n, n, density=0.08, random_state=np.random.RandomState(5), format="csc")
+        Pt = sp.triu(S + S.T + sp.diags(np.asarray(abs(S + S.T).sum(axis=1)).ravel() + 0.5), format="csc")
+        A = sp.random(int(numel.sum()), n, density=0.15, random_state=np.random.RandomState(6), format="csc")
+        desc = (numel, hs_dense, sparse_kind, dim1)
+    elif name == "p_without_diagonal":
+        n = 40
+        S = sp.random(n, n, density=0.1, random_state=np.random.RandomState(8), format="csc")
+        Pt = sp.triu(S + S.T, k=0, format="csc").tolil()
+        for j in range(0, n, 3):
+            Pt[j, j] = 0.0                                   # columns without a stored diagonal -> structural zero inserted
+        Pt = sp.csc_matrix(Pt)
+        Pt.eliminate_zeros()
+        A = sp.random(70, n, density=0.1, random_state=np.random.RandomState(9), format="csc")
+        desc = (np.array([70]), np.zeros(1, dtype=np.int32), np.zeros(1, dtype=np.int32), np.zeros(1, dtype=np.int64))
+    else:
+        Pt, A, cones = _prep(PROBLEMS[name]())
+        desc = cones.kkt_descriptors()
+    Pt.sort_indices()
+    A.sort_indices()
+    hd = hipkkt.Handle.from_parts(Pt, A, *desc)                 # device assembly
+    monkeypatch.setenv("HIPKKT_HOST_ASSEMBLY", "1")
+    hh = hipkkt.Handle.from_parts(Pt, A, *desc)
+    a, b = _image(hd), _image(hh)
+    assert (hd.N, hd.p, hd.nnzK, hd.nHs) == (hh.N, hh.p, hh.nnzK, hh.nHs)
+    for x, y in zip(a[:3], b[:3]):
+        assert np.array_equal(x, y)
+    for x, y in zip(a[3], b[3]):
+        assert np.array_equal(x, y)
+    assert len(a[4]) == len(b[4])
+    for sx, sy in zip(a[4], b[4]):
+        for x, y in zip(sx, sy):
+            assert np.array_equal(x, y)
+    assert np.array_equal(a[5], b[5])
+    hd.close()
+    hh.close()
