@@ -50,15 +50,18 @@ def pmc_traffic(cfg):
     so the figure is read from profiles/ for the workload it was measured on, else null."""
     if cfg != "2a":
         return None
-    path = os.path.join(ROOT, "profiles", "r01_i_cfg2a_pmc_hbm_traffic.txt")
-    try:
-        for line in open(path):
-            if "k_update_denseILi4" in line:
-                f = line.split()
-                return {"bytes_per_launch": round((float(f[4]) + float(f[5])) * 1e6), "read_x2_MB": float(f[4]),
-                        "write_MB": float(f[5]), "source": "profiles/r01_i_cfg2a_pmc_hbm_traffic.txt"}
-    except OSError:
-        pass
+    import glob
+
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_cfg2a_pmc_hbm_traffic.txt")))
+    for path in reversed(cands):          # newest round / tag first
+        try:
+            for line in open(path):
+                if "k_update_denseILi4" in line:
+                    f = line.split()
+                    return {"bytes_per_launch": round((float(f[4]) + float(f[5])) * 1e6), "read_x2_MB": float(f[4]),
+                            "write_MB": float(f[5]), "source": os.path.relpath(path, ROOT)}
+        except OSError:
+            pass
     return None
 
 
