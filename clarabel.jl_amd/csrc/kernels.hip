@@ -1,12 +1,17 @@
-// HIP kernels of the KKT path for gfx950 (MI355X / CDNA4).  See DESIGN.md §5 for the roofline
-// that bounds each one.  Everything is Float64; indices are int32 except panel offsets (int64).
+// HIP kernels of the KKT path for gfx950 (MI355X / CDNA4).  See DESIGN.md section 5 for the roofline that bounds each
+// one.  Everything is Float64; indices are int32 except panel offsets (int64).  (KKT assembly: assemble_dev.hip.)
 //
-//   value updates     k_scatter_values / k_scale_values / k_set_hs          (HBM/latency, K1-K2)
-//   regulariser       k_maxabs_diag + k_init_panels                          (K3)
-//   numeric LDL^T     k_factor_level  (LDS-resident diagonal block + TRSM)   (K4, latency/LDS)
-//                     k_update_stage  (gather - MFMA f64 16x16x4 - scatter)  (K4, MFMA bound)
-//   triangular solves k_fwd_level / k_bwd_partial / k_bwd_final              (K5, latency/HBM)
-//   refinement        k_spmv_residual, k_norm_inf, k_axpy ...                (K6-K8)
+//   value updates     k_scatter_values / k_scale_values / k_soc_batch / k_psd_hs                (K1-K2, HBM / latency)
+//   regulariser       k_maxabs_gather + k_init_panels (+-eps folded into the K -> panel scatter)  (K3)
+//   numeric LDL^T     k_factor_panel (w > 8: register-resident, 8-pivot blocks), k_factor_level   (K4, dependency latency)
+//                     k_update_dense<NT,NR> (FP64 matrix-core tiles: <4,4> far, <1,2> just in time), k_update_gather
+//                     (per-entry lists of the leaves), k_update_stage (relative-index scatter, fallback)   (K4, MFMA)
+//                     k_invert_diag / k_invert_diag_wide (explicit inverses of the diagonal blocks for the solves)
+//   triangular solves k_front_fwd / k_front_bwd (persistent sweeps over a front), k_fwd_seg / k_bwd_seg (persistent,
+//                     ticket-ordered sweeps over the regular supernodes), k_fwd_level / k_bwd_partial / k_bwd_final and
+//                     k_fwd_narrow / k_bwd_narrow (one launch per level: wide bottom levels, time-out fallback)  (K5)
+//   refinement        k_spmv_residual(_cand), k_norm_inf, k_refine_decide / _add / _copy_out (decided on the device)  (K6-K8)
+//   residuals (N4)    k_residuals + k_residuals_finish;  k_block_products
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
