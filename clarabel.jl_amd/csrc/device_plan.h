@@ -27,6 +27,17 @@ struct RefineState {
     double lastnorme, normb, norme;
 };
 
+// One contribution to one target entry of the per-entry gather lists: sum_k L_s[i,k] d_k L_s[j,k] with everything the kernel
+// needs in ONE 24-byte load (was: three index arrays, then two supernode tables, then the data: three dependent round trips).
+struct GathPair {
+    int64_t src;                  // Lx offset of L_s[i, 0]
+    int32_t dj;                   // offset of L_s[j, 0] relative to src
+    int32_t r;                    // rows of the source panel (column stride)
+    int32_t K;                    // its width
+    int32_t dfirst;               // first pivot of the source in D
+};
+constexpr int kGathHeavy = 24;    // target entries with more pairs than this get a wavefront of their own
+
 struct DevPlan {
     // structure (read-only after setup)
     const int *sn_first;
@@ -54,9 +65,8 @@ struct DevPlan {
     const DenseTask *dtasks;      // parallel to upd_tasks
     const int64_t *gath_tgt;
     const int64_t *gath_pptr;
-    const int64_t *gath_src;
-    const int32_t *gath_dj;
-    const int32_t *gath_sn;
+    const GathPair *gath_pairs;   // one self-contained record per (target entry, source) pair (k_update_gather)
+    const int64_t *gath_heavy;    // entries with more than kGathHeavy pairs: one wavefront each (k_update_gather_heavy)
     const int64_t *g_ptr;
     const int *g_idx;
     const int64_t *kmap;
@@ -64,6 +74,8 @@ struct DevPlan {
     const int64_t *sym_rowptr;
     const int *sym_col;
     const int64_t *sym_q;
+    const int *long_rows;        // rows of that view with more than long_row_threshold() entries (one workgroup each in the SpMV)
+    int n_long_rows;
     const FrontPanel *front_panels;
     const int64_t *front_gptr;
     const int *front_gidx;

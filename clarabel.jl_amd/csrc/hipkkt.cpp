@@ -127,6 +127,7 @@ struct hipkkt_solver {
     int wmax_all = 1;
     int inv_nsmall = 0, inv_wsmall = 1, inv_nwide = 0;   // split of the diagonal-block inversions (kernels.hip)
     std::vector<int64_t> p_off;
+    std::vector<int64_t> gath_heavy_ptr;   // [nlevels+1] into the list of heavy gather entries (kernels.hip k_update_gather_heavy)
 
     // device index arrays for value updates
     int64_t *d_mapHs = nullptr, *d_mapP = nullptr, *d_mapA = nullptr, *d_diag_full = nullptr;
@@ -530,9 +531,22 @@ void setup_device(hipkkt_solver *S) {
     }
     D.gath_tgt = S->upload(P.gath_tgt);
     D.gath_pptr = S->upload(P.gath_pptr);
-    D.gath_src = S->upload(P.gath_src);
-    D.gath_dj = S->upload(P.gath_dj);
-    D.gath_sn = S->upload(P.gath_sn);
+    {
+        std::vector<GathPair> gp(P.gath_src.size());
+        for (size_t q = 0; q < gp.size(); q++) {
+            const int s = P.gath_sn[q];
+            gp[q] = {P.gath_src[q], P.gath_dj[q], (int32_t)(P.sn_rowptr[s + 1] - P.sn_rowptr[s]), P.sn_first[s + 1] - P.sn_first[s], P.sn_first[s]};
+        }
+        D.gath_pairs = S->upload(gp);
+        std::vector<int64_t> heavy;
+        S->gath_heavy_ptr.assign(P.nlevels + 1, 0);
+        for (int l = 0; l < P.nlevels; l++) {
+            for (int64_t e = P.gath_stage_ptr[l]; e < P.gath_stage_ptr[l + 1]; e++)
+                if (P.gath_pptr[e + 1] - P.gath_pptr[e] > kGathHeavy) heavy.push_back(e);
+            S->gath_heavy_ptr[l + 1] = (int64_t)heavy.size();
+        }
+        D.gath_heavy = S->upload(heavy);
+    }
     D.g_ptr = S->upload(P.g_ptr);
     D.g_idx = S->upload(P.g_idx);
     D.kmap = S->upload(P.kmap);
@@ -540,6 +554,14 @@ void setup_device(hipkkt_solver *S) {
     D.sym_rowptr = S->upload(P.sym_rowptr);
     D.sym_col = S->upload(P.sym_col);
     D.sym_q = S->upload(P.sym_q);
+    {
+        std::vector<int> lr;
+        const int thr = long_row_threshold();
+        for (int i = 0; i < N; i++)
+            if (P.sym_rowptr[i + 1] - P.sym_rowptr[i] > thr) lr.push_back(i);
+        D.long_rows = S->upload(lr);
+        D.n_long_rows = (int)lr.size();
+    }
     D.front_panels = S->upload(P.front_panels);
     D.front_gptr = S->upload(P.front_gptr);
     D.front_gidx = S->upload(P.front_gidx);
@@ -689,7 +711,8 @@ void enqueue_updates(hipkkt_solver *S, int l, bool split_far = false) {
     if (l + 1 < P.nlevels && P.lvl_fused[l + 1]) return;   // applied inside the next level's panel kernel
     const int g0 = P.upd_stage_ptr[l], nd = P.upd_stage_ndense[l], ng = P.upd_stage_ngather[l];
     launch_update_dense(st, S->dp, g0, nd - (split_far ? P.upd_stage_nfar[l] : 0));
-    launch_update_gather(st, S->dp, P.gath_stage_ptr[l], P.gath_stage_ptr[l + 1] - P.gath_stage_ptr[l]);
+    launch_update_gather(st, S->dp, P.gath_stage_ptr[l], P.gath_stage_ptr[l + 1] - P.gath_stage_ptr[l], S->gath_heavy_ptr[l],
+                         S->gath_heavy_ptr[l + 1] - S->gath_heavy_ptr[l]);
     launch_update_stage(st, S->dp, g0 + nd + ng, P.upd_stage_ptr[l + 1] - g0 - nd - ng);
 }
 
@@ -1554,7 +1577,8 @@ static int32_t refactor_once(hipkkt_handle h, int32_t static_reg_enable, double 
                     evd.push_back(c2);
                     evd_level.push_back(l);
                 }
-                launch_update_gather(st, S->dp, P.gath_stage_ptr[l], P.gath_stage_ptr[l + 1] - P.gath_stage_ptr[l]);
+                launch_update_gather(st, S->dp, P.gath_stage_ptr[l], P.gath_stage_ptr[l + 1] - P.gath_stage_ptr[l], S->gath_heavy_ptr[l],
+                         S->gath_heavy_ptr[l + 1] - S->gath_heavy_ptr[l]);
                 launch_update_stage(st, S->dp, g0 + nd + ng, P.upd_stage_ptr[l + 1] - g0 - nd - ng);
                 HK_CHECK(hipEventRecord(b, st));
                 evs.push_back(a);

@@ -22,7 +22,7 @@ void launch_psd_hs(hipStream_t st, double *kval, const int64_t *map_hs, int64_t 
 void launch_block_products(hipStream_t st, const DevPlan &P, const double *x, const double *z, double *Px, double *ATz,
                            double *Ax, int n, int m);
 void launch_zero_words(hipStream_t st, void *p, int nwords);
-void launch_update_gather(hipStream_t st, const DevPlan &P, int64_t ebegin, int64_t n);
+void launch_update_gather(hipStream_t st, const DevPlan &P, int64_t ebegin, int64_t n, int64_t hbegin, int64_t nheavy);
 void launch_invert_diag(hipStream_t st, const DevPlan &P, int n_small, int wmax_small, int n_wide);
 void launch_mfma_probe(hipStream_t st, const double *A, const double *B, double *out);
 void launch_permute_in(hipStream_t st, const double *b, const int *perm, double *y, int n, int *epoch, int *ticks, int nticks);
@@ -43,6 +43,7 @@ void launch_refine_copy_out(hipStream_t st, const RefineState *rs, const double 
 void launch_spmv_residual_cand(hipStream_t st, const DevPlan &P, const double *b, const RefineState *rs, const double *x0,
                                const double *x1, double *e, int n, unsigned long long *slot);
 int residual_blocks(int n, int m);
+int long_row_threshold();   // rows of the symmetric CSR view with more entries are taken by k_spmv_long
 void launch_residuals(hipStream_t st, const DevPlan &P, const double *x, const double *z, const double *s, const double *q,
                       const double *b, double tau, double kappa, double *out, double *part, double *scal, int n, int m);
 void launch_norm_inf(hipStream_t st, const double *v, int n, unsigned long long *slot);

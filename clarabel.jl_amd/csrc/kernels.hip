@@ -875,18 +875,37 @@ k_update_gather(DevPlan P, int64_t ebegin, int64_t n) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n) return;
     const int64_t p0 = P.gath_pptr[ebegin + e], p1 = P.gath_pptr[ebegin + e + 1];
+    if (p1 - p0 > kGathHeavy) return;          // k_update_gather_heavy
     double acc = 0.0;
     for (int64_t p = p0; p < p1; p++) {
-        const int s = P.gath_sn[p];
-        const int fs = P.sn_first[s];
-        const int K = P.sn_first[s + 1] - fs;
-        const int64_t r = P.sn_rowptr[s + 1] - P.sn_rowptr[s];
-        const double *li = P.Lx + P.gath_src[p];
-        const double *lj = li + P.gath_dj[p];
-        const double *dv = P.D + fs;
-        for (int k = 0; k < K; k++) acc = fma(li[k * r] * dv[k], lj[k * r], acc);
+        const GathPair G = P.gath_pairs[p];
+        const double *li = P.Lx + G.src;
+        const double *lj = li + G.dj;
+        const double *dv = P.D + G.dfirst;
+        for (int k = 0; k < G.K; k++) acc = fma(li[(int64_t)k * G.r] * dv[k], lj[(int64_t)k * G.r], acc);
     }
     P.Lx[P.gath_tgt[ebegin + e]] -= acc;
+}
+// target entries with long pair lists (a dense row / column of the root that every leaf touches: 1189 pairs on cfg 3) kept
+// ONE thread busy for a millisecond while the rest of the launch had finished: one wavefront each, lane l takes the
+// pairs l, l + 64, ... in order and the 64 partial sums are added in a fixed tree -- deterministic, like the thread version
+__global__ void __launch_bounds__(256)
+k_update_gather_heavy(DevPlan P, int64_t hbegin, int64_t n) {
+    const int64_t h = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (h >= n) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t e = P.gath_heavy[hbegin + h];
+    const int64_t p0 = P.gath_pptr[e], p1 = P.gath_pptr[e + 1];
+    double acc = 0.0;
+    for (int64_t p = p0 + lane; p < p1; p += 64) {
+        const GathPair G = P.gath_pairs[p];
+        const double *li = P.Lx + G.src;
+        const double *lj = li + G.dj;
+        const double *dv = P.D + G.dfirst;
+        for (int k = 0; k < G.K; k++) acc = fma(li[(int64_t)k * G.r] * dv[k], lj[(int64_t)k * G.r], acc);
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if (lane == 0) P.Lx[P.gath_tgt[e]] -= acc;
 }
 
 // probe used by hipkkt's self test: D = A(16x4) * B(4x16) through the same MFMA form and the
@@ -1837,26 +1856,63 @@ k_bwd_seg(DevPlan P, int seg, int item_begin, int nitems, int nsuper, int first_
 // K6-K8: iterative refinement pieces (ref: kktsolver_directldl.jl:389-466)
 // e = b - K*xi with the symmetric CSR view of the unregularised K; 8 lanes per row
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-k_spmv_residual(const int64_t *__restrict__ rowptr, const int *__restrict__ col, const int64_t *__restrict__ qidx,
-                const double *__restrict__ kval, const double *__restrict__ b, const double *__restrict__ xi,
-                double *__restrict__ e, int n, unsigned long long *__restrict__ norm_slot) {
+// Rows longer than kLongRow entries (a budget row 1'x = 1, the expansion columns of big cones, dense PSD blocks) would keep
+// their 4 lanes busy for thousands of sequential iterations (cfg 3: 0.3 ms per SpMV for 70 000 nonzeros): they are left
+// out here and taken by k_spmv_long, one workgroup each.
+constexpr int kLongRow = 192;
+__device__ __forceinline__ void spmv_short_rows(const int64_t *__restrict__ rowptr, const int *__restrict__ col,
+                                                const int64_t *__restrict__ qidx, const double *__restrict__ kval,
+                                                const double *__restrict__ b, const double *__restrict__ xi, double *__restrict__ e,
+                                                int n, unsigned long long *__restrict__ norm_slot) {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     const int row = gid >> 2, sub = gid & 3;
     double acc = 0.0;
+    bool mine = false;
     if (row < n) {
         const int64_t p0 = rowptr[row], p1 = rowptr[row + 1];
-        for (int64_t p = p0 + sub; p < p1; p += 4) acc += kval[qidx[p]] * xi[col[p]];
+        mine = p1 - p0 <= kLongRow;
+        if (mine)
+            for (int64_t p = p0 + sub; p < p1; p += 4) acc += kval[qidx[p]] * xi[col[p]];
     }
     acc += __shfl_xor(acc, 1, 64);
     acc += __shfl_xor(acc, 2, 64);
     double a = 0.0;
-    if (row < n && sub == 0) {
+    if (mine && sub == 0) {
         const double ev = b[row] - acc;
         e[row] = ev;
         a = fabs(ev);
     }
     block_atomic_max_abs(norm_slot, a);
+}
+// one workgroup per long row: fixed partition of the entries over the 256 threads, fixed reduction tree (deterministic)
+__device__ __forceinline__ void spmv_long_row(int row, const int64_t *__restrict__ rowptr, const int *__restrict__ col,
+                                              const int64_t *__restrict__ qidx, const double *__restrict__ kval,
+                                              const double *__restrict__ b, const double *__restrict__ xi, double *__restrict__ e,
+                                              unsigned long long *__restrict__ norm_slot) {
+    __shared__ double red[4];
+    const int64_t p0 = rowptr[row], p1 = rowptr[row + 1];
+    double acc = 0.0;
+    for (int64_t p = p0 + threadIdx.x; p < p1; p += 256) acc += kval[qidx[p]] * xi[col[p]];
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double ev = b[row] - (((red[0] + red[1]) + red[2]) + red[3]);
+        e[row] = ev;
+        atomic_max_abs(norm_slot, ev);
+    }
+}
+__global__ void __launch_bounds__(256)
+k_spmv_residual(const int64_t *__restrict__ rowptr, const int *__restrict__ col, const int64_t *__restrict__ qidx,
+                const double *__restrict__ kval, const double *__restrict__ b, const double *__restrict__ xi,
+                double *__restrict__ e, int n, unsigned long long *__restrict__ norm_slot) {
+    spmv_short_rows(rowptr, col, qidx, kval, b, xi, e, n, norm_slot);
+}
+__global__ void __launch_bounds__(256)
+k_spmv_long(const int *__restrict__ long_rows, const int64_t *__restrict__ rowptr, const int *__restrict__ col,
+            const int64_t *__restrict__ qidx, const double *__restrict__ kval, const double *__restrict__ b,
+            const double *__restrict__ xi, double *__restrict__ e, unsigned long long *__restrict__ norm_slot) {
+    spmv_long_row(long_rows[blockIdx.x], rowptr, col, qidx, kval, b, xi, e, norm_slot);
 }
 
 // the three sparse products of residuals_update! (residuals.jl:12-25) from the RESIDENT KKT
@@ -2036,23 +2092,15 @@ k_spmv_residual_cand(const int64_t *__restrict__ rowptr, const int *__restrict__
                      const double *__restrict__ x0, const double *__restrict__ x1, double *__restrict__ e, int n,
                      unsigned long long *__restrict__ norm_slot) {
     if (!st->active) return;           // the norm slot keeps its previous value; k_refine_decide ignores it when inactive
-    const double *xi = st->cur ? x0 : x1;
-    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    const int row = gid >> 2, sub = gid & 3;
-    double acc = 0.0;
-    if (row < n) {
-        const int64_t p0 = rowptr[row], p1 = rowptr[row + 1];
-        for (int64_t p = p0 + sub; p < p1; p += 4) acc += kval[qidx[p]] * xi[col[p]];
-    }
-    acc += __shfl_xor(acc, 1, 64);
-    acc += __shfl_xor(acc, 2, 64);
-    double a = 0.0;
-    if (row < n && sub == 0) {
-        const double ev = b[row] - acc;
-        e[row] = ev;
-        a = fabs(ev);
-    }
-    block_atomic_max_abs(norm_slot, a);
+    spmv_short_rows(rowptr, col, qidx, kval, b, st->cur ? x0 : x1, e, n, norm_slot);
+}
+__global__ void __launch_bounds__(256)
+k_spmv_long_cand(const int *__restrict__ long_rows, const int64_t *__restrict__ rowptr, const int *__restrict__ col,
+                 const int64_t *__restrict__ qidx, const double *__restrict__ kval, const double *__restrict__ b,
+                 const RefineState *st, const double *__restrict__ x0, const double *__restrict__ x1, double *__restrict__ e,
+                 unsigned long long *__restrict__ norm_slot) {
+    if (!st->active) return;
+    spmv_long_row(long_rows[blockIdx.x], rowptr, col, qidx, kval, b, st->cur ? x0 : x1, e, norm_slot);
 }
 
 __global__ void k_add(double *__restrict__ dst, const double *__restrict__ a, int n) {
@@ -2195,8 +2243,9 @@ void launch_psd_hs(hipStream_t st, double *kval, const int64_t *map_hs, int64_t 
 void launch_zero_words(hipStream_t st, void *p, int nwords) {
     if (nwords > 0) hipLaunchKernelGGL(k_zero_words, dim3(nblk(nwords, 64)), dim3(64), 0, st, (int *)p, nwords);
 }
-void launch_update_gather(hipStream_t st, const DevPlan &P, int64_t ebegin, int64_t n) {
+void launch_update_gather(hipStream_t st, const DevPlan &P, int64_t ebegin, int64_t n, int64_t hbegin, int64_t nheavy) {
     if (n > 0) hipLaunchKernelGGL(k_update_gather, dim3(nblk(n)), dim3(256), 0, st, P, ebegin, n);
+    if (nheavy > 0) hipLaunchKernelGGL(k_update_gather_heavy, dim3(nblk(nheavy, 4)), dim3(256), 0, st, P, hbegin, nheavy);
 }
 // inv_list = [n_small supernodes of width <= wmax_small | n_wide supernodes of width in (16, 64]]
 void launch_invert_diag(hipStream_t st, const DevPlan &P, int n_small, int wmax_small, int n_wide) {
@@ -2238,6 +2287,9 @@ void launch_spmv_residual(hipStream_t st, const DevPlan &P, const double *b, con
     if (n > 0)
         hipLaunchKernelGGL(k_spmv_residual, dim3(nblk((int64_t)n * 4)), dim3(256), 0, st, P.sym_rowptr, P.sym_col, P.sym_q,
                            P.kval, b, xi, e, n, slot);
+    if (P.n_long_rows > 0)
+        hipLaunchKernelGGL(k_spmv_long, dim3(P.n_long_rows), dim3(256), 0, st, P.long_rows, P.sym_rowptr, P.sym_col, P.sym_q, P.kval, b,
+                           xi, e, slot);
 }
 void launch_block_products(hipStream_t st, const DevPlan &P, const double *x, const double *z, double *Px, double *ATz,
                            double *Ax, int n, int m) {
@@ -2261,7 +2313,11 @@ void launch_spmv_residual_cand(hipStream_t st, const DevPlan &P, const double *b
     if (n > 0)
         hipLaunchKernelGGL(k_spmv_residual_cand, dim3(nblk((int64_t)n * 4)), dim3(256), 0, st, P.sym_rowptr, P.sym_col, P.sym_q,
                            P.kval, b, rs, x0, x1, e, n, slot);
+    if (P.n_long_rows > 0)
+        hipLaunchKernelGGL(k_spmv_long_cand, dim3(P.n_long_rows), dim3(256), 0, st, P.long_rows, P.sym_rowptr, P.sym_col, P.sym_q, P.kval,
+                           b, rs, x0, x1, e, slot);
 }
+int long_row_threshold() { return kLongRow; }
 int residual_blocks(int n, int m) { return (int)nblk((int64_t)(n + m) * 4); }
 void launch_residuals(hipStream_t st, const DevPlan &P, const double *x, const double *z, const double *s, const double *q,
                       const double *b, double tau, double kappa, double *out, double *part, double *scal, int n, int m) {

@@ -30,6 +30,18 @@ int main(int argc, char **argv) {
            P.N, (long)P.nnzK, (long)P.nnzL, P.nsuper, P.nlevels, (long)P.panel_doubles, P.flops_colcount, P.flops_update, P.flops_exec,
            std::chrono::duration<double>(t1 - t0).count());
     printf("ntasks %zu ngroups %zu ordering_used %d fronts %zu | model: md %.3f ms (%d levels)  nd %.3f ms (%d levels)\n", P.upd_tasks.size(), P.upd_groups.size(), P.ordering_used, P.fronts.size(), 1e3 * P.cost_md_seconds, P.cost_md_levels, 1e3 * P.cost_nd_seconds, P.cost_nd_levels);
+    for (int l = 0; l < P.nlevels; l++) {   // per stage: per-entry gather lists (k_update_gather)
+        const int64_t e0 = P.gath_stage_ptr[l], e1 = P.gath_stage_ptr[l + 1];
+        if (e1 == e0) continue;
+        int64_t maxp = 0, pairs = 0; double fma = 0, maxf = 0;
+        for (int64_t e = e0; e < e1; e++) {
+            const int64_t np = P.gath_pptr[e + 1] - P.gath_pptr[e];
+            double f = 0;
+            for (int64_t q = P.gath_pptr[e]; q < P.gath_pptr[e + 1]; q++) f += P.sn_first[P.gath_sn[q] + 1] - P.sn_first[P.gath_sn[q]];
+            maxp = std::max(maxp, np); pairs += np; fma += f; maxf = std::max(maxf, f);
+        }
+        printf("  gather stage %d: %ld entries, %ld pairs (max %ld per entry), %.3e fma (max %.0f per entry)\n", l, (long)(e1 - e0), (long)pairs, (long)maxp, fma, maxf);
+    }
     for (int l = 0; l < P.nlevels; l++) {   // per stage: dense tiles by average coverage per task, and sub-blocks touched per task
         double cov = 0, nt = 0, sb = 0, kk = 0; int ng = 0;
         int hist[6] = {0, 0, 0, 0, 0, 0};
