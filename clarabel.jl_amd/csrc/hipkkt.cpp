@@ -377,10 +377,12 @@ void setup_device(hipkkt_solver *S) {
                 // one thread per supernode pays for every gather of a child's update vector with a serial memory round trip:
                 // a level goes to the thread kernels as a whole when all of it is tiny; otherwise only its childless
                 // supernodes (leaves: nothing to gather) do, up to kNarrowW x kNarrowR
-                const bool thr = all_tiny || (!has_child[s] && w <= kNarrowW && r - w <= kNarrowR);
+                // (a thread walks its w x (r - w) panel entries one strided load after the other: bounded work per thread, and
+                // only worth it where the workgroup-per-item kernel would need several rounds of the chip: >= 2048 leaves)
+                const bool thr = all_tiny || (!has_child[s] && w <= kNarrowW && r - w <= kNarrowR && (int64_t)w * (r - w) <= 128);
                 (allow_narrow && own_launches && thr ? nar : reg).push_back(s);
             }
-            if (nar.size() < (all_tiny ? 256u : 64u)) { reg.insert(reg.end(), nar.begin(), nar.end()); std::sort(reg.begin(), reg.end()); nar.clear(); }
+            if (nar.size() < (all_tiny ? 256u : 2048u)) { reg.insert(reg.end(), nar.begin(), nar.end()); std::sort(reg.begin(), reg.end()); nar.clear(); }
             nnarrow[l] = (int)nar.size();
             for (int s : nar) wnarrow[l] = std::max(wnarrow[l], P.sn_first[s + 1] - P.sn_first[s]);
             S->reg_lvl_sn.insert(S->reg_lvl_sn.end(), nar.begin(), nar.end());
