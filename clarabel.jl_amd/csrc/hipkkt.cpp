@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -1044,13 +1045,19 @@ int32_t finish_create(hipkkt_solver *S, const hipkkt_opts *opts, hipkkt_handle *
         uperm = up.data();
     }
     if (S->img.N >= ((int64_t)1 << 31)) { g_create_error = "N exceeds int32"; delete S; return HIPKKT_ERR_ARGUMENT; }
+    const auto t_a = std::chrono::steady_clock::now();
     std::string err = build_plan((int)S->img.N, S->img.colptr.data(), S->img.rowval.data(), uperm, po, S->plan);
     if (!err.empty()) { g_create_error = err; delete S; return HIPKKT_ERR_ARGUMENT; }
     S->plan_opts = po;
+    const auto t_b = std::chrono::steady_clock::now();
     try {
         if (!S->runtime_ready) init_runtime(S);
         S->runtime_ready = true;
         setup_device(S);
+        if (getenv("HIPKKT_VERBOSE"))
+            fprintf(stderr, "hipkkt: N %d nnzL %lld levels %d ordering %d: symbolic %.2f ms (%s), device set-up %.2f ms\n", S->plan.N, (long long)S->plan.nnzL,
+                    S->plan.nlevels, S->plan.ordering_used, 1e3 * std::chrono::duration<double>(t_b - t_a).count(), S->plan.timing_note.c_str(),
+                    1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t_b).count());
     } catch (const DeviceError &e) {
         g_create_error = e.msg; delete S; return HIPKKT_ERR_DEVICE;
     } catch (const std::bad_alloc &) {

@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <array>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <numeric>
@@ -131,6 +132,14 @@ std::string build_plan(int N, const int64_t *Ap, const int64_t *Ai, const int64_
     P.nnzK = Ap[N];
     const int maxw = std::max(1, std::min(opt.max_width, kMaxSnWidth));
 
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char *name) {
+        const auto now = std::chrono::steady_clock::now();
+        char buf[64];
+        snprintf(buf, sizeof buf, "%s %.2f ", name, 1e3 * std::chrono::duration<double>(now - t_last).count());
+        P.timing_note += buf;
+        t_last = now;
+    };
     // ---- 1. ordering
     std::vector<int> perm0;
     if (user_perm) {
@@ -146,45 +155,39 @@ std::string build_plan(int N, const int64_t *Ap, const int64_t *Ai, const int64_
     } else {
         amd_order(N, Ap, Ai, opt.amd_dense_scale, perm0);
         if ((int)perm0.size() != N) return "internal: ordering size mismatch";
-        if (opt.n_hold > 0 && opt.n_hold < N) {
+        // the alternatives below are only worth their set-up time when minimum degree leaves something to gain: an
+        // expensive factorisation (-> cone rows first) or a long dependent chain (-> nested dissection)
+        const OrderCost c_md = order_cost(N, Ap, Ai, perm0, maxw);
+        P.cost_md_seconds = c_md.seconds;
+        P.cost_md_levels = c_md.levels;
+        if (opt.n_hold > 0 && opt.n_hold < N && c_md.flops > 1e9) {
             // second candidate: eliminate the cone rows first, the variables last; keep the cheaper one
             std::vector<int> perm1;
             std::vector<char> hold(N, 0);
             for (int i = 0; i < opt.n_hold; i++) hold[i] = 1;
             amd_order(N, Ap, Ai, opt.amd_dense_scale, perm1, hold.data());
             if ((int)perm1.size() == N) {
-                double cost[2];
-                const std::vector<int> *cand[2] = {&perm0, &perm1};
-                for (int c = 0; c < 2; c++) {
-                    std::vector<int> ip(N);
-                    for (int k = 0; k < N; k++) ip[(*cand[c])[k]] = k;
-                    std::vector<int64_t> up_;
-                    std::vector<int> ui_, par_, cnt_;
-                    permuted_upper(N, Ap, Ai, ip, up_, ui_);
-                    etree_counts(N, up_, ui_, par_, cnt_);
-                    double fl = 0;
-                    for (int j = 0; j < N; j++) fl += (double)cnt_[j] * cnt_[j] + 3.0 * cnt_[j];
-                    cost[c] = fl;
-                }
-                // only worth a different elimination order when the factorisation is expensive at all
-                if (cost[0] > 1e9 && cost[1] < 0.7 * cost[0]) { perm0.swap(perm1); P.ordering_used = 1; }
+                const OrderCost c_b = order_cost(N, Ap, Ai, perm1, maxw);
+                if (c_b.flops < 0.7 * c_md.flops) { perm0.swap(perm1); P.ordering_used = 1; P.cost_md_seconds = c_b.seconds; P.cost_md_levels = c_b.levels; }
             }
         }
     }
-    if (!user_perm && opt.nd_mode > 0 && N >= 64 && (opt.nd_mode >= 2 || Ap[N] <= (int64_t)64 * N)) {   // (dense blocks: no separators)
+    if (!user_perm && opt.nd_mode > 0 && N >= 64 &&
+        (opt.nd_mode >= 2 || (Ap[N] <= (int64_t)64 * N && P.cost_md_levels >= 24))) {   // (dense blocks: no separators; short chains: nothing to gain)
         // third candidate: nested dissection (ordering.cpp) -- far fewer dependent levels on banded / grid-like systems
         std::vector<int> permN;
         nd_order(N, Ap, Ai, opt.amd_dense_scale, opt.nd_leaf, permN);
         if ((int)permN.size() == N) {
-            const OrderCost c0 = order_cost(N, Ap, Ai, perm0, maxw), c1 = order_cost(N, Ap, Ai, permN, maxw);
-            P.cost_md_seconds = c0.seconds; P.cost_nd_seconds = c1.seconds;
-            P.cost_md_levels = c0.levels; P.cost_nd_levels = c1.levels;
-            if (opt.nd_mode >= 2 || c1.seconds < 0.8 * c0.seconds) { perm0.swap(permN); P.ordering_used = 3; }
+            const OrderCost c1 = order_cost(N, Ap, Ai, permN, maxw);
+            P.cost_nd_seconds = c1.seconds;
+            P.cost_nd_levels = c1.levels;
+            if (opt.nd_mode >= 2 || c1.seconds < 0.8 * P.cost_md_seconds) { perm0.swap(permN); P.ordering_used = 3; }
         }
     }
     std::vector<int> iperm0(N);
     for (int k = 0; k < N; k++) iperm0[perm0[k]] = k;
 
+    lap("ordering");
     // ---- 2-4. etree, postorder, final permutation
     std::vector<int64_t> up;
     std::vector<int> ui, parent, cnt, post;
@@ -366,6 +369,7 @@ std::string build_plan(int N, const int64_t *Ap, const int64_t *Ai, const int64_
         for (int s = 0; s < S; s++) P.lvl_sn[nxt[P.sn_level[s]]++] = s;
     }
 
+    lap("structure");
     // ---- 12. scatter map of the original nonzeros into the panels
     P.kmap.resize(P.nnzK);
     P.diag_dst.assign(N, -1);
@@ -412,6 +416,7 @@ std::string build_plan(int N, const int64_t *Ap, const int64_t *Ai, const int64_
     }
     P.update_batch_used = update_batch;
 
+    lap("kmap+items");
     // ---- 14. update tasks, owned by target row-blocks
     {
         std::vector<TaskKey> keys;
@@ -667,6 +672,7 @@ std::string build_plan(int N, const int64_t *Ap, const int64_t *Ai, const int64_
             P.lvl_fused[l] = 1;
         }
 
+    lap("update-tasks");
     // ---- 15. gather lists for the forward solve (multifrontal style): every panel row slot
     //          (s, li) collects the update-vector entries of the CHILDREN of s that land on it.
     //          Fan-in per slot <= #children; each ubuf entry is consumed exactly once, by the parent.
@@ -772,6 +778,7 @@ std::string build_plan(int N, const int64_t *Ap, const int64_t *Ai, const int64_
         P.front_sync_ints = sync_ints;
     }
 
+    lap("solve-lists");
     // ---- 16. symmetric CSR view of K in the ORIGINAL ordering (iterative-refinement SpMV)
     P.sym_rowptr.assign(N + 1, 0);
     for (int j = 0; j < N; j++)
@@ -792,6 +799,7 @@ std::string build_plan(int N, const int64_t *Ap, const int64_t *Ai, const int64_
                 if (i != j) { P.sym_col[nxt[j]] = i; P.sym_q[nxt[j]++] = q; }
             }
     }
+    lap("symcsr");
     return "";
 }
 

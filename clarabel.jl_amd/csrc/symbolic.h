@@ -188,6 +188,7 @@ struct HostPlan {
     int ordering_used = 0;       // 0 = minimum degree on K, 1 = cone rows first / variables last, 2 = user, 3 = nested dissection
     double cost_md_seconds = 0, cost_nd_seconds = 0;   // predicted seconds per KKT iteration unit of the two candidates
     int cost_md_levels = 0, cost_nd_levels = 0;
+    std::string timing_note;     // milliseconds per phase of build_plan (HIPKKT_VERBOSE)
     double flops_colcount = 0;   // sum_j c_j^2 + 3 c_j
     double flops_update = 0;     // executed flops of the dense update tasks (2*rows*cols*k)
     double flops_exec = 0;       // update + diagonal-block + TRSM flops actually executed
