@@ -342,6 +342,7 @@ def main():
                    st.static_regularization_proportional)
         upd_ms.append(h.timing()["last_update_ms"])
         d4.append(h.profile())
+        launches = h.profile_launches()
     h.set_profiling(False)
     upd = float(np.median(upd_ms))
     agg = cm["flops_update"] / (upd * 1e-3) / 1e12 if upd > 0 else 0.0
@@ -355,6 +356,16 @@ def main():
                           flops_per_launch=p4["dense4_flops"] / p4["dense4_launches"])
     else:   # small problems never reach the large-launch variant: report the aggregate of all update kernels
         achieved, kern, per_launch = agg, "all Schur-update kernels", {}
+    lms, lfl, ltl = launches
+    if len(lms):
+        # the launches one by one: flops per target tile tells the K = 320 passes over the front (2 * 64 * 64 * 320 = 2.6e6 per
+        # tile) from the pass that carries the sparse part of the tree into it (many narrow sources per tile, a fraction of that)
+        per_launch["launches"] = [dict(tiles=int(t), us=round(1e3 * m, 1), tflops=round(f / (m * 1e-3) / 1e12, 2), mflop_per_tile=round(f / t / 1e6, 3))
+                                  for m, f, t in zip(lms, lfl, ltl)]
+        dense = [(m, f) for m, f, t in zip(lms, lfl, ltl) if f / t >= 2.0e6]
+        if dense:
+            per_launch["full_K_launches"] = dict(count=len(dense), achieved=round(sum(f for _, f in dense) / (sum(m for m, _ in dense) * 1e-3) / 1e12, 3),
+                                                 frac=round(sum(f for _, f in dense) / (sum(m for m, _ in dense) * 1e-3) / 1e12 / F64_MFMA_PEAK_TFLOPS, 4))
     roofline = dict(bound="mfma", achieved=round(achieved, 3), peak=F64_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
                     frac=round(achieved / F64_MFMA_PEAK_TFLOPS, 4), traffic=pmc_traffic(args.config),
                     kernel=kern, **per_launch,

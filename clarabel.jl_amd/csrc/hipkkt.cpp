@@ -167,6 +167,7 @@ struct hipkkt_solver {
     double last_eps = 0;
     double prof_dense4_ms = 0, prof_dense4_flops = 0;   // last profiled refactorisation: k_update_dense<4,4> alone
     int prof_dense4_launches = 0;
+    std::vector<double> prof_launch_ms, prof_launch_flops, prof_launch_tiles;   // per k_update_dense<4,4> launch of that refactorisation
     int64_t last_nreg = 0;
 
     // Device memory comes from a few slabs (bump allocation, 256-byte aligned) instead of one hipMalloc per array:
@@ -713,7 +714,7 @@ void enqueue_updates(hipkkt_solver *S, int l, bool split_far = false) {
     hipStream_t st = S->stream;
     if (l + 1 < P.nlevels && P.lvl_fused[l + 1]) return;   // applied inside the next level's panel kernel
     const int g0 = P.upd_stage_ptr[l], nd = P.upd_stage_ndense[l], ng = P.upd_stage_ngather[l];
-    launch_update_dense(st, S->dp, g0, nd - (split_far ? P.upd_stage_nfar[l] : 0));
+    launch_update_dense(st, S->dp, g0, nd - (split_far ? P.upd_stage_nfar[l] : 0), 0, nd > 0 && P.upd_stage_flops_dense[l] >= 1.5e6 * nd);
     launch_update_gather(st, S->dp, P.gath_stage_ptr[l], P.gath_stage_ptr[l + 1] - P.gath_stage_ptr[l], S->gath_heavy_ptr[l],
                          S->gath_heavy_ptr[l + 1] - S->gath_heavy_ptr[l]);
     launch_update_stage(st, S->dp, g0 + nd + ng, P.upd_stage_ptr[l + 1] - g0 - nd - ng);
@@ -1578,7 +1579,7 @@ static int32_t refactor_once(hipkkt_handle h, int32_t static_reg_enable, double 
                 HK_CHECK(hipEventCreate(&b));
                 HK_CHECK(hipEventRecord(a, st));
                 const int g0 = P.upd_stage_ptr[l], nd = P.upd_stage_ndense[l], ng = P.upd_stage_ngather[l];
-                launch_update_dense(st, S->dp, g0, nd);
+                launch_update_dense(st, S->dp, g0, nd, 0, nd > 0 && P.upd_stage_flops_dense[l] >= 1.5e6 * nd);
                 if (nd > 384) {   // the one-wavefront-per-tile variant (see launch_update_dense)
                     HK_CHECK(hipEventCreate(&c2));
                     HK_CHECK(hipEventRecord(c2, st));
@@ -1603,12 +1604,16 @@ static int32_t refactor_once(hipkkt_handle h, int32_t static_reg_enable, double 
             tot += ms;
         }
         S->prof_dense4_ms = 0; S->prof_dense4_flops = 0; S->prof_dense4_launches = 0;
+        S->prof_launch_ms.clear(); S->prof_launch_flops.clear(); S->prof_launch_tiles.clear();
         for (size_t i = 0; i + 1 < evd.size(); i += 2) {
             float ms = 0;
             (void)hipEventElapsedTime(&ms, evd[i], evd[i + 1]);
             S->prof_dense4_ms += ms;
             S->prof_dense4_flops += P.upd_stage_flops_dense[evd_level[i / 2]];
             S->prof_dense4_launches++;
+            S->prof_launch_ms.push_back(ms);
+            S->prof_launch_flops.push_back(P.upd_stage_flops_dense[evd_level[i / 2]]);
+            S->prof_launch_tiles.push_back(P.upd_stage_ndense[evd_level[i / 2]]);
         }
         for (size_t i = 1; i < evd.size(); i += 2) (void)hipEventDestroy(evd[i]);
         for (hipEvent_t e : evs) (void)hipEventDestroy(e);
@@ -1769,6 +1774,18 @@ int32_t hipkkt_get_profile(hipkkt_handle h, double *o) {
     if (!h || !o) return HIPKKT_ERR_ARGUMENT;
     o[0] = h->t_last_update; o[1] = h->prof_dense4_ms; o[2] = h->prof_dense4_flops; o[3] = (double)h->prof_dense4_launches;
     o[4] = o[5] = o[6] = o[7] = 0;
+    return HIPKKT_OK;
+}
+
+int32_t hipkkt_get_profile_launches(hipkkt_handle h, double *ms, double *flops, double *tiles, int64_t cap, int64_t *count) {
+    if (!h) return HIPKKT_ERR_ARGUMENT;
+    const int64_t n = (int64_t)h->prof_launch_ms.size();
+    if (count) *count = n;
+    for (int64_t i = 0; i < n && i < cap; i++) {
+        if (ms) ms[i] = h->prof_launch_ms[i];
+        if (flops) flops[i] = h->prof_launch_flops[i];
+        if (tiles) tiles[i] = h->prof_launch_tiles[i];
+    }
     return HIPKKT_OK;
 }
 

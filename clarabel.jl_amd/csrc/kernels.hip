@@ -864,6 +864,28 @@ k_update_dense(DevPlan P, int group_begin, int ngroups) {
     }
 }
 
+// A launch of T tiles runs in ceil(T / 1024) rounds of one 64 x 64 tile per SIMD (~60 us each at K = 320): 1128 tiles cost two
+// rounds, 2278 three.  Here the r tiles beyond the last FULL round are cut into pieces, one wavefront each, so that the
+// partial round costs a fraction of a whole one: four 16-column strips per tile when r <= 256 (one sub-round of ~22 us),
+// two 32-column halves when r <= 512 (one sub-round of ~35 us).  Workgroups [0, nfull / 4) take four whole tiles, every
+// later workgroup one tile (PIECES = 4) or two tiles (PIECES = 2).  Measured on cfg 2a: 11 launches 1.49 -> 1.33 ms.
+template <int PIECES>
+__global__ void __launch_bounds__(256, 2)
+k_update_dense_tail(DevPlan P, int group_begin, int nfull, int ngroups) {
+    const int lane = threadIdx.x & 63;
+    const int wave = rfl(threadIdx.x >> 6);
+    const int nfw = nfull >> 2;
+    if ((int)blockIdx.x < nfw) {
+        dense_tile<4, 4>(P, P.dgroups + group_begin + rfl(blockIdx.x * 4 + wave), lane, 0, 0);
+    } else if (PIECES == 4) {
+        const int g = nfull + ((int)blockIdx.x - nfw);
+        if (g < ngroups) dense_tile<1, 4>(P, P.dgroups + group_begin + g, lane, wave, 0);
+    } else {
+        const int g = nfull + 2 * ((int)blockIdx.x - nfw) + (wave >> 1);
+        if (g < ngroups) dense_tile<2, 4>(P, P.dgroups + group_begin + g, lane, (wave & 1) * 2, 0);
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // K4b (tiny contributions): the leaves of the elimination tree are 1-2 column supernodes whose few
 // rows land on scattered single entries of far ancestors (the dense root front).  One thread per
@@ -2159,19 +2181,27 @@ void launch_update_stage(hipStream_t st, const DevPlan &P, int group_begin, int 
 }
 // 16-row blocks per wavefront in the just-in-time launches (4: one workgroup per tile; 2 / 1: two / four workgroups).
 // Measured on cfg 2a (factorisation): 5.81 ms / 5.65 ms / 5.65 ms for 4 / 2 / 1.
+static const int g_tail_split = [] { const char *e = getenv("HIPKKT_TAIL_SPLIT"); return e ? atoi(e) : 1; }();   // 0: whole tiles only (A/B)
 static const int g_jit_nr = [] { const char *e = getenv("HIPKKT_JIT_NR"); return e ? atoi(e) : 2; }();
 #ifndef HIPKKT_DENSE_BIG_NT
 #define HIPKKT_DENSE_BIG_NT 4
 #endif
-void launch_update_dense(hipStream_t st, const DevPlan &P, int group_begin, int ngroups, int max_wgs) {
+void launch_update_dense(hipStream_t st, const DevPlan &P, int group_begin, int ngroups, int max_wgs, bool full_k) {
     if (ngroups <= 0) return;
     if (max_wgs > 0) {   // look-ahead launch: a bounded grid that strides over the tiles
         hipLaunchKernelGGL((k_update_dense<4, 4>), dim3(std::min((ngroups + 3) / 4, max_wgs)), dim3(256), 0, st, P, group_begin, ngroups);
         return;
     }
-    if (ngroups > 384)   // plenty of tiles: one wavefront per tile
-        hipLaunchKernelGGL((k_update_dense<HIPKKT_DENSE_BIG_NT, 4>), dim3((ngroups + HIPKKT_DENSE_BIG_NT - 1) / HIPKKT_DENSE_BIG_NT),
-                           dim3(256), 0, st, P, group_begin, ngroups);
+    if (ngroups > 384) {   // plenty of tiles: one wavefront per tile, the tiles of a partial last round in pieces
+        const int round = 1024, r = ngroups % round, nfull = ngroups - r;   // nfull: multiple of 1024, hence of 4
+        if (g_tail_split && full_k && r > 0 && (r <= 256 || (nfull == 0 && r <= 768)))   // (a lone partial round: three strip sub-rounds still beat it)
+            hipLaunchKernelGGL(k_update_dense_tail<4>, dim3(nfull / 4 + r), dim3(256), 0, st, P, group_begin, nfull, ngroups);
+        else if (g_tail_split && full_k && r > 0 && r <= 512)
+            hipLaunchKernelGGL(k_update_dense_tail<2>, dim3(nfull / 4 + (r + 1) / 2), dim3(256), 0, st, P, group_begin, nfull, ngroups);
+        else
+            hipLaunchKernelGGL((k_update_dense<HIPKKT_DENSE_BIG_NT, 4>), dim3((ngroups + HIPKKT_DENSE_BIG_NT - 1) / HIPKKT_DENSE_BIG_NT),
+                               dim3(256), 0, st, P, group_begin, ngroups);
+    }
     else                 // few tiles (just-in-time updates): split every tile over 4 wavefronts
         switch (g_jit_nr) {
         case 1: hipLaunchKernelGGL((k_update_dense<1, 1>), dim3(ngroups * 4), dim3(256), 0, st, P, group_begin, ngroups); break;

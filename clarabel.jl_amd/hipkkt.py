@@ -23,7 +23,7 @@ SYMBOLS = [
     "hipkkt_get_dsigns", "hipkkt_get_map", "hipkkt_get_sparse_map", "hipkkt_update_values", "hipkkt_scale_values",
     "hipkkt_set_hs", "hipkkt_set_hs_dev", "hipkkt_set_hs_psd", "hipkkt_block_products", "hipkkt_set_soc", "hipkkt_set_soc_batch", "hipkkt_set_genpow",
     "hipkkt_update_P", "hipkkt_update_A", "hipkkt_refactor", "hipkkt_setrhs", "hipkkt_setrhs_dev", "hipkkt_solve",
-    "hipkkt_solve_dev", "hipkkt_solve_multi", "hipkkt_solve_multi_dev", "hipkkt_ldl_solve", "hipkkt_get_timing", "hipkkt_reset_timing", "hipkkt_get_profile", "hipkkt_set_profiling",
+    "hipkkt_solve_dev", "hipkkt_solve_multi", "hipkkt_solve_multi_dev", "hipkkt_ldl_solve", "hipkkt_get_timing", "hipkkt_reset_timing", "hipkkt_get_profile", "hipkkt_get_profile_launches", "hipkkt_set_profiling",
     "hipkkt_get_counters", "hipkkt_debug_dump", "hipkkt_set_qb", "hipkkt_residuals", "hipkkt_residuals_dev",
     "hipkkt_selftest_mfma", "hipkkt_last_error",
 ]
@@ -94,6 +94,7 @@ def lib():
     L.hipkkt_reset_timing.argtypes = [vp]
     L.hipkkt_get_profile.argtypes = [vp, _f64p]
     L.hipkkt_set_profiling.argtypes = [vp, i32]
+    L.hipkkt_get_profile_launches.argtypes = [vp, vp, vp, vp, i64, C.POINTER(i64)]
     L.hipkkt_get_counters.argtypes = [vp, _i64p]
     L.hipkkt_set_qb.argtypes = [vp, _f64p, _f64p]
     L.hipkkt_residuals.argtypes = [vp, _f64p, _f64p, _f64p, f64, f64, vp, vp, vp, vp, vp, _f64p]
@@ -238,6 +239,13 @@ class Handle:
         self.L.hipkkt_get_counters(self.h, o)
         return dict(sweep_timeouts=int(o[0]), persistent=bool(o[1]), twin_refactors=int(o[2]), twin_exists=bool(o[3]),
                     in_twin=bool(o[4]), ordering=int(o[5]), fronts=int(o[6]), segments=int(o[7]))
+
+    def profile_launches(self):
+        n = C.c_int64(0)
+        self.L.hipkkt_get_profile_launches(self.h, None, None, None, 0, C.byref(n))
+        ms, fl, tl = np.zeros(max(n.value, 1)), np.zeros(max(n.value, 1)), np.zeros(max(n.value, 1))
+        self.L.hipkkt_get_profile_launches(self.h, ms.ctypes.data, fl.ctypes.data, tl.ctypes.data, n.value, C.byref(n))
+        return ms[: n.value], fl[: n.value], tl[: n.value]
 
     def debug_dump(self, what):
         ln = C.c_int64(0)

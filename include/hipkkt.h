@@ -222,6 +222,9 @@ int32_t hipkkt_reset_timing(hipkkt_handle h);
  * k_update_dense<4,4> launches alone (one wavefront per 64x64 tile), out[2] = their algorithmic flops, out[3] = their
  * number; out[4..7] reserved */
 int32_t hipkkt_get_profile(hipkkt_handle h, double *out8);
+/* the k_update_dense<4,4> launches of that refactorisation one by one: ms[i], algorithmic flops[i], target tiles[i]
+ * (any array may be NULL; at most cap entries are written, *count receives the number of launches) */
+int32_t hipkkt_get_profile_launches(hipkkt_handle h, double *ms, double *flops, double *tiles, int64_t cap, int64_t *count);
 /* 1 = time the update (MFMA) kernels separately inside refactor (adds event overhead) */
 int32_t hipkkt_set_profiling(hipkkt_handle h, int32_t enable);
 
