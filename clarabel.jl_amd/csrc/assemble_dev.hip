@@ -114,12 +114,16 @@ __global__ void k_asm_scatter_A(AsmDev D) {
     }
 }
 
-// one wavefront per row of A: rank of every entry = number of entries of the row in smaller columns
+// one wavefront per row of A: rank of every entry = number of entries of the row in smaller columns.  Rows with more than
+// kAsmLongRow entries (a budget row 1'x = 1 has n of them: O(k^2 / 64) per lane was 29 ms on cfg 3) are left to
+// k_asm_place_A_long, one workgroup each with the row's columns staged through LDS in chunks.
+constexpr int kAsmLongRow = 512;
 __global__ void __launch_bounds__(256) k_asm_place_A(AsmDev D) {
     const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= D.m) return;
     const int lane = threadIdx.x & 63;
     const int64_t base = D.colptr[D.n + i], k = D.rowcnt[i];
+    if (k > kAsmLongRow) return;
     for (int64_t a = lane; a < k; a += 64) {
         const int64_t c = D.tcol[base + a], q = D.tq[base + a];
         int64_t rank = 0;
@@ -128,6 +132,32 @@ __global__ void __launch_bounds__(256) k_asm_place_A(AsmDev D) {
         D.rowval[d] = c;
         D.nzval[d] = D.Ax[q];
         D.mapA[q] = d;
+    }
+}
+
+__global__ void __launch_bounds__(1024) k_asm_place_A_long(AsmDev D, const int64_t *__restrict__ long_rows) {
+    __shared__ int64_t chunk[2048];
+    const int64_t i = long_rows[blockIdx.x];
+    const int64_t base = D.colptr[D.n + i], k = D.rowcnt[i];
+    // every thread ranks the entries a = tid, tid + 1024, ... against the whole row, read chunk by chunk through LDS
+    for (int64_t a0 = 0; a0 < k; a0 += 1024) {
+        const int64_t a = a0 + threadIdx.x;
+        const int64_t c = a < k ? D.tcol[base + a] : 0;
+        int64_t rank = 0;
+        for (int64_t b0 = 0; b0 < k; b0 += 2048) {
+            __syncthreads();
+            for (int64_t b = threadIdx.x; b < 2048 && b0 + b < k; b += 1024) chunk[b] = D.tcol[base + b0 + b];
+            __syncthreads();
+            const int64_t nb_ = k - b0 < 2048 ? k - b0 : 2048;
+            if (a < k)
+                for (int64_t b = 0; b < nb_; b++) rank += chunk[b] < c ? 1 : 0;
+        }
+        if (a < k) {
+            const int64_t q = D.tq[base + a], d = base + rank;
+            D.rowval[d] = c;
+            D.nzval[d] = D.Ax[q];
+            D.mapA[q] = d;
+        }
     }
 }
 
@@ -283,6 +313,18 @@ std::string assemble_kkt_device(void *stream_, int64_t n, int64_t m, const int64
     if (n) hipLaunchKernelGGL(k_asm_fill_P, dim3(nb(n)), dim3(256), 0, st, D);
     if (n) hipLaunchKernelGGL(k_asm_scatter_A, dim3(nb(n)), dim3(256), 0, st, D);
     if (m) hipLaunchKernelGGL(k_asm_place_A, dim3(nb(m, 4)), dim3(256), 0, st, D);
+    {   // long rows of A (from A's row histogram, computed here on the host: O(nnz))
+        std::vector<int64_t> cnt(m, 0), longs;
+        for (int64_t q = 0; q < K.nnzA; q++) cnt[Ai[q]]++;
+        for (int64_t i = 0; i < m; i++)
+            if (cnt[i] > kAsmLongRow) longs.push_back(i);
+        if (!longs.empty()) {
+            const int64_t *dl = B.up(longs.data(), longs.size());
+            if (!B.ok) return "device allocation failed during the KKT assembly";
+            hipLaunchKernelGGL(k_asm_place_A_long, dim3((unsigned)longs.size()), dim3(1024), 0, st, D, dl);
+            if (hipStreamSynchronize(st) != hipSuccess) return "device error during the KKT assembly (long rows)";   // `longs` is a local
+        }
+    }
     if (m) hipLaunchKernelGGL(k_asm_fill_Hs, dim3(nb(m)), dim3(256), 0, st, D);
     if (next) hipLaunchKernelGGL(k_asm_fill_ext, dim3(nb(next)), dim3(256), 0, st, D);
     K.rowval.assign(nnz, 0); K.nzval.assign(nnz, 0.0);

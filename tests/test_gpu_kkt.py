@@ -587,7 +587,7 @@ def _image(h):
 
 
 @pytest.mark.parametrize("name", ["qp_fixture", "socp_fixture", "sdp_fixture", "lasso_sparse_soc", "cfg1", "portfolio_small",
-                                  "sdp_small", "genpow_mix", "p_without_diagonal"])
+                                  "sdp_small", "genpow_mix", "p_without_diagonal", "long_rows"])
 def test_device_assembly_equals_host_assembly(name, monkeypatch):
     """J1: the count -> scan -> fill kernels of assemble_dev.hip (the default of hipkkt_create_from_parts) against the host
     twin assemble.cpp (HIPKKT_HOST_ASSEMBLY=1), which tests/test_gpu_kkt.py::test_assembly_bit_exact_... and the hand-derived
@@ -610,6 +610,16 @@ def test_device_assembly_equals_host_assembly(name, monkeypatch):
         Pt.eliminate_zeros()
         A = sp.random(70, n, density=0.1, random_state=np.random.RandomState(9), format="csc")
         desc = (np.array([70]), np.zeros(1, dtype=np.int32), np.zeros(1, dtype=np.int32), np.zeros(1, dtype=np.int64))
+    elif name == "long_rows":                                # rows of A beyond the wavefront-per-row ranking (k_asm_place_A_long)
+        n = 3000
+        rng = np.random.default_rng(4)
+        Pt = sp.identity(n, format="csc")
+        A = sp.random(40, n, density=0.01, random_state=np.random.RandomState(3), format="lil")
+        A[3, :] = rng.standard_normal(n)                     # a budget row: n entries
+        A[17, ::2] = rng.standard_normal(n // 2)             # 1500 entries
+        A[25, :600] = 1.0                                    # 600 entries
+        A = sp.csc_matrix(A)
+        desc = (np.array([40]), np.zeros(1, dtype=np.int32), np.zeros(1, dtype=np.int32), np.zeros(1, dtype=np.int64))
     else:
         Pt, A, cones = _prep(PROBLEMS[name]())
         desc = cones.kkt_descriptors()
