@@ -557,8 +557,7 @@ std::string build_plan(int N, const int64_t *Ap, const int64_t *Ai, const int64_
         P.upd_stage_nfar.assign(P.nlevels, 0);
         P.gath_stage_ptr.assign(P.nlevels + 1, 0);
         P.gath_pptr.push_back(0);
-        struct Pair { int64_t tgt, src; int32_t dj, sn; };
-        std::vector<Pair> pairs;
+        std::vector<int> gcount;
         for (int l = 0; l < P.nlevels; l++) {
             auto b = P.upd_groups.begin() + P.upd_stage_ptr[l], e = P.upd_groups.begin() + P.upd_stage_ptr[l + 1];
             auto mid = std::stable_partition(b, e, [](const UpdGroup &g) { return g.dense == 1; });
@@ -600,39 +599,53 @@ std::string build_plan(int N, const int64_t *Ap, const int64_t *Ai, const int64_
                     const UpdTask &T = P.upd_tasks[q];
                     P.upd_stage_flops_dense[l] += 2.0 * T.nrows * T.ncols * (P.sn_first[T.src + 1] - P.sn_first[T.src]);
                 }
-            // gather lists of this stage: every (target entry, source) pair, ordered by target entry and,
-            // within an entry, by the task order (fixed summation order)
-            pairs.clear();
+            // gather lists of this stage: every (target entry, source) pair, grouped by target entry and, within an entry, in
+            // the task order (fixed summation order).  A group's entries live in one 64-row block of one panel, so the
+            // grouping is a counting sort per group over <= 64 * 64 keys (a global stable sort of the pairs was 2/3 of the
+            // symbolic analysis on cfg 3 and most of the set-up time of the mid-size batch problems).
             for (auto it = mid; it != mid2; ++it) {
                 const UpdGroup &G = *it;
                 const int t = G.tgt, ft = P.sn_first[t], wt = P.sn_first[t + 1] - ft;
                 const int64_t rt = P.sn_rowptr[t + 1] - P.sn_rowptr[t];
-                for (int q = G.task_begin; q < G.task_end; q++) {
-                    const UpdTask &T = P.upd_tasks[q];
-                    const int *srows = &P.sn_rows[P.sn_rowptr[T.src]];
-                    const int *rel = &P.rel[T.rel_off];
-                    for (int j = 0; j < T.ncols; j++) {
-                        const int cpos = srows[T.col_lo + j] - ft;
-                        for (int i = 0; i < T.nrows; i++) {
-                            const int rpos = rel[T.row_lo + i - T.col_lo];
-                            if (rpos < wt && rpos < cpos) continue;     // strictly upper part of the diagonal block
-                            pairs.push_back({P.sn_panel[t] + rpos + (int64_t)cpos * rt, P.sn_panel[T.src] + T.row_lo + i,
-                                             (int32_t)(T.col_lo + j - (T.row_lo + i)), (int32_t)T.src});
+                gcount.assign((size_t)kUpdRows * wt + 1, 0);
+                auto for_pairs = [&](auto &&f) {
+                    for (int q = G.task_begin; q < G.task_end; q++) {
+                        const UpdTask &T = P.upd_tasks[q];
+                        const int *srows = &P.sn_rows[P.sn_rowptr[T.src]];
+                        const int *rel = &P.rel[T.rel_off];
+                        for (int j = 0; j < T.ncols; j++) {
+                            const int cpos = srows[T.col_lo + j] - ft;
+                            for (int i = 0; i < T.nrows; i++) {
+                                const int rpos = rel[T.row_lo + i - T.col_lo];
+                                if (rpos < wt && rpos < cpos) continue;     // strictly upper part of the diagonal block
+                                f((rpos - G.row_base) + kUpdRows * cpos, T, i, j);
+                            }
                         }
                     }
+                };
+                for_pairs([&](int key, const UpdTask &, int, int) { gcount[key + 1]++; });
+                const int64_t pbase = (int64_t)P.gath_src.size();
+                int64_t total = 0;
+                for (size_t k = 0; k + 1 < gcount.size(); k++) {    // entries with pairs, in key order; gcount becomes the cursor
+                    const int c = gcount[k + 1];
+                    gcount[k + 1] = (int)total;                    // (shifted by one: gcount[k + 1] = start of key k)
+                    if (c) {
+                        const int rpos = G.row_base + (int)(k % kUpdRows), cpos = (int)(k / kUpdRows);
+                        P.gath_tgt.push_back(P.sn_panel[t] + rpos + (int64_t)cpos * rt);
+                        P.gath_pptr.push_back(pbase + total + c);
+                    }
+                    total += c;
                 }
+                P.gath_src.resize(pbase + total);
+                P.gath_dj.resize(pbase + total);
+                P.gath_sn.resize(pbase + total);
+                for_pairs([&](int key, const UpdTask &T, int i, int j) {
+                    const int64_t d = pbase + gcount[key + 1]++;
+                    P.gath_src[d] = P.sn_panel[T.src] + T.row_lo + i;
+                    P.gath_dj[d] = (int32_t)(T.col_lo + j - (T.row_lo + i));
+                    P.gath_sn[d] = (int32_t)T.src;
+                });
             }
-            std::stable_sort(pairs.begin(), pairs.end(), [](const Pair &x, const Pair &y) { return x.tgt < y.tgt; });
-            for (size_t q = 0; q < pairs.size(); q++) {
-                if (q == 0 || pairs[q].tgt != pairs[q - 1].tgt) {
-                    if (q) P.gath_pptr.push_back((int64_t)P.gath_src.size());
-                    P.gath_tgt.push_back(pairs[q].tgt);
-                }
-                P.gath_src.push_back(pairs[q].src);
-                P.gath_dj.push_back(pairs[q].dj);
-                P.gath_sn.push_back(pairs[q].sn);
-            }
-            if (!pairs.empty()) P.gath_pptr.push_back((int64_t)P.gath_src.size());
             P.gath_stage_ptr[l + 1] = (int64_t)P.gath_tgt.size();
         }
     }
