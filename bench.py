@@ -199,6 +199,7 @@ def main():
     ap.add_argument("--update-policy", type=int, default=None)
     ap.add_argument("--in-flight", type=int, default=1, help="cfg 4: problems solved concurrently per host process (threads)")
     ap.add_argument("--workers", type=int, default=6, help="cfg 4: host processes per GPU, each with its own HIP context")
+    ap.add_argument("--device-scaling", action="store_true", help="also solve once end to end with N1 on (update_scaling!/get_Hs! on the device) and report it under end_to_end")
     ap.add_argument("--sequential-solves", action="store_true", help="three separate solve calls per unit instead of 2 concurrent + 1")
     args = ap.parse_args()
 
@@ -396,6 +397,17 @@ def main():
                        "setup_s": round(t_setup, 3)},
         "roofline": roofline,
     }
+    if args.device_scaling and rank == 0:
+        # SURVEY section 8(f) row N1 end to end: the same solve with update_scaling! / get_Hs! formed by the plugin from (s, z)
+        # (hipkkt_update_scaling): no Hs vector, no SOC (u, v, eta) and no PSD block crosses PCIe
+        st1 = cl.Settings(device_id=local, device_scaling=True)
+        s1 = cl.Solver(P, q, A, b, cones, st1, kktsolver_factory=lambda *a: HipKKTSolver(*a, **optkw))
+        sol1 = s1.solve()
+        result["end_to_end"]["with_device_scaling"] = {
+            "status": sol1.status, "ipm_iterations": sol1.iterations,
+            "iterations_per_s": round(sol1.iterations / s1.info.timers["IP iteration"], 4),
+            "objective_rel_diff": float(abs(sol1.obj_val - sol.obj_val) / max(1.0, abs(sol.obj_val)))}
+        del s1
 
     # ---- 4. CPU baseline + parity: the oracle (C restatement of the reference's :qdldl path), 1 thread, same
     #         permutation, KKT iteration units of the same trace; its solutions are compared with the HIP path's

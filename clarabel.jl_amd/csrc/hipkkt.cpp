@@ -140,6 +140,17 @@ struct hipkkt_solver {
     int64_t *d_soc_uidx = nullptr, *d_soc_vidx = nullptr, *d_soc_didx = nullptr;
     int *d_soc_cone = nullptr;
     double *d_soc_u = nullptr, *d_soc_v = nullptr, *d_soc_eta2 = nullptr;
+    // N1: update_scaling! / get_Hs! on the device (hipkkt_set_cone_types + hipkkt_update_scaling, scaling.hip)
+    std::vector<int64_t> cone_numel;                       // as given to hipkkt_create_from_parts
+    std::vector<int32_t> cone_hs_dense, cone_sparse_kind;
+    bool sc_ready = false;
+    int sc_nsoc = 0;                                       // ALL second-order cones (sparse and dense), cone order
+    std::vector<int64_t> sc_psd_hs, sc_psd_n;              // per PSD cone: first Hs entry, matrix dimension
+    int64_t sc_psd_total = 0;                              // sum of n * n
+    signed char *d_sc_kind = nullptr;
+    int64_t *d_sc_rowhs = nullptr, *d_sc_socdesc = nullptr;
+    double *d_sc_sz = nullptr, *d_sc_wl = nullptr, *d_sc_eta = nullptr, *d_sc_R = nullptr, *d_sc_W = nullptr;
+    int *d_sc_fail = nullptr;
 
     // vectors
     double *d_b = nullptr, *d_x = nullptr, *d_dx = nullptr, *d_e = nullptr;
@@ -1165,6 +1176,11 @@ int32_t hipkkt_create_from_parts(int32_t device_id, int64_t n, int64_t m, const 
         for (int64_t q = 0; q < Ap[n]; q++) Ai[q] = Arowval[q] - base;
         std::vector<int64_t> dim1(ncones, 0);
         if (cone_dim1) for (int64_t c = 0; c < ncones; c++) dim1[c] = cone_dim1[c];
+        if (ncones > 0 && cone_numel && cone_hs_dense && cone_sparse_kind) {
+            S->cone_numel.assign(cone_numel, cone_numel + ncones);
+            S->cone_hs_dense.assign(cone_hs_dense, cone_hs_dense + ncones);
+            S->cone_sparse_kind.assign(cone_sparse_kind, cone_sparse_kind + ncones);
+        }
         // the image is assembled by count -> scan -> fill kernels on the device (assemble_dev.hip); HIPKKT_HOST_ASSEMBLY=1
         // selects the host twin (assemble.cpp), which the GPU tests compare the device image with
         const char *ha = getenv("HIPKKT_HOST_ASSEMBLY");
@@ -1422,6 +1438,122 @@ int32_t hipkkt_set_hs_psd(hipkkt_handle h, int64_t npsd, const int64_t *hs_off, 
     HK_CHECK(hipStreamSynchronize(S->stream));
     return HIPKKT_OK;
     HK_LEAVE
+}
+
+// ---- N1: update_scaling! + get_Hs! of the symmetric cones on the device (scaling.hip) ---------------------------------
+// kinds[c]: 0 ZeroCone, 1 NonnegativeCone, 2 SecondOrderCone, 3 PSDTriangleCone, anything else = a cone whose block the
+// caller keeps setting through hipkkt_set_hs / hipkkt_set_genpow (ref: the SupportedCone types of cone_types.jl / cone_api.py)
+int32_t hipkkt_set_cone_types(hipkkt_handle h, int64_t ncones, const int32_t *kinds) {
+    HK_ENTER(h)
+    if (!S->l1 || ncones != (int64_t)S->cone_numel.size() || (ncones && !kinds)) { S->err = "set_cone_types: not an L1 handle / wrong number of cones"; return HIPKKT_ERR_ARGUMENT; }
+    const int64_t m = S->img.m;
+    std::vector<signed char> kind((size_t)std::max<int64_t>(m, 1), 2);
+    std::vector<int64_t> rowhs((size_t)std::max<int64_t>(m, 1), 0), socdesc;
+    S->sc_psd_hs.clear(); S->sc_psd_n.clear(); S->sc_psd_total = 0; S->sc_nsoc = 0;
+    int64_t row = 0, hs = 0;
+    int sparse_idx = 0;
+    for (int64_t c = 0; c < ncones; c++) {
+        const int64_t numel = S->cone_numel[c];
+        const bool dense = S->cone_hs_dense[c] != 0;
+        const int sk = S->cone_sparse_kind[c];
+        const int64_t blk = dense ? numel * (numel + 1) / 2 : numel;
+        if (kinds[c] == 0 || kinds[c] == 1) {
+            if (dense || sk != 0) { S->err = "set_cone_types: a Zero / Nonnegative cone has a diagonal Hs block and no expansion"; return HIPKKT_ERR_ARGUMENT; }
+            for (int64_t i = 0; i < numel; i++) { kind[row + i] = (signed char)kinds[c]; rowhs[row + i] = hs + i; }
+        } else if (kinds[c] == 2) {
+            int64_t uv0 = -1, ord = -1;
+            if (sk == 1) {
+                ord = S->soc_of_sparse[sparse_idx];
+                uv0 = S->soc_off[ord];
+                if (dense || S->soc_off[ord + 1] - uv0 != numel) { S->err = "set_cone_types: sparse second-order cone does not match its expansion map"; return HIPKKT_ERR_ARGUMENT; }
+            } else if (!dense || numel < 2 || numel > 4 || sk != 0) {
+                // cone_types.jl:86-118: dim <= SOC_NO_EXPANSION_MAX_SIZE (4) is the dense form, everything larger the sparse one
+                S->err = "set_cone_types: a second-order cone is either sparse-expanded or dense with dim <= 4"; return HIPKKT_ERR_ARGUMENT;
+            }
+            const int64_t d5[5] = {row, numel, hs, uv0, ord};
+            socdesc.insert(socdesc.end(), d5, d5 + 5);
+            S->sc_nsoc++;
+        } else if (kinds[c] == 3) {
+            int64_t n = (int64_t)((std::sqrt(8.0 * (double)numel + 1.0) - 1.0) * 0.5 + 0.5);
+            if (!dense || sk != 0 || n * (n + 1) / 2 != numel) { S->err = "set_cone_types: a PSD triangle cone has a dense block of triangular size"; return HIPKKT_ERR_ARGUMENT; }
+            S->sc_psd_hs.push_back(hs);
+            S->sc_psd_n.push_back(n);
+            S->sc_psd_total += n * n;
+        }
+        if (sk != 0) sparse_idx++;
+        row += numel;
+        hs += blk;
+    }
+    if (row != m || hs != S->img.nHs) { S->err = "set_cone_types: cone sizes do not add up to m / the Hs vector"; return HIPKKT_ERR_ARGUMENT; }
+    S->d_sc_kind = S->upload(kind);
+    S->d_sc_rowhs = S->upload(rowhs);
+    if (socdesc.empty()) socdesc.assign(5, 0);
+    S->d_sc_socdesc = S->upload(socdesc);
+    S->d_sc_sz = S->dalloc<double>(2 * m);
+    S->d_sc_wl = S->dalloc<double>(2 * m);
+    S->d_sc_eta = S->dalloc<double>(S->sc_nsoc);
+    S->d_sc_R = S->dalloc<double>(S->sc_psd_total);
+    S->d_sc_W = S->dalloc<double>(S->sc_psd_total);
+    S->d_sc_fail = S->dalloc<int>(1);
+    S->sc_ready = true;
+    return HIPKKT_OK;
+    HK_LEAVE
+}
+
+// s, z (length m), psd_R (concatenated n x n column-major R factors, NULL = leave the PSD blocks to hipkkt_set_hs_psd) and the three
+// outputs (w and lambda of length m, eta per second-order cone; any may be NULL) are host pointers, or device pointers when `dev`
+static int32_t update_scaling_impl(hipkkt_handle h, const double *s, const double *z, const double *psd_R, double *w_out,
+                                   double *lambda_out, double *soc_eta_out, int32_t *scaling_ok, bool dev) {
+    HK_ENTER(h)
+    if (!S->sc_ready) { S->err = "update_scaling: call hipkkt_set_cone_types first"; return HIPKKT_ERR_ARGUMENT; }
+    const int64_t m = S->img.m;
+    if (m && (!s || !z)) { S->err = "update_scaling: null s / z"; return HIPKKT_ERR_ARGUMENT; }
+    const double *ds = s, *dz = z, *dR = psd_R;
+    if (!dev) {
+        if (m) {
+            HK_CHECK(hipMemcpyAsync(S->d_sc_sz, s, m * sizeof(double), hipMemcpyHostToDevice, S->stream));
+            HK_CHECK(hipMemcpyAsync(S->d_sc_sz + m, z, m * sizeof(double), hipMemcpyHostToDevice, S->stream));
+        }
+        ds = S->d_sc_sz; dz = S->d_sc_sz + m;
+        if (psd_R && S->sc_psd_total) {
+            HK_CHECK(hipMemcpyAsync(S->d_sc_R, psd_R, (size_t)S->sc_psd_total * sizeof(double), hipMemcpyHostToDevice, S->stream));
+            dR = S->d_sc_R;
+        }
+    }
+    double *dw = S->d_sc_wl, *dl = S->d_sc_wl + m;
+    launch_zero_words(S->stream, S->d_sc_fail, 1);
+    launch_scaling_diag(S->stream, S->d_sc_kind, S->d_sc_rowhs, S->d_mapHs, ds, dz, dw, dl, S->dp.kval, m);
+    launch_scaling_soc(S->stream, S->sc_nsoc, S->d_sc_socdesc, S->d_mapHs, ds, dz, dw, dl, S->d_sc_eta, S->d_soc_u, S->d_soc_v,
+                       S->d_soc_eta2, S->dp.kval, S->d_sc_fail);
+    if (S->nsoc > 0)      // u, v, D entries of the sparse cones (the same kernel hipkkt_set_soc_batch uses)
+        launch_soc_batch(S->stream, S->dp.kval, S->d_soc_uidx, S->d_soc_vidx, S->d_soc_cone, S->d_soc_u, S->d_soc_v, S->d_soc_eta2,
+                         S->soc_total, S->d_soc_didx, S->nsoc);
+    if (dR) {
+        int64_t off = 0;
+        for (size_t c = 0; c < S->sc_psd_n.size(); c++) {
+            const int n = (int)S->sc_psd_n[c];
+            launch_psd_rrt(S->stream, dR + off, S->d_sc_W + off, n);
+            launch_psd_hs(S->stream, S->dp.kval, S->d_mapHs, S->sc_psd_hs[c], S->d_sc_W + off, n);
+            off += (int64_t)n * n;
+        }
+    }
+    const hipMemcpyKind kind = dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+    if (w_out && m) HK_CHECK(hipMemcpyAsync(w_out, dw, m * sizeof(double), kind, S->stream));
+    if (lambda_out && m) HK_CHECK(hipMemcpyAsync(lambda_out, dl, m * sizeof(double), kind, S->stream));
+    if (soc_eta_out && S->sc_nsoc) HK_CHECK(hipMemcpyAsync(soc_eta_out, S->d_sc_eta, S->sc_nsoc * sizeof(double), kind, S->stream));
+    int fail = 0;
+    copy_sync(S->stream, &fail, S->d_sc_fail, sizeof(int), hipMemcpyDeviceToHost);
+    if (scaling_ok) *scaling_ok = fail ? 0 : 1;
+    return HIPKKT_OK;
+    HK_LEAVE
+}
+int32_t hipkkt_update_scaling(hipkkt_handle h, const double *s, const double *z, const double *psd_R, double *w_out,
+                              double *lambda_out, double *soc_eta_out, int32_t *scaling_ok) {
+    return update_scaling_impl(h, s, z, psd_R, w_out, lambda_out, soc_eta_out, scaling_ok, false);
+}
+int32_t hipkkt_update_scaling_dev(hipkkt_handle h, const double *s_dev, const double *z_dev, const double *psd_R_dev, double *w_out_dev,
+                                  double *lambda_out_dev, double *soc_eta_out_dev, int32_t *scaling_ok) {
+    return update_scaling_impl(h, s_dev, z_dev, psd_R_dev, w_out_dev, lambda_out_dev, soc_eta_out_dev, scaling_ok, true);
 }
 
 int32_t hipkkt_set_soc_batch(hipkkt_handle h, int64_t nsoc, const double *eta2, const double *u_all, const double *v_all,
@@ -1797,7 +1929,8 @@ int32_t hipkkt_get_counters(hipkkt_handle h, int64_t *o) {
 }
 
 // developer diagnostic (not part of the plugin contract): internal vectors of the last LDL solve / plan tables as doubles.
-// what: 0 = the permuted right-hand side, 1 = z (forward result / D), 2 = x (permuted), 3 = ubuf, 10 = sn_first, 11 = sn_level,
+// what: 0 = the permuted right-hand side, 1 = z (forward result / D), 2 = x (permuted), 3 = ubuf, 4 = the unregularised KKT values,
+// 5 = D and 6 = 1/D of the last factorisation (permuted order), 7 / 8 = u / v of the sparse second-order cones (concatenated), 10 = sn_first, 11 = sn_level,
 // 12 = rows per supernode, 13 = sn_parent, 14 = persistent-sweep membership (1 = item of a segment launch)
 int32_t hipkkt_debug_dump(hipkkt_handle h, int32_t what, double *out, int64_t cap, int64_t *len) {
     HK_ENTER(h)
@@ -1815,6 +1948,11 @@ int32_t hipkkt_debug_dump(hipkkt_handle h, int32_t what, double *out, int64_t ca
         case 1: dev(S->d_z, S->N); break;
         case 2: dev(S->d_xp, S->N); break;
         case 3: dev(S->dp.ubuf, P.ubuf_len); break;
+        case 4: dev(S->dp.kval, S->nnzK); break;
+        case 5: dev(S->dp.D, S->N); break;
+        case 6: dev(S->dp.Dinv, S->N); break;
+        case 7: dev(S->d_soc_u, S->soc_total); break;
+        case 8: dev(S->d_soc_v, S->soc_total); break;
         case 10: host(P.nsuper + 1, [&](int64_t i) { return P.sn_first[i]; }); break;
         case 11: host(P.nsuper, [&](int64_t i) { return P.sn_level[i]; }); break;
         case 12: host(P.nsuper, [&](int64_t i) { return P.sn_rowptr[i + 1] - P.sn_rowptr[i]; }); break;

@@ -20,6 +20,13 @@ void launch_update_dense(hipStream_t st, const DevPlan &P, int group_begin, int 
 void launch_fwd_narrow(hipStream_t st, const DevPlan &P, int sn_begin, int n, int wmax, double *y, double *z);
 void launch_bwd_narrow(hipStream_t st, const DevPlan &P, int sn_begin, int n, int wmax, const double *z, double *x, double *xout);
 void launch_psd_hs(hipStream_t st, double *kval, const int64_t *map_hs, int64_t hs_off, const double *W, int n);
+// scaling.hip (N1)
+void launch_scaling_diag(hipStream_t st, const signed char *row_kind, const int64_t *row_hs, const int64_t *map_hs, const double *s,
+                         const double *z, double *w, double *lam, double *kval, int64_t m);
+void launch_scaling_soc(hipStream_t st, int nsoc, const int64_t *desc, const int64_t *map_hs, const double *s, const double *z,
+                        double *w, double *lam, double *eta_out, double *soc_u, double *soc_v, double *soc_eta2, double *kval,
+                        int *fail);
+void launch_psd_rrt(hipStream_t st, const double *R, double *W, int n);
 void launch_block_products(hipStream_t st, const DevPlan &P, const double *x, const double *z, double *Px, double *ATz,
                            double *Ax, int n, int m);
 void launch_zero_words(hipStream_t st, void *p, int nwords);

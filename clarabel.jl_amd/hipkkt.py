@@ -21,7 +21,7 @@ SYMBOLS = [
     "hipkkt_default_opts", "hipkkt_is_available", "hipkkt_create", "hipkkt_create_from_parts", "hipkkt_destroy",
     "hipkkt_get_dims", "hipkkt_info", "hipkkt_get_cost_model", "hipkkt_get_kkt", "hipkkt_get_perm",
     "hipkkt_get_dsigns", "hipkkt_get_map", "hipkkt_get_sparse_map", "hipkkt_update_values", "hipkkt_scale_values",
-    "hipkkt_set_hs", "hipkkt_set_hs_dev", "hipkkt_set_hs_psd", "hipkkt_block_products", "hipkkt_set_soc", "hipkkt_set_soc_batch", "hipkkt_set_genpow",
+    "hipkkt_set_hs", "hipkkt_set_hs_dev", "hipkkt_set_hs_psd", "hipkkt_set_cone_types", "hipkkt_update_scaling", "hipkkt_update_scaling_dev", "hipkkt_block_products", "hipkkt_set_soc", "hipkkt_set_soc_batch", "hipkkt_set_genpow",
     "hipkkt_update_P", "hipkkt_update_A", "hipkkt_refactor", "hipkkt_setrhs", "hipkkt_setrhs_dev", "hipkkt_solve",
     "hipkkt_solve_dev", "hipkkt_solve_multi", "hipkkt_solve_multi_dev", "hipkkt_ldl_solve", "hipkkt_get_timing", "hipkkt_reset_timing", "hipkkt_get_profile", "hipkkt_get_profile_launches", "hipkkt_set_profiling",
     "hipkkt_get_counters", "hipkkt_debug_dump", "hipkkt_set_qb", "hipkkt_residuals", "hipkkt_residuals_dev",
@@ -76,6 +76,9 @@ def lib():
     L.hipkkt_set_hs.argtypes = [vp, _f64p, i64]
     L.hipkkt_set_hs_dev.argtypes = [vp, vp, i64]
     L.hipkkt_set_hs_psd.argtypes = [vp, i64, _i64p, _i64p, _f64p]
+    L.hipkkt_set_cone_types.argtypes = [vp, i64, _i32p]
+    L.hipkkt_update_scaling.argtypes = [vp, _f64p, _f64p, vp, vp, vp, vp, C.POINTER(i32)]
+    L.hipkkt_update_scaling_dev.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.POINTER(i32)]
     L.hipkkt_block_products.argtypes = [vp, _f64p, _f64p, _f64p, _f64p, _f64p]
     L.hipkkt_set_soc.argtypes = [vp, i64, f64, _f64p, _f64p, i64]
     L.hipkkt_set_soc_batch.argtypes = [vp, i64, _f64p, _f64p, _f64p, i64]
@@ -276,6 +279,34 @@ class Handle:
         hs_off = np.ascontiguousarray(hs_off, dtype=np.int64)
         dims = np.ascontiguousarray(dims, dtype=np.int64)
         self._chk(self.L.hipkkt_set_hs_psd(self.h, len(dims), hs_off, dims, np.ascontiguousarray(w_all, dtype=np.float64)), "set_hs_psd")
+
+    # ---- N1: update_scaling! + get_Hs! on the device (include/hipkkt.h hipkkt_update_scaling)
+    def set_cone_types(self, kinds):
+        kinds = np.ascontiguousarray(kinds, dtype=np.int32)
+        self._chk(self.L.hipkkt_set_cone_types(self.h, len(kinds), kinds), "set_cone_types")
+        self._n_soc_all = int(np.sum(kinds == 2))
+
+    def update_scaling(self, s, z, psd_R=None, want_outputs=True):
+        """-> (ok, w, lam, soc_eta): Hs blocks / sparse second-order terms of K are rewritten on the device from (s, z)."""
+        s = np.ascontiguousarray(s, dtype=np.float64)
+        z = np.ascontiguousarray(z, dtype=np.float64)
+        if len(s) != self.m or len(z) != self.m:
+            raise ValueError("update_scaling: s and z must have length m")
+        R = None if psd_R is None else np.ascontiguousarray(psd_R, dtype=np.float64)
+        w = np.zeros(max(self.m, 1)) if want_outputs else None
+        lam = np.zeros(max(self.m, 1)) if want_outputs else None
+        eta = np.zeros(max(self._n_soc_all, 1)) if want_outputs else None
+        ok = C.c_int32(0)
+        p = lambda a: None if a is None else a.ctypes.data
+        self._chk(self.L.hipkkt_update_scaling(self.h, s, z, p(R), p(w), p(lam), p(eta), C.byref(ok)), "update_scaling")
+        if not want_outputs:
+            return bool(ok.value), None, None, None
+        return bool(ok.value), w[: self.m], lam[: self.m], eta[: self._n_soc_all]
+
+    def update_scaling_dev(self, s_ptr, z_ptr, R_ptr=None, w_ptr=None, lam_ptr=None, eta_ptr=None):
+        ok = C.c_int32(0)
+        self._chk(self.L.hipkkt_update_scaling_dev(self.h, s_ptr, z_ptr, R_ptr, w_ptr, lam_ptr, eta_ptr, C.byref(ok)), "update_scaling_dev")
+        return bool(ok.value)
 
     def set_soc(self, i, eta2, u, v):
         self._chk(self.L.hipkkt_set_soc(self.h, i, eta2, np.ascontiguousarray(u), np.ascontiguousarray(v), len(u)), "set_soc")

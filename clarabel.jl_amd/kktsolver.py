@@ -42,6 +42,11 @@ class HipKKTSolver:
         self._psd_off = np.array([off for _, off in self._psd], dtype=np.int64)
         self._psd_dim = np.array([c.n for c, _ in self._psd], dtype=np.int64)
         self._psd_cones = tuple(c for c, _ in self._psd)
+        # N1: cone types for the on-device update_scaling! / get_Hs! (hipkkt_set_cone_types); optional in the cones object
+        self._has_cone_kinds = hasattr(cones, "kkt_cone_kinds")
+        if self._has_cone_kinds:
+            self.h.set_cone_types(cones.kkt_cone_kinds())
+        self.scaling_w = self.scaling_lambda = self.scaling_soc_eta = None
         self.diagonal_regularizer = 0.0
         self.last_ir_steps = 0
         self.total_ir_steps = 0
@@ -66,6 +71,9 @@ class HipKKTSolver:
                 self._eta2[i] = c.eta * c.eta
                 off += c.dim
             self.h.set_soc_batch(self._eta2, self._u, self._v)
+        return self._refactor()
+
+    def _refactor(self) -> bool:
         st = self.settings                             # :243, :247-294
         ok, eps, nreg = self.h.refactor(st.static_regularization_enable, st.static_regularization_constant,
                                         st.static_regularization_proportional)
@@ -74,6 +82,18 @@ class HipKKTSolver:
         if _DEBUG:
             print(f"[hipkkt] refactor ok={ok} eps={eps:.3e} dynamic_regularisations={nreg}")
         return ok
+
+    # kktsolver_update! fed with the iterate instead of the cones' scaling -- update_scaling! + get_Hs! of
+    # the Zero / Nonnegative / SecondOrder cones and skron(R R^T) of the PSD cones run on the device (hipkkt_update_scaling); nothing
+    # but (s, z) and the PSD cones' R factors crosses PCIe.  The device's (w, lambda, eta) are kept for the caller.
+    def kktsolver_update_scaled(self, cones, s, z) -> bool:
+        if not self._has_cone_kinds:
+            raise hipkkt.HipKKTError("kktsolver_update_scaled: the cones object does not provide kkt_cone_kinds()")
+        R = np.concatenate([c.R.ravel(order="F") for c in self._psd_cones]) if self._psd_cones else None
+        ok, self.scaling_w, self.scaling_lambda, self.scaling_soc_eta = self.h.update_scaling(s, z, R)
+        if not ok:
+            return False
+        return self._refactor()
 
     # ref: kktsolver_setrhs!, :313-327
     def kktsolver_setrhs(self, rhsx, rhsz):

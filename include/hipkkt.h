@@ -143,6 +143,31 @@ int32_t hipkkt_set_hs_dev(hipkkt_handle h, const double *hs_dev, int64_t nHs);
  * as the reference's skron! loop, so K is bit-identical to the host path.  Saves the O(numel^2) host loop and the
  * upload of the block (813 450 doubles per 50 x 50 cone). */
 int32_t hipkkt_set_hs_psd(hipkkt_handle h, int64_t npsd, const int64_t *hs_off, const int64_t *dim, const double *w_all);
+
+/* SURVEY section 8(f) row N1 (completion): update_scaling! + get_Hs! of the symmetric cones ON THE DEVICE -- the caller ships the
+ * iterate (s, z) (2 m doubles) instead of the Hs vector and the (u, v, eta) of every second-order cone.
+ *   hipkkt_set_cone_types   once per handle: kinds[c] = 0 ZeroCone, 1 NonnegativeCone, 2 SecondOrderCone, 3 PSDTriangleCone
+ *                           (cone_types.jl:6-67), anything else = a cone the caller keeps updating with hipkkt_set_hs / _set_genpow.
+ *                           Checked against the (numel, hs_dense, sparse_kind) the handle was created with.
+ *   hipkkt_update_scaling   per IPM iteration, replaces update_scaling!(cones,s,z,mu,PrimalDual) + get_Hs! + the Hs / sparse-cone
+ *                           part of _kktsolver_update_inner! (kktsolver_directldl.jl:197-245):
+ *      Zero          Hs = 0                                                      coneops_zerocone.jl:91
+ *      Nonnegative   lambda = sqrt(s z), w = sqrt(s/z), Hs = w^2 (bit-exact)     coneops_nncone.jl:77-101
+ *      SecondOrder   eta, w, lambda, and (d, u, v) of the sparse form or the dense block for dim <= 4, with the reference's
+ *                    expressions and association (sums of squares are tree sums)  coneops_socone.jl:75-192
+ *      PSDTriangle   psd_R = the cones' R factors (n x n, column-major, concatenated; the Cholesky / SVD of
+ *                    coneops_psdtrianglecone.jl:78-143 stay with the caller): W = R R^T and triu(skron(W)) are formed on the
+ *                    device (:145-161, :502-540).  psd_R = NULL leaves the PSD blocks to hipkkt_set_hs_psd.
+ *    Outputs (any may be NULL): w_out, lambda_out of length m in cone order (NN: w, lambda; SOC: the normalised w and lambda; zero
+ *    on other rows) -- what the host loop needs for mul_Hs! / step directions; soc_eta_out[k] = eta of the k-th second-order cone;
+ *    *scaling_ok = 0 when a second-order cone's s or z is not interior (update_scaling! returns false, coneops_socone.jl:88-90;
+ *    that cone's entries are left untouched).
+ *   hipkkt_update_scaling_dev  the same with every pointer except scaling_ok in device memory (s, z resident: no PCIe at all). */
+int32_t hipkkt_set_cone_types(hipkkt_handle h, int64_t ncones, const int32_t *kinds);
+int32_t hipkkt_update_scaling(hipkkt_handle h, const double *s, const double *z, const double *psd_R, double *w_out,
+                              double *lambda_out, double *soc_eta_out, int32_t *scaling_ok);
+int32_t hipkkt_update_scaling_dev(hipkkt_handle h, const double *s_dev, const double *z_dev, const double *psd_R_dev,
+                                  double *w_out_dev, double *lambda_out_dev, double *soc_eta_out_dev, int32_t *scaling_ok);
 /* ref: _csc_update_sparsecone(::SecondOrderCone,...), directldl_datamaps.jl:61-79 */
 int32_t hipkkt_set_soc(hipkkt_handle h, int64_t sparse_idx, double eta2, const double *u, const double *v,
                        int64_t dim);
@@ -236,7 +261,7 @@ int32_t hipkkt_set_profiling(hipkkt_handle h, int32_t enable);
 int32_t hipkkt_get_counters(hipkkt_handle h, int64_t *out8);
 
 /* developer diagnostic, not part of the plugin contract: copies an internal vector of the last LDL solve (what = 0 the
- * permuted right-hand side, 1 z = D^-1 L^-1 b, 2 x in permuted order, 3 the forward update vectors) or a plan table converted to doubles (10 supernode first
+ * permuted right-hand side, 1 z = D^-1 L^-1 b, 2 x in permuted order, 3 the forward update vectors, 4 the unregularised KKT values in nz order, 5 D and 6 1/D of the last factorisation, 7 / 8 the u / v vectors of the sparse second-order cones) or a plan table converted to doubles (10 supernode first
  * columns, 11 levels, 12 rows per supernode, 13 parents, 14 membership in the persistent sweeps); *len receives the
  * length, nothing is copied when cap is too small */
 int32_t hipkkt_debug_dump(hipkkt_handle h, int32_t what, double *out, int64_t cap, int64_t *len);

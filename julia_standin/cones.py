@@ -32,6 +32,8 @@ class ZeroCone:
     is_sparse_expandable = False
     hs_is_diagonal = True
 
+    kind_code = 0   # include/hipkkt.h hipkkt_set_cone_types
+
     def __init__(self, dim):
         self.dim = dim
         self.numel = dim
@@ -78,6 +80,8 @@ class NonnegativeCone:
 
     is_sparse_expandable = False
     hs_is_diagonal = True
+
+    kind_code = 1   # include/hipkkt.h hipkkt_set_cone_types
 
     def __init__(self, dim):
         self.dim = dim
@@ -154,6 +158,8 @@ def _sqrt_soc_residual(z):
 
 class SecondOrderCone:
     """coneops_socone.jl; sparse rank-2 expansion data for dim > 4 (cone_types.jl:86-118)."""
+
+    kind_code = 2   # include/hipkkt.h hipkkt_set_cone_types
 
     def __init__(self, dim):
         if dim < 2:
@@ -329,6 +335,8 @@ class PSDTriangleCone:
 
     is_sparse_expandable = False
     hs_is_diagonal = False
+
+    kind_code = 3   # include/hipkkt.h hipkkt_set_cone_types
 
     def __init__(self, n):
         self.n = n
@@ -603,3 +611,7 @@ class CompositeCone:
         sparse_kind = np.array([1 if c.is_sparse_expandable else 0 for c in self.cones], dtype=np.int32)
         dim1 = np.zeros(len(self.cones), dtype=np.int64)
         return numel, hs_dense, sparse_kind, dim1
+
+    def kkt_cone_kinds(self):
+        """cone type codes for the plugin's on-device scaling"""
+        return np.array([c.kind_code for c in self.cones], dtype=np.int32)

@@ -253,11 +253,18 @@ class KKTSystem:
         self.work_conic = np.zeros(m)
         self._multi = hasattr(kktsolver, "kktsolver_solve_multi") and getattr(kktsolver, "batch_constant_rhs", True)
         self._const_pending = False
+        self._device_scaling = bool(getattr(getattr(kktsolver, "settings", None), "device_scaling", False)) and \
+            hasattr(kktsolver, "kktsolver_update_scaled")
         self._rx2, self._rz2 = np.zeros((2, n)), np.zeros((2, m))
         self._lx2, self._lz2 = np.zeros((2, n)), np.zeros((2, m))
 
-    def kkt_update(self, data, cones):  # :62-78
-        if not self.kktsolver.kktsolver_update(cones):
+    def kkt_update(self, data, cones, sz=None):  # :62-78
+        if sz is not None and self._device_scaling:
+            # the plugin forms the Hs blocks / sparse-cone terms of K from the iterate (s, z) itself
+            ok = self.kktsolver.kktsolver_update_scaled(cones, sz[0], sz[1])
+        else:
+            ok = self.kktsolver.kktsolver_update(cones)
+        if not ok:
             return False
         if self._multi:
             # the constant-rhs solve of :80-92 is left pending and batched with the first
@@ -582,7 +589,7 @@ class Solver:
                 break
             it += 1
             t0 = time.perf_counter()
-            ok = self.kktsystem.kkt_update(data, cones)
+            ok = self.kktsystem.kkt_update(data, cones, sz=(v.s, v.z))
             tm["kkt update"] += time.perf_counter() - t0
             # variables_affine_step_rhs!, variables.jl:107-121
             rhs.x[:] = r.rx

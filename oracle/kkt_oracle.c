@@ -406,5 +406,7 @@ int oracle_kkt_solve(oracle_kkt *k, double *lhsx, double *lhsz, int ir_enable, d
     return ok;
 }
 
+/* D of the last numeric factorisation, permuted order (diagnostics: pivot-by-pivot comparison with the HIP path) */
+const double *oracle_kkt_D(const oracle_kkt *k) { return k->ldl ? qdldl_oracle_D(k->ldl) : 0; }
 int64_t oracle_kkt_nreg(const oracle_kkt *k) { return k->ldl ? qdldl_oracle_nreg(k->ldl) : 0; }
 double oracle_kkt_sum_colcount_sq(const oracle_kkt *k) { return k->ldl ? qdldl_oracle_sum_colcount_sq(k->ldl) : 0.0; }

@@ -89,6 +89,7 @@ void oracle_kkt_ldl_solve(const oracle_kkt *k, double *x, const double *b);
 void oracle_kkt_symv(const oracle_kkt *k, const double *x, double *y);
 
 int64_t oracle_kkt_nreg(const oracle_kkt *k);
+const double *oracle_kkt_D(const oracle_kkt *k);   /* D of the last factorisation, permuted order */
 double oracle_kkt_sum_colcount_sq(const oracle_kkt *k);
 
 #ifdef __cplusplus

@@ -68,6 +68,8 @@ def lib():
     L.oracle_kkt_get_x.argtypes = [vp, _f64p]
     L.oracle_kkt_ldl_solve.argtypes = [vp, _f64p, _f64p]
     L.oracle_kkt_symv.argtypes = [vp, _f64p, _f64p]
+    L.oracle_kkt_D.restype = C.POINTER(C.c_double)
+    L.oracle_kkt_D.argtypes = [vp]
     L.oracle_kkt_nreg.restype = C.c_int64
     L.oracle_kkt_nreg.argtypes = [vp]
     L.oracle_kkt_sum_colcount_sq.restype = C.c_double
@@ -157,6 +159,10 @@ class OracleKKT:
         sz = np.zeros(8, dtype=np.int64)
         self.L.oracle_kkt_sizes(self.h, sz)
         self.nnzL = int(sz[7])
+
+    def factor_D(self):
+        """D of the last numeric factorisation in permuted order (copy)"""
+        return np.ctypeslib.as_array(self.L.oracle_kkt_D(self.h), shape=(self.N,)).copy()
 
     def symv(self, x):
         y = np.zeros(self.N)

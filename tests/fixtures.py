@@ -128,3 +128,4 @@ def scale_cones(cones, rng):
             s[r] = rng.random(c.numel) + 0.2
             z[r] = rng.random(c.numel) + 0.2
     assert cones.update_scaling(s, z, 1.0)
+    return s, z

@@ -641,3 +641,136 @@ def test_device_assembly_equals_host_assembly(name, monkeypatch):
     assert np.array_equal(a[5], b[5])
     hd.close()
     hh.close()
+
+
+# ---- update_scaling! + get_Hs! on the device ------------------------------------------------
+def _mixed_cone_problem(seed=77, n=30):
+    rng = np.random.default_rng(seed)
+    specs = [cl.ZeroConeT(3), cl.NonnegativeConeT(40), cl.SecondOrderConeT(3), cl.SecondOrderConeT(4), cl.SecondOrderConeT(7),
+             cl.PSDTriangleConeT(4), cl.SecondOrderConeT(300), cl.NonnegativeConeT(5), cl.PSDTriangleConeT(2), cl.SecondOrderConeT(2)]
+    from clarabel_jl_amd.cone_api import nvars
+    m = sum(nvars(c) for c in specs)
+    A = sp.random(m, n, density=0.15, random_state=np.random.RandomState(seed), format="csc") + \
+        sp.vstack([sp.identity(n), sp.csc_matrix((m - n, n))]).tocsc()
+    Pm = sp.random(n, n, density=0.1, random_state=np.random.RandomState(seed + 1))
+    P = (Pm @ Pm.T + sp.identity(n)).tocsc()
+    return P, rng.standard_normal(n), A.tocsc(), rng.standard_normal(m), specs
+
+
+def test_update_scaling_on_device_matches_host_cone_algebra():
+    """coneops_nncone.jl:77-101 (bit-exact), coneops_socone.jl:75-192 (the identities of test_coneops_secondordercone.jl:31-66 and
+    the host values to rounding), coneops_psdtrianglecone.jl:145-161 (R R^T + skron), scattered as kktsolver_directldl.jl:223-241"""
+    Pt, A, cones = _prep(_mixed_cone_problem())
+    m, n = A.shape
+    st = cl.Settings()
+    host = HipKKTSolver(Pt, A, cones, m, n, st)
+    dev = HipKKTSolver(Pt, A, cones, m, n, st)
+    rng = np.random.default_rng(5)
+    for trial in range(2):
+        s, z = _scale_cones(cones, rng)                    # host: update_scaling!(cones, s, z, mu)
+        if trial == 1:                                     # a badly scaled iterate, as late IPM iterations produce
+            s *= 1e-6; z *= 1e4
+            assert cones.update_scaling(s, z, 1.0)
+        assert host.kktsolver_update(cones)                # host get_Hs! + uploads (the reference's call pattern)
+        assert dev.kktsolver_update_scaled(cones, s, z)    # only (s, z) and the PSD R factors cross PCIe
+        K1, K2 = host.h.debug_dump(4), dev.h.debug_dump(4)
+        map_hs = host.h.map(2)
+        scale = np.maximum(np.abs(K1), 1e-300)
+        # per cone: NN / Zero blocks bit-exact, SOC and PSD to rounding of the (tree) sums
+        soc_k = 0
+        u_all, v_all = dev.h.debug_dump(7), dev.h.debug_dump(8)
+        uoff = 0
+        for c, r, rb in zip(cones.cones, cones.rng_cones, cones.rng_blocks):
+            idx = map_hs[rb.start:rb.stop]
+            if c.kind_code in (0, 1):
+                assert np.array_equal(K1[idx], K2[idx]), type(c).__name__
+                if c.kind_code == 1:
+                    assert np.array_equal(dev.scaling_w[r], c.w) and np.array_equal(dev.scaling_lambda[r], c.lam)
+            else:
+                assert np.max(np.abs(K1[idx] - K2[idx]) / scale[idx]) < 5e-13, (type(c).__name__, c.numel)
+            if c.kind_code == 2:
+                w, lam, eta = dev.scaling_w[r], dev.scaling_lambda[r], dev.scaling_soc_eta[soc_k]
+                soc_k += 1
+                assert np.allclose(w, c.w, rtol=1e-12, atol=1e-14) and np.allclose(lam, c.lam, rtol=1e-12, atol=1e-14)
+                assert abs(eta - c.eta) <= 1e-14 * c.eta
+                assert abs(w[0] ** 2 - w[1:] @ w[1:] - 1.0) < 1e-10           # w is on the hyperboloid
+                if c.is_sparse_expandable:
+                    # test_coneops_secondordercone.jl:31-66: eta^2 (D + u u' - v v') == eta^2 (2 w w' - J)
+                    u, v = u_all[uoff:uoff + c.dim], v_all[uoff:uoff + c.dim]
+                    uoff += c.dim
+                    d = -K2[idx[0]] / eta ** 2
+                    D = np.eye(c.dim); D[0, 0] = d
+                    J = -np.eye(c.dim); J[0, 0] = 1.0
+                    lhs, rhs = D + np.outer(u, u) - np.outer(v, v), 2.0 * np.outer(w, w) - J
+                    assert np.linalg.norm(lhs - rhs) < 1e-12 * max(1.0, np.linalg.norm(rhs))
+        # everything else, i.e. the u / v columns of the sparse cones: the residual (z0 - |z1|)(z0 + |z1|) amplifies the last-bit
+        # differences of the tree sums
+        assert np.max(np.abs(K1 - K2) / scale) < 2e-11
+        # and the factorisations / refined solves agree
+        rx, rz = rng.standard_normal(n), rng.standard_normal(m)
+        xs = []
+        for k in (host, dev):
+            k.kktsolver_setrhs(rx, rz)
+            x, zz = np.zeros(n), np.zeros(m)
+            assert k.kktsolver_solve(x, zz)
+            xs.append(np.concatenate([x, zz]))
+        assert np.max(np.abs(xs[0] - xs[1])) <= 1e-9 * max(1.0, np.max(np.abs(xs[0])))
+    # a second-order cone with z on the boundary: update_scaling! reports failure (coneops_socone.jl:88-90)
+    r7 = [r for c, r in zip(cones.cones, cones.rng_cones) if c.kind_code == 2 and c.dim == 7][0]
+    zb = z.copy(); zb[r7] = 0.0
+    ok, *_ = dev.h.update_scaling(s, zb, None)
+    assert not ok
+    with pytest.raises(ValueError):
+        dev.h.update_scaling(s[:-1], z)
+
+
+class _DevBuf:
+    """device memory through the HIP runtime the library is linked with (PyTorch would bring a second runtime into the process)"""
+    _hip = None
+
+    def __init__(self, arr_or_n):
+        import ctypes as C
+        if _DevBuf._hip is None:
+            _DevBuf._hip = C.CDLL("libamdhip64.so")
+        self.C, self.hip = C, _DevBuf._hip
+        host = np.zeros(arr_or_n) if isinstance(arr_or_n, int) else np.ascontiguousarray(arr_or_n, dtype=np.float64)
+        self.n = host.size
+        self.ptr = C.c_void_p()
+        assert self.hip.hipMalloc(C.byref(self.ptr), C.c_size_t(max(host.nbytes, 8))) == 0
+        assert self.hip.hipMemcpy(self.ptr, host.ctypes.data_as(C.c_void_p), C.c_size_t(host.nbytes), 1) == 0
+
+    def get(self):
+        out = np.zeros(self.n)
+        assert self.hip.hipMemcpy(out.ctypes.data_as(self.C.c_void_p), self.ptr, self.C.c_size_t(out.nbytes), 2) == 0
+        return out
+
+    def __del__(self):
+        self.hip.hipFree(self.ptr)
+
+
+def test_update_scaling_dev_keeps_everything_in_hbm():
+    Pt, A, cones = _prep(_mixed_cone_problem(seed=78))
+    m, n = A.shape
+    k = HipKKTSolver(Pt, A, cones, m, n, cl.Settings())
+    s, z = _scale_cones(cones, np.random.default_rng(6))
+    R = np.concatenate([c.R.ravel(order="F") for c in k._psd_cones])
+    ok, w, lam, eta = k.h.update_scaling(s, z, R)
+    assert ok
+    K_host_ptrs = k.h.debug_dump(4)
+    sd, zd, Rd = _DevBuf(s), _DevBuf(z), _DevBuf(R)
+    wd, ld, ed = _DevBuf(m), _DevBuf(m), _DevBuf(len(eta))
+    k.h.update_values(k.h.map(2), np.zeros(k.h.nHs))       # wipe the blocks so that the second call must rewrite them
+    assert not np.array_equal(k.h.debug_dump(4), K_host_ptrs)
+    assert k.h.update_scaling_dev(sd.ptr, zd.ptr, Rd.ptr, wd.ptr, ld.ptr, ed.ptr)
+    assert np.array_equal(k.h.debug_dump(4), K_host_ptrs)
+    assert np.array_equal(wd.get(), w) and np.array_equal(ld.get(), lam) and np.array_equal(ed.get(), eta)
+
+
+@pytest.mark.parametrize("name", ["socp_fixture", "lasso_sparse_soc", "portfolio_small", "sdp_small"])
+def test_ipm_with_device_scaling_reaches_the_same_answer(name):
+    prob = PROBLEMS[name]()
+    ref = cl.Solver(*prob, cl.Settings(), kktsolver_factory=lambda *a: HipKKTSolver(*a)).solve()
+    got = cl.Solver(*prob, cl.Settings(device_scaling=True), kktsolver_factory=lambda *a: HipKKTSolver(*a)).solve()
+    assert got.status == ref.status and abs(got.iterations - ref.iterations) <= 1
+    assert abs(got.obj_val - ref.obj_val) <= 1e-8 * max(1.0, abs(ref.obj_val))
+    assert np.max(np.abs(got.x - ref.x)) <= 1e-6 * max(1.0, np.max(np.abs(ref.x)))

@@ -29,6 +29,7 @@ int main(int argc, char **argv) {
     printf("N %d nnzK %ld nnzL %ld nsuper %d nlevels %d panel_doubles %ld flops_colcount %.3e flops_update %.3e flops_exec %.3e plan_s %.3f\n",
            P.N, (long)P.nnzK, (long)P.nnzL, P.nsuper, P.nlevels, (long)P.panel_doubles, P.flops_colcount, P.flops_update, P.flops_exec,
            std::chrono::duration<double>(t1 - t0).count());
+    printf("phases [%s]\n", P.timing_note.c_str());
     printf("ntasks %zu ngroups %zu ordering_used %d fronts %zu | model: md %.3f ms (%d levels)  nd %.3f ms (%d levels)\n", P.upd_tasks.size(), P.upd_groups.size(), P.ordering_used, P.fronts.size(), 1e3 * P.cost_md_seconds, P.cost_md_levels, 1e3 * P.cost_nd_seconds, P.cost_nd_levels);
     for (int l = 0; l < P.nlevels; l++) {   // per stage: per-entry gather lists (k_update_gather)
         const int64_t e0 = P.gath_stage_ptr[l], e1 = P.gath_stage_ptr[l + 1];
