@@ -13,8 +13,9 @@ for f in hipkkt.cpp symbolic.cpp ordering.cpp assemble.cpp; do
 done
 $HIPCC $FLAGS -c kernels.hip -o $OBJ/kernels.o & pids+=($!)
 $HIPCC $FLAGS -c assemble_dev.hip -o $OBJ/assemble_dev.o & pids+=($!)
+$HIPCC $FLAGS -c front_block.hip -o $OBJ/front_block.o & pids+=($!)
 # scaling.hip mirrors the reference's cone formulas operation by operation: no FMA contraction
 $HIPCC $FLAGS -ffp-contract=off -c scaling.hip -o $OBJ/scaling.o & pids+=($!)
 for p in "${pids[@]}"; do wait $p; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT $OBJ/hipkkt.o $OBJ/symbolic.o $OBJ/ordering.o $OBJ/assemble.o $OBJ/assemble_dev.o $OBJ/scaling.o $OBJ/kernels.o
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT $OBJ/hipkkt.o $OBJ/symbolic.o $OBJ/ordering.o $OBJ/assemble.o $OBJ/assemble_dev.o $OBJ/scaling.o $OBJ/front_block.o $OBJ/kernels.o
 echo "built $(readlink -f $OUT)"

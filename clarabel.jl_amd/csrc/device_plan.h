@@ -7,7 +7,7 @@
 namespace hipkkt {
 
 enum { SC_MAXDIAG = 0, SC_NORMB = 1, SC_NORME = 2, SC_COUNT = 8 };  // 64-bit scalar slots
-enum { FL_NONFINITE = 0, FL_NREG = 1, FL_FRONTFAIL = 2, FL_COUNT = 4 };                // int flags
+enum { FL_NONFINITE = 0, FL_NREG = 1, FL_FRONTFAIL = 2, FL_FACFAIL = 3, FL_COUNT = 4 };   // int flags (FL_FACFAIL: k_front_block gave up)
 
 // hand-off slot of the persistent sweeps: a value and its self-validating tag (kernels.hip front_slot_* / seg_slot_*)
 struct __attribute__((aligned(16))) FrontSlot {
@@ -36,6 +36,15 @@ struct GathPair {
     int32_t K;                    // its width
     int32_t dfirst;               // first pivot of the source in D
 };
+// One update batch of a front factored by ONE launch of k_front_block (front_block.hip): nb consecutive 64-column panels
+constexpr int kFbMax = 5;         // panels per launch (= the longest update batch)
+struct FrontBatch {
+    int64_t fp_off;               // front_panels[fp_off + q], q = 0 .. nb-1
+    int64_t scratch_off;          // doubles: kFbMax x (64 x 64 inverse + 64 pivots), then the L tiles of the diagonal workgroups
+    int32_t nb, nblk, r0;         // panels, 64-row blocks (= workgroups), rows of the first panel
+    int32_t sync_off;             // ints: {ticket, error} | 32: Minv flags | 64 + 8 k + j: L(k,j) flags   (128 ints per batch)
+};
+constexpr int64_t kFbScratch = (int64_t)kFbMax * 4160 + (int64_t)(kFbMax * (kFbMax - 1) / 2) * 4096;   // doubles per batch
 constexpr int kGathHeavy = 24;    // target entries with more pairs than this get a wavefront of their own
 
 struct DevPlan {

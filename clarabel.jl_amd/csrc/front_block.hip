@@ -1,0 +1,411 @@
+// K4 over a FRONT, one launch per update batch: the nb <= 5 consecutive 64-column panels of a front that share
+// an update batch are factored by ONE kernel instead of nb x (panel kernel + just-in-time update kernel).  Workgroup b owns the b-th
+// 64-row block of the batch's first panel (tickets in arrival order, like the front sweeps of the solves); it keeps its rows of all nb
+// column blocks in matrix-core accumulators and walks the columns left to right:
+//     step j:   X_j = A_j * (L_jj^-T D_j^-1)              16x16x4 FP64 MFMA against the published inverse of the diagonal block
+//               A_k -= (X_j D_j) * L(k,j)^T   for k > j    MFMA against the published rows of the diagonal workgroups
+// The workgroups of the first nb blocks ("diagonal" workgroups) stop at their own diagonal tile, eliminate it with the 8-pivot-blocked
+// in-register LDL^T of k_factor_panel (same pivot rule, kernels.hip), invert the unit-lower factor and publish  L^-T D^-1  and their
+// L(k,j) tiles through a scratch area of whole, 128-byte aligned tiles (write-through stores + drained flag; consumers: one relaxed
+// poll, one agent acquire, sc1 loads -- MI355X_MICROARCH.md "inter-workgroup visibility").  Nothing another workgroup reads is read
+// before its flag, no scratch line is shared between producers, and a workgroup only ever waits for lower tickets (already running):
+// no deadlock at any grid size; every spin is bounded and aborts the whole factorisation through FL_FACFAIL (the host then repeats it
+// with one launch per panel).  Cost per panel on the critical path: pivots + inverse + one tile hand-off + two 64x64x64 products,
+// instead of two dependent launches in which every workgroup repeats the diagonal tile.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels.h"
+
+namespace hipkkt {
+
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+constexpr int FLD = 65;   // LDS row stride of a 64 x 64 tile
+
+__device__ __forceinline__ int fb_ldi(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double fb_ld(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void fb_st(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double fb_readlane(double x, int l) {   // l wave-uniform
+    const unsigned long long u = (unsigned long long)__double_as_longlong(x);
+    const unsigned lo = __builtin_amdgcn_readlane((unsigned)u, l), hi = __builtin_amdgcn_readlane((unsigned)(u >> 32), l);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ __forceinline__ double fb_rcp(double d) {   // kernels.hip pivot_rcp
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma(fma(-d, r, 1.0), r, r);
+    r = fma(fma(-d, r, 1.0), r, r);
+    return r;
+}
+
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ double2 fb_unpack(v4u r) {
+    double2 d;
+    d.x = __longlong_as_double((long long)(((unsigned long long)r[1] << 32) | r[0]));
+    d.y = __longlong_as_double((long long)(((unsigned long long)r[3] << 32) | r[2]));
+    return d;
+}
+// four 16-byte sc1 loads in flight per lane (issue and wait in ONE asm statement: kernels.hip, inline-asm lessons)
+__device__ __forceinline__ void fb_ld16x4(const double *p0, const double *p1, const double *p2, const double *p3, double2 &d0,
+                                          double2 &d1, double2 &d2, double2 &d3) {
+    v4u r0, r1, r2, r3;
+    asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %5, off sc1\n\t"
+                 "global_load_dwordx4 %2, %6, off sc1\n\tglobal_load_dwordx4 %3, %7, off sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
+                 : "v"(p0), "v"(p1), "v"(p2), "v"(p3)
+                 : "memory");
+    d0 = fb_unpack(r0); d1 = fb_unpack(r1); d2 = fb_unpack(r2); d3 = fb_unpack(r3);
+}
+__device__ __forceinline__ void fb_st16(double *p, double a, double b) {
+    const unsigned long long ua = (unsigned long long)__double_as_longlong(a), ub = (unsigned long long)__double_as_longlong(b);
+    v4u r = {(unsigned)ua, (unsigned)(ua >> 32), (unsigned)ub, (unsigned)(ub >> 32)};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 2" : : "v"(p), "v"(r) : "memory");
+}
+// a 64 x 64 row-major scratch tile <-> an LDS tile [row * FLD + col]: 8 chunks of 16 bytes per thread
+__device__ __forceinline__ void fb_tile_load(const double *tl, double *S, int tid) {
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        double2 d[4];
+        const int i0 = tid + 1024 * h;
+        fb_ld16x4(tl + 2 * i0, tl + 2 * (i0 + 256), tl + 2 * (i0 + 512), tl + 2 * (i0 + 768), d[0], d[1], d[2], d[3]);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int idx = i0 + 256 * q, row = idx >> 5, c = 2 * (idx & 31);
+            S[row * FLD + c] = d[q].x;
+            S[row * FLD + c + 1] = d[q].y;
+        }
+    }
+}
+__device__ __forceinline__ void fb_tile_store(double *tl, const double *S, int tid) {
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        const int idx = tid + 256 * q, row = idx >> 5, c = 2 * (idx & 31);
+        fb_st16(tl + 2 * idx, S[row * FLD + c], S[row * FLD + c + 1]);
+    }
+}
+
+// whole-workgroup wait for a flag of another workgroup; false = timed out / somebody else failed (uniform over the workgroup)
+__device__ __forceinline__ bool fb_wait(const int *flag, int *err, int *failflag, unsigned lim, int *sres) {
+    if (threadIdx.x == 0) {
+        int ok = 1;
+        for (unsigned spins = 0; fb_ldi(flag) == 0; spins++) {
+            if ((spins & 63u) == 63u || lim < 64u) {
+                if (spins > lim) {
+                    __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    atomicOr(failflag, 1);
+                    ok = 0;
+                    break;
+                }
+                if (fb_ldi(err) != 0) { ok = 0; break; }
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        *sres = ok;
+    }
+    __syncthreads();
+    const bool ok = *sres != 0;           // no acquire fence: every hand-off payload is stored AND loaded with sc1 (bypasses this CU's L1)
+    __syncthreads();                      // *sres may be rewritten by the next wait
+    return ok;
+}
+// all payload stores of the workgroup drained (write-through sc1 stores: no L2 write-back needed), then the flag
+__device__ __forceinline__ void fb_publish(int *flag) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// one 16 x 16 product on the matrix core, operands in LDS: C = sum_k A[ar + l15][ac + k] B[br + k][bc + l15], k < 4 * nk
+__device__ __forceinline__ v4f64 fb_mm16(const double *A, int ar, int ac, const double *Bm, int br, int bc, int nk, int l15, int lk) {
+    v4f64 c = {0.0, 0.0, 0.0, 0.0};
+    for (int kk = 0; kk < nk; kk++)
+        c = __builtin_amdgcn_mfma_f64_16x16x4f64(A[(ar + l15) * FLD + ac + 4 * kk + lk], Bm[(br + 4 * kk + lk) * FLD + bc + l15], c, 0, 0, 0);
+    return c;
+}
+// panel rows of this block (column-major) and their row-major copy for the backward solves, from an LDS tile
+__device__ __forceinline__ void fb_store_panel(const DevPlan &P, const FrontPanel &pj, int roff, int nr, const double *S, int tid) {
+    double *dst = P.Lx + pj.panel_off + roff;
+    for (int idx = tid; idx < 4096; idx += 256) {
+        const int row = idx & 63, col = idx >> 6;
+        if (row < nr) dst[row + (int64_t)col * pj.r] = S[row * FLD + col];
+    }
+    double *lt = P.LT + pj.lt_off + (int64_t)(roff - 64) * 64;
+    for (int idx = tid; idx < 4096; idx += 256) {
+        const int col = idx & 63, row = idx >> 6;
+        if (row < nr) lt[idx] = S[row * FLD + col];
+    }
+}
+
+#define FB_T(slot) do { if (trace && tid == 0 && i < 8) trace[(B.sync_off / 128 * 8 + i) * 16 + (slot)] = (long long)wall_clock64(); } while (0)
+__global__ void __launch_bounds__(256)
+k_front_block(DevPlan P, FrontBatch B, int *sync_all, double *scratch_all, double dyn_eps, double dyn_delta, long long *trace) {
+    __shared__ double Sa[64 * FLD];     // this workgroup's 64 x 64 strip: A_j, then X_j; the pivot loop's small buffers; the inverse
+    __shared__ double Sb[64 * FLD];     // the other operand: Minv_j, then L(k,j); the pivot loop's result L11
+    __shared__ double St[64 * FLD];     // products of the blocked inverse
+    __shared__ double Sd[64];           // D_j
+    __shared__ int sblk, sres;
+    int *sync = sync_all + B.sync_off;
+    int *err = sync + 1, *fl_minv = sync + 32, *fl_L = sync + 64;
+    double *scratch = scratch_all + B.scratch_off;
+    double *ltiles = scratch + (int64_t)kFbMax * 4160;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, lk = lane >> 4;
+    if (tid == 0) sblk = atomicAdd(sync, 1);
+    __syncthreads();
+    const int i = sblk;                                   // row block of this workgroup
+    if (i >= B.nblk) return;
+    FB_T(0);
+    const FrontPanel *fp = P.front_panels + B.fp_off;
+    const int nb = B.nb;
+    const bool diag = i < nb;
+    const int ncb = diag ? i + 1 : nb;                    // column blocks held here
+    const int nsteps = diag ? i : nb;
+    const int nr = min(64, B.r0 - 64 * i);
+    v4f64 acc[kFbMax][4];
+    // ---- load the row block (coalesced over rows, through LDS into the accumulator layout: lane (col l15, row lk + 4 reg))
+#pragma unroll
+    for (int k = 0; k < kFbMax; k++) {
+        if (k < ncb) {
+            const FrontPanel pk = fp[k];
+            const double *src = P.Lx + pk.panel_off + 64 * (i - k);
+            double tmp[16];
+#pragma unroll
+            for (int q = 0; q < 16; q++) tmp[q] = lane < nr ? src[lane + (int64_t)(wv + 4 * q) * pk.r] : 0.0;
+#pragma unroll
+            for (int q = 0; q < 16; q++) Sa[lane * FLD + wv + 4 * q] = tmp[q];
+            __syncthreads();
+#pragma unroll
+            for (int sub = 0; sub < 4; sub++)
+#pragma unroll
+                for (int reg = 0; reg < 4; reg++) acc[k][sub][reg] = Sa[(16 * wv + lk + 4 * reg) * FLD + 16 * sub + l15];
+            __syncthreads();
+        }
+    }
+    FB_T(1);
+    // ---- the columns left of this block's own tile
+#pragma unroll
+    for (int j = 0; j < kFbMax; j++) {
+        if (j < nsteps) {                                  // workgroup-uniform
+            const bool last = diag && j == nsteps - 1;     // next: this workgroup's own diagonal tile (critical path of the front)
+            if (!fb_wait(fl_minv + j, err, P.flags + FL_FACFAIL, P.spin_limit, &sres)) return;
+            if (j == nsteps - 1) FB_T(2);
+            const double *mv = scratch + (int64_t)j * 4160;
+            fb_tile_load(mv, Sb, tid);                                                                        // Minv[k][c]
+            if (tid < 64) Sd[tid] = fb_ld(mv + 4096 + tid);
+#pragma unroll
+            for (int sub = 0; sub < 4; sub++)
+#pragma unroll
+                for (int reg = 0; reg < 4; reg++) Sa[(16 * wv + lk + 4 * reg) * FLD + 16 * sub + l15] = acc[j][sub][reg];
+            __syncthreads();
+            if (j == nsteps - 1) FB_T(3);
+            // X_j = A_j Minv_j (Minv upper triangular: k-steps below a 16-column strip's diagonal are skipped)
+            v4f64 x[4];
+#pragma unroll
+            for (int sub = 0; sub < 4; sub++) x[sub] = (v4f64){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int kk = 0; kk < 16; kk++) {
+                const double a = Sa[(16 * wv + l15) * FLD + 4 * kk + lk];
+#pragma unroll
+                for (int sub = 0; sub < 4; sub++)
+                    if (4 * kk <= 16 * sub + 15)
+                        x[sub] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Sb[(4 * kk + lk) * FLD + 16 * sub + l15], x[sub], 0, 0, 0);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int sub = 0; sub < 4; sub++)
+#pragma unroll
+                for (int reg = 0; reg < 4; reg++) Sa[(16 * wv + lk + 4 * reg) * FLD + 16 * sub + l15] = x[sub][reg];
+            __syncthreads();
+            if (j == nsteps - 1) FB_T(4);
+            // L(i,j): diagonal workgroups hand their tile to the workgroups below through the scratch area; the panel (column-major)
+            // and its row-major copy for the backward solves are written now, or -- before a diagonal tile -- after the pivots
+            if (diag) fb_tile_store(ltiles + (int64_t)(i * (i - 1) / 2 + j) * 4096, Sa, tid);
+            if (!last) {
+                fb_store_panel(P, fp[j], 64 * (i - j), nr, Sa, tid);
+                if (diag) fb_publish(fl_L + 8 * i + j);
+            }   // (last: the panel copy is made from the scratch tile after this workgroup's own pivots)
+            if (j == nsteps - 1) FB_T(5);
+            // A_k -= (X_j D_j) L(k,j)^T
+#pragma unroll
+            for (int k = j + 1; k < kFbMax; k++) {
+                if (k < ncb) {
+                    const bool own = diag && k == i;       // the diagonal tile: L(i,j) is this workgroup's X_j
+                    if (!own) {
+                        if (!fb_wait(fl_L + 8 * k + j, err, P.flags + FL_FACFAIL, P.spin_limit, &sres)) return;
+                        fb_tile_load(ltiles + (int64_t)(k * (k - 1) / 2 + j) * 4096, Sb, tid);
+                        __syncthreads();
+                    }
+                    const double *Bs = own ? Sa : Sb;
+#pragma unroll
+                    for (int kk = 0; kk < 16; kk++) {
+                        const double a = -(Sa[(16 * wv + l15) * FLD + 4 * kk + lk] * Sd[4 * kk + lk]);
+#pragma unroll
+                        for (int sub = 0; sub < 4; sub++)
+                            acc[k][sub] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Bs[(16 * sub + l15) * FLD + 4 * kk + lk], acc[k][sub], 0, 0, 0);
+                    }
+                    __syncthreads();                      // Sb is overwritten by the next tile / the next step
+                }
+            }
+        }
+    }
+    FB_T(6);
+    if (!diag) return;
+    // ---- the diagonal tile: 8-pivot-blocked in-register LDL^T (k_factor_panel's group D), lane = row, wave v owns the column
+    //      blocks {v, v + 4}
+#pragma unroll
+    for (int sub = 0; sub < 4; sub++)
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) {
+            double v = 0.0;
+#pragma unroll
+            for (int k = 0; k < kFbMax; k++) if (k == i) v = acc[k][sub][reg];
+            Sb[(16 * wv + lk + 4 * reg) * FLD + 16 * sub + l15] = v;
+        }
+    __syncthreads();
+    const FrontPanel pi = fp[i];
+    const int f = pi.f, v = wv;
+    double a[16];
+#pragma unroll
+    for (int c = 0; c < 16; c++) a[c] = Sb[lane * FLD + 8 * (v + 4 * (c >> 3)) + (c & 7)];
+    __syncthreads();                                      // Sb becomes L11
+    double (*colL)[8][64] = (double (*)[8][64])Sa;                   // [2][8][64]
+    double (*colC)[8][64] = (double (*)[8][64])(Sa + 2 * 8 * 64);    // [2][8][64]
+    double *dsave = Sa + 4 * 8 * 64;                                 // [64]
+    FB_T(7);
+    const unsigned long long spos = __ballot(P.sgn_perm[f + lane] > 0);
+    double *myY = &Sb[lane * FLD];
+    int nreg = 0;
+#pragma unroll
+    for (int Bk = 0; Bk < 8; Bk++) {
+        const int pb = Bk & 1;
+        if (v == (Bk & 3)) {                              // owner of block Bk: 8 pivots without leaving the wavefront
+            const int rb = 8 * (Bk >> 2);
+#pragma unroll
+            for (int kk = 0; kk < 8; kk++) {
+                const int k = 8 * Bk + kk;
+                const double reg = a[rb + kk];
+                double d = fb_readlane(reg, k);
+                const double sg = ((spos >> k) & 1ull) ? 1.0 : -1.0;
+                if (d * sg < dyn_eps) { d = dyn_delta * sg; nreg++; }
+                const double dinv = fb_rcp(d);
+                const double li = reg * dinv;
+                colL[pb][kk][lane] = li;
+                colC[pb][kk][lane] = reg;
+                myY[k] = li;
+                if (lane == k) dsave[k] = d;
+#pragma unroll
+                for (int jj = kk + 1; jj < 8; jj++) {
+                    const double cj = fb_readlane(reg, 8 * Bk + jj);
+                    a[rb + jj] = fma(-li, cj, a[rb + jj]);
+                }
+            }
+        }
+        if (Bk == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the L tile stores issued before the pivots have drained ...
+        __syncthreads();
+        if (Bk == 0 && i > 0 && tid == 0)                                // ... for every thread: hand the tile over
+            __hip_atomic_store(fl_L + 8 * i + (i - 1), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        {
+            double lk_[8];
+#pragma unroll
+            for (int kk = 0; kk < 8; kk++) lk_[kk] = colL[pb][kk][lane];
+#pragma unroll
+            for (int h = 0; h < 2; h++)
+                if (v + 4 * h > Bk) {
+#pragma unroll
+                    for (int jj = 0; jj < 8; jj++) {
+                        const int jc = 8 * (v + 4 * h) + jj;
+#pragma unroll
+                        for (int kk = 0; kk < 8; kk++) a[8 * h + jj] = fma(-lk_[kk], colC[pb][kk][jc], a[8 * h + jj]);
+                    }
+                }
+        }
+        // the buffers of parity pb are rewritten two iterations later; the barrier of the next iteration separates them
+    }
+    __syncthreads();
+    FB_T(8);
+    // ---- L11^-1 (blocked: 16 x 16 diagonal blocks by substitution, the rest on the matrix core), then  Minv = L11^-T D^-1
+    double dkeep = 0.0;
+    if (tid < 64) { dkeep = dsave[tid]; Sd[tid] = 1.0 / dkeep; }
+    __syncthreads();
+    for (int idx = tid; idx < 64 * FLD; idx += 256) Sa[idx] = 0.0;
+    __syncthreads();
+    if (tid < 64) {   // thread = column j of diagonal block bq
+        const int bq = tid >> 4, jc = tid & 15, o = 16 * bq;
+        double xx[16];
+#pragma unroll
+        for (int c = 0; c < 16; c++) xx[c] = c == jc ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+#pragma unroll
+            for (int r_ = k + 1; r_ < 16; r_++) xx[r_] = fma(-Sb[(o + r_) * FLD + o + k], xx[k], xx[r_]);
+#pragma unroll
+        for (int c = 0; c < 16; c++) Sa[(o + c) * FLD + o + jc] = xx[c];
+    }
+    __syncthreads();
+    if (wv < 2) {     // block size 16, pairs (0,1) and (2,3):  T = L21 X11
+        const int o = 32 * wv;
+        const v4f64 c = fb_mm16(Sb, o + 16, o, Sa, o, o, 4, l15, lk);
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) St[(o + 16 + lk + 4 * reg) * FLD + o + l15] = c[reg];
+    }
+    __syncthreads();
+    if (wv < 2) {     // X21 = -X22 T
+        const int o = 32 * wv;
+        const v4f64 c = fb_mm16(Sa, o + 16, o + 16, St, o + 16, o, 4, l15, lk);
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) Sa[(o + 16 + lk + 4 * reg) * FLD + o + l15] = -c[reg];
+    }
+    __syncthreads();
+    {                 // block size 32:  T = L21 X11, one 16 x 16 piece per wave
+        const int ti = wv >> 1, tj = wv & 1;
+        const v4f64 c = fb_mm16(Sb, 32 + 16 * ti, 0, Sa, 0, 16 * tj, 8, l15, lk);
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) St[(32 + 16 * ti + lk + 4 * reg) * FLD + 16 * tj + l15] = c[reg];
+    }
+    __syncthreads();
+    {                 // X21 = -X22 T
+        const int ti = wv >> 1, tj = wv & 1;
+        const v4f64 c = fb_mm16(Sa, 32 + 16 * ti, 32, St, 32, 16 * tj, 8, l15, lk);
+        __syncthreads();                                  // every wave has read the X22 rows it needs before X21 is written
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) Sa[(32 + 16 * ti + lk + 4 * reg) * FLD + 16 * tj + l15] = -c[reg];
+    }
+    __syncthreads();
+    FB_T(9);
+    {
+        // Minv[k][c] = W[c][k] / d_c  (upper triangular), row-major in the scratch area, then the pivots
+        double *mv = scratch + (int64_t)i * 4160;
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const int idx = tid + 256 * q, k = idx >> 5, c = 2 * (idx & 31);
+            fb_st16(mv + 2 * idx, c >= k ? Sa[c * FLD + k] * Sd[c] : 0.0, c + 1 >= k ? Sa[(c + 1) * FLD + k] * Sd[c + 1] : 0.0);
+        }
+        if (tid < 64) fb_st(mv + 4096 + tid, dkeep);
+        fb_publish(fl_minv + i);
+    }
+    FB_T(10);
+    // ---- off the critical path: the factored block for the solves' explicit inverses, D and 1/D (exact division), the last X_j
+    {
+        double *ld = P.Ldiag + pi.diag_off;
+        for (int idx = tid; idx < 4096; idx += 256) {
+            const int r_ = idx & 63, k = idx >> 6;
+            ld[idx] = r_ > k ? Sb[r_ * FLD + k] : (r_ == k ? 1.0 : 0.0);
+        }
+        if (tid < 64) {
+            P.D[f + tid] = dkeep;
+            P.Dinv[f + tid] = Sd[tid];
+            if (!isfinite(Sd[tid])) atomicOr(P.flags + FL_NONFINITE, 1);
+        }
+        if (lane == 0 && nreg) atomicAdd(P.flags + FL_NREG, nreg);
+    }
+    if (i > 0) {
+        __syncthreads();
+        fb_tile_load(ltiles + (int64_t)(i * (i - 1) / 2 + i - 1) * 4096, Sa, tid);   // this workgroup's own L(i, i-1)
+        __syncthreads();
+        fb_store_panel(P, fp[i - 1], 64, nr, Sa, tid);
+    }
+    FB_T(11);
+}
+
+void launch_front_block(hipStream_t st, const DevPlan &P, const FrontBatch &B, int *sync_all, double *scratch_all, double dyn_eps,
+                        double dyn_delta, long long *trace) {
+    hipLaunchKernelGGL(k_front_block, dim3(B.nblk), dim3(256), 0, st, P, B, sync_all, scratch_all, dyn_eps, dyn_delta, trace);
+}
+
+}  // namespace hipkkt

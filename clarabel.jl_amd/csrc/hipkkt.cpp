@@ -114,6 +114,14 @@ struct hipkkt_solver {
     std::vector<int> all_lvl_nnarrow;
     // persistent sweeps over the regular supernodes: segments = level ranges between front kernels
     bool use_persist = true;
+    // front batches factored by one launch each (front_block.hip); a time-out inside one downgrades the handle to one launch per panel
+    bool use_front_block = true;
+    std::vector<FrontBatch> fbatches;
+    std::vector<int> lvl_fb;             // [nlevels] index of the batch that starts at this level, -2 inside a batch, -1 otherwise
+    std::vector<int> fb_last_level;      // per batch
+    int *d_fb_sync = nullptr;
+    double *d_fb_scratch = nullptr;
+    long long *d_fb_trace = nullptr;     // HIPKKT_FB_TRACE=1: wall-clock stamps of the first 8 workgroups of every batch (debug_dump 9)
     bool persist_allowed = true;         // false: HIPKKT_NO_PERSIST (never tried)
     int64_t persist_retry_at = -1;       // after a sweep time-out: the LDL-solve count at which the persistent kernels are tried again
     int64_t persist_backoff = 0;         // doubles with every time-out (64, 128, ...); HIPKKT_PERSIST_RETRY=0 disables the retry
@@ -282,6 +290,7 @@ void init_runtime(hipkkt_solver *S) {
 }
 
 // (re)builds every device-resident structure from S->plan and S->img (values included)
+static void build_front_batches(hipkkt_solver *S);
 void setup_device(hipkkt_solver *S) {
     HK_CHECK(hipSetDevice(S->device));
     for (GraphSlot *g : {&S->g_factor, &S->ctx[0].g_ldl, &S->ctx[0].g_first, &S->ctx[0].g_step, &S->ctx[1].g_ldl, &S->ctx[1].g_first,
@@ -603,6 +612,7 @@ void setup_device(hipkkt_solver *S) {
     }
     D.front_sync = S->dalloc<int>(std::max(P.front_sync_ints, 16));
     fill_async(S->stream, D.front_sync, 0, (size_t)std::max(P.front_sync_ints, 16) * sizeof(int));
+    build_front_batches(S);
     D.kval = S->upload(S->img.nzval);
     D.Lx = S->dalloc<double>(P.panel_doubles);
     D.Ldiag = S->dalloc<double>(P.diag_doubles);
@@ -703,6 +713,68 @@ void setup_device(hipkkt_solver *S) {
     HK_CHECK(hipStreamSynchronize(S->stream));
 }
 
+// The panels of a front that share an update batch (levels with the same floor(level / batch)) are factored by ONE launch of
+// k_front_block when every such level holds nothing but its front panel, all of them are 64 wide and the stages between them
+// carry nothing but the batch's own just-in-time updates (which the kernel applies itself).  HIPKKT_FRONT_BLOCK=0: never.
+static void build_front_batches(hipkkt_solver *S) {
+    const HostPlan &P = S->plan;
+    S->fbatches.clear(); S->fb_last_level.clear();
+    S->lvl_fb.assign(std::max(P.nlevels, 1), -1);
+    const char *e = getenv("HIPKKT_FRONT_BLOCK");
+    if (e && e[0] == '0') S->use_front_block = false;
+    const int Bu = std::min(P.update_batch_used, kFbMax);
+    if (S->use_front_block && P.update_batch_used >= 2 && P.update_batch_used <= kFbMax && S->plan_opts.update_policy == 2)
+        for (const FrontDesc &F : P.fronts) {
+            int p = 0;
+            while (p < F.np) {
+                const int l0 = F.level_first + p, win = l0 / Bu;
+                int q = p;
+                while (q < F.np && (F.level_first + q) / Bu == win) q++;
+                const int nb = q - p;
+                bool ok = nb >= 2 && F.cw == 64;
+                for (int t = p; t < q && ok; t++) {
+                    const FrontPanel &fp = P.front_panels[F.fp_off + t];
+                    const int l = F.level_first + t;
+                    ok = fp.w == 64 && P.sn_level[fp.sn] == l && P.lvl_ptr[l + 1] - P.lvl_ptr[l] == 1 && P.lvl_sn[P.lvl_ptr[l]] == fp.sn &&
+                         fp.r == P.front_panels[F.fp_off + p].r - 64 * (t - p) && !P.lvl_fused[l];
+                    // stage l (between panel t and t + 1): only contributions of this batch's panels to panel t + 1, all dense
+                    if (ok && t + 1 < q) {
+                        const int tgt = P.front_panels[F.fp_off + t + 1].sn, smin = P.front_panels[F.fp_off + p].sn;
+                        ok = P.upd_stage_ndense[l] == P.upd_stage_ptr[l + 1] - P.upd_stage_ptr[l];
+                        for (int g = P.upd_stage_ptr[l]; g < P.upd_stage_ptr[l + 1] && ok; g++) {
+                            ok = P.upd_groups[g].tgt == tgt;
+                            for (int u = P.upd_groups[g].task_begin; u < P.upd_groups[g].task_end && ok; u++)
+                                ok = P.upd_tasks[u].src >= smin && P.upd_tasks[u].src < tgt && P.sn_front[P.upd_tasks[u].src] == P.sn_front[tgt];
+                        }
+                    }
+                }
+                if (ok) {
+                    FrontBatch B;
+                    B.fp_off = F.fp_off + p;
+                    B.nb = nb;
+                    B.r0 = P.front_panels[F.fp_off + p].r;
+                    B.nblk = (B.r0 + 63) / 64;
+                    B.sync_off = 128 * (int)S->fbatches.size();
+                    B.scratch_off = kFbScratch * (int64_t)S->fbatches.size();
+                    S->lvl_fb[l0] = (int)S->fbatches.size();
+                    for (int t = p + 1; t < q; t++) S->lvl_fb[F.level_first + t] = -2;
+                    S->fbatches.push_back(B);
+                    S->fb_last_level.push_back(F.level_first + q - 1);
+                }
+                p = q;
+            }
+        }
+    if (getenv("HIPKKT_VERBOSE")) fprintf(stderr, "hipkkt: %zu front batch(es) factored by one launch each (fronts %zu, update batch %d)\n", S->fbatches.size(), P.fronts.size(), P.update_batch_used);
+    const size_t nb_ = std::max<size_t>(S->fbatches.size(), 1);
+    S->d_fb_sync = S->dalloc<int>(128 * nb_);
+    S->d_fb_scratch = S->dalloc<double>((size_t)kFbScratch * nb_);
+    fill_async(S->stream, S->d_fb_sync, 0, 128 * nb_ * sizeof(int));
+    if (getenv("HIPKKT_FB_TRACE")) {
+        S->d_fb_trace = (long long *)S->dalloc<double>(nb_ * 128);
+        fill_async(S->stream, S->d_fb_trace, 0, nb_ * 128 * sizeof(double));
+    }
+}
+
 // ---- enqueue helpers (no synchronisation inside; capturable) ---------------------------------
 
 // narrow levels (w <= 8): LDS-resident kernel; wide panels: the register-resident 8-wave kernel
@@ -750,7 +822,18 @@ void enqueue_factor(hipkkt_solver *S, int static_enable, double eps_const, doubl
     const bool fork = S->use_side && P.lookahead > 0;
     hipEvent_t pending = nullptr;
     int pending_level = -1;
+    const bool fb = S->use_front_block && !S->fbatches.empty();
+    if (fb) launch_zero_words(st, S->d_fb_sync, 128 * (int)S->fbatches.size());
     for (int l = 0; l < P.nlevels; l++) {
+        if (fb && S->lvl_fb[l] != -1) {
+            // a front's update batch: one launch for its panels and their just-in-time updates, then the batch's far stage
+            if (S->lvl_fb[l] >= 0)
+                launch_front_block(st, S->dp, S->fbatches[S->lvl_fb[l]], S->d_fb_sync, S->d_fb_scratch, S->opts.dynamic_reg_eps,
+                                   S->opts.dynamic_reg_delta, S->d_fb_trace);
+            const bool last = l + 1 >= P.nlevels || S->lvl_fb[l + 1] != -2;
+            if (last) enqueue_updates(S, l, false);
+            continue;
+        }
         enqueue_factor_level(S, l);
         const int nfar = fork ? P.upd_stage_nfar[l] : 0;
         if (pending && (nfar > 0 || l >= pending_level + P.lookahead)) {
@@ -1764,6 +1847,13 @@ static int32_t refactor_once(hipkkt_handle h, int32_t static_reg_enable, double 
     S->t_last_factor = ms;
     S->t_acc_factor += ms;
     S->n_factor++;
+    if (S->h_flags[FL_FACFAIL] && S->use_front_block) {
+        // a spin of k_front_block ran out (a stalled workgroup): repeat this factorisation with one launch per panel, and keep that
+        S->use_front_block = false;
+        S->g_factor.valid = false;
+        S->n_sweep_timeouts++;
+        return refactor_once(h, static_reg_enable, eps_const, eps_prop, eps_used, n_dynamic_reg);
+    }
     const double maxdiag = slot_value(S, SC_MAXDIAG);
     S->last_eps = static_reg_enable ? eps_const + eps_prop * maxdiag : 0.0;
     S->last_nreg = S->h_flags[FL_NREG];
@@ -1951,6 +2041,10 @@ int32_t hipkkt_debug_dump(hipkkt_handle h, int32_t what, double *out, int64_t ca
         case 4: dev(S->dp.kval, S->nnzK); break;
         case 5: dev(S->dp.D, S->N); break;
         case 6: dev(S->dp.Dinv, S->N); break;
+        case 9:
+            if (!S->d_fb_trace) return HIPKKT_ERR_ARGUMENT;
+            dev((const double *)S->d_fb_trace, (int64_t)S->fbatches.size() * 128);   // raw int64 stamps (100 MHz) in double-sized words
+            break;
         case 7: dev(S->d_soc_u, S->soc_total); break;
         case 8: dev(S->d_soc_v, S->soc_total); break;
         case 10: host(P.nsuper + 1, [&](int64_t i) { return P.sn_first[i]; }); break;

@@ -20,6 +20,9 @@ void launch_update_dense(hipStream_t st, const DevPlan &P, int group_begin, int 
 void launch_fwd_narrow(hipStream_t st, const DevPlan &P, int sn_begin, int n, int wmax, double *y, double *z);
 void launch_bwd_narrow(hipStream_t st, const DevPlan &P, int sn_begin, int n, int wmax, const double *z, double *x, double *xout);
 void launch_psd_hs(hipStream_t st, double *kval, const int64_t *map_hs, int64_t hs_off, const double *W, int n);
+// front_block.hip
+void launch_front_block(hipStream_t st, const DevPlan &P, const FrontBatch &B, int *sync_all, double *scratch_all, double dyn_eps,
+                        double dyn_delta, long long *trace = nullptr);
 // scaling.hip (N1)
 void launch_scaling_diag(hipStream_t st, const signed char *row_kind, const int64_t *row_hs, const int64_t *map_hs, const double *s,
                          const double *z, double *w, double *lam, double *kval, int64_t m);

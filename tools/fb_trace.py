@@ -1,0 +1,29 @@
+"""developer tool: phase breakdown of k_front_block (front_block.hip) on cfg 2a from its wall-clock stamps (HIPKKT_FB_TRACE=1)"""
+import os, sys
+os.environ["HIPKKT_FB_TRACE"] = "1"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, scipy.sparse as sp
+import clarabel_jl_amd  # noqa
+import julia_standin as cl
+from clarabel_jl_amd import problems
+from clarabel_jl_amd.kktsolver import HipKKTSolver
+from tests.fixtures import scale_cones
+P, q, A, b, specs = problems.random_sparse_qp()
+cones = cl.CompositeCone(cl.cones_new_collapsed(specs))
+Pt = sp.triu(sp.csc_matrix(P), format="csc"); Pt.sort_indices()
+A = sp.csc_matrix(A); A.sort_indices()
+m, n = A.shape
+hk = HipKKTSolver(Pt, A, cones, m, n, cl.Settings())
+scale_cones(cones, np.random.default_rng(1))
+for _ in range(3):
+    assert hk.kktsolver_update(cones)
+print("factor ms", hk.h.timing())
+t = hk.h.debug_dump(9).view(np.int64).reshape(-1, 8, 16) * 0.01   # microseconds
+names = ["start", "loaded", "minv seen", "minv in LDS", "trsm", "stores+pub", "updates", "tile->regs", "pivoted", "Ldiag/D", "inverse", "published"]
+for bi in (1, 8, 15):
+    if bi >= len(t): continue
+    t0 = t[bi, 0, 0]
+    print(f"batch {bi}: stamps relative to workgroup 0's start (us)")
+    for i in range(7):
+        row = t[bi, i]
+        print("  wg", i, " ".join(f"{nm}={row[k]-t0:7.2f}" for k, nm in enumerate(names) if row[k] > 0))
