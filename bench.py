@@ -197,6 +197,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=30.0, help="seconds of CPU-oracle work allowed for cpu_baseline/parity")
     ap.add_argument("--update-policy", type=int, default=None)
+    ap.add_argument("--update-batch", type=int, default=None, help="levels per update batch (default: automatic)")
     ap.add_argument("--in-flight", type=int, default=1, help="cfg 4: problems solved concurrently per host process (threads)")
     ap.add_argument("--workers", type=int, default=6, help="cfg 4: host processes per GPU, each with its own HIP context")
     ap.add_argument("--device-scaling", action="store_true", help="also solve once end to end with N1 on (update_scaling!/get_Hs! on the device) and report it under end_to_end")
@@ -260,6 +261,8 @@ def main():
     optkw = {}
     if args.update_policy is not None:
         optkw["update_policy"] = args.update_policy
+    if args.update_batch is not None:
+        optkw["update_batch"] = args.update_batch
     st = cl.Settings(device_id=local)
     t0 = time.perf_counter()
     solver = cl.Solver(P, q, A, b, cones, st, kktsolver_factory=lambda *a: Recorder(*a, **optkw))

@@ -246,76 +246,77 @@ k_front_block(DevPlan P, FrontBatch B, int *sync_all, double *scratch_all, doubl
     }
     FB_T(6);
     if (!diag) return;
-    // ---- the diagonal tile: 8-pivot-blocked in-register LDL^T (k_factor_panel's group D), lane = row, wave v owns the column
-    //      blocks {v, v + 4}
+    // ---- the diagonal tile stays in the accumulators (rows 16 wv + lk + 4 reg, columns 16 sub + l15).  Per block of 8 pivots: the
+    //      waves hand the block's 8 columns to wave 0 through LDS, wave 0 eliminates them without leaving the wavefront (lane = row;
+    //      the pivot rule and arithmetic of k_factor_panel, kernels.hip), and every wave applies the rank-8 update to its 16 rows
+    //      on the matrix core.  L11 is collected in Sb for the inverse and the solves.
+    v4f64 tacc[4];
 #pragma unroll
-    for (int sub = 0; sub < 4; sub++)
+    for (int sub = 0; sub < 4; sub++) {
+        tacc[sub] = (v4f64){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int reg = 0; reg < 4; reg++) {
-            double v = 0.0;
-#pragma unroll
-            for (int k = 0; k < kFbMax; k++) if (k == i) v = acc[k][sub][reg];
-            Sb[(16 * wv + lk + 4 * reg) * FLD + 16 * sub + l15] = v;
-        }
-    __syncthreads();
+        for (int k = 0; k < kFbMax; k++) if (k == i) tacc[sub] = acc[k][sub];
+    }
     const FrontPanel pi = fp[i];
-    const int f = pi.f, v = wv;
-    double a[16];
-#pragma unroll
-    for (int c = 0; c < 16; c++) a[c] = Sb[lane * FLD + 8 * (v + 4 * (c >> 3)) + (c & 7)];
-    __syncthreads();                                      // Sb becomes L11
-    double (*colL)[8][64] = (double (*)[8][64])Sa;                   // [2][8][64]
-    double (*colC)[8][64] = (double (*)[8][64])(Sa + 2 * 8 * 64);    // [2][8][64]
-    double *dsave = Sa + 4 * 8 * 64;                                 // [64]
+    const int f = pi.f;
+    double *Pc = Sa;                                                 // [64][9]   the block's columns, by row
+    double (*colL)[64] = (double (*)[64])(Sa + 64 * 9);              // [8][64]   l_ik
+    double (*colC)[64] = (double (*)[64])(Sa + 64 * 9 + 512);        // [8][64]   raw a_ik = d_k l_ik
+    double *dsave = Sa + 64 * 9 + 1024;                              // [64]
     FB_T(7);
     const unsigned long long spos = __ballot(P.sgn_perm[f + lane] > 0);
-    double *myY = &Sb[lane * FLD];
     int nreg = 0;
+    __syncthreads();                                      // Sa (X_j) and Sb (the last operand tile) are free
 #pragma unroll
     for (int Bk = 0; Bk < 8; Bk++) {
-        const int pb = Bk & 1;
-        if (v == (Bk & 3)) {                              // owner of block Bk: 8 pivots without leaving the wavefront
-            const int rb = 8 * (Bk >> 2);
+        {
+            const int sub = Bk >> 1, c0 = 8 * (Bk & 1);
+            if (l15 >= c0 && l15 < c0 + 8) {
 #pragma unroll
-            for (int kk = 0; kk < 8; kk++) {
-                const int k = 8 * Bk + kk;
-                const double reg = a[rb + kk];
-                double d = fb_readlane(reg, k);
-                const double sg = ((spos >> k) & 1ull) ? 1.0 : -1.0;
-                if (d * sg < dyn_eps) { d = dyn_delta * sg; nreg++; }
-                const double dinv = fb_rcp(d);
-                const double li = reg * dinv;
-                colL[pb][kk][lane] = li;
-                colC[pb][kk][lane] = reg;
-                myY[k] = li;
-                if (lane == k) dsave[k] = d;
-#pragma unroll
-                for (int jj = kk + 1; jj < 8; jj++) {
-                    const double cj = fb_readlane(reg, 8 * Bk + jj);
-                    a[rb + jj] = fma(-li, cj, a[rb + jj]);
-                }
+                for (int reg = 0; reg < 4; reg++) Pc[(16 * wv + lk + 4 * reg) * 9 + l15 - c0] = tacc[sub][reg];
             }
         }
         if (Bk == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the L tile stores issued before the pivots have drained ...
         __syncthreads();
         if (Bk == 0 && i > 0 && tid == 0)                                // ... for every thread: hand the tile over
             __hip_atomic_store(fl_L + 8 * i + (i - 1), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        {
-            double lk_[8];
+        if (wv == 0) {
+            double pcol[8];
 #pragma unroll
-            for (int kk = 0; kk < 8; kk++) lk_[kk] = colL[pb][kk][lane];
+            for (int q = 0; q < 8; q++) pcol[q] = Pc[lane * 9 + q];
 #pragma unroll
-            for (int h = 0; h < 2; h++)
-                if (v + 4 * h > Bk) {
+            for (int kk = 0; kk < 8; kk++) {
+                const int k = 8 * Bk + kk;
+                const double reg = pcol[kk];
+                double d = fb_readlane(reg, k);
+                const double sg = ((spos >> k) & 1ull) ? 1.0 : -1.0;
+                if (d * sg < dyn_eps) { d = dyn_delta * sg; nreg++; }
+                const double dinv = fb_rcp(d);
+                const double li = reg * dinv;
+                colL[kk][lane] = li;
+                colC[kk][lane] = reg;
+                Sb[lane * FLD + k] = li;
+                if (lane == k) dsave[k] = d;
 #pragma unroll
-                    for (int jj = 0; jj < 8; jj++) {
-                        const int jc = 8 * (v + 4 * h) + jj;
-#pragma unroll
-                        for (int kk = 0; kk < 8; kk++) a[8 * h + jj] = fma(-lk_[kk], colC[pb][kk][jc], a[8 * h + jj]);
-                    }
+                for (int jj = kk + 1; jj < 8; jj++) {
+                    const double cj = fb_readlane(reg, 8 * Bk + jj);
+                    pcol[jj] = fma(-li, cj, pcol[jj]);
                 }
+            }
         }
-        // the buffers of parity pb are rewritten two iterations later; the barrier of the next iteration separates them
+        __syncthreads();
+        if (Bk < 7) {
+            // a_ij -= sum_k l_ik a_jk over the block's 8 pivots, for the 16-column strips that still hold live columns
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++) {
+                const double av = -colL[4 * ks + lk][16 * wv + l15];
+#pragma unroll
+                for (int sub = 0; sub < 4; sub++)
+                    if (sub >= ((8 * Bk + 8) >> 4))
+                        tacc[sub] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, colC[4 * ks + lk][16 * sub + l15], tacc[sub], 0, 0, 0);
+            }
+        }
+        // Pc / colL / colC are rewritten after the next iteration's first barrier / by wave 0 after it: every wave is past its reads
     }
     __syncthreads();
     FB_T(8);

@@ -713,56 +713,27 @@ void setup_device(hipkkt_solver *S) {
     HK_CHECK(hipStreamSynchronize(S->stream));
 }
 
-// The panels of a front that share an update batch (levels with the same floor(level / batch)) are factored by ONE launch of
-// k_front_block when every such level holds nothing but its front panel, all of them are 64 wide and the stages between them
-// carry nothing but the batch's own just-in-time updates (which the kernel applies itself).  HIPKKT_FRONT_BLOCK=0: never.
+// One launch of k_front_block per qualifying update batch of a front (symbolic.cpp front_batches).  HIPKKT_FRONT_BLOCK=0: never.
 static void build_front_batches(hipkkt_solver *S) {
     const HostPlan &P = S->plan;
     S->fbatches.clear(); S->fb_last_level.clear();
     S->lvl_fb.assign(std::max(P.nlevels, 1), -1);
     const char *e = getenv("HIPKKT_FRONT_BLOCK");
     if (e && e[0] == '0') S->use_front_block = false;
-    const int Bu = std::min(P.update_batch_used, kFbMax);
-    if (S->use_front_block && P.update_batch_used >= 2 && P.update_batch_used <= kFbMax && S->plan_opts.update_policy == 2)
-        for (const FrontDesc &F : P.fronts) {
-            int p = 0;
-            while (p < F.np) {
-                const int l0 = F.level_first + p, win = l0 / Bu;
-                int q = p;
-                while (q < F.np && (F.level_first + q) / Bu == win) q++;
-                const int nb = q - p;
-                bool ok = nb >= 2 && F.cw == 64;
-                for (int t = p; t < q && ok; t++) {
-                    const FrontPanel &fp = P.front_panels[F.fp_off + t];
-                    const int l = F.level_first + t;
-                    ok = fp.w == 64 && P.sn_level[fp.sn] == l && P.lvl_ptr[l + 1] - P.lvl_ptr[l] == 1 && P.lvl_sn[P.lvl_ptr[l]] == fp.sn &&
-                         fp.r == P.front_panels[F.fp_off + p].r - 64 * (t - p) && !P.lvl_fused[l];
-                    // stage l (between panel t and t + 1): only contributions of this batch's panels to panel t + 1, all dense
-                    if (ok && t + 1 < q) {
-                        const int tgt = P.front_panels[F.fp_off + t + 1].sn, smin = P.front_panels[F.fp_off + p].sn;
-                        ok = P.upd_stage_ndense[l] == P.upd_stage_ptr[l + 1] - P.upd_stage_ptr[l];
-                        for (int g = P.upd_stage_ptr[l]; g < P.upd_stage_ptr[l + 1] && ok; g++) {
-                            ok = P.upd_groups[g].tgt == tgt;
-                            for (int u = P.upd_groups[g].task_begin; u < P.upd_groups[g].task_end && ok; u++)
-                                ok = P.upd_tasks[u].src >= smin && P.upd_tasks[u].src < tgt && P.sn_front[P.upd_tasks[u].src] == P.sn_front[tgt];
-                        }
-                    }
-                }
-                if (ok) {
-                    FrontBatch B;
-                    B.fp_off = F.fp_off + p;
-                    B.nb = nb;
-                    B.r0 = P.front_panels[F.fp_off + p].r;
-                    B.nblk = (B.r0 + 63) / 64;
-                    B.sync_off = 128 * (int)S->fbatches.size();
-                    B.scratch_off = kFbScratch * (int64_t)S->fbatches.size();
-                    S->lvl_fb[l0] = (int)S->fbatches.size();
-                    for (int t = p + 1; t < q; t++) S->lvl_fb[F.level_first + t] = -2;
-                    S->fbatches.push_back(B);
-                    S->fb_last_level.push_back(F.level_first + q - 1);
-                }
-                p = q;
-            }
+    if (S->use_front_block)
+        for (const FrontBatchHost &H : front_batches(P, S->plan_opts.update_policy, kFbMax)) {
+            const FrontDesc &F = P.fronts[H.front];
+            FrontBatch B;
+            B.fp_off = F.fp_off + H.p0;
+            B.nb = H.nb;
+            B.r0 = P.front_panels[F.fp_off + H.p0].r;
+            B.nblk = (B.r0 + 63) / 64;
+            B.sync_off = 128 * (int)S->fbatches.size();
+            B.scratch_off = kFbScratch * (int64_t)S->fbatches.size();
+            S->lvl_fb[H.level_first] = (int)S->fbatches.size();
+            for (int l = H.level_first + 1; l <= H.level_last; l++) S->lvl_fb[l] = -2;
+            S->fbatches.push_back(B);
+            S->fb_last_level.push_back(H.level_last);
         }
     if (getenv("HIPKKT_VERBOSE")) fprintf(stderr, "hipkkt: %zu front batch(es) factored by one launch each (fronts %zu, update batch %d)\n", S->fbatches.size(), P.fronts.size(), P.update_batch_used);
     const size_t nb_ = std::max<size_t>(S->fbatches.size(), 1);
@@ -831,10 +802,10 @@ void enqueue_factor(hipkkt_solver *S, int static_enable, double eps_const, doubl
                 launch_front_block(st, S->dp, S->fbatches[S->lvl_fb[l]], S->d_fb_sync, S->d_fb_scratch, S->opts.dynamic_reg_eps,
                                    S->opts.dynamic_reg_delta, S->d_fb_trace);
             const bool last = l + 1 >= P.nlevels || S->lvl_fb[l + 1] != -2;
-            if (last) enqueue_updates(S, l, false);
-            continue;
+            if (!last) continue;                          // the stages inside the batch are applied by the kernel itself
+        } else {
+            enqueue_factor_level(S, l);
         }
-        enqueue_factor_level(S, l);
         const int nfar = fork ? P.upd_stage_nfar[l] : 0;
         if (pending && (nfar > 0 || l >= pending_level + P.lookahead)) {
             HK_CHECK(hipStreamWaitEvent(st, pending, 0));
@@ -1117,6 +1088,8 @@ int32_t finish_create(hipkkt_solver *S, const hipkkt_opts *opts, hipkkt_handle *
     {
         const char *ns = getenv("HIPKKT_SIDE_STREAM");
         po.split_far = ns && ns[0] == '1';
+        const char *mr = getenv("HIPKKT_FRONT_BLOCK_MIN_ROWS");   // tests: 0, so that small fronts take the front-batch kernel too
+        if (mr) po.front_block_min_width = atoi(mr);
         const char *dc = getenv("HIPKKT_DENSE_COVER");   // A/B: threshold between the tile path and the gather lists
         if (dc && atof(dc) > 0) po.dense_min_cover = atof(dc);
         const char *nf = getenv("HIPKKT_FUSE_JIT");    // experiment: just-in-time updates inside the panel kernel
@@ -1851,6 +1824,7 @@ static int32_t refactor_once(hipkkt_handle h, int32_t static_reg_enable, double 
         // a spin of k_front_block ran out (a stalled workgroup): repeat this factorisation with one launch per panel, and keep that
         S->use_front_block = false;
         S->g_factor.valid = false;
+        fprintf(stderr, "hipkkt: a hand-off of the front-batch factorisation timed out; repeating it with one launch per panel (kept from now on)\n");
         S->n_sweep_timeouts++;
         return refactor_once(h, static_reg_enable, eps_const, eps_prop, eps_used, n_dynamic_reg);
     }
@@ -2015,6 +1989,7 @@ int32_t hipkkt_get_counters(hipkkt_handle h, int64_t *o) {
     if (!h || !o) return HIPKKT_ERR_ARGUMENT;
     o[0] = h->n_sweep_timeouts; o[1] = h->use_persist ? 1 : 0; o[2] = h->n_twin_refactors; o[3] = h->fallback ? 1 : 0;
     o[4] = h->using_fallback ? 1 : 0; o[5] = h->plan.ordering_used; o[6] = (int64_t)h->plan.fronts.size(); o[7] = h->nseg;
+    o[8] = (int64_t)h->fbatches.size(); o[9] = h->use_front_block ? 1 : 0; o[10] = o[11] = 0;
     return HIPKKT_OK;
 }
 

@@ -285,6 +285,9 @@ std::string build_plan(int N, const int64_t *Ap, const int64_t *Ai, const int64_
             if (w > maxw) {
                 int nch = (w + maxw - 1) / maxw;
                 int cw = (w + nch - 1) / nch;
+                // chains long enough to become a front keep full-width panels (the last one takes the remainder): k_front_block
+                // (front_block.hip) factors whole update batches of 64-column panels in one launch
+                if (opt.front_min_panels > 0 && nch >= opt.front_min_panels && maxw == kMaxSnWidth && w >= opt.front_block_min_width) cw = maxw;
                 for (int c = f + cw; c <= l; c += cw) is_start[c] = 1;
                 splits.push_back({f, (w + cw - 1) / cw, cw});
             }
@@ -814,6 +817,41 @@ std::string build_plan(int N, const int64_t *Ap, const int64_t *Ai, const int64_
     }
     lap("symcsr");
     return "";
+}
+
+std::vector<FrontBatchHost> front_batches(const HostPlan &P, int update_policy, int max_nb) {
+    std::vector<FrontBatchHost> out;
+    const int Bu = P.update_batch_used;
+    if (update_policy != 2 || Bu < 2 || Bu > max_nb) return out;
+    for (size_t fi = 0; fi < P.fronts.size(); fi++) {
+        const FrontDesc &F = P.fronts[fi];
+        int p = 0;
+        while (p < F.np) {
+            const int win = (F.level_first + p) / Bu;
+            int q = p;
+            while (q < F.np && (F.level_first + q) / Bu == win) q++;
+            bool ok = q - p >= 2 && F.cw == 64;
+            for (int t = p; t < q && ok; t++) {
+                const FrontPanel &fp = P.front_panels[F.fp_off + t];
+                const int l = F.level_first + t;
+                ok = fp.w == 64 && P.sn_level[fp.sn] == l && P.lvl_ptr[l + 1] - P.lvl_ptr[l] == 1 && P.lvl_sn[P.lvl_ptr[l]] == fp.sn &&
+                     fp.r == P.front_panels[F.fp_off + p].r - 64 * (t - p) && !P.lvl_fused[l];
+                // stage l (between panel t and t + 1): only contributions of this batch's panels to panel t + 1, all dense tiles
+                if (ok && t + 1 < q) {
+                    const int tgt = P.front_panels[F.fp_off + t + 1].sn, smin = P.front_panels[F.fp_off + p].sn;
+                    ok = P.upd_stage_ndense[l] == P.upd_stage_ptr[l + 1] - P.upd_stage_ptr[l];
+                    for (int g = P.upd_stage_ptr[l]; g < P.upd_stage_ptr[l + 1] && ok; g++) {
+                        ok = P.upd_groups[g].tgt == tgt;
+                        for (int u = P.upd_groups[g].task_begin; u < P.upd_groups[g].task_end && ok; u++)
+                            ok = P.upd_tasks[u].src >= smin && P.upd_tasks[u].src < tgt && P.sn_front[P.upd_tasks[u].src] == P.sn_front[tgt];
+                    }
+                }
+            }
+            if (ok) out.push_back({(int)fi, p, q - p, F.level_first + p, F.level_first + q - 1});
+            p = q;
+        }
+    }
+    return out;
 }
 
 }  // namespace hipkkt

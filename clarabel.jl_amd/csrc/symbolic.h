@@ -109,6 +109,9 @@ struct PlanOptions {
     bool xcd_order = false;    // order the dense tiles of a stage so that each XCD's L2 sees 1/8 of the source rows
     int n_hold = 0;            // > 0: also try the "variables last" order (nodes < n_hold held back) and keep
                                // whichever order predicts fewer factor flops
+    int front_block_min_width = 1024;   // supernodes at least this wide are cut into full 64-column panels (remainder last) so that
+                               // k_front_block can take their update batches; narrower ones keep balanced panel widths (measured:
+                               // cfg 1's 710-column root is 15 % slower to factor with 11 x 64 + 6 than with 12 x 60)
     int front_min_panels = 4;  // chains at least this long are solved by the persistent front kernels (0 = never)
     int nd_mode = 1;           // nested dissection candidate: 0 never, 1 when the latency + throughput model predicts a
                                // >= 20 % cheaper KKT iteration than minimum degree, 2 always
@@ -193,6 +196,12 @@ struct HostPlan {
     double flops_update = 0;     // executed flops of the dense update tasks (2*rows*cols*k)
     double flops_exec = 0;       // update + diagonal-block + TRSM flops actually executed
 };
+
+// The panels of a front that share an update batch (levels with the same floor(level / batch)) can be factored by ONE launch
+// (front_block.hip) when every such level holds nothing but its front panel, all of them are 64 wide and the stages between them
+// carry nothing but the batch's own just-in-time updates.  Returns those batches (at least 2 and at most max_nb panels each).
+struct FrontBatchHost { int front, p0, nb, level_first, level_last; };
+std::vector<FrontBatchHost> front_batches(const HostPlan &P, int update_policy, int max_nb);
 
 // Ap/Ai: upper-triangular CSC pattern (diagonal present), 0-based.
 // user_perm: optional (size N) or nullptr.  Returns empty string on success.

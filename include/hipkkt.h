@@ -257,8 +257,9 @@ int32_t hipkkt_set_profiling(hipkkt_handle h, int32_t enable);
  * kernels and suspends the persistent kernels for a while), out[1] = persistent sweeps currently enabled (0/1),
  * out[2] = factorisations repeated on the robust-order twin, out[3] = twin exists, out[4] = the current factorisation
  * lives in the twin, out[5] = ordering in use (0 minimum degree on K, 1 cone rows first, 2 user), out[6] = #fronts,
- * out[7] = #segments */
-int32_t hipkkt_get_counters(hipkkt_handle h, int64_t *out8);
+ * out[7] = #segments, out[8] = update batches of fronts factored by one launch each (front_block.hip), out[9] = that path is
+ * enabled (0 after one of its hand-offs timed out: the handle then keeps one launch per panel), out[10..11] reserved (0) */
+int32_t hipkkt_get_counters(hipkkt_handle h, int64_t *out12);
 
 /* developer diagnostic, not part of the plugin contract: copies an internal vector of the last LDL solve (what = 0 the
  * permuted right-hand side, 1 z = D^-1 L^-1 b, 2 x in permuted order, 3 the forward update vectors, 4 the unregularised KKT values in nz order, 5 D and 6 1/D of the last factorisation, 7 / 8 the u / v vectors of the sparse second-order cones) or a plan table converted to doubles (10 supernode first

@@ -28,6 +28,13 @@ from tests.fixtures import scale_cones as _scale_cones
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True)
+def _front_batches_on_small_fronts(monkeypatch):
+    """the problems of this file are small: let their fronts take the one-launch-per-update-batch factorisation (front_block.hip)
+    that the product reserves for fronts of >= 1024 rows, so that it is covered here against the oracle as well"""
+    monkeypatch.setenv("HIPKKT_FRONT_BLOCK_MIN_ROWS", "0")
+
 EPS2 = float(np.finfo(np.float64).eps) ** 2
 
 
@@ -143,6 +150,7 @@ def test_plan_variants_agree(policy, maxw, oracle_factory):
     {"HIPKKT_FUSE_JIT": "1"},
     {"HIPKKT_SIDE_STREAM": "1", "HIPKKT_FAR_WGS": "64"},
     {"HIPKKT_ORDERING": "amd"},
+    {"HIPKKT_FRONT_BLOCK": "0"},
 ])
 def test_developer_switches_keep_parity(env, oracle_factory, monkeypatch):
     for k, v in env.items():
@@ -458,8 +466,12 @@ def test_sweep_timeout_recovers_with_oracle_equal_results(oracle_factory, monkey
     hk = HipKKTSolver(Pt, A, cones, m, n, st)
     ok_ = oracle_factory(Pt, A, cones, m, n, st, ordering=hk.h.perm())
     assert hk.h.counters()["persistent"] and hk.h.counters()["fronts"] >= 1
+    assert hk.h.counters()["front_batches"] >= 1 and hk.h.counters()["front_block"]
     _scale_cones(cones, rng)
     assert hk.kktsolver_update(cones) and ok_.kktsolver_update(cones)
+    # the front-batch factorisation kernel (front_block.hip) shares the spin bound: its first hand-off gave up, the factorisation
+    # was repeated with one launch per panel and the handle keeps that path
+    assert not hk.h.counters()["front_block"] and hk.h.counters()["sweep_timeouts"] >= 1
     for rep in range(8):
         b = rng.standard_normal(hk.h.N)
         xg, xc = hk.h.ldl_solve(b), ok_.k.ldl_solve(b)
@@ -473,7 +485,8 @@ def test_sweep_timeout_recovers_with_oracle_equal_results(oracle_factory, monkey
     assert hk.kktsolver_solve(lx_g, lz_g) and ok_.kktsolver_solve(lx_c, lz_c)
     scale = max(1.0, np.max(np.abs(lx_c)), np.max(np.abs(lz_c)))
     assert np.max(np.abs(lx_g - lx_c)) <= 1e-10 * scale and np.max(np.abs(lz_g - lz_c)) <= 1e-10 * scale
-    assert "timed out" in capfd.readouterr().err
+    err_text = capfd.readouterr().err
+    assert "timed out" in err_text and "front-batch factorisation timed out" in err_text
 
 
 def test_output_arrays_are_validated():

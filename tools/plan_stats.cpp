@@ -30,6 +30,8 @@ int main(int argc, char **argv) {
            P.N, (long)P.nnzK, (long)P.nnzL, P.nsuper, P.nlevels, (long)P.panel_doubles, P.flops_colcount, P.flops_update, P.flops_exec,
            std::chrono::duration<double>(t1 - t0).count());
     printf("phases [%s]\n", P.timing_note.c_str());
+    { auto fbs = front_batches(P, opt.update_policy, 5); printf("front batches %zu:", fbs.size()); for (auto &h : fbs) printf(" (p%d x%d)", h.p0, h.nb); printf("\n");
+      for (auto &F : P.fronts) printf("front: np %d cw %d W %d rF %d levels %d..%d\n", F.np, F.cw, F.W, F.rF, F.level_first, F.level_last); }
     printf("ntasks %zu ngroups %zu ordering_used %d fronts %zu | model: md %.3f ms (%d levels)  nd %.3f ms (%d levels)\n", P.upd_tasks.size(), P.upd_groups.size(), P.ordering_used, P.fronts.size(), 1e3 * P.cost_md_seconds, P.cost_md_levels, 1e3 * P.cost_nd_seconds, P.cost_nd_levels);
     for (int l = 0; l < P.nlevels; l++) {   // per stage: per-entry gather lists (k_update_gather)
         const int64_t e0 = P.gath_stage_ptr[l], e1 = P.gath_stage_ptr[l + 1];
