@@ -55,11 +55,16 @@ def pmc_traffic(cfg):
     cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_cfg2a_pmc_hbm_traffic.txt")))
     for path in reversed(cands):          # newest round / tag first
         try:
+            # a big dense-update launch is ONE kernel: k_update_dense<4,4>, or its piece-wise variant k_update_dense_tail<P> when
+            # the tiles do not fill the chip's last round; the per-launch figure is the call-weighted mean over all of them
+            calls = rd = wr = 0.0
             for line in open(path):
-                if "k_update_denseILi4" in line:
+                if "k_update_denseILi4" in line or "k_update_dense_tail" in line:
                     f = line.split()
-                    return {"bytes_per_launch": round((float(f[4]) + float(f[5])) * 1e6), "read_x2_MB": float(f[4]),
-                            "write_MB": float(f[5]), "source": os.path.relpath(path, ROOT)}
+                    calls += float(f[1]); rd += float(f[1]) * float(f[4]); wr += float(f[1]) * float(f[5])
+            if calls:
+                return {"bytes_per_launch": round((rd + wr) / calls * 1e6), "read_x2_MB": round(rd / calls, 3),
+                        "write_MB": round(wr / calls, 3), "launches_in_trace": int(calls), "source": os.path.relpath(path, ROOT)}
         except OSError:
             pass
     return None

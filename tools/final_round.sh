@@ -6,8 +6,9 @@ mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 (timeout 900 python -m pytest tests -m gpu -q > gpurun_out/pytest_gpu_$tag.log 2>&1; echo "pytest rc=$?" >> gpurun_out/pytest_gpu_$tag.log); tail -3 gpurun_out/pytest_gpu_$tag.log
 timeout 600 python bench.py > gpurun_out/bench_2a_$tag.log 2>&1; tail -1 gpurun_out/bench_2a_$tag.log | cut -c1-200
-for c in 2b 1 3; do timeout 400 python bench.py --config $c > gpurun_out/bench_${c}_$tag.log 2>&1; tail -1 gpurun_out/bench_${c}_$tag.log | cut -c1-160; done
-timeout 400 python bench.py --config 5 --steps 10 --warmup 2 --cpu-budget 60 > gpurun_out/bench_5_$tag.log 2>&1; tail -1 gpurun_out/bench_5_$tag.log | cut -c1-160
+for c in 2b 1; do timeout 400 python bench.py --config $c > gpurun_out/bench_${c}_$tag.log 2>&1; tail -1 gpurun_out/bench_${c}_$tag.log | cut -c1-160; done
+timeout 400 python bench.py --config 3 --device-scaling > gpurun_out/bench_3_$tag.log 2>&1; tail -1 gpurun_out/bench_3_$tag.log | cut -c1-160
+timeout 400 python bench.py --config 5 --steps 10 --warmup 2 --cpu-budget 60 --device-scaling > gpurun_out/bench_5_$tag.log 2>&1; tail -1 gpurun_out/bench_5_$tag.log | cut -c1-160
 timeout 600 python bench.py --config 4 --steps 128 --warmup 4 > gpurun_out/bench_4_$tag.log 2>&1; tail -1 gpurun_out/bench_4_$tag.log | cut -c1-300
 for c in 2a 2b; do
   rm -rf gpurun_out/prof_${c}_$tag
