@@ -482,6 +482,7 @@ std::string build_plan(int N, const int64_t *Ap, const int64_t *Ai, const int64_
                 a = b;
             }
         }
+        lap("ut:gen");
         std::sort(keys.begin(), keys.end(), [](const TaskKey &x, const TaskKey &y) {
             if (x.stage != y.stage) return x.stage < y.stage;
             if (x.tgt != y.tgt) return x.tgt < y.tgt;
@@ -489,6 +490,7 @@ std::string build_plan(int N, const int64_t *Ap, const int64_t *Ai, const int64_
             if (x.src != y.src) return x.src < y.src;
             return x.task < y.task;
         });
+        lap("ut:sort");
         std::vector<UpdTask> sorted(keys.size());
         P.upd_stage_ptr.assign(P.nlevels + 1, 0);
         for (size_t q = 0; q < keys.size(); q++) {
@@ -513,6 +515,7 @@ std::string build_plan(int N, const int64_t *Ap, const int64_t *Ai, const int64_
         //           accumulated in registers over ALL their sources by k_update_dense; the others go
         //           through the relative-index scatter of k_update_stage.  Dense groups are moved to the
         //           front of their stage.
+        lap("ut:groups");
         P.upd_stage_ndense.assign(P.nlevels, 0);
         P.upd_stage_flops_dense.assign(P.nlevels, 0.0);
         {
@@ -556,6 +559,7 @@ std::string build_plan(int N, const int64_t *Ap, const int64_t *Ai, const int64_
                 for (int j = 0; j < T.ncols; j++) P.upd_tmap[base + 64 + (srows[T.col_lo + j] - ft)] = (int16_t)j;
             }
         }
+        lap("ut:classify");
         P.upd_stage_ngather.assign(P.nlevels, 0);
         P.upd_stage_nfar.assign(P.nlevels, 0);
         P.gath_stage_ptr.assign(P.nlevels + 1, 0);
@@ -653,6 +657,7 @@ std::string build_plan(int N, const int64_t *Ap, const int64_t *Ai, const int64_
         }
     }
 
+    lap("ut:lists");
     // ---- 14b. fused just-in-time updates: inside a front, the stage before panel p+1 holds nothing but the dense
     //           tiles of that one panel (sources: the batch-mates factored just before it).  The panel kernel of
     //           p+1 then applies them to the rows it owns (every workgroup: the diagonal tile, redundantly, and
@@ -688,7 +693,7 @@ std::string build_plan(int N, const int64_t *Ap, const int64_t *Ai, const int64_
             P.lvl_fused[l] = 1;
         }
 
-    lap("update-tasks");
+    lap("ut:jit");
     // ---- 15. gather lists for the forward solve (multifrontal style): every panel row slot
     //          (s, li) collects the update-vector entries of the CHILDREN of s that land on it.
     //          Fan-in per slot <= #children; each ubuf entry is consumed exactly once, by the parent.
