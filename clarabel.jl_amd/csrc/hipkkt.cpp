@@ -184,6 +184,9 @@ struct hipkkt_solver {
     double t_last_factor = 0, t_last_solve = 0, t_acc_factor = 0, t_acc_solve = 0, t_last_update = 0;
     int64_t n_factor = 0, n_solvecalls = 0, n_ldlsolves = 0, n_rhs_solved = 0;
     double last_eps = 0;
+    double prof_fb_flops = 0;
+    double prof_fb_ms = 0;               // last profiled refactorisation: the k_front_block launches
+    int prof_fb_launches = 0, prof_fb_panels = 0;
     double prof_dense4_ms = 0, prof_dense4_flops = 0;   // last profiled refactorisation: k_update_dense<4,4> alone
     int prof_dense4_launches = 0;
     std::vector<double> prof_launch_ms, prof_launch_flops, prof_launch_tiles;   // per k_update_dense<4,4> launch of that refactorisation
@@ -1758,8 +1761,29 @@ static int32_t refactor_once(hipkkt_handle h, int32_t static_reg_enable, double 
         launch_init_panels(st, S->dp, S->nnzK, static_reg_enable, eps_const, eps_prop);
         std::vector<hipEvent_t> evs, evd;   // evs: all update kernels of a stage; evd: its k_update_dense<4,4> launch alone
         std::vector<int> evd_level;
+        const bool fb = S->use_front_block && !S->fbatches.empty();
+        if (fb) launch_zero_words(st, S->d_fb_sync, 128 * (int)S->fbatches.size());
+        std::vector<hipEvent_t> evf;        // around every k_front_block launch
+        int fb_panels = 0;
+        double fb_flops = 0;                // update flops of the stages inside the batches (executed by k_front_block)
         for (int l = 0; l < P.nlevels; l++) {
-            enqueue_factor_level(S, l);
+            if (fb && S->lvl_fb[l] != -1) {
+                if (S->lvl_fb[l] >= 0) {
+                    hipEvent_t a, b;
+                    HK_CHECK(hipEventCreate(&a));
+                    HK_CHECK(hipEventCreate(&b));
+                    HK_CHECK(hipEventRecord(a, st));
+                    launch_front_block(st, S->dp, S->fbatches[S->lvl_fb[l]], S->d_fb_sync, S->d_fb_scratch, S->opts.dynamic_reg_eps,
+                                       S->opts.dynamic_reg_delta, S->d_fb_trace);
+                    HK_CHECK(hipEventRecord(b, st));
+                    evf.push_back(a);
+                    evf.push_back(b);
+                    fb_panels += S->fbatches[S->lvl_fb[l]].nb;
+                }
+                if (l + 1 < P.nlevels && S->lvl_fb[l + 1] == -2) { fb_flops += P.upd_stage_flops_dense[l]; continue; }   // applied by the kernel
+            } else {
+                enqueue_factor_level(S, l);
+            }
             const bool fused_next = l + 1 < P.nlevels && P.lvl_fused[l + 1];   // applied by the next panel kernel
             if (P.upd_stage_ptr[l + 1] > P.upd_stage_ptr[l] && !fused_next) {
                 hipEvent_t a, b, c2;
@@ -1805,6 +1829,13 @@ static int32_t refactor_once(hipkkt_handle h, int32_t static_reg_enable, double 
         }
         for (size_t i = 1; i < evd.size(); i += 2) (void)hipEventDestroy(evd[i]);
         for (hipEvent_t e : evs) (void)hipEventDestroy(e);
+        S->prof_fb_ms = 0; S->prof_fb_launches = (int)(evf.size() / 2); S->prof_fb_panels = fb_panels; S->prof_fb_flops = fb_flops;
+        for (size_t i = 0; i + 1 < evf.size(); i += 2) {
+            float ms = 0;
+            (void)hipEventElapsedTime(&ms, evf[i], evf[i + 1]);
+            S->prof_fb_ms += ms;
+        }
+        for (hipEvent_t e : evf) (void)hipEventDestroy(e);
         S->t_last_update = tot;
     } else {
         GraphSlot &g = S->g_factor;
@@ -1969,7 +2000,7 @@ int32_t hipkkt_get_timing(hipkkt_handle h, double *o) {
 int32_t hipkkt_get_profile(hipkkt_handle h, double *o) {
     if (!h || !o) return HIPKKT_ERR_ARGUMENT;
     o[0] = h->t_last_update; o[1] = h->prof_dense4_ms; o[2] = h->prof_dense4_flops; o[3] = (double)h->prof_dense4_launches;
-    o[4] = o[5] = o[6] = o[7] = 0;
+    o[4] = h->prof_fb_ms; o[5] = (double)h->prof_fb_launches; o[6] = (double)h->prof_fb_panels; o[7] = h->prof_fb_flops;
     return HIPKKT_OK;
 }
 

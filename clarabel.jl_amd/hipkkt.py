@@ -261,7 +261,8 @@ class Handle:
     def profile(self):
         o = np.zeros(8)
         self.L.hipkkt_get_profile(self.h, o)
-        return dict(update_ms=o[0], dense4_ms=o[1], dense4_flops=o[2], dense4_launches=int(o[3]))
+        return dict(update_ms=o[0], dense4_ms=o[1], dense4_flops=o[2], dense4_launches=int(o[3]), front_block_ms=o[4],
+                    front_block_launches=int(o[5]), front_block_panels=int(o[6]), front_block_update_flops=o[7])
 
     # ---- numeric
     def update_values(self, index, values):
