@@ -166,7 +166,9 @@ class Handle:
             C.byref(out))
         if rc != 0:
             raise HipKKTError(f"hipkkt_create_from_parts failed ({rc}): {L.hipkkt_last_error(None).decode()}")
-        return cls(out)
+        obj = cls(out)
+        obj._cone_numel = np.array(numel, dtype=np.int64)
+        return obj
 
     def close(self):
         if getattr(self, "h", None):
@@ -287,6 +289,10 @@ class Handle:
         kinds = np.ascontiguousarray(kinds, dtype=np.int32)
         self._chk(self.L.hipkkt_set_cone_types(self.h, len(kinds), kinds), "set_cone_types")
         self._n_soc_all = int(np.sum(kinds == 2))
+        # doubles of the concatenated n x n R factors of the PSD cones (numel = n (n + 1) / 2), for the length check of update_scaling
+        nel = getattr(self, "_cone_numel", np.zeros(0, dtype=np.int64))[kinds == 3]
+        nn = ((np.sqrt(8.0 * nel + 1.0) - 1.0) / 2.0 + 0.5).astype(np.int64)
+        self._psd_r_len = int(np.sum(nn * nn))
 
     def update_scaling(self, s, z, psd_R=None, want_outputs=True):
         """-> (ok, w, lam, soc_eta): Hs blocks / sparse second-order terms of K are rewritten on the device from (s, z)."""
@@ -295,6 +301,8 @@ class Handle:
         if len(s) != self.m or len(z) != self.m:
             raise ValueError("update_scaling: s and z must have length m")
         R = None if psd_R is None else np.ascontiguousarray(psd_R, dtype=np.float64)
+        if R is not None and R.size != self._psd_r_len:
+            raise ValueError(f"update_scaling: psd_R must hold {self._psd_r_len} doubles (the n x n factors of the PSD cones), got {R.size}")
         w = np.zeros(max(self.m, 1)) if want_outputs else None
         lam = np.zeros(max(self.m, 1)) if want_outputs else None
         eta = np.zeros(max(self._n_soc_all, 1)) if want_outputs else None

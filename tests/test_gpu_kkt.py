@@ -735,6 +735,8 @@ def test_update_scaling_on_device_matches_host_cone_algebra():
     assert not ok
     with pytest.raises(ValueError):
         dev.h.update_scaling(s[:-1], z)
+    with pytest.raises(ValueError):
+        dev.h.update_scaling(s, z, np.zeros(3))          # wrong length of the concatenated R factors
 
 
 class _DevBuf:
