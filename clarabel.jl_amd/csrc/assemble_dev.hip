@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "assemble.h"
+#include "runtime_pool.h"
 
 namespace hipkkt {
 
@@ -196,15 +197,19 @@ __global__ void k_asm_fill_ext(AsmDev D) {
     D.extD[e] = base + len;
 }
 
+// temporaries of one assembly: blocks of the process-wide cache (runtime_pool.h), handed back once the stream is idle
 struct DevBuf {
-    std::vector<void *> ptrs;
+    std::vector<std::pair<void *, size_t>> ptrs;
     hipStream_t st;
+    int device = 0;
     bool ok = true;
+    DevBuf() { (void)hipGetDevice(&device); }
     template <class T>
     T *alloc(size_t n) {
-        void *p = nullptr;
-        if (hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T)) != hipSuccess) { ok = false; return nullptr; }
-        ptrs.push_back(p);
+        size_t cap = 0;
+        void *p = hipkkt::RuntimePool::get().dev_alloc(device, std::max<size_t>(n, 1) * sizeof(T), &cap);
+        if (!p) { ok = false; return nullptr; }
+        ptrs.push_back({p, cap});
         return (T *)p;
     }
     template <class T>
@@ -214,7 +219,8 @@ struct DevBuf {
         return p;
     }
     ~DevBuf() {
-        for (void *p : ptrs) (void)hipFree(p);
+        if (!ptrs.empty()) (void)hipStreamSynchronize(st);      // hipFree used to wait implicitly
+        for (auto &a : ptrs) hipkkt::RuntimePool::get().dev_free(device, a.first, a.second);
     }
 };
 

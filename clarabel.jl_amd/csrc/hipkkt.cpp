@@ -19,6 +19,7 @@
 #include "assemble.h"
 #include "device_plan.h"
 #include "kernels.h"
+#include "runtime_pool.h"
 #include "symbolic.h"
 
 using namespace hipkkt;
@@ -97,7 +98,7 @@ struct hipkkt_solver {
     KKTImage img;      // L1: assembled image; L0: colptr/rowval/nzval/dsigns copied in
     HostPlan plan;
     DevPlan dp{};
-    std::vector<void *> allocs;
+    std::vector<std::pair<void *, size_t>> allocs;   // device slabs (RuntimePool blocks: pointer, capacity)
     std::string err;
 
     int N = 0;
@@ -114,6 +115,8 @@ struct hipkkt_solver {
     std::vector<int> all_lvl_nnarrow;
     // persistent sweeps over the regular supernodes: segments = level ranges between front kernels
     bool use_persist = true;
+    double t_init_runtime = 0;           // seconds (HIPKKT_VERBOSE)
+    std::chrono::steady_clock::time_point t_created{};   // when the assembly returned
     // front batches factored by one launch each (front_block.hip); a time-out inside one downgrades the handle to one launch per panel
     bool use_front_block = true;
     std::vector<FrontBatch> fbatches;
@@ -202,10 +205,10 @@ struct hipkkt_solver {
         if (n == 0) n = 1;
         const size_t bytes = (n * sizeof(T) + 255) & ~(size_t)255;
         if (bytes > slab_left) {
-            const size_t slab = std::max<size_t>(bytes, (size_t)8 << 20);
-            void *p = nullptr;
-            if (hipMalloc(&p, slab) != hipSuccess) throw std::bad_alloc();
-            allocs.push_back(p);
+            size_t slab = std::max<size_t>(bytes, (size_t)8 << 20);
+            void *p = RuntimePool::get().dev_alloc(device, slab, &slab);
+            if (!p) throw std::bad_alloc();
+            allocs.push_back({p, slab});
             slab_cur = (char *)p;
             slab_left = slab;
         }
@@ -231,24 +234,28 @@ struct hipkkt_solver {
     ~hipkkt_solver() {
         delete fallback;
         (void)hipSetDevice(device);
+        // everything below goes back to the process-wide cache (runtime_pool.h): the streams must be idle first
+        RuntimePool &rp = RuntimePool::get();
+        if (stream) (void)hipStreamSynchronize(stream);
+        if (side) (void)hipStreamSynchronize(side);
+        for (SolveCtx &C : ctx)
+            if (C.own_stream && C.stream) (void)hipStreamSynchronize(C.stream);
         if (g_factor.exec) (void)hipGraphExecDestroy(g_factor.exec);
         for (SolveCtx &C : ctx) {
             for (GraphSlot *g : {&C.g_ldl, &C.g_first, &C.g_step})
                 if (g->exec) (void)hipGraphExecDestroy(g->exec);
-            if (C.h_rs) (void)hipHostFree(C.h_rs);
-            if (C.h_flags) (void)hipHostFree(C.h_flags);
-            for (hipEvent_t e : {C.ev_a, C.ev_b})
-                if (e) (void)hipEventDestroy(e);
-            if (C.own_stream && C.stream) (void)hipStreamDestroy(C.stream);
+            rp.pinned_free(device, C.h_rs);
+            rp.pinned_free(device, C.h_flags);
+            for (hipEvent_t e : {C.ev_a, C.ev_b}) rp.event_put(device, e);
+            if (C.own_stream) rp.stream_put(device, 2, C.stream);
         }
-        for (void *p : allocs) (void)hipFree(p);
-        if (h_scal) (void)hipHostFree(h_scal);
-        if (h_flags) (void)hipHostFree(h_flags);
-        for (hipEvent_t e : {ev0, ev1, ev2, ev3})
-            if (e) (void)hipEventDestroy(e);
+        for (auto &a : allocs) rp.dev_free(device, a.first, a.second);
+        rp.pinned_free(device, h_scal);
+        rp.pinned_free(device, h_flags);
+        for (hipEvent_t e : {ev0, ev1, ev2, ev3}) rp.event_put(device, e);
         for (hipEvent_t e : fork_events) (void)hipEventDestroy(e);
-        if (side) (void)hipStreamDestroy(side);
-        if (stream) (void)hipStreamDestroy(stream);
+        rp.stream_put(device, 1, side);
+        rp.stream_put(device, 0, stream);
     }
 };
 
@@ -261,11 +268,12 @@ static size_t seg_sync_ints(int nseg, int nsuper) { return (size_t)((2 * nseg + 
 void init_runtime(hipkkt_solver *S) {
     { const char *pz = getenv("HIPKKT_POISON"); S->poison = pz && pz[0] == '1'; }
     HK_CHECK(hipSetDevice(S->device));
+    RuntimePool &rp = RuntimePool::get();
+    auto need = [&](void *p) { if (!p) throw DeviceError{"creating a stream / event / pinned buffer failed"}; return p; };
     {
-        int lo = 0, hi = 0;   // the critical path (panel factorisations) gets the higher priority
-        HK_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
-        HK_CHECK(hipStreamCreateWithPriority(&S->stream, hipStreamNonBlocking, hi));
-        HK_CHECK(hipStreamCreateWithPriority(&S->side, hipStreamNonBlocking, lo));
+        // the critical path (panel factorisations) gets the higher priority
+        S->stream = (hipStream_t)need(rp.stream_get(S->device, 0));
+        S->side = (hipStream_t)need(rp.stream_get(S->device, 1));
         // measured on MI355X (cfg 2a): forking the far updates gives no net gain inside a hipGraph -- the far
         // kernel fills every CU and the panel kernels on the critical path slow down by what the overlap
         // saves -- so the fork is opt-in (HIPKKT_SIDE_STREAM=1)
@@ -274,19 +282,22 @@ void init_runtime(hipkkt_solver *S) {
         const char *fw = getenv("HIPKKT_FAR_WGS");
         if (fw) S->far_wgs = atoi(fw);
     }
-    for (hipEvent_t *e : {&S->ev0, &S->ev1, &S->ev2, &S->ev3}) HK_CHECK(hipEventCreate(e));
-    HK_CHECK(hipHostMalloc((void **)&S->h_scal, SC_COUNT * sizeof(double), hipHostMallocDefault));
-    HK_CHECK(hipHostMalloc((void **)&S->h_flags, FL_COUNT * sizeof(int), hipHostMallocDefault));
+    static_assert(SC_COUNT * sizeof(double) <= RuntimePool::kPinned && sizeof(RefineState) <= RuntimePool::kPinned, "pinned chunk too small");
+    for (hipEvent_t *e : {&S->ev0, &S->ev1, &S->ev2, &S->ev3}) *e = (hipEvent_t)need(rp.event_get(S->device));
+    S->h_scal = (double *)need(rp.pinned_alloc(S->device));
+    S->h_flags = (int *)need(rp.pinned_alloc(S->device));
+    memset(S->h_scal, 0, SC_COUNT * sizeof(double));
+    memset(S->h_flags, 0, FL_COUNT * sizeof(int));
     const char *ng = getenv("HIPKKT_NO_GRAPH");
     if (ng && ng[0] == '1') S->use_graph = false;
     for (int c = 0; c < kNumCtx; c++) {
         SolveCtx &C = S->ctx[c];
         if (c == 0) C.stream = S->stream;
-        else { HK_CHECK(hipStreamCreateWithFlags(&C.stream, hipStreamNonBlocking)); C.own_stream = true; }
-        HK_CHECK(hipEventCreate(&C.ev_a));
-        HK_CHECK(hipEventCreate(&C.ev_b));
-        HK_CHECK(hipHostMalloc((void **)&C.h_rs, sizeof(RefineState), hipHostMallocDefault));
-        HK_CHECK(hipHostMalloc((void **)&C.h_flags, FL_COUNT * sizeof(int), hipHostMallocDefault));
+        else { C.stream = (hipStream_t)need(rp.stream_get(S->device, 2)); C.own_stream = true; }
+        C.ev_a = (hipEvent_t)need(rp.event_get(S->device));
+        C.ev_b = (hipEvent_t)need(rp.event_get(S->device));
+        C.h_rs = (RefineState *)need(rp.pinned_alloc(S->device));
+        C.h_flags = (int *)need(rp.pinned_alloc(S->device));
         memset(C.h_rs, 0, sizeof(RefineState));
         memset(C.h_flags, 0, FL_COUNT * sizeof(int));
     }
@@ -301,7 +312,8 @@ void setup_device(hipkkt_solver *S) {
         if (g->exec) (void)hipGraphExecDestroy(g->exec);
         *g = GraphSlot();
     }
-    for (void *p : S->allocs) (void)hipFree(p);
+    if (!S->allocs.empty() && S->stream) (void)hipStreamSynchronize(S->stream);   // hipFree used to wait implicitly
+    for (auto &a : S->allocs) RuntimePool::get().dev_free(S->device, a.first, a.second);
     S->allocs.clear();
     S->slab_cur = nullptr;
     S->slab_left = 0;
@@ -1126,9 +1138,9 @@ int32_t finish_create(hipkkt_solver *S, const hipkkt_opts *opts, hipkkt_handle *
         S->runtime_ready = true;
         setup_device(S);
         if (getenv("HIPKKT_VERBOSE"))
-            fprintf(stderr, "hipkkt: N %d nnzL %lld levels %d ordering %d: symbolic %.2f ms (%s), device set-up %.2f ms\n", S->plan.N, (long long)S->plan.nnzL,
+            fprintf(stderr, "hipkkt: N %d nnzL %lld levels %d ordering %d: symbolic %.2f ms (%s), device set-up %.2f ms, runtime objects %.2f ms\n", S->plan.N, (long long)S->plan.nnzL,
                     S->plan.nlevels, S->plan.ordering_used, 1e3 * std::chrono::duration<double>(t_b - t_a).count(), S->plan.timing_note.c_str(),
-                    1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t_b).count());
+                    1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t_b).count(), 1e3 * S->t_init_runtime);
     } catch (const DeviceError &e) {
         g_create_error = e.msg; delete S; return HIPKKT_ERR_DEVICE;
     } catch (const std::bad_alloc &) {
@@ -1248,12 +1260,14 @@ int32_t hipkkt_create_from_parts(int32_t device_id, int64_t n, int64_t m, const 
             err = assemble_kkt(n, m, Pp.data(), Pi.data(), Pnzval, Ap.data(), Ai.data(), Anzval, ncones, cone_numel, cone_hs_dense,
                                cone_sparse_kind, dim1.data(), S->img);
         } else {
+            const auto t0 = std::chrono::steady_clock::now();
             try {
                 init_runtime(S);
                 S->runtime_ready = true;
             } catch (const DeviceError &e) {
                 g_create_error = e.msg; delete S; return HIPKKT_ERR_DEVICE;
             }
+            S->t_init_runtime = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             err = assemble_kkt_device((void *)S->stream, n, m, Pp.data(), Pi.data(), Pnzval, Ap.data(), Ai.data(), Anzval, ncones, cone_numel,
                                       cone_hs_dense, cone_sparse_kind, dim1.data(), S->img);
         }
@@ -1263,10 +1277,19 @@ int32_t hipkkt_create_from_parts(int32_t device_id, int64_t n, int64_t m, const 
         g_create_error = "out of memory";
         return HIPKKT_ERR_ALLOC;
     }
+    S->t_created = std::chrono::steady_clock::now();
     return finish_create(S, opts, out);
 }
 
-void hipkkt_destroy(hipkkt_handle h) { delete h; }
+void hipkkt_destroy(hipkkt_handle h) {
+    if (h && getenv("HIPKKT_VERBOSE")) {
+        const auto t0 = std::chrono::steady_clock::now();
+        delete h;
+        fprintf(stderr, "hipkkt: destroy %.2f ms\n", 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+        return;
+    }
+    delete h;
+}
 
 int32_t hipkkt_get_dims(hipkkt_handle h, int64_t *o) {
     if (!h || !o) return HIPKKT_ERR_ARGUMENT;
