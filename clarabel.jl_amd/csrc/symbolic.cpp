@@ -521,6 +521,7 @@ std::string build_plan(int N, const int64_t *Ap, const int64_t *Ai, const int64_
         {
             // stage of a group = position in upd_stage_ptr (groups are stage-ordered at this point)
         }
+        int64_t gather_pairs_bound = 0;     // pairs of the per-entry gather lists (before the upper-triangle entries are dropped)
         for (auto &G : P.upd_groups) {
             const int t = G.tgt, ft = P.sn_first[t];
             bool all_contig = true;
@@ -542,7 +543,7 @@ std::string build_plan(int N, const int64_t *Ap, const int64_t *Ai, const int64_
             // dense enough per contribution -> matrix-core path; otherwise the contributions are single
             // entries of tiny leaf supernodes -> per-entry gather
             G.dense = ((all_contig && fill >= 0.4) || fill >= 0.3 || covered >= opt.dense_min_cover * ntasks) ? 1 : 2;
-            if (G.dense != 1) continue;
+            if (G.dense != 1) { gather_pairs_bound += (int64_t)covered; continue; }
             P.flops_update_dense += flops;
             // contributions that do not land contiguously get explicit tile maps (tile row / column ->
             // source row offset or -1): k_update_dense then gathers its operands through them
@@ -564,6 +565,8 @@ std::string build_plan(int N, const int64_t *Ap, const int64_t *Ai, const int64_
         P.upd_stage_nfar.assign(P.nlevels, 0);
         P.gath_stage_ptr.assign(P.nlevels + 1, 0);
         P.gath_pptr.push_back(0);
+        P.gath_src.reserve(gather_pairs_bound); P.gath_dj.reserve(gather_pairs_bound); P.gath_sn.reserve(gather_pairs_bound);
+        P.gath_tgt.reserve(gather_pairs_bound); P.gath_pptr.reserve(gather_pairs_bound + 1);
         std::vector<int> gcount;
         for (int l = 0; l < P.nlevels; l++) {
             auto b = P.upd_groups.begin() + P.upd_stage_ptr[l], e = P.upd_groups.begin() + P.upd_stage_ptr[l + 1];
@@ -614,7 +617,9 @@ std::string build_plan(int N, const int64_t *Ap, const int64_t *Ai, const int64_
                 const UpdGroup &G = *it;
                 const int t = G.tgt, ft = P.sn_first[t], wt = P.sn_first[t + 1] - ft;
                 const int64_t rt = P.sn_rowptr[t + 1] - P.sn_rowptr[t];
-                gcount.assign((size_t)kUpdRows * wt + 1, 0);
+                // gcount is all zero between groups; only the key range a group touches is scanned and cleared again
+                if (gcount.size() < (size_t)kUpdRows * kMaxSnWidth + 2) gcount.assign((size_t)kUpdRows * kMaxSnWidth + 2, 0);
+                int kmin = kUpdRows * kMaxSnWidth, kmax = -1;
                 auto for_pairs = [&](auto &&f) {
                     for (int q = G.task_begin; q < G.task_end; q++) {
                         const UpdTask &T = P.upd_tasks[q];
@@ -630,10 +635,10 @@ std::string build_plan(int N, const int64_t *Ap, const int64_t *Ai, const int64_
                         }
                     }
                 };
-                for_pairs([&](int key, const UpdTask &, int, int) { gcount[key + 1]++; });
+                for_pairs([&](int key, const UpdTask &, int, int) { gcount[key + 1]++; kmin = std::min(kmin, key); kmax = std::max(kmax, key); });
                 const int64_t pbase = (int64_t)P.gath_src.size();
                 int64_t total = 0;
-                for (size_t k = 0; k + 1 < gcount.size(); k++) {    // entries with pairs, in key order; gcount becomes the cursor
+                for (int k = kmin; k <= kmax; k++) {    // entries with pairs, in key order; gcount becomes the cursor
                     const int c = gcount[k + 1];
                     gcount[k + 1] = (int)total;                    // (shifted by one: gcount[k + 1] = start of key k)
                     if (c) {
@@ -652,6 +657,8 @@ std::string build_plan(int N, const int64_t *Ap, const int64_t *Ai, const int64_
                     P.gath_dj[d] = (int32_t)(T.col_lo + j - (T.row_lo + i));
                     P.gath_sn[d] = (int32_t)T.src;
                 });
+                for (int k = kmin; k <= kmax + 1 && k >= 0; k++) gcount[k] = 0;
+                if (kmax >= 0) gcount[kmax + 1] = 0;
             }
             P.gath_stage_ptr[l + 1] = (int64_t)P.gath_tgt.size();
         }
