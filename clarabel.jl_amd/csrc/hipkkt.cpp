@@ -1747,11 +1747,17 @@ int32_t hipkkt_refactor(hipkkt_handle h, int32_t static_reg_enable, double eps_c
             T->img = S->img;
             PlanOptions po = S->plan_opts;
             po.n_hold = 0;
+            const auto t_a = std::chrono::steady_clock::now();
             std::string err = build_plan((int)T->img.N, T->img.colptr.data(), T->img.rowval.data(), nullptr, po, T->plan);
             if (!err.empty()) return rc;
+            const auto t_b = std::chrono::steady_clock::now();
             T->plan_opts = po;
             init_runtime(T.get());
             setup_device(T.get());
+            if (getenv("HIPKKT_VERBOSE"))
+                fprintf(stderr, "hipkkt: robust-order twin (minimum degree on K): N %d nnzL %lld levels %d: symbolic %.2f ms (%s), device set-up %.2f ms\n",
+                        T->plan.N, (long long)T->plan.nnzL, T->plan.nlevels, 1e3 * std::chrono::duration<double>(t_b - t_a).count(),
+                        T->plan.timing_note.c_str(), 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t_b).count());
             S->fallback = T.release();
         }
         copy_sync(S->stream, S->fallback->dp.kval, S->dp.kval, (size_t)S->nnzK * sizeof(double), hipMemcpyDeviceToDevice);

@@ -423,6 +423,12 @@ std::string build_plan(int N, const int64_t *Ap, const int64_t *Ai, const int64_
     // ---- 14. update tasks, owned by target row-blocks
     {
         std::vector<TaskKey> keys;
+        {
+            int64_t max_r = 0;
+            for (int s = 0; s < S; s++) max_r = std::max<int64_t>(max_r, P.sn_rowptr[s + 1] - P.sn_rowptr[s]);
+            P.rel.resize((size_t)max_r);
+            for (int64_t q = 0; q < max_r; q++) P.rel[q] = (int)q;     // the shared identity segment (see below)
+        }
         for (int s = 0; s < S; s++) {
             int w = P.sn_first[s + 1] - P.sn_first[s];
             const int *rows = &P.sn_rows[P.sn_rowptr[s]];
@@ -437,7 +443,12 @@ std::string build_plan(int N, const int64_t *Ap, const int64_t *Ai, const int64_
                 if (P.rel.size() + (size_t)(r - a) >= ((size_t)1 << 31)) return "problem too large: relative index table exceeds int32";
                 int rel_off = (int)P.rel.size();
                 // positions of rows[a..r) inside the target's row list (both sorted)
-                if ((int64_t)(r - a) * 16 < tr) {
+                if (tr == r - a) {
+                    // rows[a..r) is a subset of the target's rows (elimination-tree structure) with the same cardinality: the two
+                    // lists are equal and the positions are 0, 1, 2, ... -- every such pair (the panels of a front above all: a
+                    // 400-panel front would need 1.4e9 entries of its own) shares the identity segment at the start of rel[]
+                    rel_off = 0;
+                } else if ((int64_t)(r - a) * 16 < tr) {
                     const int *lo = trows;
                     for (int i = a; i < r; i++) {
                         lo = std::lower_bound(lo, trows + tr, rows[i]);
