@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <future>
 #include <memory>
 #include <new>
 #include <string>
@@ -181,6 +182,9 @@ struct hipkkt_solver {
     // robust-order twin (minimum degree on K), created on the first factorisation that fails in the
     // "variables last" order; every later factorisation still tries the fast order first
     hipkkt_solver *fallback = nullptr;
+    // the twin's symbolic analysis runs on a host thread from the moment the cheap order is chosen (finish_create)
+    std::unique_ptr<hipkkt_solver> twin_pending;
+    std::future<std::string> twin_future;
     bool using_fallback = false;
     bool profiling = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
@@ -232,6 +236,8 @@ struct hipkkt_solver {
         stage_cap = cap;
     }
     ~hipkkt_solver() {
+        if (twin_future.valid()) twin_future.wait();     // the thread reads twin_pending's image
+        twin_pending.reset();
         delete fallback;
         (void)hipSetDevice(device);
         // everything below goes back to the process-wide cache (runtime_pool.h): the streams must be idle first
@@ -1128,8 +1134,34 @@ int32_t finish_create(hipkkt_solver *S, const hipkkt_opts *opts, hipkkt_handle *
         uperm = up.data();
     }
     if (S->img.N >= ((int64_t)1 << 31)) { g_create_error = "N exceeds int32"; delete S; return HIPKKT_ERR_ARGUMENT; }
+    {
+        // The "cone rows first" order can break down on an ill-conditioned iterate; the factorisation is
+        // then repeated on a twin handle in the minimum-degree order.  Its symbolic analysis is seconds of host work on the
+        // problems that take this path (dense PSD blocks), so it starts on a host thread the moment that order is chosen
+        // (HIPKKT_TWIN_AHEAD=0: only when it is needed).
+        const char *ta = getenv("HIPKKT_TWIN_AHEAD");
+        if (!(ta && ta[0] == '0') && S->l1)
+            po.on_alternative_order = [S, &po](const std::vector<int> &perm_md) {
+                std::unique_ptr<hipkkt_solver> T(new hipkkt_solver());
+                T->device = S->device;
+                T->opts = S->opts;
+                T->l1 = S->l1;
+                T->img = S->img;
+                PlanOptions po2 = po;
+                po2.n_hold = 0;
+                po2.on_alternative_order = nullptr;
+                T->plan_opts = po2;
+                hipkkt_solver *Tp = T.get();
+                std::vector<int64_t> pv(perm_md.begin(), perm_md.end());
+                S->twin_pending = std::move(T);
+                S->twin_future = std::async(std::launch::async, [Tp, pv, po2]() {
+                    return build_plan((int)Tp->img.N, Tp->img.colptr.data(), Tp->img.rowval.data(), pv.data(), po2, Tp->plan);
+                });
+            };
+    }
     const auto t_a = std::chrono::steady_clock::now();
     std::string err = build_plan((int)S->img.N, S->img.colptr.data(), S->img.rowval.data(), uperm, po, S->plan);
+    po.on_alternative_order = nullptr;
     if (!err.empty()) { g_create_error = err; delete S; return HIPKKT_ERR_ARGUMENT; }
     S->plan_opts = po;
     const auto t_b = std::chrono::steady_clock::now();
@@ -1740,22 +1772,30 @@ int32_t hipkkt_refactor(hipkkt_handle h, int32_t static_reg_enable, double eps_c
         if (!S->fallback) {
             // built in a local owner: a set-up that throws half-way (e.g. device OOM) must not leave a twin with null
             // streams / device pointers behind -- the next failing factorisation then simply tries again
-            std::unique_ptr<hipkkt_solver> T(new hipkkt_solver());
-            T->device = S->device;
-            T->opts = S->opts;
-            T->l1 = S->l1;
-            T->img = S->img;
-            PlanOptions po = S->plan_opts;
-            po.n_hold = 0;
+            std::unique_ptr<hipkkt_solver> T;
             const auto t_a = std::chrono::steady_clock::now();
-            std::string err = build_plan((int)T->img.N, T->img.colptr.data(), T->img.rowval.data(), nullptr, po, T->plan);
-            if (!err.empty()) return rc;
+            if (S->twin_future.valid()) {               // analysed ahead on a host thread (finish_create): wait for it
+                const std::string err = S->twin_future.get();
+                T = std::move(S->twin_pending);
+                if (!err.empty()) T.reset();
+            }
+            if (!T) {
+                T.reset(new hipkkt_solver());
+                T->device = S->device;
+                T->opts = S->opts;
+                T->l1 = S->l1;
+                T->img = S->img;
+                PlanOptions po = S->plan_opts;
+                po.n_hold = 0;
+                std::string err = build_plan((int)T->img.N, T->img.colptr.data(), T->img.rowval.data(), nullptr, po, T->plan);
+                if (!err.empty()) return rc;
+                T->plan_opts = po;
+            }
             const auto t_b = std::chrono::steady_clock::now();
-            T->plan_opts = po;
             init_runtime(T.get());
             setup_device(T.get());
             if (getenv("HIPKKT_VERBOSE"))
-                fprintf(stderr, "hipkkt: robust-order twin (minimum degree on K): N %d nnzL %lld levels %d: symbolic %.2f ms (%s), device set-up %.2f ms\n",
+                fprintf(stderr, "hipkkt: robust-order twin (minimum degree on K): N %d nnzL %lld levels %d: waited %.2f ms for its symbolic analysis (%s), device set-up %.2f ms\n",
                         T->plan.N, (long long)T->plan.nnzL, T->plan.nlevels, 1e3 * std::chrono::duration<double>(t_b - t_a).count(),
                         T->plan.timing_note.c_str(), 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t_b).count());
             S->fallback = T.release();

@@ -4,6 +4,7 @@
 #include "symbolic.h"
 
 #include <algorithm>
+#include <future>
 #include <array>
 #include <chrono>
 #include <cmath>
@@ -168,7 +169,10 @@ std::string build_plan(int N, const int64_t *Ap, const int64_t *Ai, const int64_
             amd_order(N, Ap, Ai, opt.amd_dense_scale, perm1, hold.data());
             if ((int)perm1.size() == N) {
                 const OrderCost c_b = order_cost(N, Ap, Ai, perm1, maxw);
-                if (c_b.flops < 0.7 * c_md.flops) { perm0.swap(perm1); P.ordering_used = 1; P.cost_md_seconds = c_b.seconds; P.cost_md_levels = c_b.levels; }
+                if (c_b.flops < 0.7 * c_md.flops) {
+                    perm0.swap(perm1); P.ordering_used = 1; P.cost_md_seconds = c_b.seconds; P.cost_md_levels = c_b.levels;
+                    if (opt.on_alternative_order) opt.on_alternative_order(perm1);     // perm1 = minimum degree on K now
+                }
             }
         }
     }
@@ -373,24 +377,31 @@ std::string build_plan(int N, const int64_t *Ap, const int64_t *Ai, const int64_
     }
 
     lap("structure");
-    // ---- 12. scatter map of the original nonzeros into the panels
+    // ---- 12. scatter map of the original nonzeros into the panels.  Independent of the work lists built below: on big images
+    //          (the dense PSD blocks of an SDP: 1.6e7 binary searches) it runs on a second host thread meanwhile.
     P.kmap.resize(P.nnzK);
     P.diag_dst.assign(N, -1);
-    for (int j = 0; j < N; j++)
-        for (int64_t q = Ap[j]; q < Ap[j + 1]; q++) {
-            int pi = P.iperm[Ai[q]], pj = P.iperm[j];
-            int c = std::min(pi, pj), r = std::max(pi, pj);
-            int s = P.sn_of_col[c];
-            const int *rows = &P.sn_rows[P.sn_rowptr[s]];
-            int64_t nr = P.sn_rowptr[s + 1] - P.sn_rowptr[s];
-            const int *it = std::lower_bound(rows, rows + nr, r);
-            if (it == rows + nr || *it != r) return "internal: entry outside the symbolic structure";
-            int64_t dest = P.sn_panel[s] + (it - rows) + (int64_t)(c - P.sn_first[s]) * nr;
-            P.kmap[q] = dest;
-            if (pi == pj) P.diag_dst[c] = dest;
-        }
-    for (int k = 0; k < N; k++)
-        if (P.diag_dst[k] < 0) return "KKT matrix has a column without a diagonal entry";
+    auto kmap_job = [&P, N, Ap, Ai]() -> const char * {
+        for (int j = 0; j < N; j++)
+            for (int64_t q = Ap[j]; q < Ap[j + 1]; q++) {
+                int pi = P.iperm[Ai[q]], pj = P.iperm[j];
+                int c = std::min(pi, pj), r = std::max(pi, pj);
+                int s = P.sn_of_col[c];
+                const int *rows = &P.sn_rows[P.sn_rowptr[s]];
+                int64_t nr = P.sn_rowptr[s + 1] - P.sn_rowptr[s];
+                const int *it = std::lower_bound(rows, rows + nr, r);
+                if (it == rows + nr || *it != r) return "internal: entry outside the symbolic structure";
+                int64_t dest = P.sn_panel[s] + (it - rows) + (int64_t)(c - P.sn_first[s]) * nr;
+                P.kmap[q] = dest;
+                if (pi == pj) P.diag_dst[c] = dest;
+            }
+        for (int k = 0; k < N; k++)
+            if (P.diag_dst[k] < 0) return "KKT matrix has a column without a diagonal entry";
+        return nullptr;
+    };
+    std::future<const char *> kmap_future;      // (a std::async future joins in its destructor: early returns below are safe)
+    if (P.nnzK > ((int64_t)1 << 21)) kmap_future = std::async(std::launch::async, kmap_job);
+    else if (const char *e = kmap_job()) return e;
 
     // ---- 13. factor items
     P.fac_lvl_ptr.assign(P.nlevels + 1, 0);
@@ -712,6 +723,9 @@ std::string build_plan(int N, const int64_t *Ap, const int64_t *Ai, const int64_
         }
 
     lap("ut:jit");
+    if (kmap_future.valid())
+        if (const char *e = kmap_future.get()) return e;
+    lap("kmap-join");
     // ---- 15. gather lists for the forward solve (multifrontal style): every panel row slot
     //          (s, li) collects the update-vector entries of the CHILDREN of s that land on it.
     //          Fan-in per slot <= #children; each ubuf entry is consumed exactly once, by the parent.

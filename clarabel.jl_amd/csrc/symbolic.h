@@ -5,6 +5,7 @@
 // ("host C++ acceptable").
 #pragma once
 #include <cstdint>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -116,6 +117,9 @@ struct PlanOptions {
     int nd_mode = 1;           // nested dissection candidate: 0 never, 1 when the latency + throughput model predicts a
                                // >= 20 % cheaper KKT iteration than minimum degree, 2 always
     int nd_leaf = 256;         // subgraphs of at most this many nodes are ordered by minimum degree
+    // called (synchronously, from build_plan) with the minimum-degree order on K at the moment the "cone rows first" order is
+    // preferred to it: the caller may start preparing the robust fallback for that order while this analysis goes on
+    std::function<void(const std::vector<int> &)> on_alternative_order;
 };
 
 struct HostPlan {
