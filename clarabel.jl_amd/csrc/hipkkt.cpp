@@ -185,6 +185,7 @@ struct hipkkt_solver {
     // the twin's symbolic analysis runs on a host thread from the moment the cheap order is chosen (finish_create)
     std::unique_ptr<hipkkt_solver> twin_pending;
     std::future<std::string> twin_future;
+    std::shared_ptr<std::atomic<bool>> twin_cancel;   // set when the twin turns out not to be needed
     bool using_fallback = false;
     bool profiling = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
@@ -236,7 +237,8 @@ struct hipkkt_solver {
         stage_cap = cap;
     }
     ~hipkkt_solver() {
-        if (twin_future.valid()) twin_future.wait();     // the thread reads twin_pending's image
+        if (twin_cancel) twin_cancel->store(true);
+        if (twin_future.valid()) twin_future.wait();     // the thread reads twin_pending's image (a cancelled one ends at its next phase)
         twin_pending.reset();
         delete fallback;
         (void)hipSetDevice(device);
@@ -1137,8 +1139,9 @@ int32_t finish_create(hipkkt_solver *S, const hipkkt_opts *opts, hipkkt_handle *
     {
         // The "cone rows first" order can break down on an ill-conditioned iterate; the factorisation is
         // then repeated on a twin handle in the minimum-degree order.  Its symbolic analysis is seconds of host work on the
-        // problems that take this path (dense PSD blocks), so it starts on a host thread the moment that order is chosen
-        // (HIPKKT_TWIN_AHEAD=0: only when it is needed).
+        // problems that take this path (dense PSD blocks), so it starts on a host thread as soon as the minimum-degree order is
+        // known and the cheap order is about to be evaluated against it -- speculatively: if the cheap order is not chosen the
+        // thread is cancelled at its next phase boundary (HIPKKT_TWIN_AHEAD=0: analysed only when it is needed).
         const char *ta = getenv("HIPKKT_TWIN_AHEAD");
         if (!(ta && ta[0] == '0') && S->l1)
             po.on_alternative_order = [S, &po](const std::vector<int> &perm_md) {
@@ -1150,6 +1153,8 @@ int32_t finish_create(hipkkt_solver *S, const hipkkt_opts *opts, hipkkt_handle *
                 PlanOptions po2 = po;
                 po2.n_hold = 0;
                 po2.on_alternative_order = nullptr;
+                S->twin_cancel = std::make_shared<std::atomic<bool>>(false);
+                po2.cancel = S->twin_cancel.get();
                 T->plan_opts = po2;
                 hipkkt_solver *Tp = T.get();
                 std::vector<int64_t> pv(perm_md.begin(), perm_md.end());
@@ -1163,6 +1168,7 @@ int32_t finish_create(hipkkt_solver *S, const hipkkt_opts *opts, hipkkt_handle *
     std::string err = build_plan((int)S->img.N, S->img.colptr.data(), S->img.rowval.data(), uperm, po, S->plan);
     po.on_alternative_order = nullptr;
     if (!err.empty()) { g_create_error = err; delete S; return HIPKKT_ERR_ARGUMENT; }
+    if (S->plan.ordering_used != 1 && S->twin_cancel) S->twin_cancel->store(true);   // speculative twin not needed: the thread stops at its next phase
     S->plan_opts = po;
     const auto t_b = std::chrono::steady_clock::now();
     try {
@@ -1778,6 +1784,7 @@ int32_t hipkkt_refactor(hipkkt_handle h, int32_t static_reg_enable, double eps_c
                 const std::string err = S->twin_future.get();
                 T = std::move(S->twin_pending);
                 if (!err.empty()) T.reset();
+                else T->plan_opts.cancel = nullptr;
             }
             if (!T) {
                 T.reset(new hipkkt_solver());

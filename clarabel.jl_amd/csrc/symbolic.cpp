@@ -134,7 +134,9 @@ std::string build_plan(int N, const int64_t *Ap, const int64_t *Ai, const int64_
     const int maxw = std::max(1, std::min(opt.max_width, kMaxSnWidth));
 
     auto t_last = std::chrono::steady_clock::now();
+    bool cancelled = false;
     auto lap = [&](const char *name) {
+        if (opt.cancel && opt.cancel->load(std::memory_order_relaxed)) cancelled = true;
         const auto now = std::chrono::steady_clock::now();
         char buf[64];
         snprintf(buf, sizeof buf, "%s %.2f ", name, 1e3 * std::chrono::duration<double>(now - t_last).count());
@@ -163,6 +165,7 @@ std::string build_plan(int N, const int64_t *Ap, const int64_t *Ai, const int64_
         P.cost_md_levels = c_md.levels;
         if (opt.n_hold > 0 && opt.n_hold < N && c_md.flops > 1e9) {
             // second candidate: eliminate the cone rows first, the variables last; keep the cheaper one
+            if (opt.on_alternative_order) opt.on_alternative_order(perm0);     // perm0 = minimum degree on K (speculative head start)
             std::vector<int> perm1;
             std::vector<char> hold(N, 0);
             for (int i = 0; i < opt.n_hold; i++) hold[i] = 1;
@@ -171,7 +174,6 @@ std::string build_plan(int N, const int64_t *Ap, const int64_t *Ai, const int64_
                 const OrderCost c_b = order_cost(N, Ap, Ai, perm1, maxw);
                 if (c_b.flops < 0.7 * c_md.flops) {
                     perm0.swap(perm1); P.ordering_used = 1; P.cost_md_seconds = c_b.seconds; P.cost_md_levels = c_b.levels;
-                    if (opt.on_alternative_order) opt.on_alternative_order(perm1);     // perm1 = minimum degree on K now
                 }
             }
         }
@@ -192,6 +194,8 @@ std::string build_plan(int N, const int64_t *Ap, const int64_t *Ai, const int64_
     for (int k = 0; k < N; k++) iperm0[perm0[k]] = k;
 
     lap("ordering");
+
+    if (cancelled) return "cancelled";
     // ---- 2-4. etree, postorder, final permutation
     std::vector<int64_t> up;
     std::vector<int> ui, parent, cnt, post;
@@ -377,6 +381,8 @@ std::string build_plan(int N, const int64_t *Ap, const int64_t *Ai, const int64_
     }
 
     lap("structure");
+
+    if (cancelled) return "cancelled";
     // ---- 12. scatter map of the original nonzeros into the panels.  Independent of the work lists built below: on big images
     //          (the dense PSD blocks of an SDP: 1.6e7 binary searches) it runs on a second host thread meanwhile.
     P.kmap.resize(P.nnzK);
@@ -431,6 +437,8 @@ std::string build_plan(int N, const int64_t *Ap, const int64_t *Ai, const int64_
     P.update_batch_used = update_batch;
 
     lap("kmap+items");
+
+    if (cancelled) return "cancelled";
     // ---- 14. update tasks, owned by target row-blocks
     {
         std::vector<TaskKey> keys;
@@ -505,6 +513,7 @@ std::string build_plan(int N, const int64_t *Ap, const int64_t *Ai, const int64_
             }
         }
         lap("ut:gen");
+        if (cancelled) return "cancelled";
         std::sort(keys.begin(), keys.end(), [](const TaskKey &x, const TaskKey &y) {
             if (x.stage != y.stage) return x.stage < y.stage;
             if (x.tgt != y.tgt) return x.tgt < y.tgt;
@@ -513,6 +522,7 @@ std::string build_plan(int N, const int64_t *Ap, const int64_t *Ai, const int64_
             return x.task < y.task;
         });
         lap("ut:sort");
+        if (cancelled) return "cancelled";
         std::vector<UpdTask> sorted(keys.size());
         P.upd_stage_ptr.assign(P.nlevels + 1, 0);
         for (size_t q = 0; q < keys.size(); q++) {
@@ -538,6 +548,7 @@ std::string build_plan(int N, const int64_t *Ap, const int64_t *Ai, const int64_
         //           through the relative-index scatter of k_update_stage.  Dense groups are moved to the
         //           front of their stage.
         lap("ut:groups");
+        if (cancelled) return "cancelled";
         P.upd_stage_ndense.assign(P.nlevels, 0);
         P.upd_stage_flops_dense.assign(P.nlevels, 0.0);
         {
@@ -583,6 +594,7 @@ std::string build_plan(int N, const int64_t *Ap, const int64_t *Ai, const int64_
             }
         }
         lap("ut:classify");
+        if (cancelled) return "cancelled";
         P.upd_stage_ngather.assign(P.nlevels, 0);
         P.upd_stage_nfar.assign(P.nlevels, 0);
         P.gath_stage_ptr.assign(P.nlevels + 1, 0);
@@ -687,6 +699,8 @@ std::string build_plan(int N, const int64_t *Ap, const int64_t *Ai, const int64_
     }
 
     lap("ut:lists");
+
+    if (cancelled) return "cancelled";
     // ---- 14b. fused just-in-time updates: inside a front, the stage before panel p+1 holds nothing but the dense
     //           tiles of that one panel (sources: the batch-mates factored just before it).  The panel kernel of
     //           p+1 then applies them to the rows it owns (every workgroup: the diagonal tile, redundantly, and
@@ -723,9 +737,12 @@ std::string build_plan(int N, const int64_t *Ap, const int64_t *Ai, const int64_
         }
 
     lap("ut:jit");
+
+    if (cancelled) return "cancelled";
     if (kmap_future.valid())
         if (const char *e = kmap_future.get()) return e;
     lap("kmap-join");
+    if (cancelled) return "cancelled";
     // ---- 15. gather lists for the forward solve (multifrontal style): every panel row slot
     //          (s, li) collects the update-vector entries of the CHILDREN of s that land on it.
     //          Fan-in per slot <= #children; each ubuf entry is consumed exactly once, by the parent.
@@ -832,6 +849,8 @@ std::string build_plan(int N, const int64_t *Ap, const int64_t *Ai, const int64_
     }
 
     lap("solve-lists");
+
+    if (cancelled) return "cancelled";
     // ---- 16. symmetric CSR view of K in the ORIGINAL ordering (iterative-refinement SpMV)
     P.sym_rowptr.assign(N + 1, 0);
     for (int j = 0; j < N; j++)
@@ -853,6 +872,7 @@ std::string build_plan(int N, const int64_t *Ap, const int64_t *Ai, const int64_
             }
     }
     lap("symcsr");
+    if (cancelled) return "cancelled";
     return "";
 }
 

@@ -4,6 +4,7 @@
 // for the triangular solves and the symmetric SpMV index.  Runs once per problem on the host
 // ("host C++ acceptable").
 #pragma once
+#include <atomic>
 #include <cstdint>
 #include <functional>
 #include <string>
@@ -117,9 +118,12 @@ struct PlanOptions {
     int nd_mode = 1;           // nested dissection candidate: 0 never, 1 when the latency + throughput model predicts a
                                // >= 20 % cheaper KKT iteration than minimum degree, 2 always
     int nd_leaf = 256;         // subgraphs of at most this many nodes are ordered by minimum degree
-    // called (synchronously, from build_plan) with the minimum-degree order on K at the moment the "cone rows first" order is
-    // preferred to it: the caller may start preparing the robust fallback for that order while this analysis goes on
+    // called (synchronously, from build_plan) with the minimum-degree order on K just BEFORE the "cone rows first" candidate is
+    // evaluated against it: the caller may start preparing the robust fallback (a twin analysed in that order) speculatively
+    // while this analysis goes on; HostPlan::ordering_used tells afterwards whether it will ever be needed
     std::function<void(const std::vector<int> &)> on_alternative_order;
+    // polled at every phase boundary: build_plan returns "cancelled" once it reads true
+    const std::atomic<bool> *cancel = nullptr;
 };
 
 struct HostPlan {
