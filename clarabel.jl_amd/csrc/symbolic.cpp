@@ -514,13 +514,25 @@ std::string build_plan(int N, const int64_t *Ap, const int64_t *Ai, const int64_
         }
         lap("ut:gen");
         if (cancelled) return "cancelled";
-        std::sort(keys.begin(), keys.end(), [](const TaskKey &x, const TaskKey &y) {
-            if (x.stage != y.stage) return x.stage < y.stage;
-            if (x.tgt != y.tgt) return x.tgt < y.tgt;
-            if (x.rb != y.rb) return x.rb < y.rb;
-            if (x.src != y.src) return x.src < y.src;
-            return x.task < y.task;
-        });
+        // order: (stage, target, row block, source, task).  The keys are generated source by source, task by task, i.e. already in
+        // (source, task) order: three stable counting sorts -- by row block, by target, by stage -- finish the job in O(n)
+        // (a comparison sort of the 1.2e7 keys of an SDP twin took half a second).
+        {
+            std::vector<TaskKey> tmp(keys.size());
+            std::vector<int64_t> cnt;
+            auto pass = [&](auto field, int64_t nbuckets) {
+                cnt.assign((size_t)nbuckets + 1, 0);
+                for (const TaskKey &k : keys) cnt[(size_t)field(k) + 1]++;
+                for (int64_t b = 0; b < nbuckets; b++) cnt[b + 1] += cnt[b];
+                for (const TaskKey &k : keys) tmp[(size_t)cnt[(size_t)field(k)]++] = k;
+                keys.swap(tmp);
+            };
+            int max_rb = 0;
+            for (const TaskKey &k : keys) max_rb = std::max(max_rb, k.rb);
+            pass([](const TaskKey &k) { return k.rb; }, (int64_t)max_rb + 1);
+            pass([](const TaskKey &k) { return k.tgt; }, S);
+            pass([](const TaskKey &k) { return k.stage; }, P.nlevels);
+        }
         lap("ut:sort");
         if (cancelled) return "cancelled";
         std::vector<UpdTask> sorted(keys.size());
