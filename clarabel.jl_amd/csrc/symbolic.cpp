@@ -179,7 +179,8 @@ std::string build_plan(int N, const int64_t *Ap, const int64_t *Ai, const int64_
         }
     }
     if (!user_perm && opt.nd_mode > 0 && N >= 64 &&
-        (opt.nd_mode >= 2 || (Ap[N] <= (int64_t)64 * N && P.cost_md_levels >= 24))) {   // (dense blocks: no separators; short chains: nothing to gain)
+        (opt.nd_mode >= 2 || (Ap[N] <= (int64_t)64 * N && P.cost_md_levels >= 36))) {   // (dense blocks: no separators; short chains: nothing to
+                                                                                   // gain -- on the 256 batch problems nested dissection never won below 41 levels, and evaluating it cost more than the minimum-degree order itself)
         // third candidate: nested dissection (ordering.cpp) -- far fewer dependent levels on banded / grid-like systems
         std::vector<int> permN;
         nd_order(N, Ap, Ai, opt.amd_dense_scale, opt.nd_leaf, permN);
