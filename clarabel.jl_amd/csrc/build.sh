@@ -8,7 +8,7 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-result"
 mkdir -p ../../build/obj
 OBJ=../../build/obj
 pids=()
-for f in hipkkt.cpp symbolic.cpp ordering.cpp assemble.cpp; do
+for f in hipkkt_abi.cpp hipkkt_setup.cpp hipkkt_factor.cpp hipkkt_solve.cpp symbolic.cpp ordering.cpp assemble.cpp; do
   $HIPCC $FLAGS -x c++ -I/opt/rocm/include -D__HIP_PLATFORM_AMD__ -c $f -o $OBJ/${f%.cpp}.o & pids+=($!)
 done
 $HIPCC $FLAGS -c kernels.hip -o $OBJ/kernels.o & pids+=($!)
@@ -17,5 +17,5 @@ $HIPCC $FLAGS -c front_block.hip -o $OBJ/front_block.o & pids+=($!)
 # scaling.hip mirrors the reference's cone formulas operation by operation: no FMA contraction
 $HIPCC $FLAGS -ffp-contract=off -c scaling.hip -o $OBJ/scaling.o & pids+=($!)
 for p in "${pids[@]}"; do wait $p; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT $OBJ/hipkkt.o $OBJ/symbolic.o $OBJ/ordering.o $OBJ/assemble.o $OBJ/assemble_dev.o $OBJ/scaling.o $OBJ/front_block.o $OBJ/kernels.o
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT $OBJ/hipkkt_abi.o $OBJ/hipkkt_setup.o $OBJ/hipkkt_factor.o $OBJ/hipkkt_solve.o $OBJ/symbolic.o $OBJ/ordering.o $OBJ/assemble.o $OBJ/assemble_dev.o $OBJ/scaling.o $OBJ/front_block.o $OBJ/kernels.o
 echo "built $(readlink -f $OUT)"

@@ -1,0 +1,280 @@
+// The factorisation: launch sequence (levels, front batches, Schur updates), its hipGraph, hipkkt_refactor and the
+// robust-order twin (see hipkkt_internal.h for the file map).
+#include "hipkkt_internal.h"
+
+using namespace hipkkt;
+using namespace hipkkt_host;
+
+namespace hipkkt_host {
+
+// ---- enqueue helpers (no synchronisation inside; capturable) ---------------------------------
+
+// narrow levels (w <= 8): LDS-resident kernel; wide panels: the register-resident 8-wave kernel
+void enqueue_factor_level(hipkkt_solver *S, int l) {
+    const HostPlan &P = S->plan;
+    const int n = P.fac_lvl_ptr[l + 1] - P.fac_lvl_ptr[l];
+    if (P.fac_lvl_maxw[l] <= 8)
+        launch_factor_level(S->stream, S->dp, P.fac_lvl_ptr[l], n, P.fac_lvl_maxw[l], S->opts.dynamic_reg_eps,
+                            S->opts.dynamic_reg_delta);
+    else
+        launch_factor_panel(S->stream, S->dp, P.fac_lvl_ptr[l], n, S->opts.dynamic_reg_eps, S->opts.dynamic_reg_delta,
+                            P.lvl_fused[l] != 0);
+}
+
+// Schur-complement updates applied after level l is factored: dense register tiles (matrix cores),
+// per-entry gather lists (tiny scattered contributions), relative-index scatter (whatever is left).
+// The three kinds own disjoint target tiles, so their order inside a stage is immaterial.
+void enqueue_updates(hipkkt_solver *S, int l, bool split_far = false) {
+    const HostPlan &P = S->plan;
+    hipStream_t st = S->stream;
+    if (l + 1 < P.nlevels && P.lvl_fused[l + 1]) return;   // applied inside the next level's panel kernel
+    const int g0 = P.upd_stage_ptr[l], nd = P.upd_stage_ndense[l], ng = P.upd_stage_ngather[l];
+    launch_update_dense(st, S->dp, g0, nd - (split_far ? P.upd_stage_nfar[l] : 0), 0, nd > 0 && P.upd_stage_flops_dense[l] >= 1.5e6 * nd);
+    launch_update_gather(st, S->dp, P.gath_stage_ptr[l], P.gath_stage_ptr[l + 1] - P.gath_stage_ptr[l], S->gath_heavy_ptr[l],
+                         S->gath_heavy_ptr[l + 1] - S->gath_heavy_ptr[l]);
+    launch_update_stage(st, S->dp, g0 + nd + ng, P.upd_stage_ptr[l + 1] - g0 - nd - ng);
+}
+
+void enqueue_factor(hipkkt_solver *S, int static_enable, double eps_const, double eps_prop) {
+    const HostPlan &P = S->plan;
+    hipStream_t st = S->stream;
+    launch_zero_words(st, S->dp.scal, 2);                 // SC_MAXDIAG  (kernels.hip: why not hipMemsetAsync)
+    launch_zero_words(st, S->dp.flags, FL_COUNT);
+    launch_maxabs_gather(st, S->dp.kval, S->d_diag_full, S->N, (unsigned long long *)S->dp.scal + SC_MAXDIAG);
+    HK_CHECK(hipMemsetAsync(S->dp.Lx, 0, (size_t)P.panel_doubles * sizeof(double), st));
+    launch_init_panels(st, S->dp, S->nnzK, static_enable, eps_const, eps_prop);
+    // Far updates (targets more than `lookahead` levels ahead) are forked to the side stream right after the
+    // level's factorisation and joined before the next batch end touches the same targets (symbolic.h).
+    auto new_event = [&]() {
+        hipEvent_t e = nullptr;
+        HK_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        S->fork_events.push_back(e);
+        return e;
+    };
+    const bool fork = S->use_side && P.lookahead > 0;
+    hipEvent_t pending = nullptr;
+    int pending_level = -1;
+    const bool fb = S->use_front_block && !S->fbatches.empty();
+    if (fb) launch_zero_words(st, S->d_fb_sync, 128 * (int)S->fbatches.size());
+    for (int l = 0; l < P.nlevels; l++) {
+        if (fb && S->lvl_fb[l] != -1) {
+            // a front's update batch: one launch for its panels and their just-in-time updates, then the batch's far stage
+            if (S->lvl_fb[l] >= 0)
+                launch_front_block(st, S->dp, S->fbatches[S->lvl_fb[l]], S->d_fb_sync, S->d_fb_scratch, S->opts.dynamic_reg_eps,
+                                   S->opts.dynamic_reg_delta, S->d_fb_trace);
+            const bool last = l + 1 >= P.nlevels || S->lvl_fb[l + 1] != -2;
+            if (!last) continue;                          // the stages inside the batch are applied by the kernel itself
+        } else {
+            enqueue_factor_level(S, l);
+        }
+        const int nfar = fork ? P.upd_stage_nfar[l] : 0;
+        if (pending && (nfar > 0 || l >= pending_level + P.lookahead)) {
+            HK_CHECK(hipStreamWaitEvent(st, pending, 0));
+            pending = nullptr;
+        }
+        enqueue_updates(S, l, nfar > 0);
+        if (nfar > 0) {   // forked AFTER the near updates: the far tiles must not compete with them for the CUs
+            hipEvent_t e1 = new_event(), e2 = new_event();
+            HK_CHECK(hipEventRecord(e1, st));
+            HK_CHECK(hipStreamWaitEvent(S->side, e1, 0));
+            launch_update_dense(S->side, S->dp, P.upd_stage_ptr[l] + P.upd_stage_ndense[l] - nfar, nfar, S->far_wgs);
+            HK_CHECK(hipEventRecord(e2, S->side));
+            pending = e2;
+            pending_level = l;
+        }
+    }
+    if (pending) HK_CHECK(hipStreamWaitEvent(st, pending, 0));
+    launch_invert_diag(st, S->dp, S->inv_nsmall, S->inv_wsmall, S->inv_nwide);
+}
+
+}  // namespace hipkkt_host
+
+extern "C" {
+
+// ---- factor ------------------------------------------------------------------------------------
+
+static int32_t refactor_once(hipkkt_handle h, int32_t static_reg_enable, double eps_const, double eps_prop,
+                             double *eps_used, int64_t *n_dynamic_reg);
+
+// The "variables last" order (plan.ordering_used == 1) can be far cheaper than minimum degree on K but
+// eliminates the ill-conditioned cone blocks first; if a factorisation in that order ends with a
+// non-finite pivot, the handle is rebuilt ONCE with the minimum-degree order on K (the reference's
+// choice) and the factorisation is repeated, so robustness is never worse than with that order.
+int32_t hipkkt_refactor(hipkkt_handle h, int32_t static_reg_enable, double eps_const, double eps_prop,
+                        double *eps_used, int64_t *n_dynamic_reg) {
+    if (h) h->using_fallback = false;
+    int32_t rc = refactor_once(h, static_reg_enable, eps_const, eps_prop, eps_used, n_dynamic_reg);
+    if (rc != HIPKKT_NUMERICAL_FAILURE || !h || h->plan.ordering_used != 1) return rc;
+    hipkkt_solver *S = h;
+    try {
+        if (hipSetDevice(S->device) != hipSuccess) return rc;
+        if (!S->fallback) {
+            // built in a local owner: a set-up that throws half-way (e.g. device OOM) must not leave a twin with null
+            // streams / device pointers behind -- the next failing factorisation then simply tries again
+            std::unique_ptr<hipkkt_solver> T;
+            const auto t_a = std::chrono::steady_clock::now();
+            if (S->twin_future.valid()) {               // analysed ahead on a host thread (finish_create): wait for it
+                const std::string err = S->twin_future.get();
+                T = std::move(S->twin_pending);
+                if (!err.empty()) T.reset();
+                else T->plan_opts.cancel = nullptr;
+            }
+            if (!T) {
+                T.reset(new hipkkt_solver());
+                T->device = S->device;
+                T->opts = S->opts;
+                T->l1 = S->l1;
+                T->img = S->img;
+                PlanOptions po = S->plan_opts;
+                po.n_hold = 0;
+                std::string err = build_plan((int)T->img.N, T->img.colptr.data(), T->img.rowval.data(), nullptr, po, T->plan);
+                if (!err.empty()) return rc;
+                T->plan_opts = po;
+            }
+            const auto t_b = std::chrono::steady_clock::now();
+            init_runtime(T.get());
+            setup_device(T.get());
+            if (getenv("HIPKKT_VERBOSE"))
+                fprintf(stderr, "hipkkt: robust-order twin (minimum degree on K): N %d nnzL %lld levels %d: waited %.2f ms for its symbolic analysis (%s), device set-up %.2f ms\n",
+                        T->plan.N, (long long)T->plan.nnzL, T->plan.nlevels, 1e3 * std::chrono::duration<double>(t_b - t_a).count(),
+                        T->plan.timing_note.c_str(), 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t_b).count());
+            S->fallback = T.release();
+        }
+        copy_sync(S->stream, S->fallback->dp.kval, S->dp.kval, (size_t)S->nnzK * sizeof(double), hipMemcpyDeviceToDevice);
+    } catch (...) {
+        S->err = "building the fallback (minimum-degree) factorisation failed";
+        return HIPKKT_ERR_DEVICE;
+    }
+    rc = refactor_once(S->fallback, static_reg_enable, eps_const, eps_prop, eps_used, n_dynamic_reg);
+    S->using_fallback = true;
+    S->n_twin_refactors++;
+    S->last_eps = S->fallback->last_eps;
+    S->last_nreg = S->fallback->last_nreg;
+    S->t_last_factor += S->fallback->t_last_factor;      // the failed attempt + the repeated one
+    S->t_acc_factor += S->fallback->t_last_factor;
+    return rc;
+}
+
+static int32_t refactor_once(hipkkt_handle h, int32_t static_reg_enable, double eps_const, double eps_prop,
+                             double *eps_used, int64_t *n_dynamic_reg) {
+    HK_ENTER(h)
+    HK_CHECK(hipEventRecord(S->ev0, S->stream));
+    if (S->profiling) {
+        // eager, with the dense-update launches timed separately (adds event overhead)
+        const HostPlan &P = S->plan;
+        hipStream_t st = S->stream;
+        launch_zero_words(st, S->dp.scal, 2);
+        launch_zero_words(st, S->dp.flags, FL_COUNT);
+        launch_maxabs_gather(st, S->dp.kval, S->d_diag_full, S->N, (unsigned long long *)S->dp.scal + SC_MAXDIAG);
+        HK_CHECK(hipMemsetAsync(S->dp.Lx, 0, (size_t)P.panel_doubles * sizeof(double), st));
+        launch_init_panels(st, S->dp, S->nnzK, static_reg_enable, eps_const, eps_prop);
+        std::vector<hipEvent_t> evs, evd;   // evs: all update kernels of a stage; evd: its k_update_dense<4,4> launch alone
+        std::vector<int> evd_level;
+        const bool fb = S->use_front_block && !S->fbatches.empty();
+        if (fb) launch_zero_words(st, S->d_fb_sync, 128 * (int)S->fbatches.size());
+        std::vector<hipEvent_t> evf;        // around every k_front_block launch
+        int fb_panels = 0;
+        double fb_flops = 0;                // update flops of the stages inside the batches (executed by k_front_block)
+        for (int l = 0; l < P.nlevels; l++) {
+            if (fb && S->lvl_fb[l] != -1) {
+                if (S->lvl_fb[l] >= 0) {
+                    hipEvent_t a, b;
+                    HK_CHECK(hipEventCreate(&a));
+                    HK_CHECK(hipEventCreate(&b));
+                    HK_CHECK(hipEventRecord(a, st));
+                    launch_front_block(st, S->dp, S->fbatches[S->lvl_fb[l]], S->d_fb_sync, S->d_fb_scratch, S->opts.dynamic_reg_eps,
+                                       S->opts.dynamic_reg_delta, S->d_fb_trace);
+                    HK_CHECK(hipEventRecord(b, st));
+                    evf.push_back(a);
+                    evf.push_back(b);
+                    fb_panels += S->fbatches[S->lvl_fb[l]].nb;
+                }
+                if (l + 1 < P.nlevels && S->lvl_fb[l + 1] == -2) { fb_flops += P.upd_stage_flops_dense[l]; continue; }   // applied by the kernel
+            } else {
+                enqueue_factor_level(S, l);
+            }
+            const bool fused_next = l + 1 < P.nlevels && P.lvl_fused[l + 1];   // applied by the next panel kernel
+            if (P.upd_stage_ptr[l + 1] > P.upd_stage_ptr[l] && !fused_next) {
+                hipEvent_t a, b, c2;
+                HK_CHECK(hipEventCreate(&a));
+                HK_CHECK(hipEventCreate(&b));
+                HK_CHECK(hipEventRecord(a, st));
+                const int g0 = P.upd_stage_ptr[l], nd = P.upd_stage_ndense[l], ng = P.upd_stage_ngather[l];
+                launch_update_dense(st, S->dp, g0, nd, 0, nd > 0 && P.upd_stage_flops_dense[l] >= 1.5e6 * nd);
+                if (nd > 384) {   // the one-wavefront-per-tile variant (see launch_update_dense)
+                    HK_CHECK(hipEventCreate(&c2));
+                    HK_CHECK(hipEventRecord(c2, st));
+                    evd.push_back(a);
+                    evd.push_back(c2);
+                    evd_level.push_back(l);
+                }
+                launch_update_gather(st, S->dp, P.gath_stage_ptr[l], P.gath_stage_ptr[l + 1] - P.gath_stage_ptr[l], S->gath_heavy_ptr[l],
+                         S->gath_heavy_ptr[l + 1] - S->gath_heavy_ptr[l]);
+                launch_update_stage(st, S->dp, g0 + nd + ng, P.upd_stage_ptr[l + 1] - g0 - nd - ng);
+                HK_CHECK(hipEventRecord(b, st));
+                evs.push_back(a);
+                evs.push_back(b);
+            }
+        }
+        launch_invert_diag(st, S->dp, S->inv_nsmall, S->inv_wsmall, S->inv_nwide);
+        HK_CHECK(hipStreamSynchronize(st));
+        double tot = 0;
+        for (size_t i = 0; i + 1 < evs.size(); i += 2) {
+            float ms = 0;
+            (void)hipEventElapsedTime(&ms, evs[i], evs[i + 1]);
+            tot += ms;
+        }
+        S->prof_dense4_ms = 0; S->prof_dense4_flops = 0; S->prof_dense4_launches = 0;
+        S->prof_launch_ms.clear(); S->prof_launch_flops.clear(); S->prof_launch_tiles.clear();
+        for (size_t i = 0; i + 1 < evd.size(); i += 2) {
+            float ms = 0;
+            (void)hipEventElapsedTime(&ms, evd[i], evd[i + 1]);
+            S->prof_dense4_ms += ms;
+            S->prof_dense4_flops += P.upd_stage_flops_dense[evd_level[i / 2]];
+            S->prof_dense4_launches++;
+            S->prof_launch_ms.push_back(ms);
+            S->prof_launch_flops.push_back(P.upd_stage_flops_dense[evd_level[i / 2]]);
+            S->prof_launch_tiles.push_back(P.upd_stage_ndense[evd_level[i / 2]]);
+        }
+        for (size_t i = 1; i < evd.size(); i += 2) (void)hipEventDestroy(evd[i]);
+        for (hipEvent_t e : evs) (void)hipEventDestroy(e);
+        S->prof_fb_ms = 0; S->prof_fb_launches = (int)(evf.size() / 2); S->prof_fb_panels = fb_panels; S->prof_fb_flops = fb_flops;
+        for (size_t i = 0; i + 1 < evf.size(); i += 2) {
+            float ms = 0;
+            (void)hipEventElapsedTime(&ms, evf[i], evf[i + 1]);
+            S->prof_fb_ms += ms;
+        }
+        for (hipEvent_t e : evf) (void)hipEventDestroy(e);
+        S->t_last_update = tot;
+    } else {
+        GraphSlot &g = S->g_factor;
+        const bool same = g.static_enable == static_reg_enable && g.eps_const == eps_const && g.eps_prop == eps_prop;
+        run_graphed(S, S->stream, g, same, [&] { enqueue_factor(S, static_reg_enable, eps_const, eps_prop); });
+        g.static_enable = static_reg_enable; g.eps_const = eps_const; g.eps_prop = eps_prop;
+    }
+    HK_CHECK(hipEventRecord(S->ev1, S->stream));
+    HK_CHECK(hipMemcpyAsync(S->h_flags, S->dp.flags, FL_COUNT * sizeof(int), hipMemcpyDeviceToHost, S->stream));
+    read_scalars(S);
+    float ms = 0;
+    HK_CHECK(hipEventElapsedTime(&ms, S->ev0, S->ev1));
+    S->t_last_factor = ms;
+    S->t_acc_factor += ms;
+    S->n_factor++;
+    if (S->h_flags[FL_FACFAIL] && S->use_front_block) {
+        // a spin of k_front_block ran out (a stalled workgroup): repeat this factorisation with one launch per panel, and keep that
+        S->use_front_block = false;
+        S->g_factor.valid = false;
+        fprintf(stderr, "hipkkt: a hand-off of the front-batch factorisation timed out; repeating it with one launch per panel (kept from now on)\n");
+        S->n_sweep_timeouts++;
+        return refactor_once(h, static_reg_enable, eps_const, eps_prop, eps_used, n_dynamic_reg);
+    }
+    const double maxdiag = slot_value(S, SC_MAXDIAG);
+    S->last_eps = static_reg_enable ? eps_const + eps_prop * maxdiag : 0.0;
+    S->last_nreg = S->h_flags[FL_NREG];
+    if (eps_used) *eps_used = S->last_eps;
+    if (n_dynamic_reg) *n_dynamic_reg = S->last_nreg;
+    return S->h_flags[FL_NONFINITE] ? HIPKKT_NUMERICAL_FAILURE : HIPKKT_OK;
+    HK_LEAVE
+}
+
+}  // extern "C"

@@ -1,0 +1,595 @@
+// Runtime objects, device residency of a symbolic plan and handle creation (see hipkkt_internal.h for the file map).
+#include "hipkkt_internal.h"
+
+using namespace hipkkt;
+using namespace hipkkt_host;
+
+namespace hipkkt_host {
+
+void init_runtime(hipkkt_solver *S) {
+    { const char *pz = getenv("HIPKKT_POISON"); S->poison = pz && pz[0] == '1'; }
+    HK_CHECK(hipSetDevice(S->device));
+    RuntimePool &rp = RuntimePool::get();
+    auto need = [&](void *p) { if (!p) throw DeviceError{"creating a stream / event / pinned buffer failed"}; return p; };
+    {
+        // the critical path (panel factorisations) gets the higher priority
+        S->stream = (hipStream_t)need(rp.stream_get(S->device, 0));
+        S->side = (hipStream_t)need(rp.stream_get(S->device, 1));
+        // measured on MI355X (cfg 2a): forking the far updates gives no net gain inside a hipGraph -- the far
+        // kernel fills every CU and the panel kernels on the critical path slow down by what the overlap
+        // saves -- so the fork is opt-in (HIPKKT_SIDE_STREAM=1)
+        const char *ns = getenv("HIPKKT_SIDE_STREAM");
+        S->use_side = ns && ns[0] == '1';
+        const char *fw = getenv("HIPKKT_FAR_WGS");
+        if (fw) S->far_wgs = atoi(fw);
+    }
+    static_assert(SC_COUNT * sizeof(double) <= RuntimePool::kPinned && sizeof(RefineState) <= RuntimePool::kPinned, "pinned chunk too small");
+    for (hipEvent_t *e : {&S->ev0, &S->ev1, &S->ev2, &S->ev3}) *e = (hipEvent_t)need(rp.event_get(S->device));
+    S->h_scal = (double *)need(rp.pinned_alloc(S->device));
+    S->h_flags = (int *)need(rp.pinned_alloc(S->device));
+    memset(S->h_scal, 0, SC_COUNT * sizeof(double));
+    memset(S->h_flags, 0, FL_COUNT * sizeof(int));
+    const char *ng = getenv("HIPKKT_NO_GRAPH");
+    if (ng && ng[0] == '1') S->use_graph = false;
+    for (int c = 0; c < kNumCtx; c++) {
+        SolveCtx &C = S->ctx[c];
+        if (c == 0) C.stream = S->stream;
+        else { C.stream = (hipStream_t)need(rp.stream_get(S->device, 2)); C.own_stream = true; }
+        C.ev_a = (hipEvent_t)need(rp.event_get(S->device));
+        C.ev_b = (hipEvent_t)need(rp.event_get(S->device));
+        C.h_rs = (RefineState *)need(rp.pinned_alloc(S->device));
+        C.h_flags = (int *)need(rp.pinned_alloc(S->device));
+        memset(C.h_rs, 0, sizeof(RefineState));
+        memset(C.h_flags, 0, FL_COUNT * sizeof(int));
+    }
+}
+
+
+// (re)builds every device-resident structure from S->plan and S->img (values included)
+static void build_front_batches(hipkkt_solver *S);
+void setup_device(hipkkt_solver *S) {
+    HK_CHECK(hipSetDevice(S->device));
+    for (GraphSlot *g : {&S->g_factor, &S->ctx[0].g_ldl, &S->ctx[0].g_first, &S->ctx[0].g_step, &S->ctx[1].g_ldl, &S->ctx[1].g_first,
+                         &S->ctx[1].g_step}) {
+        if (g->exec) (void)hipGraphExecDestroy(g->exec);
+        *g = GraphSlot();
+    }
+    if (!S->allocs.empty() && S->stream) (void)hipStreamSynchronize(S->stream);   // hipFree used to wait implicitly
+    for (auto &a : S->allocs) RuntimePool::get().dev_free(S->device, a.first, a.second);
+    S->allocs.clear();
+    S->slab_cur = nullptr;
+    S->slab_left = 0;
+    S->slv_items.clear(); S->bwd_items.clear(); S->reg_lvl_sn.clear(); S->pbwd_items.clear();
+    {
+        const char *np_ = getenv("HIPKKT_NO_PERSIST");
+        S->use_persist = !(np_ && np_[0] == '1');
+        S->persist_allowed = S->use_persist;
+        S->persist_retry_at = -1;
+    }
+    S->soc_off.clear(); S->soc_of_sparse.clear();
+    S->nsoc = 0; S->soc_total = 0; S->wmax_all = 1;
+    S->stage_cap = 0; S->d_stage = nullptr; S->d_stage_idx = nullptr;
+    S->d_qb = S->d_res_in = S->d_res_out = S->d_res_part = nullptr;
+
+    HostPlan &P = S->plan;
+    const int N = P.N;
+    S->N = N;
+    S->nnzK = P.nnzK;
+    // solve items: 64-row blocks (kSlvRows in kernels.hip)
+    S->slv_lvl_ptr.assign(P.nlevels + 1, 0);
+    S->bwd_lvl_ptr.assign(P.nlevels + 1, 0);
+    S->p_off.assign(P.nsuper + 1, 0);
+    for (int s = 0; s < P.nsuper; s++) {
+        int w = P.sn_first[s + 1] - P.sn_first[s];
+        int64_t r = P.sn_rowptr[s + 1] - P.sn_rowptr[s];
+        int64_t nb = std::max<int64_t>(1, (r - w + 63) / 64);
+        S->p_off[s + 1] = S->p_off[s] + nb * w;
+    }
+    S->reg_lvl_ptr.assign(P.nlevels + 1, 0);
+    const char *nn = getenv("HIPKKT_NO_NARROW");
+    const bool allow_narrow = !(nn && nn[0] == '1');
+    // ---- segments of the persistent sweeps = level ranges between two front kernels; inside a segment the wide bottom
+    //      levels (thousands of leaf supernodes) are cheaper as one launch per level, the persistent kernels take over
+    //      from the first level with fewer than kPersistMaxItems items (seg_lstar)
+    std::vector<int> dep_ptr(P.nsuper + 1, 0), dep_idx, sn_nitems(P.nsuper, 0), sn_bparent(P.nsuper, -1);
+    std::vector<int> rows_seg;
+    {
+        S->seg_of_level.assign(P.nlevels, 0);
+        std::vector<char> boundary(P.nlevels + 1, 0);
+        for (const FrontDesc &F : P.fronts) boundary[F.level_last] = 1;   // the front runs after regular level level_last
+        int sg = 0;
+        for (int l = 0; l < P.nlevels; l++) { S->seg_of_level[l] = sg; if (boundary[l]) sg++; }
+        S->nseg = sg + 1;
+        std::vector<int> lvl_items(P.nlevels, 0);      // forward items of the regular (non-front) supernodes of a level
+        for (int s = 0; s < P.nsuper; s++) {
+            if (P.sn_front[s] >= 0) continue;
+            const int64_t r = P.sn_rowptr[s + 1] - P.sn_rowptr[s];
+            const int w = P.sn_first[s + 1] - P.sn_first[s];
+            lvl_items[P.sn_level[s]] += (int)std::max<int64_t>(1, (r - w + 63) / 64);
+        }
+        const int kPersistMaxItems = 1024;
+        S->seg_lo.assign(S->nseg, P.nlevels); S->seg_hi.assign(S->nseg, -1); S->seg_lstar.assign(S->nseg, 0);
+        for (int l = 0; l < P.nlevels; l++) {
+            const int g = S->seg_of_level[l];
+            S->seg_lo[g] = std::min(S->seg_lo[g], l);
+            S->seg_hi[g] = std::max(S->seg_hi[g], l);
+        }
+        for (int g = 0; g < S->nseg; g++) {
+            int ls = S->seg_lo[g];
+            while (ls <= S->seg_hi[g] && lvl_items[ls] >= kPersistMaxItems) ls++;
+            S->seg_lstar[g] = ls;
+        }
+    }
+    // Level lists of the per-level solve kernels, appended to slv_items / bwd_items / reg_lvl_sn.  Variant 0 leaves out the
+    // panels of the fronts (the persistent front kernels solve those); variant 1 holds EVERY supernode and is what a
+    // handle falls back to after a persistent sweep timed out (front kernels included: no persistent kernel at all).
+    // On a level that gets its own launches the NARROW supernodes (<= kNarrowW columns, <= kNarrowR rows below the
+    // block: the leaves) are listed first and solved one THREAD each (k_fwd_narrow / k_bwd_narrow); they have no items.
+    std::vector<char> has_child(P.nsuper, 0);
+    for (int c = 0; c < P.nsuper; c++)
+        if (P.sn_parent[c] >= 0) has_child[P.sn_parent[c]] = 1;
+    auto build_level_lists = [&](bool with_fronts, std::vector<int> &slv_ptr, std::vector<int> &bwd_ptr, std::vector<int> &reg_ptr,
+                                 std::vector<int> &nnarrow, std::vector<int> &wnarrow) {
+        slv_ptr.assign(P.nlevels + 1, (int)S->slv_items.size());
+        bwd_ptr.assign(P.nlevels + 1, (int)S->bwd_items.size());
+        reg_ptr.assign(P.nlevels + 1, (int)S->reg_lvl_sn.size());
+        nnarrow.assign(P.nlevels, 0);
+        wnarrow.assign(P.nlevels, 1);
+        std::vector<int> nar, reg;
+        for (int l = 0; l < P.nlevels; l++) {
+            const bool own_launches = with_fronts || l < S->seg_lstar[S->seg_of_level[l]];
+            nar.clear(); reg.clear();
+            bool all_tiny = true;    // every supernode of the level has <= 4 columns and <= 16 rows below the block
+            for (int q = P.lvl_ptr[l]; q < P.lvl_ptr[l + 1]; q++) {
+                int s = P.lvl_sn[q];
+                int w = P.sn_first[s + 1] - P.sn_first[s];
+                S->wmax_all = std::max(S->wmax_all, w);
+                if (!with_fronts && P.sn_front[s] >= 0) continue;      // solved by the persistent front kernels
+                int64_t r = P.sn_rowptr[s + 1] - P.sn_rowptr[s];
+                all_tiny = all_tiny && w <= 4 && r - w <= 16;
+            }
+            for (int q = P.lvl_ptr[l]; q < P.lvl_ptr[l + 1]; q++) {
+                int s = P.lvl_sn[q];
+                int w = P.sn_first[s + 1] - P.sn_first[s];
+                if (!with_fronts && P.sn_front[s] >= 0) continue;
+                int64_t r = P.sn_rowptr[s + 1] - P.sn_rowptr[s];
+                // one thread per supernode pays for every gather of a child's update vector with a serial memory round trip:
+                // a level goes to the thread kernels as a whole when all of it is tiny; otherwise only its childless
+                // supernodes (leaves: nothing to gather) do, up to kNarrowW x kNarrowR
+                // (a thread walks its w x (r - w) panel entries one strided load after the other: bounded work per thread, and
+                // only worth it where the workgroup-per-item kernel would need several rounds of the chip: >= 2048 leaves)
+                const bool thr = all_tiny || (!has_child[s] && w <= kNarrowW && r - w <= kNarrowR && (int64_t)w * (r - w) <= 128);
+                (allow_narrow && own_launches && thr ? nar : reg).push_back(s);
+            }
+            if (nar.size() < (all_tiny ? 256u : 2048u)) { reg.insert(reg.end(), nar.begin(), nar.end()); std::sort(reg.begin(), reg.end()); nar.clear(); }
+            nnarrow[l] = (int)nar.size();
+            for (int s : nar) wnarrow[l] = std::max(wnarrow[l], P.sn_first[s + 1] - P.sn_first[s]);
+            S->reg_lvl_sn.insert(S->reg_lvl_sn.end(), nar.begin(), nar.end());
+            for (int s : reg) {
+                int w = P.sn_first[s + 1] - P.sn_first[s];
+                int64_t r = P.sn_rowptr[s + 1] - P.sn_rowptr[s];
+                int nb = (int)std::max<int64_t>(1, (r - w + 63) / 64);
+                for (int b = 0; b < nb; b++) S->slv_items.push_back({s, b});
+                if (nb > 1)
+                    for (int b = 0; b < nb; b++) S->bwd_items.push_back({s, b});
+                S->reg_lvl_sn.push_back(s);
+            }
+            slv_ptr[l + 1] = (int)S->slv_items.size();
+            bwd_ptr[l + 1] = (int)S->bwd_items.size();
+            reg_ptr[l + 1] = (int)S->reg_lvl_sn.size();
+        }
+    };
+    build_level_lists(false, S->slv_lvl_ptr, S->bwd_lvl_ptr, S->reg_lvl_ptr, S->lvl_nnarrow, S->lvl_wnarrow);
+    if (!P.fronts.empty() || S->nseg > 0) build_level_lists(true, S->all_slv_lvl_ptr, S->all_bwd_lvl_ptr, S->all_reg_lvl_ptr, S->all_lvl_nnarrow, S->all_lvl_wnarrow);
+    // ---- persistent sweeps: dependency lists, backward item order
+    {
+        auto seg_of = [&](int s) { return S->seg_of_level[P.sn_level[s]]; };
+        auto persistent = [&](int s) { return P.sn_level[s] >= S->seg_lstar[seg_of(s)]; };
+        std::vector<std::vector<int>> kids(P.nsuper);
+        for (int c = 0; c < P.nsuper; c++) {
+            const int p = P.sn_parent[c];
+            if (P.sn_front[c] >= 0) continue;
+            const int64_t r = P.sn_rowptr[c + 1] - P.sn_rowptr[c];
+            const int w = P.sn_first[c + 1] - P.sn_first[c];
+            sn_nitems[c] = (int)std::max<int64_t>(1, (r - w + 63) / 64);
+            if (p >= 0 && P.sn_front[p] < 0 && seg_of(p) == seg_of(c) && persistent(c) && persistent(p)) {
+                kids[p].push_back(c);
+                sn_bparent[c] = p;
+            }
+        }
+        for (int s = 0; s < P.nsuper; s++) {
+            dep_ptr[s + 1] = dep_ptr[s] + (int)kids[s].size();
+            dep_idx.insert(dep_idx.end(), kids[s].begin(), kids[s].end());
+        }
+        // tagged hand-off of the persistent backward sweep: mark the rows whose x is produced inside the same launch
+        {
+            auto in_seg_kernel = [&](int s) { return P.sn_front[s] < 0 && persistent(s); };
+            std::vector<int> col_sn(N, -1);
+            for (int c = 0; c < P.nsuper; c++)
+                for (int k = P.sn_first[c]; k < P.sn_first[c + 1]; k++) col_sn[k] = c;
+            rows_seg.assign(P.sn_rows.begin(), P.sn_rows.end());
+            for (int s = 0; s < P.nsuper; s++) {
+                if (!in_seg_kernel(s)) continue;
+                for (int64_t slot = P.sn_rowptr[s]; slot < P.sn_rowptr[s + 1]; slot++) {
+                    const int a = col_sn[P.sn_rows[slot]];
+                    if (a != s && a >= 0 && in_seg_kernel(a) && seg_of(a) == seg_of(s)) rows_seg[(size_t)slot] = P.sn_rows[slot] | 0x40000000;
+                }
+            }
+        }
+        // forward segments: slv_items is level-ordered, a segment is a level range
+        S->fseg_ptr.assign(2 * S->nseg, 0);   // [2g] first persistent item, [2g+1] end, of segment g
+        for (int g = 0; g < S->nseg; g++) {
+            const int ls = std::min(S->seg_lstar[g], P.nlevels);
+            S->fseg_ptr[2 * g] = S->seg_hi[g] >= 0 ? S->slv_lvl_ptr[std::min(ls, S->seg_hi[g] + 1)] : 0;
+            S->fseg_ptr[2 * g + 1] = S->seg_hi[g] >= 0 ? S->slv_lvl_ptr[S->seg_hi[g] + 1] : 0;
+        }
+        // backward items: segments in DESCENDING order of level; inside a segment levels descending, partial
+        // blocks of a level before its finalisers
+        S->bseg_ptr.assign(S->nseg + 1, 0);
+        for (int g = S->nseg - 1; g >= 0; g--) {
+            for (int l = P.nlevels - 1; l >= 0; l--) {
+                if (S->seg_of_level[l] != g || l < S->seg_lstar[g]) continue;
+                for (int q = S->reg_lvl_ptr[l]; q < S->reg_lvl_ptr[l + 1]; q++) {
+                    const int s = S->reg_lvl_sn[q];
+                    if (sn_nitems[s] > 1)
+                        for (int b = 0; b < sn_nitems[s]; b++) S->pbwd_items.push_back({s, b});
+                }
+                for (int q = S->reg_lvl_ptr[l]; q < S->reg_lvl_ptr[l + 1]; q++) S->pbwd_items.push_back({S->reg_lvl_sn[q], -1});
+            }
+            S->bseg_ptr[S->nseg - g] = (int)S->pbwd_items.size();   // bseg_ptr is indexed by launch order
+        }
+    }
+    std::vector<signed char> sgn_perm(N), kdiag(S->nnzK, 0);
+    for (int k = 0; k < N; k++) sgn_perm[k] = (signed char)(S->img.dsigns[P.perm[k]] >= 0 ? 1 : -1);
+    for (int j = 0; j < N; j++)
+        for (int64_t q = S->img.colptr[j]; q < S->img.colptr[j + 1]; q++)
+            if (S->img.rowval[q] == j) kdiag[q] = (signed char)(S->img.dsigns[j] >= 0 ? 1 : -1);
+
+    DevPlan &D = S->dp;
+    D.sn_first = S->upload(P.sn_first);
+    D.sn_rowptr = S->upload(P.sn_rowptr);
+    D.sn_rows = S->upload(P.sn_rows);
+    D.sn_panel = S->upload(P.sn_panel);
+    D.sn_diag = S->upload(P.sn_diag);
+    D.u_off = S->upload(P.u_off);
+    D.p_off = S->upload(S->p_off);
+    D.lt_off = S->upload(P.lt_off);
+    D.bwd_items = S->upload(S->bwd_items);
+    D.lvl_sn = S->upload(S->reg_lvl_sn);
+    D.perm = S->upload(P.perm);
+    D.sgn_perm = S->upload(sgn_perm);
+    {
+        // diagonal blocks wider than 16 columns (and at most 64, the blocked kernel's size) are inverted by
+        // k_invert_diag_wide, the rest by the one-wave kernel with LDS sized for the widest of them
+        std::vector<int> small, wide;
+        S->inv_wsmall = 1;
+        for (int s = 0; s < P.nsuper; s++) {
+            const int w = P.sn_first[s + 1] - P.sn_first[s];
+            if (w > 16 && w <= 64) wide.push_back(s);
+            else { small.push_back(s); S->inv_wsmall = std::max(S->inv_wsmall, w); }
+        }
+        S->inv_nsmall = (int)small.size();
+        S->inv_nwide = (int)wide.size();
+        small.insert(small.end(), wide.begin(), wide.end());
+        D.inv_list = S->upload(small);
+    }
+    D.fac_items = S->upload(P.fac_items);
+    {
+        std::vector<FacRec> recs(P.fac_items.size());
+        for (size_t q = 0; q < recs.size(); q++) {
+            const int s = P.fac_items[q].sn;
+            recs[q] = {P.sn_panel[s], P.sn_diag[s], P.lt_off[s], P.sn_first[s], P.sn_first[s + 1] - P.sn_first[s],
+                       (int32_t)(P.sn_rowptr[s + 1] - P.sn_rowptr[s]), P.fac_items[q].blk};
+        }
+        D.fac_recs = S->upload(recs);
+    }
+    D.fac_jit = S->upload(P.fac_jit);
+    D.slv_items = S->upload(S->slv_items);
+    D.rel = S->upload(P.rel);
+    D.upd_tasks = S->upload(P.upd_tasks);
+    D.upd_groups = S->upload(P.upd_groups);
+    {
+        std::vector<DenseGroup> dg(P.upd_groups.size());
+        for (size_t q = 0; q < dg.size(); q++) {
+            const UpdGroup &G = P.upd_groups[q];
+            const int t = G.tgt;
+            const int rt = (int)(P.sn_rowptr[t + 1] - P.sn_rowptr[t]);
+            dg[q] = {P.sn_panel[t] + G.row_base, rt, std::min(kUpdRows, rt - G.row_base), P.sn_first[t + 1] - P.sn_first[t],
+                     G.task_begin, G.task_end, 0};
+        }
+        D.dgroups = S->upload(dg);
+    }
+    D.upd_tmap = S->upload(P.upd_tmap);
+    {
+        std::vector<DenseTask> dt(P.upd_tasks.size());
+        for (size_t q = 0; q < dt.size(); q++) {
+            const UpdTask &T = P.upd_tasks[q];
+            const int s = T.src;
+            dt[q] = {P.sn_panel[s], (int32_t)((P.sn_rowptr[s + 1] - P.sn_rowptr[s]) * 8), P.sn_first[s + 1] - P.sn_first[s],
+                     P.sn_first[s], T.row_lo, T.nrows, T.col_lo, T.ncols, T.geom, T.vt_begin, 0};
+        }
+        D.dtasks = S->upload(dt);
+    }
+    D.gath_tgt = S->upload(P.gath_tgt);
+    D.gath_pptr = S->upload(P.gath_pptr);
+    {
+        std::vector<GathPair> gp(P.gath_src.size());
+        for (size_t q = 0; q < gp.size(); q++) {
+            const int s = P.gath_sn[q];
+            gp[q] = {P.gath_src[q], P.gath_dj[q], (int32_t)(P.sn_rowptr[s + 1] - P.sn_rowptr[s]), P.sn_first[s + 1] - P.sn_first[s], P.sn_first[s]};
+        }
+        D.gath_pairs = S->upload(gp);
+        std::vector<int64_t> heavy;
+        S->gath_heavy_ptr.assign(P.nlevels + 1, 0);
+        for (int l = 0; l < P.nlevels; l++) {
+            for (int64_t e = P.gath_stage_ptr[l]; e < P.gath_stage_ptr[l + 1]; e++)
+                if (P.gath_pptr[e + 1] - P.gath_pptr[e] > kGathHeavy) heavy.push_back(e);
+            S->gath_heavy_ptr[l + 1] = (int64_t)heavy.size();
+        }
+        D.gath_heavy = S->upload(heavy);
+    }
+    D.g_ptr = S->upload(P.g_ptr);
+    D.g_idx = S->upload(P.g_idx);
+    D.kmap = S->upload(P.kmap);
+    D.kdiag_sign = S->upload(kdiag);
+    D.sym_rowptr = S->upload(P.sym_rowptr);
+    D.sym_col = S->upload(P.sym_col);
+    D.sym_q = S->upload(P.sym_q);
+    {
+        std::vector<int> lr;
+        const int thr = long_row_threshold();
+        for (int i = 0; i < N; i++)
+            if (P.sym_rowptr[i + 1] - P.sym_rowptr[i] > thr) lr.push_back(i);
+        D.long_rows = S->upload(lr);
+        D.n_long_rows = (int)lr.size();
+    }
+    D.front_panels = S->upload(P.front_panels);
+    D.front_gptr = S->upload(P.front_gptr);
+    D.front_gidx = S->upload(P.front_gidx);
+    D.pbwd_items = S->upload(S->pbwd_items);
+    {
+        std::vector<int> dep_total(P.nsuper, 0);
+        for (int s = 0; s < P.nsuper; s++)
+            for (int q = dep_ptr[s]; q < dep_ptr[s + 1]; q++) dep_total[s] += sn_nitems[dep_idx[q]];
+        D.dep_total = S->upload(dep_total);
+    }
+    D.sn_nitems = S->upload(sn_nitems);
+    D.sn_bparent = S->upload(sn_bparent);
+    D.nseg = S->nseg;
+    {
+        const char *tk = getenv("HIPKKT_SEG_TICKET");      // 0: item = blockIdx (A/B timing of the ticket's cost)
+        D.seg_ticket = tk ? atoi(tk) : 3;                  // bit 0: forward sweep, bit 1: backward sweep
+        const char *sl = getenv("HIPKKT_SPIN_LIMIT");      // tests force a sweep time-out with a tiny bound
+        D.spin_limit = sl ? (unsigned)strtoul(sl, nullptr, 10) : (1u << 20);
+    }
+    {
+        const size_t nsync = seg_sync_ints(S->nseg, P.nsuper);
+        D.seg_sync = S->dalloc<int>(nsync);
+        fill_async(S->stream, D.seg_sync, 0, nsync * sizeof(int));
+    }
+    D.front_sync = S->dalloc<int>(std::max(P.front_sync_ints, 16));
+    fill_async(S->stream, D.front_sync, 0, (size_t)std::max(P.front_sync_ints, 16) * sizeof(int));
+    build_front_batches(S);
+    D.kval = S->upload(S->img.nzval);
+    D.Lx = S->dalloc<double>(P.panel_doubles);
+    D.Ldiag = S->dalloc<double>(P.diag_doubles);
+    D.Linv = S->dalloc<double>(P.diag_doubles);
+    D.LinvT = S->dalloc<double>(P.diag_doubles);
+    D.LT = S->dalloc<double>(P.lt_off[P.nsuper]);
+    D.D = S->dalloc<double>(N);
+    D.Dinv = S->dalloc<double>(N);
+    D.ubuf = S->dalloc<double>(P.ubuf_len);
+    D.pbuf = S->dalloc<double>(S->p_off[P.nsuper]);
+    {
+        // slots start out all-zero = invalid in every epoch
+        const size_t nx = (size_t)std::max(N, 1), np_ = (size_t)std::max<int64_t>(S->p_off[P.nsuper], 1);
+        D.xseg = (FrontSlot *)S->dalloc<double>(2 * nx);
+        D.pseg = (FrontSlot *)S->dalloc<double>(2 * np_);
+        fill_async(S->stream, D.xseg, 0, 16 * nx);
+        fill_async(S->stream, D.pseg, 0, 16 * np_);
+        D.seg_epoch = S->dalloc<int>(4);
+        fill_async(S->stream, D.seg_epoch, 0, 4 * sizeof(int));
+        D.rows_seg = S->upload(rows_seg);
+    }
+    D.scal = S->dalloc<double>(SC_COUNT);
+    D.flags = S->dalloc<int>(FL_COUNT);
+    fill_async(S->stream, D.scal, 0, SC_COUNT * sizeof(double));
+    fill_async(S->stream, D.flags, 0, FL_COUNT * sizeof(int));
+    fill_async(S->stream, D.Dinv, 0, (size_t)std::max(N, 1) * sizeof(double));
+    fill_async(S->stream, D.Ldiag, 0, (size_t)std::max<int64_t>(P.diag_doubles, 1) * sizeof(double));
+
+    S->d_diag_full = S->upload(S->img.diag_full);
+    if (S->l1) {
+        S->d_mapHs = S->upload(S->img.mapHs);
+        S->d_mapP = S->upload(S->img.mapP);
+        S->d_mapA = S->upload(S->img.mapA);
+        // concatenated SOC expansion maps
+        std::vector<int64_t> uidx, vidx, didx;
+        std::vector<int> coneof;
+        S->soc_of_sparse.assign(S->img.smaps.size(), -1);
+        for (size_t i = 0; i < S->img.smaps.size(); i++) {
+            const SparseMap &sm = S->img.smaps[i];
+            if (sm.kind != 1) continue;
+            S->soc_of_sparse[i] = S->nsoc;
+            S->soc_off.push_back((int64_t)uidx.size());
+            for (size_t q = 0; q < sm.vec[0].size(); q++) {
+                uidx.push_back(sm.vec[0][q]);
+                vidx.push_back(sm.vec[1][q]);
+                coneof.push_back(S->nsoc);
+            }
+            didx.push_back(sm.D[0]);
+            didx.push_back(sm.D[1]);
+            S->nsoc++;
+        }
+        S->soc_off.push_back((int64_t)uidx.size());
+        S->soc_total = (int64_t)uidx.size();
+        S->d_soc_uidx = S->upload(uidx);
+        S->d_soc_vidx = S->upload(vidx);
+        S->d_soc_didx = S->upload(didx);
+        S->d_soc_cone = S->upload(coneof);
+        S->d_soc_u = S->dalloc<double>(S->soc_total);
+        S->d_soc_v = S->dalloc<double>(S->soc_total);
+        S->d_soc_eta2 = S->dalloc<double>(S->nsoc);
+    }
+    for (int c = 0; c < kNumCtx; c++) {
+        SolveCtx &C = S->ctx[c];
+        for (double **v : {&C.d_b, &C.d_x0, &C.d_x1, &C.d_e, &C.d_corr, &C.d_y, &C.d_z, &C.d_xp}) {
+            *v = S->dalloc<double>(N);
+            fill_async(S->stream, *v, 0, (size_t)std::max(N, 1) * sizeof(double));
+        }
+        C.d_rs = (RefineState *)S->dalloc<double>(sizeof(RefineState) / sizeof(double) + 1);
+        fill_async(S->stream, C.d_rs, 0, sizeof(RefineState));
+        C.dp = D;
+        if (c > 0) {   // private copies of everything a solve writes besides its vectors
+            const size_t nx = (size_t)std::max(N, 1), np_ = (size_t)std::max<int64_t>(S->p_off[P.nsuper], 1);
+            const size_t nsync = seg_sync_ints(S->nseg, P.nsuper), nfs = (size_t)std::max(P.front_sync_ints, 16);
+            C.dp.ubuf = S->dalloc<double>(P.ubuf_len);
+            C.dp.pbuf = S->dalloc<double>(S->p_off[P.nsuper]);
+            C.dp.xseg = (FrontSlot *)S->dalloc<double>(2 * nx);
+            C.dp.pseg = (FrontSlot *)S->dalloc<double>(2 * np_);
+            fill_async(S->stream, C.dp.xseg, 0, 16 * nx);
+            fill_async(S->stream, C.dp.pseg, 0, 16 * np_);
+            C.dp.seg_epoch = S->dalloc<int>(4);
+            fill_async(S->stream, C.dp.seg_epoch, 0, 4 * sizeof(int));
+            C.dp.seg_sync = S->dalloc<int>(nsync);
+            fill_async(S->stream, C.dp.seg_sync, 0, nsync * sizeof(int));
+            C.dp.front_sync = S->dalloc<int>(nfs);
+            fill_async(S->stream, C.dp.front_sync, 0, nfs * sizeof(int));
+            C.dp.scal = S->dalloc<double>(SC_COUNT);
+            C.dp.flags = S->dalloc<int>(FL_COUNT);
+            fill_async(S->stream, C.dp.scal, 0, SC_COUNT * sizeof(double));
+            fill_async(S->stream, C.dp.flags, 0, FL_COUNT * sizeof(int));
+        }
+        C.ir_used = false;
+        C.h_rs->cur = 0;
+    }
+    // legacy names = context 0
+    S->d_b = S->ctx[0].d_b; S->d_x = S->ctx[0].d_x0; S->d_dx = S->ctx[0].d_x1; S->d_e = S->ctx[0].d_e;
+    S->d_sin = S->ctx[0].d_b; S->d_sout = S->ctx[0].d_corr; S->d_y = S->ctx[0].d_y; S->d_z = S->ctx[0].d_z; S->d_xp = S->ctx[0].d_xp;
+    S->ensure_stage(std::max<int64_t>(1024, std::max<int64_t>(S->img.nHs, N)));
+    HK_CHECK(hipStreamSynchronize(S->stream));
+}
+
+// One launch of k_front_block per qualifying update batch of a front (symbolic.cpp front_batches).  HIPKKT_FRONT_BLOCK=0: never.
+static void build_front_batches(hipkkt_solver *S) {
+    const HostPlan &P = S->plan;
+    S->fbatches.clear(); S->fb_last_level.clear();
+    S->lvl_fb.assign(std::max(P.nlevels, 1), -1);
+    const char *e = getenv("HIPKKT_FRONT_BLOCK");
+    if (e && e[0] == '0') S->use_front_block = false;
+    if (S->use_front_block)
+        for (const FrontBatchHost &H : front_batches(P, S->plan_opts.update_policy, kFbMax)) {
+            const FrontDesc &F = P.fronts[H.front];
+            FrontBatch B;
+            B.fp_off = F.fp_off + H.p0;
+            B.nb = H.nb;
+            B.r0 = P.front_panels[F.fp_off + H.p0].r;
+            B.nblk = (B.r0 + 63) / 64;
+            B.sync_off = 128 * (int)S->fbatches.size();
+            B.scratch_off = kFbScratch * (int64_t)S->fbatches.size();
+            S->lvl_fb[H.level_first] = (int)S->fbatches.size();
+            for (int l = H.level_first + 1; l <= H.level_last; l++) S->lvl_fb[l] = -2;
+            S->fbatches.push_back(B);
+            S->fb_last_level.push_back(H.level_last);
+        }
+    if (getenv("HIPKKT_VERBOSE")) fprintf(stderr, "hipkkt: %zu front batch(es) factored by one launch each (fronts %zu, update batch %d)\n", S->fbatches.size(), P.fronts.size(), P.update_batch_used);
+    const size_t nb_ = std::max<size_t>(S->fbatches.size(), 1);
+    S->d_fb_sync = S->dalloc<int>(128 * nb_);
+    S->d_fb_scratch = S->dalloc<double>((size_t)kFbScratch * nb_);
+    fill_async(S->stream, S->d_fb_sync, 0, 128 * nb_ * sizeof(int));
+    if (getenv("HIPKKT_FB_TRACE")) {
+        S->d_fb_trace = (long long *)S->dalloc<double>(nb_ * 128);
+        fill_async(S->stream, S->d_fb_trace, 0, nb_ * 128 * sizeof(double));
+    }
+}
+
+int32_t finish_create(hipkkt_solver *S, const hipkkt_opts *opts, hipkkt_handle *out) {
+    PlanOptions po;
+    po.max_width = opts->supernode_max_width > 0 ? opts->supernode_max_width : kMaxSnWidth;
+    po.relax = opts->relax_supernodes != 0;
+    po.update_policy = opts->update_policy;
+    if (opts->update_batch > 0) po.update_batch = opts->update_batch;
+    po.amd_dense_scale = opts->amd_dense_scale > 0 ? opts->amd_dense_scale : 1.5;
+    po.front_min_panels = opts->front_min_panels == 0 ? 4 : std::max(0, opts->front_min_panels);
+    po.n_hold = S->l1 ? (int)S->img.n : 0;
+    {
+        const char *ns = getenv("HIPKKT_SIDE_STREAM");
+        po.split_far = ns && ns[0] == '1';
+        const char *mr = getenv("HIPKKT_FRONT_BLOCK_MIN_ROWS");   // tests: 0, so that small fronts take the front-batch kernel too
+        if (mr) po.front_block_min_width = atoi(mr);
+        const char *dc = getenv("HIPKKT_DENSE_COVER");   // A/B: threshold between the tile path and the gather lists
+        if (dc && atof(dc) > 0) po.dense_min_cover = atof(dc);
+        const char *nf = getenv("HIPKKT_FUSE_JIT");    // experiment: just-in-time updates inside the panel kernel
+        if (nf && nf[0] == '1') po.fuse_jit = true;
+        const char *nx = getenv("HIPKKT_XCD_ORDER");   // measured: no effect on cfg 2a (L2 locality is not the limiter)
+        po.xcd_order = nx && nx[0] == '1';
+    }
+    {
+        const char *nh = getenv("HIPKKT_ORDERING");   // "amd": minimum degree on K only
+        if (nh && nh[0] == 'a') po.n_hold = 0;
+    }
+    {
+        const char *nf = getenv("HIPKKT_NO_FRONT");
+        if (nf && nf[0] == '1') po.front_min_panels = 0;
+    }
+    std::vector<int64_t> up;
+    const int64_t *uperm = nullptr;
+    if (opts->user_perm) {
+        up.resize(S->img.N);
+        for (int64_t k = 0; k < S->img.N; k++) up[k] = opts->user_perm[k] - opts->index_base;
+        uperm = up.data();
+    }
+    if (S->img.N >= ((int64_t)1 << 31)) { g_create_error = "N exceeds int32"; delete S; return HIPKKT_ERR_ARGUMENT; }
+    {
+        // The "cone rows first" order can break down on an ill-conditioned iterate; the factorisation is
+        // then repeated on a twin handle in the minimum-degree order.  Its symbolic analysis is seconds of host work on the
+        // problems that take this path (dense PSD blocks), so it starts on a host thread as soon as the minimum-degree order is
+        // known and the cheap order is about to be evaluated against it -- speculatively: if the cheap order is not chosen the
+        // thread is cancelled at its next phase boundary (HIPKKT_TWIN_AHEAD=0: analysed only when it is needed).
+        const char *ta = getenv("HIPKKT_TWIN_AHEAD");
+        if (!(ta && ta[0] == '0') && S->l1)
+            po.on_alternative_order = [S, &po](const std::vector<int> &perm_md) {
+                std::unique_ptr<hipkkt_solver> T(new hipkkt_solver());
+                T->device = S->device;
+                T->opts = S->opts;
+                T->l1 = S->l1;
+                T->img = S->img;
+                PlanOptions po2 = po;
+                po2.n_hold = 0;
+                po2.on_alternative_order = nullptr;
+                S->twin_cancel = std::make_shared<std::atomic<bool>>(false);
+                po2.cancel = S->twin_cancel.get();
+                T->plan_opts = po2;
+                hipkkt_solver *Tp = T.get();
+                std::vector<int64_t> pv(perm_md.begin(), perm_md.end());
+                S->twin_pending = std::move(T);
+                S->twin_future = std::async(std::launch::async, [Tp, pv, po2]() {
+                    return build_plan((int)Tp->img.N, Tp->img.colptr.data(), Tp->img.rowval.data(), pv.data(), po2, Tp->plan);
+                });
+            };
+    }
+    const auto t_a = std::chrono::steady_clock::now();
+    std::string err = build_plan((int)S->img.N, S->img.colptr.data(), S->img.rowval.data(), uperm, po, S->plan);
+    po.on_alternative_order = nullptr;
+    if (!err.empty()) { g_create_error = err; delete S; return HIPKKT_ERR_ARGUMENT; }
+    if (S->plan.ordering_used != 1 && S->twin_cancel) S->twin_cancel->store(true);   // speculative twin not needed: the thread stops at its next phase
+    S->plan_opts = po;
+    const auto t_b = std::chrono::steady_clock::now();
+    try {
+        if (!S->runtime_ready) init_runtime(S);
+        S->runtime_ready = true;
+        setup_device(S);
+        if (getenv("HIPKKT_VERBOSE"))
+            fprintf(stderr, "hipkkt: N %d nnzL %lld levels %d ordering %d: symbolic %.2f ms (%s), device set-up %.2f ms, runtime objects %.2f ms\n", S->plan.N, (long long)S->plan.nnzL,
+                    S->plan.nlevels, S->plan.ordering_used, 1e3 * std::chrono::duration<double>(t_b - t_a).count(), S->plan.timing_note.c_str(),
+                    1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t_b).count(), 1e3 * S->t_init_runtime);
+    } catch (const DeviceError &e) {
+        g_create_error = e.msg; delete S; return HIPKKT_ERR_DEVICE;
+    } catch (const std::bad_alloc &) {
+        g_create_error = "out of (device) memory"; delete S; return HIPKKT_ERR_ALLOC;
+    }
+    *out = S;
+    return HIPKKT_OK;
+}
+
+}  // namespace hipkkt_host

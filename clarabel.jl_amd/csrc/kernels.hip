@@ -844,7 +844,7 @@ __device__ __forceinline__ void dense_tile(const DevPlan &P, const DenseGroup *G
     dense_tile_core<NT, NR, false>(P, tp, rt, nrt, wt, task_begin, task_end, lane, tj0, ti0, nullptr);
 }
 
-// Grid-stride over the tiles of a launch (a bounded grid is used by the look-ahead experiments, hipkkt.cpp).
+// Grid-stride over the tiles of a launch (a bounded grid is used by the look-ahead experiments, hipkkt_factor.cpp).
 template <int NT, int NR>
 __global__ void __launch_bounds__(256, NT == 2 ? 4 : 2)
 k_update_dense(DevPlan P, int group_begin, int ngroups) {
@@ -1536,7 +1536,7 @@ __device__ __forceinline__ SegSync seg_sync(const DevPlan &P, int nsuper) {
     SegSync s;
     s.ftick = P.seg_sync;                                 // ticket words: [0, 2 nseg), padded to whole 128-byte lines
     s.btick = P.seg_sync + P.nseg;
-    s.fdone = P.seg_sync + ((2 * P.nseg + 31) & ~31);     // (mirrored by seg_sync_ints() in hipkkt.cpp)
+    s.fdone = P.seg_sync + ((2 * P.nseg + 31) & ~31);     // (mirrored by seg_sync_ints() in hipkkt_internal.h)
     s.bdone = s.fdone + nsuper;
     s.pdone = s.bdone + nsuper;
     s.err = s.pdone + nsuper;
@@ -1612,7 +1612,7 @@ k_fwd_seg(DevPlan P, int seg, int item_begin, int nitems, int nsuper, int first_
     // item = a ticket taken in arrival order (level order): an item only ever waits for items with lower tickets, whose
     // owners are therefore already running -- forward progress does not depend on the order in which the hardware
     // dispatches workgroups.  One atomic per workgroup (~11 ns each on one word); the wide bottom levels, where that
-    // would add up, are not part of the persistent launches (hipkkt.cpp kPersistMaxItems).  seg_ticket bit 0 clear selects
+    // would add up, are not part of the persistent launches (hipkkt_setup.cpp kPersistMaxItems).  seg_ticket bit 0 clear selects
     // item = blockIdx (in-order dispatch assumed; kept for A/B timing only: HIPKKT_SEG_TICKET=0; bit 1 = backward sweep).
     if (P.seg_ticket & 1) {
         if (tid == 0) sb = atomicAdd(Y.ftick + seg, 1);
@@ -2141,7 +2141,7 @@ __global__ void k_check_finite(const double *__restrict__ v, int n, int *__restr
 }
 
 // ------------------------------------------------------------------------------------------
-// host-callable launchers (used by hipkkt.cpp; all launches go to the handle's stream)
+// host-callable launchers (used by the hipkkt_*.cpp host files; all launches go to the handle's stream)
 // ------------------------------------------------------------------------------------------
 static inline unsigned nblk(int64_t n, int bs = 256) { return (unsigned)((n + bs - 1) / bs); }
 
