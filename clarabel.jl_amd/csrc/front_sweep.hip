@@ -1,0 +1,472 @@
+// K5 over a FRONT, super-block sweeps (round 3; VERDICT r2 task 1): the per-panel sweeps of kernels.hip (k_front_fwd / k_front_bwd)
+// pay one inter-workgroup hand-off per 64-column panel -- 88 dependent hops of ~1.7 us on the 5617-column root of a random sparse
+// QP, at 14 % of the HBM roofline.  Here the np panels of a front are grouped into super-blocks of kSbG = 5 consecutive panels and
+// the explicit inverse of every super-block's unit-lower diagonal block (5 x 5 tiles of 64 x 64, formed after each factorisation by
+// k_invert_super from the panels and the per-panel inverses) replaces the five dependent panel solves:
+//
+//   forward, workgroup b (row block b, super-block B = b / g):
+//       r_b = b_b - (external children) - sum_{q < gB} L[b,q] y_q          L tiles of a whole super-block per hop, prefetched
+//       publish r_b, wait for r_c of the earlier panels c of the own super-block
+//       y_b = sum_{gB <= c <= b} Inv[b,c] r_c                              Inv tiles prefetched like one more group of L tiles
+//   backward, ticket t -> panel p = np-1-t: the mirror image with L^T (row-major copy LT) and Inv^T.
+//
+// Two hand-offs per super-block instead of five: 18 x 2 hops on that root instead of 88.  The hand-off itself is unchanged
+// (self-validating 16-byte slots, sweep_common.h); a second set of slots carries the partial right-hand sides r / s.  Workgroups
+// have 16 wavefronts: wave w < 5 polls panel w of the awaited super-block, thread (lane = row, wave v) owns the columns v + 16 t of
+// every tile (4 values per tile, two groups of 5 tiles in registers).  Same guarantees as the per-panel sweeps: tickets in arrival order
+// (a workgroup only waits for lower tickets), bounded spins that fail the solve through FL_FRONTFAIL, fixed summation order.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels.h"
+#include "sweep_common.h"
+
+namespace hipkkt {
+
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+constexpr int SLD = 65;            // LDS row stride of a 64 x 64 tile
+constexpr int kSbThreads = 1024;   // 16 wavefronts: 4 values per tile and thread (two groups of 5 tiles = 80 VGPRs of the 128 available)
+constexpr int NW = kSbThreads / 64;  // wavefronts per workgroup
+constexpr int NT = 64 / NW;          // tile columns (forward) / rows (backward) per thread
+static_assert(kSbMaxPanels * 16 <= 24 * 1024, "panel table of the sweeps must fit into LDS");
+
+__device__ __forceinline__ int64_t sb_tile(const FrontDesc &F, int B, int bl, int cl) {   // symbolic.h FrontDesc::sbinv_off
+    return F.sbinv_off + ((int64_t)B * (kSbG * (kSbG - 1) / 2) + bl * (bl - 1) / 2 + cl) * 8192;
+}
+#define SB_GLOBAL __attribute__((address_space(1)))
+__device__ __forceinline__ double sb_ld(const double *base, unsigned byte_off) {   // uniform base + 32-bit lane offset (saddr form)
+    return *(const SB_GLOBAL double *)((const SB_GLOBAL char *)base + byte_off);
+}
+// wave-uniform values are forced into SGPRs (a FrontPanel record read through a plain pointer lands in VGPRs otherwise)
+__device__ __forceinline__ int sb_rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ int64_t sb_rfl64(int64_t v) {
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(uint64_t)v), hi = __builtin_amdgcn_readfirstlane((unsigned)((uint64_t)v >> 32));
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ double sum_waves(const double (*red)[64], int lane) {   // fixed tree over the NW partial sums
+    double q[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) q[c] = (red[4 * c][lane] + red[4 * c + 1][lane]) + (red[4 * c + 2][lane] + red[4 * c + 3][lane]);
+    return (q[0] + q[1]) + (q[2] + q[3]);
+}
+static_assert(NW == 16 && NT == 4, "sum_waves and the 4-way accumulators assume 16 wavefronts");
+
+// ------------------------------------------------------------------------------------------
+// Inverse of the super-blocks' diagonal blocks: Inv[b,c] = -Linv_b * sum_{c <= k < b} L[b,k] Inv[k,c]  (Inv[c,c] = Linv_c, the
+// per-panel inverse of k_invert_diag / k_invert_diag_wide).  One workgroup per (super-block, column c); the 64 x 64 x 64 products
+// run on the matrix core with both operands in LDS.  Tiles are padded to 64 x 64 with zeros (panels narrower than 64 columns).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void sb_load_linv(const DevPlan &P, const FrontPanel &pn, double *S, int tid) {   // S[row * SLD + col]
+    const double *li = P.Linv + pn.diag_off;
+    for (int idx = tid; idx < 4096; idx += 256) {
+        const int i = idx & 63, k = idx >> 6;
+        S[i * SLD + k] = (i < pn.w && k <= i) ? li[i + k * pn.w] : 0.0;
+    }
+}
+__device__ __forceinline__ void sb_mm(const double *A, const double *Bm, v4f64 (&c)[4], int wv, int l15, int lk) {
+    // c[sub] += A(rows 16 wv ..) * B(:, 16 sub ..); output layout: column 16 sub + l15, rows 16 wv + lk + 4 reg
+#pragma unroll 4
+    for (int kk = 0; kk < 16; kk++) {
+        const double a = A[(16 * wv + l15) * SLD + 4 * kk + lk];
+#pragma unroll
+        for (int sub = 0; sub < 4; sub++)
+            c[sub] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Bm[(4 * kk + lk) * SLD + 16 * sub + l15], c[sub], 0, 0, 0);
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_invert_super(DevPlan P, FrontDesc F) {
+    __shared__ double SA[64 * SLD], SB[64 * SLD];
+    const int B = blockIdx.x / (kSbG - 1), cl = blockIdx.x % (kSbG - 1);
+    const int nbB = min(kSbG, F.np - kSbG * B);
+    if (cl + 1 >= nbB) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, lk = lane >> 4;
+    const FrontPanel *fps = P.front_panels + F.fp_off;
+    const FrontPanel pc = fps[kSbG * B + cl];
+    for (int bl = cl + 1; bl < nbB; bl++) {
+        const FrontPanel pb = fps[kSbG * B + bl];
+        v4f64 acc[4];
+#pragma unroll
+        for (int sub = 0; sub < 4; sub++) acc[sub] = (v4f64){0.0, 0.0, 0.0, 0.0};
+        for (int kl = cl; kl < bl; kl++) {
+            const FrontPanel pk = fps[kSbG * B + kl];
+            const double *src = P.Lx + pk.panel_off + F.cw * (bl - kl);      // L[bl,kl]: rows of block bl inside panel kl
+            for (int idx = tid; idx < 4096; idx += 256) {
+                const int i = idx & 63, k = idx >> 6;
+                SA[i * SLD + k] = (i < pb.w && k < pk.w) ? src[i + (int64_t)k * pk.r] : 0.0;
+            }
+            if (kl == cl) {
+                sb_load_linv(P, pc, SB, tid);
+            } else {
+                const double *t = P.SbInv + sb_tile(F, B, kl, cl);           // written earlier by THIS workgroup (column-major)
+                for (int idx = tid; idx < 4096; idx += 256) SB[(idx & 63) * SLD + (idx >> 6)] = front_ld(t + idx);
+            }
+            __syncthreads();
+            sb_mm(SA, SB, acc, wv, l15, lk);
+            __syncthreads();
+        }
+#pragma unroll
+        for (int sub = 0; sub < 4; sub++)
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) SB[(16 * wv + lk + 4 * reg) * SLD + 16 * sub + l15] = acc[sub][reg];
+        sb_load_linv(P, pb, SA, tid);
+        __syncthreads();
+        v4f64 o[4];
+#pragma unroll
+        for (int sub = 0; sub < 4; sub++) o[sub] = (v4f64){0.0, 0.0, 0.0, 0.0};
+        sb_mm(SA, SB, o, wv, l15, lk);
+        __syncthreads();
+#pragma unroll
+        for (int sub = 0; sub < 4; sub++)
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) SA[(16 * wv + lk + 4 * reg) * SLD + 16 * sub + l15] = -o[sub][reg];
+        __syncthreads();
+        double *t = P.SbInv + sb_tile(F, B, bl, cl);
+        for (int idx = tid; idx < 4096; idx += 256) front_st(t + idx, SA[(idx & 63) * SLD + (idx >> 6)]);            // [i + 64 k]
+        for (int idx = tid; idx < 4096; idx += 256) t[4096 + idx] = SA[(idx >> 6) * SLD + (idx & 63)];             // [64 i + k]
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// forward sweep
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kSbThreads)
+k_front_fwd_sb(DevPlan P, FrontDesc F, double *__restrict__ y, double *__restrict__ z) {
+    __shared__ double red[NW][64];
+    __shared__ double ybuf[2][kSbG][64];
+    __shared__ double rbuf[kSbG][64];
+    __shared__ int64_t pn_off[kSbMaxPanels];   // panel table of the front in LDS: reading a record must not wait on the tile loads in flight
+    __shared__ int pn_r[kSbMaxPanels], pn_w[kSbMaxPanels];
+    __shared__ int sb, okflag;
+    int *sync = P.front_sync + F.sync_off;
+    for (int q = threadIdx.x; q < kSbG * 64; q += kSbThreads) (&rbuf[0][0])[q] = 0.0;
+    for (int q = threadIdx.x; q < F.np; q += kSbThreads) {
+        const FrontPanel *fp_ = P.front_panels + F.fp_off + q;
+        pn_off[q] = fp_->panel_off; pn_r[q] = fp_->r; pn_w[q] = fp_->w;
+    }
+    if (threadIdx.x == 0) { sb = atomicAdd(sync, 1); okflag = 1; }
+    __syncthreads();
+    const int b = sb_rfl(sb);                   // wave-uniform for the compiler too: scalar branches, SGPR tile bases
+    if (b >= F.nb) return;
+    // re-arm the backward sweep's block (idle during this launch), every workgroup a share
+    for (int q = b * kSbThreads + threadIdx.x; q < F.sync_blk; q += F.nb * kSbThreads) sync[F.sync_blk + q] = 0;
+    FrontSlot *yslots = front_slots(sync, F.np), *rslots = yslots + (int64_t)F.np * 64;
+    const int tid = threadIdx.x, lane = tid & 63, wv = sb_rfl(tid >> 6);
+    const FrontPanel *fps = P.front_panels + F.fp_off;
+    const int g = kSbG;
+    const bool own = b < F.np;
+    struct { int w, f; int64_t diag_off; } me;
+    {
+        const FrontPanel *mp = fps + (own ? b : 0);
+        me.w = sb_rfl(mp->w); me.f = sb_rfl(mp->f); me.diag_off = sb_rfl64(mp->diag_off);
+    }
+    const int B = own ? b / g : F.nsb, bl = own ? b - g * B : 0;
+    const int i0 = own ? F.cw * b : F.W + 64 * (b - F.np);
+    const int nrows = own ? me.w : min(64, F.rF - i0);
+    const int i = i0 + lane;
+    const bool valid = lane < nrows;
+    // this row's start value: own rows  b_i - (external children), rows below the front  + (external children)
+    double base = 0.0;
+    if (wv == 0 && valid) {
+        double G = 0.0;
+        const int64_t g0 = P.front_gptr[F.gptr_off + i], g1 = P.front_gptr[F.gptr_off + i + 1];
+        for (int64_t gq = g0; gq < g1; gq++) G += P.ubuf[P.front_gidx[gq]];
+        base = own ? y[me.f + lane] - G : G;
+    }
+    const double dinv_own = (own && valid && wv == 0) ? P.Dinv[me.f + lane] : 0.0;
+    const int nQ = own ? B : F.nsb;            // super-blocks whose panels this row block accumulates
+    double cur[kSbG][NT], nxt[kSbG][NT];       // the group being consumed and the one prefetched behind it
+    // the L tiles of super-block G on this row block
+    auto load_L = [&](int G, double (&dst)[kSbG][NT]) {
+#pragma unroll
+        for (int p = 0; p < kSbG; p++) {
+            const int q = g * G + p;
+            const int qc = q < F.np ? q : F.np - 1;
+            const int fq_r = sb_rfl(pn_r[qc]), fq_w = sb_rfl(pn_w[qc]);
+            const double *pb = P.Lx + sb_rfl64(pn_off[qc]);
+            const unsigned o0 = (unsigned)(i - F.cw * q + wv * fq_r) * 8u, os = (unsigned)fq_r * (8u * NW);
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+                const int k = wv + NW * t;
+                dst[p][t] = (q < F.np && valid && k < fq_w) ? sb_ld(pb, o0 + (unsigned)t * os) : 0.0;
+            }
+        }
+    };
+    // the inverse tiles Inv[b, gB .. b] (own rows; zeros for the rows below the front)
+    auto load_inv = [&](double (&dst)[kSbG][NT]) {
+#pragma unroll
+        for (int p = 0; p < kSbG; p++) {
+            if (own && p < bl) {                 // (uniform) a full tile of the super-block inverse, column-major
+                const double *tl = P.SbInv + sb_tile(F, B, bl, p);
+#pragma unroll
+                for (int t = 0; t < NT; t++) dst[p][t] = valid ? sb_ld(tl, (unsigned)(lane + 64 * (wv + NW * t)) * 8u) : 0.0;
+            } else if (own && p == bl) {         // the panel's own inverse (lower triangular, w x w column-major)
+                const double *li = P.Linv + me.diag_off;
+#pragma unroll
+                for (int t = 0; t < NT; t++) {
+                    const int k = wv + NW * t;
+                    dst[p][t] = (valid && k <= lane) ? sb_ld(li, (unsigned)(lane + k * me.w) * 8u) : 0.0;
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < NT; t++) dst[p][t] = 0.0;
+            }
+        }
+    };
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    // wait for the y of super-block Q's panels while the next group is prefetched into `nxt`, accumulate `cur`, cur <- nxt;
+    // false = give up.  The polling waves issue their share of the prefetch AFTER their poll has succeeded: a wave's loads return
+    // in order, so a poll behind 20 tile loads could not see its slot before those have landed (they then have a whole hop to land).
+    auto consume = [&](int Q, auto &&prefetch) -> bool {
+        double (*yb)[64] = ybuf[Q & 1];
+        if (wv < kSbG) {                         // wave w polls the 64 slots of panel g Q + w (value and validity in one load per lane)
+            const int q = g * Q + wv;
+            double v = 0.0;
+            if (q < F.np) {
+                const bool okw = front_slot_wait(yslots + q * 64 + lane, v, sync + 1, P.flags + FL_FRONTFAIL, P.spin_limit);
+                if (!okw) { v = 0.0; if (lane == 0) okflag = 0; }
+            }
+            yb[wv][lane] = v;
+        }
+        prefetch();
+        __syncthreads();
+        if (!okflag) return false;
+#pragma unroll
+        for (int p = 0; p < kSbG; p++) {
+            a0 = fma(cur[p][0], yb[p][wv], a0);
+            a1 = fma(cur[p][1], yb[p][wv + NW], a1);
+            a2 = fma(cur[p][2], yb[p][wv + 2 * NW], a2);
+            a3 = fma(cur[p][3], yb[p][wv + 3 * NW], a3);
+        }
+#pragma unroll
+        for (int p = 0; p < kSbG; p++)
+#pragma unroll
+            for (int t = 0; t < NT; t++) cur[p][t] = nxt[p][t];
+        return true;
+    };
+    bool ok = true;
+    if (nQ > 0) {
+        load_L(0, cur);
+        for (int Q = 0; Q + 1 < nQ && ok; Q++) ok = consume(Q, [&] { load_L(Q + 1, nxt); });
+        if (ok) ok = consume(nQ - 1, [&] { load_inv(nxt); });      // the last hop prefetches the inverse tiles instead
+    } else {
+        load_inv(cur);
+    }
+    red[wv][lane] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (!own) {
+        if (wv == 0 && valid && ok) P.ubuf[F.ubelow_off + (i - F.W)] = base + sum_waves(red, lane);
+        return;
+    }
+    if (wv == 0) {                               // partial right-hand side of this panel: to the later panels of the super-block
+        const double r = valid ? base - sum_waves(red, lane) : 0.0;
+        rbuf[bl][lane] = r;
+        if (ok) front_slot_st(rslots + b * 64 + lane, r);
+    } else if (wv <= bl) {                       // wave w polls r of panel g B + w - 1
+        const int c = wv - 1;
+        double v = 0.0;
+        const bool okw = ok && front_slot_wait(rslots + (g * B + c) * 64 + lane, v, sync + 1, P.flags + FL_FRONTFAIL, P.spin_limit);
+        if (!okw) { v = 0.0; if (lane == 0) okflag = 0; }
+        rbuf[c][lane] = v;
+    }
+    __syncthreads();
+    if (!okflag) return;
+    {   // y_b = sum_c Inv[b,c] r_c  (tiles of the panels after b in the super-block are zero)
+        auto gemv = [&](const double (&iv)[kSbG][NT]) {
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+            for (int p = 0; p < kSbG; p++) {
+                s0 = fma(iv[p][0], rbuf[p][wv], s0);
+                s1 = fma(iv[p][1], rbuf[p][wv + NW], s1);
+                s2 = fma(iv[p][2], rbuf[p][wv + 2 * NW], s2);
+                s3 = fma(iv[p][3], rbuf[p][wv + 3 * NW], s3);
+            }
+            red[wv][lane] = (s0 + s1) + (s2 + s3);
+        };
+        gemv(cur);                               // the inverse tiles were the last group prefetched
+    }
+    __syncthreads();
+    if (wv == 0) {
+        const double v = valid ? sum_waves(red, lane) : 0.0;
+        front_slot_st(yslots + b * 64 + lane, v);            // first: the next super-block is waiting for it
+        if (valid) z[me.f + lane] = v * dinv_own;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// backward sweep: ticket t owns panel p = np-1-t, lane = column k of the panel, wave v = the rows 4 v .. 4 v + 3 of every tile
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kSbThreads)
+k_front_bwd_sb(DevPlan P, FrontDesc F, const double *__restrict__ z, double *__restrict__ x, double *__restrict__ xout) {
+    __shared__ double red[NW][64];
+    __shared__ double xbuf[2][kSbG][64];
+    __shared__ double sbuf[kSbG][64];
+    __shared__ int pn_w[kSbMaxPanels];          // panel widths in LDS (see k_front_fwd_sb)
+    __shared__ int sb, okflag;
+    int *sync = P.front_sync + F.sync_off + F.sync_blk;
+    for (int q = threadIdx.x; q < kSbG * 64; q += kSbThreads) (&sbuf[0][0])[q] = 0.0;
+    for (int q = threadIdx.x; q < F.np; q += kSbThreads) pn_w[q] = P.front_panels[F.fp_off + q].w;
+    if (threadIdx.x == 0) { sb = atomicAdd(sync, 1); okflag = 1; }
+    __syncthreads();
+    const int tk = sb_rfl(sb);                  // wave-uniform for the compiler too
+    if (tk >= F.np) return;
+    // re-arm the forward sweep's block for the next solve (idle during this launch), every workgroup a share
+    for (int q = tk * kSbThreads + threadIdx.x; q < F.sync_blk; q += F.np * kSbThreads) sync[q - F.sync_blk] = 0;
+    FrontSlot *xslots = front_slots(sync, F.np), *sslots = xslots + (int64_t)F.np * 64;
+    const int p = F.np - 1 - tk;
+    const int tid = threadIdx.x, lane = tid & 63, wv = sb_rfl(tid >> 6);
+    const FrontPanel *fps = P.front_panels + F.fp_off;
+    struct { int w, f; int64_t diag_off, lt_off; } me;
+    me.w = sb_rfl(fps[p].w); me.f = sb_rfl(fps[p].f); me.diag_off = sb_rfl64(fps[p].diag_off); me.lt_off = sb_rfl64(fps[p].lt_off);
+    const int w = me.w;
+    const bool cvalid = lane < w;
+    const int g = kSbG;
+    const int B = p / g, pl = p - g * B, nbB = min(g, F.np - g * B);
+    const double *lt = P.LT + me.lt_off;            // row-major: lt[(j - w) * w + k], j = local panel row
+    const int perm_own = (cvalid && wv == 0) ? P.perm[me.f + lane] : 0;
+    const double zin = (cvalid && wv == 0) ? z[me.f + lane] : 0.0;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    // (A) rows below the front: x is final
+    {
+        const int *rows = P.sn_rows + F.rows_off;
+        for (int ib = F.W; ib < F.rF; ib += 64) {
+            const int lo = ib + NT * wv;
+            double xv[NT], l[NT];
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+                const int i = lo + t;
+                const bool in = i < F.rF;
+                xv[t] = in ? x[rows[in ? i : F.W]] : 0.0;
+                l[t] = (in && cvalid) ? lt[(int64_t)(i - F.cw * p - w) * w + lane] : 0.0;
+            }
+            a0 = fma(l[0], xv[0], a0);
+            a1 = fma(l[1], xv[1], a1);
+            a2 = fma(l[2], xv[2], a2);
+            a3 = fma(l[3], xv[3], a3);
+        }
+    }
+    // (B) later super-blocks in descending order (groups 0 .. nG-1), then (group nG) the inverse tiles Inv[p .. , p]^T
+    const int nG = F.nsb - 1 - B;
+    double cur[kSbG][NT], nxt[kSbG][NT];
+    auto load_L = [&](int G, double (&dst)[kSbG][NT]) {      // L[q, p]^T tiles of super-block Q = nsb - 1 - G, from the row-major copy
+        const int Q = F.nsb - 1 - G;
+#pragma unroll
+        for (int pp = 0; pp < kSbG; pp++) {
+            const int q = g * Q + pp;
+            const int fq_w = sb_rfl(pn_w[q < F.np ? q : F.np - 1]);
+            const unsigned o0 = (unsigned)((F.cw * (q - p) + NT * wv - w) * w + lane) * 8u, os = (unsigned)w * 8u;
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+                const int jr = NT * wv + t;
+                dst[pp][t] = (q < F.np && cvalid && jr < fq_w) ? sb_ld(lt, o0 + (unsigned)t * os) : 0.0;
+            }
+        }
+    };
+    auto load_inv = [&](double (&dst)[kSbG][NT]) {
+#pragma unroll
+        for (int cl = 0; cl < kSbG; cl++) {
+            if (cl > pl && cl < nbB) {           // (uniform) a full tile of the super-block inverse, row-major half
+                const double *tl = P.SbInv + sb_tile(F, B, cl, pl) + 4096;
+#pragma unroll
+                for (int t = 0; t < NT; t++) dst[cl][t] = cvalid ? sb_ld(tl, (unsigned)((NT * wv + t) * 64 + lane) * 8u) : 0.0;
+            } else if (cl == pl) {               // the panel's own inverse, transposed copy: Linv[i][k] at [k + i w]
+                const double *lit = P.LinvT + me.diag_off;
+#pragma unroll
+                for (int t = 0; t < NT; t++) {
+                    const int i2 = NT * wv + t;
+                    dst[cl][t] = (cvalid && i2 >= lane && i2 < w) ? sb_ld(lit, (unsigned)(lane + i2 * w) * 8u) : 0.0;
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < NT; t++) dst[cl][t] = 0.0;
+            }
+        }
+    };
+    auto consume = [&](int G, auto &&prefetch) -> bool {        // see k_front_fwd_sb
+        const int Q = F.nsb - 1 - G;
+        double (*xb)[64] = xbuf[G & 1];
+        if (wv < kSbG) {
+            const int q = g * Q + wv;
+            double v = 0.0;
+            if (q < F.np) {
+                const bool okw = front_slot_wait(xslots + q * 64 + lane, v, sync + 1, P.flags + FL_FRONTFAIL, P.spin_limit);
+                if (!okw) { v = 0.0; if (lane == 0) okflag = 0; }
+            }
+            xb[wv][lane] = v;
+        }
+        prefetch();
+        __syncthreads();
+        if (!okflag) return false;
+#pragma unroll
+        for (int pp = 0; pp < kSbG; pp++) {
+            a0 = fma(cur[pp][0], xb[pp][NT * wv], a0);
+            a1 = fma(cur[pp][1], xb[pp][NT * wv + 1], a1);
+            a2 = fma(cur[pp][2], xb[pp][NT * wv + 2], a2);
+            a3 = fma(cur[pp][3], xb[pp][NT * wv + 3], a3);
+        }
+#pragma unroll
+        for (int pp = 0; pp < kSbG; pp++)
+#pragma unroll
+            for (int t = 0; t < NT; t++) cur[pp][t] = nxt[pp][t];
+        return true;
+    };
+    bool ok = true;
+    if (nG > 0) {
+        load_L(0, cur);
+        for (int G = 0; G + 1 < nG && ok; G++) ok = consume(G, [&] { load_L(G + 1, nxt); });
+        if (ok) ok = consume(nG - 1, [&] { load_inv(nxt); });
+    } else {
+        load_inv(cur);
+    }
+    red[wv][lane] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (wv == 0) {                               // partial right-hand side of this panel: to the EARLIER panels of the super-block
+        const double s = cvalid ? zin - sum_waves(red, lane) : 0.0;
+        sbuf[pl][lane] = s;
+        if (ok) front_slot_st(sslots + p * 64 + lane, s);
+    } else if (pl + wv < nbB) {                  // wave v polls s of panel p + v
+        double v = 0.0;
+        const bool okw = ok && front_slot_wait(sslots + (p + wv) * 64 + lane, v, sync + 1, P.flags + FL_FRONTFAIL, P.spin_limit);
+        if (!okw) { v = 0.0; if (lane == 0) okflag = 0; }
+        sbuf[pl + wv][lane] = v;
+    }
+    __syncthreads();
+    if (!okflag) return;
+    {   // x_p = sum_{c >= p} Inv[c,p]^T s_c
+        auto gemv = [&](const double (&iv)[kSbG][NT]) {
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+            for (int cl = 0; cl < kSbG; cl++) {
+                s0 = fma(iv[cl][0], sbuf[cl][NT * wv], s0);
+                s1 = fma(iv[cl][1], sbuf[cl][NT * wv + 1], s1);
+                s2 = fma(iv[cl][2], sbuf[cl][NT * wv + 2], s2);
+                s3 = fma(iv[cl][3], sbuf[cl][NT * wv + 3], s3);
+            }
+            red[wv][lane] = (s0 + s1) + (s2 + s3);
+        };
+        gemv(cur);
+    }
+    __syncthreads();
+    if (wv == 0) {
+        const double v = cvalid ? sum_waves(red, lane) : 0.0;
+        front_slot_st(xslots + p * 64 + lane, v);            // first: the previous super-block is waiting for it
+        if (cvalid) {
+            x[me.f + lane] = v;
+            xout[perm_own] = v;
+        }
+    }
+}
+
+void launch_front_fwd_sb(hipStream_t st, const DevPlan &P, const FrontDesc &F, double *y, double *z) {
+    hipLaunchKernelGGL(k_front_fwd_sb, dim3(F.nb), dim3(kSbThreads), 0, st, P, F, y, z);
+}
+void launch_front_bwd_sb(hipStream_t st, const DevPlan &P, const FrontDesc &F, const double *z, double *x, double *xout) {
+    hipLaunchKernelGGL(k_front_bwd_sb, dim3(F.np), dim3(kSbThreads), 0, st, P, F, z, x, xout);
+}
+void launch_invert_super(hipStream_t st, const DevPlan &P, const FrontDesc &F) {
+    if (F.sb_g > 0 && F.nsb > 0) hipLaunchKernelGGL(k_invert_super, dim3(F.nsb * (kSbG - 1)), dim3(256), 0, st, P, F);
+}
+
+}  // namespace hipkkt

@@ -24,15 +24,38 @@ void enqueue_factor_level(hipkkt_solver *S, int l) {
 // Schur-complement updates applied after level l is factored: dense register tiles (matrix cores),
 // per-entry gather lists (tiny scattered contributions), relative-index scatter (whatever is left).
 // The three kinds own disjoint target tiles, so their order inside a stage is immaterial.
+static hipEvent_t new_fork_event(hipkkt_solver *S) {
+    hipEvent_t e = nullptr;
+    HK_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    S->fork_events.push_back(e);
+    return e;
+}
+
 void enqueue_updates(hipkkt_solver *S, int l, bool split_far = false) {
     const HostPlan &P = S->plan;
     hipStream_t st = S->stream;
     if (l + 1 < P.nlevels && P.lvl_fused[l + 1]) return;   // applied inside the next level's panel kernel
     const int g0 = P.upd_stage_ptr[l], nd = P.upd_stage_ndense[l], ng = P.upd_stage_ngather[l];
+    const int64_t ngath = P.gath_stage_ptr[l + 1] - P.gath_stage_ptr[l];
+    // A stage that carries the sparse part of the tree into a big front has a long matrix-core launch (thousands of low-fill
+    // tiles) AND a long per-entry gather launch (latency-bound: dependent record -> operand loads per thread); they own disjoint
+    // targets and only read their sources, so the gather runs on the side stream next to the tile launch (cfg 2a: 0.32 + 0.37 ms
+    // back to back in round 2).  HIPKKT_FORK_GATHER=0: one after the other.
+    const bool par = S->fork_gather && nd > 384 && ngath >= 65536;
+    hipEvent_t joined = nullptr;
+    if (par) {
+        hipEvent_t e1 = new_fork_event(S);
+        joined = new_fork_event(S);
+        HK_CHECK(hipEventRecord(e1, st));
+        HK_CHECK(hipStreamWaitEvent(S->side, e1, 0));
+        launch_update_gather(S->side, S->dp, P.gath_stage_ptr[l], ngath, S->gath_heavy_ptr[l], S->gath_heavy_ptr[l + 1] - S->gath_heavy_ptr[l]);
+        HK_CHECK(hipEventRecord(joined, S->side));
+    }
     launch_update_dense(st, S->dp, g0, nd - (split_far ? P.upd_stage_nfar[l] : 0), 0, nd > 0 && P.upd_stage_flops_dense[l] >= 1.5e6 * nd);
-    launch_update_gather(st, S->dp, P.gath_stage_ptr[l], P.gath_stage_ptr[l + 1] - P.gath_stage_ptr[l], S->gath_heavy_ptr[l],
-                         S->gath_heavy_ptr[l + 1] - S->gath_heavy_ptr[l]);
+    if (!par)
+        launch_update_gather(st, S->dp, P.gath_stage_ptr[l], ngath, S->gath_heavy_ptr[l], S->gath_heavy_ptr[l + 1] - S->gath_heavy_ptr[l]);
     launch_update_stage(st, S->dp, g0 + nd + ng, P.upd_stage_ptr[l + 1] - g0 - nd - ng);
+    if (par) HK_CHECK(hipStreamWaitEvent(st, joined, 0));
 }
 
 void enqueue_factor(hipkkt_solver *S, int static_enable, double eps_const, double eps_prop) {
@@ -45,12 +68,7 @@ void enqueue_factor(hipkkt_solver *S, int static_enable, double eps_const, doubl
     launch_init_panels(st, S->dp, S->nnzK, static_enable, eps_const, eps_prop);
     // Far updates (targets more than `lookahead` levels ahead) are forked to the side stream right after the
     // level's factorisation and joined before the next batch end touches the same targets (symbolic.h).
-    auto new_event = [&]() {
-        hipEvent_t e = nullptr;
-        HK_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        S->fork_events.push_back(e);
-        return e;
-    };
+    auto new_event = [&]() { return new_fork_event(S); };
     const bool fork = S->use_side && P.lookahead > 0;
     hipEvent_t pending = nullptr;
     int pending_level = -1;
@@ -85,6 +103,7 @@ void enqueue_factor(hipkkt_solver *S, int static_enable, double eps_const, doubl
     }
     if (pending) HK_CHECK(hipStreamWaitEvent(st, pending, 0));
     launch_invert_diag(st, S->dp, S->inv_nsmall, S->inv_wsmall, S->inv_nwide);
+    for (const FrontDesc &F : P.fronts) launch_invert_super(st, S->dp, F);   // super-block inverses for the front sweeps
 }
 
 }  // namespace hipkkt_host
@@ -217,6 +236,7 @@ static int32_t refactor_once(hipkkt_handle h, int32_t static_reg_enable, double 
             }
         }
         launch_invert_diag(st, S->dp, S->inv_nsmall, S->inv_wsmall, S->inv_nwide);
+        for (const FrontDesc &F : P.fronts) launch_invert_super(st, S->dp, F);   // super-block inverses for the front sweeps
         HK_CHECK(hipStreamSynchronize(st));
         double tot = 0;
         for (size_t i = 0; i + 1 < evs.size(); i += 2) {

@@ -99,6 +99,7 @@ struct hipkkt_solver {
     hipStream_t side = nullptr;          // far Schur updates run here, overlapped with the critical path
     std::vector<hipEvent_t> fork_events;
     bool use_side = true;
+    bool fork_gather = true;   // a stage's per-entry gather launch next to its big dense launch (hipkkt_factor.cpp enqueue_updates)
     int far_wgs = 256;   // grid bound of the look-ahead (far) update launches; 0 = one workgroup per 4 tiles
     hipkkt_opts opts{};
     bool l1 = false;

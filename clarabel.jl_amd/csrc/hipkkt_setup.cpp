@@ -20,6 +20,8 @@ void init_runtime(hipkkt_solver *S) {
         // saves -- so the fork is opt-in (HIPKKT_SIDE_STREAM=1)
         const char *ns = getenv("HIPKKT_SIDE_STREAM");
         S->use_side = ns && ns[0] == '1';
+        const char *fg = getenv("HIPKKT_FORK_GATHER");
+        S->fork_gather = !(fg && fg[0] == '0');
         const char *fw = getenv("HIPKKT_FAR_WGS");
         if (fw) S->far_wgs = atoi(fw);
     }
@@ -361,6 +363,8 @@ void setup_device(hipkkt_solver *S) {
         D.seg_ticket = tk ? atoi(tk) : 3;                  // bit 0: forward sweep, bit 1: backward sweep
         const char *sl = getenv("HIPKKT_SPIN_LIMIT");      // tests force a sweep time-out with a tiny bound
         D.spin_limit = sl ? (unsigned)strtoul(sl, nullptr, 10) : (1u << 20);
+        const char *pm = getenv("HIPKKT_PIVOT_MODE");
+        D.pivot_mode = pm ? atoi(pm) : 1;
     }
     {
         const size_t nsync = seg_sync_ints(S->nseg, P.nsuper);
@@ -376,6 +380,8 @@ void setup_device(hipkkt_solver *S) {
     D.Linv = S->dalloc<double>(P.diag_doubles);
     D.LinvT = S->dalloc<double>(P.diag_doubles);
     D.LT = S->dalloc<double>(P.lt_off[P.nsuper]);
+    D.SbInv = S->dalloc<double>(P.sbinv_doubles);
+    fill_async(S->stream, D.SbInv, 0, (size_t)std::max<int64_t>(P.sbinv_doubles, 1) * sizeof(double));
     D.D = S->dalloc<double>(N);
     D.Dinv = S->dalloc<double>(N);
     D.ubuf = S->dalloc<double>(P.ubuf_len);
@@ -521,8 +527,10 @@ int32_t finish_create(hipkkt_solver *S, const hipkkt_opts *opts, hipkkt_handle *
         if (dc && atof(dc) > 0) po.dense_min_cover = atof(dc);
         const char *nf = getenv("HIPKKT_FUSE_JIT");    // experiment: just-in-time updates inside the panel kernel
         if (nf && nf[0] == '1') po.fuse_jit = true;
-        const char *nx = getenv("HIPKKT_XCD_ORDER");   // measured: no effect on cfg 2a (L2 locality is not the limiter)
-        po.xcd_order = nx && nx[0] == '1';
+        const char *sh = getenv("HIPKKT_SUPERHOP");    // 0: one hop per panel in the front sweeps (round-2 kernels; A/B timing)
+        if (sh) po.superhop = atoi(sh);
+        const char *nx = getenv("HIPKKT_XCD_ORDER");   // 0 / 1 / 2 (symbolic.h PlanOptions::xcd_order; default 2)
+        if (nx) po.xcd_order = atoi(nx);
     }
     {
         const char *nh = getenv("HIPKKT_ORDERING");   // "amd": minimum degree on K only

@@ -23,6 +23,10 @@ void launch_psd_hs(hipStream_t st, double *kval, const int64_t *map_hs, int64_t 
 // front_block.hip
 void launch_front_block(hipStream_t st, const DevPlan &P, const FrontBatch &B, int *sync_all, double *scratch_all, double dyn_eps,
                         double dyn_delta, long long *trace = nullptr);
+// front_sweep.hip: super-block sweeps over a front (FrontDesc::sb_g > 0) and the super-block inverses they need
+void launch_front_fwd_sb(hipStream_t st, const DevPlan &P, const FrontDesc &F, double *y, double *z);
+void launch_front_bwd_sb(hipStream_t st, const DevPlan &P, const FrontDesc &F, const double *z, double *x, double *xout);
+void launch_invert_super(hipStream_t st, const DevPlan &P, const FrontDesc &F);
 // scaling.hip (N1)
 void launch_scaling_diag(hipStream_t st, const signed char *row_kind, const int64_t *row_hs, const int64_t *map_hs, const double *s,
                          const double *z, double *w, double *lam, double *kval, int64_t m);

@@ -618,7 +618,53 @@ std::string build_plan(int N, const int64_t *Ap, const int64_t *Ai, const int64_
         for (int l = 0; l < P.nlevels; l++) {
             auto b = P.upd_groups.begin() + P.upd_stage_ptr[l], e = P.upd_groups.begin() + P.upd_stage_ptr[l + 1];
             auto mid = std::stable_partition(b, e, [](const UpdGroup &g) { return g.dense == 1; });
-            if (opt.xcd_order && mid - b >= 256) {
+            if (opt.xcd_order == 2 && mid - b >= 1024) {
+                // 2-D blocked XCD order (performance only; the groups own disjoint tiles, any order is correct).  Workgroup k of
+                // k_update_dense<4,4> takes 4 consecutive tiles and is observed to run on XCD k % 8; an XCD holds 64 such
+                // workgroups = 256 tiles at a time, and they walk their sources' columns roughly in step.  In the natural order
+                // (row blocks of one target panel after the other) the 256 tiles of an XCD share their COLUMN operand and fetch
+                // 256 different row operands through that XCD's L2 (measured: 2.4x the algorithmic bytes at the fabric side,
+                // profiles/r03_a_traffic_calibration.txt).  Here the tiles are cut into 16 x 16 super-tiles of (row block,
+                // column block) space, each XCD is dealt whole super-tiles, and the eight streams are interleaved 4 tiles at a
+                // time: the 256 concurrent tiles of an XCD then touch 16 + 16 operand blocks instead of 1 + 256.
+                constexpr int T = 16;
+                struct Key { int sk, si, gk, gi; UpdGroup g; };
+                std::vector<Key> ks;
+                ks.reserve((size_t)(mid - b));
+                for (auto it = b; it != mid; ++it) {
+                    const int gi = P.sn_rows[P.sn_rowptr[it->tgt] + it->row_base] / kUpdRows, gk = P.sn_first[it->tgt] / kMaxSnWidth;
+                    ks.push_back({gk / T, gi / T, gk, gi, *it});
+                }
+                std::stable_sort(ks.begin(), ks.end(), [](const Key &x, const Key &y) {
+                    if (x.sk != y.sk) return x.sk < y.sk;
+                    if (x.si != y.si) return x.si < y.si;
+                    if (x.gk != y.gk) return x.gk < y.gk;
+                    return x.gi < y.gi;
+                });
+                std::vector<std::vector<UpdGroup>> stream(8);
+                for (size_t q = 0; q < ks.size();) {          // whole super-tiles to the least loaded stream
+                    size_t e2 = q;
+                    while (e2 < ks.size() && ks[e2].sk == ks[q].sk && ks[e2].si == ks[q].si) e2++;
+                    int best = 0;
+                    for (int x = 1; x < 8; x++)
+                        if (stream[x].size() < stream[best].size()) best = x;
+                    for (size_t p = q; p < e2; p++) stream[best].push_back(ks[p].g);
+                    q = e2;
+                }
+                std::vector<size_t> pos(8, 0);
+                auto out = b;
+                size_t remaining = (size_t)(mid - b);
+                while (remaining > 0)
+                    for (int x = 0; x < 8 && remaining > 0; x++) {
+                        int src = x;
+                        if (pos[src] >= stream[src].size()) {   // this stream is exhausted: borrow from the fullest one
+                            size_t best = 0;
+                            for (int y = 0; y < 8; y++)
+                                if (stream[y].size() - pos[y] > best) { best = stream[y].size() - pos[y]; src = y; }
+                        }
+                        for (int c = 0; c < 4 && pos[src] < stream[src].size(); c++) { *out++ = stream[src][pos[src]++]; remaining--; }
+                    }
+            } else if (opt.xcd_order == 1 && mid - b >= 256) {
                 // XCD-aware order (performance only): workgroup k of k_update_dense<4,4> takes 4 consecutive tiles and is
                 // observed to run on XCD k % 8.  Tiles are bucketed by (global row block) % 8 and the buckets are
                 // interleaved 4 tiles at a time, so one XCD's L2 keeps re-using 1/8 of the source panels' rows (its A
@@ -826,8 +872,16 @@ std::string build_plan(int N, const int64_t *Ap, const int64_t *Ai, const int64_
             F.sync_off = sync_ints;
             // two blocks (forward sweep, backward sweep): {ticket, error, flags[np]} padded to 32 ints (128 B), then np x 64
             // hand-off slots of 16 bytes (value, self-validating tag: kernels.hip front_slot_*)
-            F.sync_blk = ((2 + np + 31) & ~31) + np * 64 * 4;   // multiple of 32 ints: the two blocks share no cache line
+            // (super-block sweeps use a second set of np x 64 slots per block: the partial right-hand sides r / s)
+            F.sync_blk = ((2 + np + 31) & ~31) + 2 * np * 64 * 4;   // multiple of 32 ints: the two blocks share no cache line
             sync_ints += 2 * F.sync_blk;
+            F.sb_g = 0; F.nsb = 0; F.sbinv_off = 0;
+            if (opt.superhop && np >= kSbMinPanels && np <= kSbMaxPanels) {
+                F.sb_g = kSbG;
+                F.nsb = (np + kSbG - 1) / kSbG;
+                F.sbinv_off = P.sbinv_doubles;
+                P.sbinv_doubles += (int64_t)F.nsb * (kSbG * (kSbG - 1) / 2) * 8192;
+            }
             for (int p = 0; p < np; p++) {
                 const int s = s0 + p;
                 P.front_panels.push_back({P.sn_panel[s], P.lt_off[s], P.sn_diag[s], (int)(P.sn_rowptr[s + 1] - P.sn_rowptr[s]),

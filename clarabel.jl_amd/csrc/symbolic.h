@@ -95,7 +95,16 @@ struct FrontDesc {
     int64_t rows_off;             // sn_rowptr[s0]: global (permuted) index of every front row
     int32_t sync_off, sync_blk;   // sync area of this front: two blocks of sync_blk ints {ticket, error, flags[np], slots},
                                   // one per sweep; each sweep's kernel re-zeroes the OTHER block for the next solve
+    // super-block sweeps (kernels.hip k_front_fwd_sb / k_front_bwd_sb): the np panels are grouped into nsb super-blocks of sb_g
+    // consecutive panels; the off-diagonal 64 x 64 tiles of every super-block's INVERSE are formed after each factorisation
+    // (k_invert_super) at sbinv_off: tile (B, bl > cl) at ((B * sb_g (sb_g - 1) / 2 + bl (bl - 1) / 2 + cl) * 8192: 4096 doubles
+    // column-major (forward sweep), then 4096 row-major (backward sweep).  sb_g = 0: one hop per panel (k_front_fwd / _bwd).
+    int32_t sb_g, nsb;
+    int64_t sbinv_off;
 };
+constexpr int kSbG = 5;           // panels per super-block of the front sweeps
+constexpr int kSbMinPanels = 10;  // fronts with fewer panels keep one hop per panel
+constexpr int kSbMaxPanels = 1024; // ... and so do fronts with more (the sweeps keep a panel table in LDS)
 
 struct PlanOptions {
     int max_width = kMaxSnWidth;
@@ -108,13 +117,15 @@ struct PlanOptions {
     bool fuse_jit = false;     // apply the just-in-time updates of a front panel inside its panel kernel
                                // (measured slower on MI355X, DESIGN.md section 9: every workgroup repeats the diagonal tile)
     bool split_far = false;    // separate the far dense tiles of a stage (side-stream experiments)
-    bool xcd_order = false;    // order the dense tiles of a stage so that each XCD's L2 sees 1/8 of the source rows
+    int xcd_order = 2;         // order of the dense tiles of a big stage (performance only): 0 natural (target panel, row block),
+                               // 1 row blocks bucketed by XCD, 2 (default) 16 x 16 super-tiles dealt to the XCDs (symbolic.cpp)
     int n_hold = 0;            // > 0: also try the "variables last" order (nodes < n_hold held back) and keep
                                // whichever order predicts fewer factor flops
     int front_block_min_width = 1024;   // supernodes at least this wide are cut into full 64-column panels (remainder last) so that
                                // k_front_block can take their update batches; narrower ones keep balanced panel widths (measured:
                                // cfg 1's 710-column root is 15 % slower to factor with 11 x 64 + 6 than with 12 x 60)
     int front_min_panels = 4;  // chains at least this long are solved by the persistent front kernels (0 = never)
+    int superhop = 1;          // 1: fronts of >= kSbMinPanels panels are swept super-block by super-block (2 hand-offs per kSbG panels)
     int nd_mode = 1;           // nested dissection candidate: 0 never, 1 when the latency + throughput model predicts a
                                // >= 20 % cheaper KKT iteration than minimum degree, 2 always
     int nd_leaf = 256;         // subgraphs of at most this many nodes are ordered by minimum degree
@@ -185,6 +196,7 @@ struct HostPlan {
     std::vector<int> front_gidx;
     std::vector<int> sn_front;        // [nsuper] front index of a panel handled by the front kernels, else -1
     int front_sync_ints = 0;
+    int64_t sbinv_doubles = 0;        // storage of the super-block inverse tiles of all fronts (FrontDesc::sbinv_off)
 
     std::vector<int64_t> sym_rowptr;  // full symmetric CSR view of K (original ordering)
     std::vector<int> sym_col;

@@ -6,6 +6,7 @@
 // structures can be validated against dense linear algebra on a machine without a GPU.
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -13,6 +14,161 @@
 #include "../../clarabel.jl_amd/csrc/symbolic.h"
 
 using namespace hipkkt;
+
+// ---- host twins of the super-block front sweeps (clarabel.jl_amd/csrc/front_sweep.hip): the same tile addresses, layouts and
+//      summation structure as k_invert_super / k_front_fwd_sb / k_front_bwd_sb, executed serially
+namespace {
+struct SbEmu {
+    const HostPlan &P;
+    const std::vector<double> &Lx;
+    std::vector<double> LT, Linv, LinvT, SbInv;
+    static int64_t tile(const FrontDesc &F, int B, int bl, int cl) {
+        return F.sbinv_off + ((int64_t)B * (kSbG * (kSbG - 1) / 2) + bl * (bl - 1) / 2 + cl) * 8192;
+    }
+    SbEmu(const HostPlan &P_, const std::vector<double> &Lx_, const std::vector<double> &Ld) : P(P_), Lx(Lx_) {
+        LT.assign((size_t)P.lt_off[P.nsuper], 0.0);
+        Linv.assign((size_t)P.diag_doubles, 0.0);
+        LinvT.assign((size_t)P.diag_doubles, 0.0);
+        SbInv.assign((size_t)std::max<int64_t>(P.sbinv_doubles, 1), 0.0);
+        for (int s = 0; s < P.nsuper; s++) {
+            const int w = P.sn_first[s + 1] - P.sn_first[s], r = (int)(P.sn_rowptr[s + 1] - P.sn_rowptr[s]);
+            const double *pan = &Lx[P.sn_panel[s]];
+            double *lt = &LT[P.lt_off[s]];
+            for (int j = w; j < r; j++)
+                for (int k = 0; k < w; k++) lt[(size_t)(j - w) * w + k] = pan[j + (size_t)k * r];
+            // explicit inverse of the unit-lower diagonal block (column by column), both layouts of k_invert_diag
+            const double *ld = &Ld[P.sn_diag[s]];
+            std::vector<double> X((size_t)w * w, 0.0);
+            for (int j = 0; j < w; j++) {
+                X[j + (size_t)j * w] = 1.0;
+                for (int k = j; k < w; k++)
+                    for (int i = k + 1; i < w; i++) X[i + (size_t)j * w] -= ld[i + (size_t)k * w] * X[k + (size_t)j * w];
+            }
+            for (int j = 0; j < w; j++)
+                for (int i = 0; i < w; i++) {
+                    Linv[P.sn_diag[s] + i + (size_t)j * w] = X[i + (size_t)j * w];
+                    LinvT[P.sn_diag[s] + j + (size_t)i * w] = X[i + (size_t)j * w];
+                }
+        }
+    }
+    void invert_super(const FrontDesc &F) {
+        const FrontPanel *fps = &P.front_panels[F.fp_off];
+        for (int B = 0; B < F.nsb; B++) {
+            const int nbB = std::min(kSbG, F.np - kSbG * B);
+            for (int cl = 0; cl + 1 < nbB; cl++) {
+                const FrontPanel pc = fps[kSbG * B + cl];
+                for (int bl = cl + 1; bl < nbB; bl++) {
+                    const FrontPanel pb = fps[kSbG * B + bl];
+                    std::vector<double> S(4096, 0.0), O(4096, 0.0);      // [i * 64 + k]
+                    for (int kl = cl; kl < bl; kl++) {
+                        const FrontPanel pk = fps[kSbG * B + kl];
+                        const double *src = &Lx[pk.panel_off + F.cw * (bl - kl)];
+                        for (int i = 0; i < 64; i++)
+                            for (int k = 0; k < 64; k++) {
+                                double a = 0;
+                                for (int m = 0; m < 64; m++) {
+                                    const double l = (i < pb.w && m < pk.w) ? src[i + (size_t)m * pk.r] : 0.0;
+                                    double bv;
+                                    if (kl == cl) bv = (m < pc.w && k <= m) ? Linv[pc.diag_off + m + (size_t)k * pc.w] : 0.0;
+                                    else bv = SbInv[tile(F, B, kl, cl) + m + 64 * k];
+                                    a += l * bv;
+                                }
+                                S[i * 64 + k] += a;
+                            }
+                    }
+                    for (int i = 0; i < 64; i++)
+                        for (int k = 0; k < 64; k++) {
+                            double a = 0;
+                            for (int m = 0; m < 64; m++) a += ((i < pb.w && m <= i) ? Linv[pb.diag_off + i + (size_t)m * pb.w] : 0.0) * S[m * 64 + k];
+                            O[i * 64 + k] = -a;
+                        }
+                    double *t = &SbInv[tile(F, B, bl, cl)];
+                    for (int i = 0; i < 64; i++)
+                        for (int k = 0; k < 64; k++) { t[i + 64 * k] = O[i * 64 + k]; t[4096 + i * 64 + k] = O[i * 64 + k]; }
+                }
+            }
+        }
+    }
+    // y: permuted right-hand side (own rows are overwritten with the solved y_J, like the serial sweep); ub: update vectors
+    void fwd(const FrontDesc &F, std::vector<double> &y, std::vector<double> &ub) {
+        const FrontPanel *fps = &P.front_panels[F.fp_off];
+        const int g = kSbG;
+        std::vector<double> ysol((size_t)F.np * 64, 0.0), rvec((size_t)F.np * 64, 0.0);
+        for (int b = 0; b < F.nb; b++) {
+            const bool own = b < F.np;
+            const FrontPanel me = fps[own ? b : 0];
+            const int B = own ? b / g : F.nsb, bl = own ? b - g * B : 0;
+            const int i0 = own ? F.cw * b : F.W + 64 * (b - F.np);
+            const int nrows = own ? me.w : std::min(64, F.rF - i0);
+            const int nQ = own ? B : F.nsb;
+            for (int lane = 0; lane < nrows; lane++) {
+                const int i = i0 + lane;
+                double G = 0;
+                for (int64_t gq = P.front_gptr[F.gptr_off + i]; gq < P.front_gptr[F.gptr_off + i + 1]; gq++) G += ub[P.front_gidx[gq]];
+                const double base = own ? y[me.f + lane] - G : G;
+                double tot = 0;
+                for (int Q = 0; Q < nQ; Q++)
+                    for (int p = 0; p < g; p++) {
+                        const int q = g * Q + p;
+                        if (q >= F.np) continue;
+                        const FrontPanel fq = fps[q];
+                        for (int k = 0; k < fq.w; k++) tot += Lx[fq.panel_off + (i - F.cw * q) + (int64_t)k * fq.r] * ysol[(size_t)q * 64 + k];
+                    }
+                if (!own) ub[F.ubelow_off + (i - F.W)] = base + tot;
+                else rvec[(size_t)b * 64 + lane] = base - tot;
+            }
+            if (!own) continue;
+            for (int lane = 0; lane < nrows; lane++) {
+                double v = 0;
+                for (int p = 0; p <= bl; p++)
+                    for (int k = 0; k < 64; k++) {
+                        double iv;
+                        if (p < bl) iv = SbInv[tile(F, B, bl, p) + lane + 64 * k];
+                        else iv = (k <= lane && k < me.w) ? Linv[me.diag_off + lane + (size_t)k * me.w] : 0.0;
+                        v += iv * rvec[(size_t)(g * B + p) * 64 + k];
+                    }
+                ysol[(size_t)b * 64 + lane] = v;
+            }
+            for (int lane = 0; lane < nrows; lane++) y[me.f + lane] = ysol[(size_t)b * 64 + lane];
+        }
+    }
+    // z: D^-1 y (permuted); x: the permuted solution, final on every row outside the front's own columns
+    void bwd(const FrontDesc &F, const std::vector<double> &z, std::vector<double> &x) {
+        const FrontPanel *fps = &P.front_panels[F.fp_off];
+        const int g = kSbG;
+        const int *rows = &P.sn_rows[F.rows_off];
+        std::vector<double> xsol((size_t)F.np * 64, 0.0), svec((size_t)F.np * 64, 0.0);
+        for (int p = F.np - 1; p >= 0; p--) {
+            const FrontPanel me = fps[p];
+            const int w = me.w, B = p / g, pl = p - g * B, nbB = std::min(g, F.np - g * B);
+            const double *lt = &LT[me.lt_off];
+            for (int lane = 0; lane < w; lane++) {
+                double a = 0;
+                for (int i = F.W; i < F.rF; i++) a += lt[(size_t)(i - F.cw * p - w) * w + lane] * x[rows[i]];
+                for (int Q = F.nsb - 1; Q > B; Q--)
+                    for (int pp = 0; pp < g; pp++) {
+                        const int q = g * Q + pp;
+                        if (q >= F.np) continue;
+                        for (int jr = 0; jr < fps[q].w; jr++) a += lt[(size_t)(F.cw * (q - p) + jr - w) * w + lane] * xsol[(size_t)q * 64 + jr];
+                    }
+                svec[(size_t)p * 64 + lane] = z[me.f + lane] - a;
+            }
+            for (int lane = 0; lane < w; lane++) {
+                double v = 0;
+                for (int cl = pl; cl < nbB; cl++)
+                    for (int i2 = 0; i2 < 64; i2++) {
+                        double iv;
+                        if (cl > pl) iv = SbInv[tile(F, B, cl, pl) + 4096 + i2 * 64 + lane];
+                        else iv = (i2 >= lane && i2 < w) ? LinvT[me.diag_off + lane + (size_t)i2 * w] : 0.0;
+                        v += iv * svec[(size_t)(g * B + cl) * 64 + i2];
+                    }
+                xsol[(size_t)p * 64 + lane] = v;
+            }
+            for (int lane = 0; lane < w; lane++) x[me.f + lane] = xsol[(size_t)p * 64 + lane];
+        }
+    }
+};
+}  // namespace
 
 extern "C" {
 
@@ -25,6 +181,8 @@ int plan_check_run(int64_t N, const int64_t *Ap, const int64_t *Ai, const double
     HostPlan P;
     PlanOptions opt;
     opt.max_width = max_width; opt.relax = relax != 0; opt.update_policy = policy & 15; if (policy >> 4) opt.update_batch = policy >> 4;
+    { const char *sh = getenv("PLANCHECK_SUPERHOP"); if (sh) opt.superhop = atoi(sh); }
+    { const char *fm = getenv("PLANCHECK_FRONT_MIN"); if (fm) opt.front_min_panels = atoi(fm); }
     std::string err = build_plan((int)N, Ap, Ai, user_perm, opt, P);
     if (!err.empty()) { fprintf(stderr, "build_plan: %s\n", err.c_str()); return -1; }
     if (perm_out) for (int k = 0; k < N; k++) perm_out[k] = P.perm[k];
@@ -37,6 +195,9 @@ int plan_check_run(int64_t N, const int64_t *Ap, const int64_t *Ai, const double
         size_t nmapped = 0, ndense = 0;
         for (auto &t : P.upd_tasks) nmapped += (t.geom >> 17) & 1;
         for (auto &g : P.upd_groups) ndense += g.dense == 1;
+        int nsbf = 0;
+        for (auto &F : P.fronts) nsbf += F.sb_g > 0;
+        if (getenv("PLANCHECK_VERBOSE")) fprintf(stderr, "plan_check: %zu fronts, %d with super-block sweeps\n", P.fronts.size(), nsbf);
         stats[12] = (double)P.fronts.size(); stats[13] = (double)P.gath_tgt.size(); stats[14] = (double)ndense; stats[15] = (double)nmapped;
     }
     if (symbolic_only) return 0;
@@ -155,6 +316,7 @@ int plan_check_run(int64_t N, const int64_t *Ap, const int64_t *Ai, const double
     // solves: y = perm(b); forward by levels with gather lists; D; backward
     std::vector<double> y(N), ub(P.ubuf_len, 0.0);
     for (int k = 0; k < N; k++) y[k] = b[P.perm[k]];
+    SbEmu sbe(P, Lx, Ld);
     for (int lvl = 0; lvl < P.nlevels; lvl++) {
         for (int q = P.lvl_ptr[lvl]; q < P.lvl_ptr[lvl + 1]; q++) {
             int s = P.lvl_sn[q], w = W(s), r = R(s), f = P.sn_first[s];
@@ -179,6 +341,7 @@ int plan_check_run(int64_t N, const int64_t *Ap, const int64_t *Ai, const double
         // fronts that end at this level: the persistent sweep (external gathers + panel-ordered accumulation)
         for (const FrontDesc &F : P.fronts) {
             if (F.level_last != lvl) continue;
+            if (F.sb_g > 0) { sbe.invert_super(F); sbe.fwd(F, y, ub); continue; }   // front_sweep.hip
             const FrontPanel *fp = &P.front_panels[F.fp_off];
             std::vector<double> acc(F.rF, 0.0);
             for (int i = 0; i < F.rF; i++)
@@ -201,9 +364,12 @@ int plan_check_run(int64_t N, const int64_t *Ap, const int64_t *Ai, const double
         }
     }
     for (int k = 0; k < N; k++) y[k] *= Dinv[k];
-    for (int lvl = P.nlevels - 1; lvl >= 0; lvl--)
+    for (int lvl = P.nlevels - 1; lvl >= 0; lvl--) {
+        for (const FrontDesc &F : P.fronts)
+            if (F.sb_g > 0 && F.level_last == lvl) { const std::vector<double> zc(y); sbe.bwd(F, zc, y); }   // k_front_bwd_sb
         for (int q = P.lvl_ptr[lvl]; q < P.lvl_ptr[lvl + 1]; q++) {
             int s = P.lvl_sn[q], w = W(s), r = R(s), f = P.sn_first[s];
+            if (P.sn_front[s] >= 0 && P.fronts[P.sn_front[s]].sb_g > 0) continue;
             const double *pan = &Lx[P.sn_panel[s]];
             const double *ld = &Ld[P.sn_diag[s]];
             const int *rows = &P.sn_rows[P.sn_rowptr[s]];
@@ -215,6 +381,7 @@ int plan_check_run(int64_t N, const int64_t *Ap, const int64_t *Ai, const double
             for (int k = w - 1; k >= 0; k--)
                 for (int i = k + 1; i < w; i++) y[f + k] -= ld[i + (size_t)k * w] * y[f + i];
         }
+    }
     for (int k = 0; k < N; k++) x[P.perm[k]] = y[k];
     return 0;
 }

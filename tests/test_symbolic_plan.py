@@ -99,3 +99,28 @@ def test_user_perm_and_dynamic_regularisation_count():
     b = rng.standard_normal(k.N)
     rc, x, perm, st = ps.run(k.N, k.colptr, k.rowval, nz2, ds, b, perm=np.arange(k.N))
     assert rc == 0 and list(perm) != [] and st["nreg"] >= 0
+
+
+@pytest.mark.parametrize("maxw", [8, 16, 64])
+def test_super_block_front_sweeps_reproduce_dense_solve(maxw, monkeypatch):
+    """front_sweep.hip's super-block sweeps (k_invert_super / k_front_fwd_sb / k_front_bwd_sb) have a serial host twin in
+    tests/support/plan_check.cpp with the same tile addresses, layouts (column-major / row-major halves of the inverse tiles,
+    the row-major copy LT) and super-block structure.  Narrow panel widths turn the dense root of a small problem into a front of
+    >= kSbMinPanels panels (incl. a partial last panel and a partial last super-block), so the index arithmetic is checked
+    against a dense solve without a GPU."""
+    rng = np.random.default_rng(11)
+    monkeypatch.setenv("PLANCHECK_SUPERHOP", "1")
+    monkeypatch.setenv("PLANCHECK_VERBOSE", "1")
+    k, nz, ds = _kkt(problems.random_sparse_qp(1000, 2000, 1, 4, 2) if maxw == 64 else problems.random_sparse_qp(300, 500, 7, 3, 1), rng)
+    b = rng.standard_normal(k.N)
+    K = sp.csc_matrix((nz, k.rowval, k.colptr), shape=(k.N, k.N)).toarray()
+    K = K + K.T - np.diag(np.diag(K))
+    xd = np.linalg.solve(K, b)
+    rc, x, perm, st = ps.run(k.N, k.colptr, k.rowval, nz, ds, b, max_width=maxw, relax=1, policy=2 + 16 * 4)
+    assert rc == 0 and st["nfronts"] >= 1
+    assert np.linalg.norm(x - xd) <= 1e-9 * max(1.0, np.linalg.norm(xd))
+    # and the same plan with one hop per panel gives the same answer (the two sweeps are interchangeable)
+    monkeypatch.setenv("PLANCHECK_SUPERHOP", "0")
+    rc0, x0, _, _ = ps.run(k.N, k.colptr, k.rowval, nz, ds, b, max_width=maxw, relax=1, policy=2 + 16 * 4)
+    assert rc0 == 0
+    assert np.linalg.norm(x - x0) <= 1e-10 * max(1.0, np.linalg.norm(x0))
