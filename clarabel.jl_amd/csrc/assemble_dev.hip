@@ -234,6 +234,8 @@ std::string assemble_kkt_device(void *stream_, int64_t n, int64_t m, const int64
                                 const int64_t *Ap, const int64_t *Ai, const double *Ax, int64_t ncones, const int64_t *numel,
                                 const int32_t *hs_dense, const int32_t *sparse_kind, const int64_t *dim1, KKTImage &K) {
     hipStream_t st = (hipStream_t)stream_;
+    (void)hipGetLastError();   // the sticky per-thread error may hold a failure that is not ours (an embedding host's, or an allocation the
+                               // runtime pool recovered from): the check at the end of this function must only see this function's launches
     K = KKTImage();
     K.n = n; K.m = m; K.nnzP = Pp[n]; K.nnzA = Ap[n];
     // ---- host: cone descriptors (structure only, O(#cones)) and the checks of the host twin

@@ -285,7 +285,7 @@ k_front_block(DevPlan P, FrontBatch B, int *sync_all, double *scratch_all, doubl
             double pcol[8];
 #pragma unroll
             for (int q = 0; q < 8; q++) pcol[q] = Pc[lane * 9 + q];
-            if (P.pivot_mode == 0) {
+            if (P.pivot_mode != 1) {
                 // round-2 form: the pivot and the entries a_jk come from the lanes that hold them (v_readlane on the chain)
 #pragma unroll
                 for (int kk = 0; kk < 8; kk++) {
@@ -293,8 +293,17 @@ k_front_block(DevPlan P, FrontBatch B, int *sync_all, double *scratch_all, doubl
                     const double reg = pcol[kk];
                     double d = fb_readlane(reg, k);
                     const double sg = ((spos >> k) & 1ull) ? 1.0 : -1.0;
-                    if (d * sg < dyn_eps) { d = dyn_delta * sg; nreg++; }
-                    const double dinv = fb_rcp(d);
+                    double dinv;
+                    if (P.pivot_mode == 2) {     // the reciprocal starts from the raw pivot while the sign test runs (bit-identical results)
+                        const double dinv0 = fb_rcp(d);
+                        const bool sub = d * sg < dyn_eps;
+                        dinv = sub ? (sg > 0.0 ? dinv_delta : -dinv_delta) : dinv0;
+                        d = sub ? dyn_delta * sg : d;
+                        nreg += sub ? 1 : 0;
+                    } else {
+                        if (d * sg < dyn_eps) { d = dyn_delta * sg; nreg++; }
+                        dinv = fb_rcp(d);
+                    }
                     const double li = reg * dinv;
                     colL[kk][lane] = li;
                     colC[kk][lane] = reg;

@@ -56,76 +56,89 @@ static_assert(NW == 16 && NT == 4, "sum_waves and the 4-way accumulators assume 
 // per-panel inverse of k_invert_diag / k_invert_diag_wide).  One workgroup per (super-block, column c); the 64 x 64 x 64 products
 // run on the matrix core with both operands in LDS.  Tiles are padded to 64 x 64 with zeros (panels narrower than 64 columns).
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void sb_load_linv(const DevPlan &P, const FrontPanel &pn, double *S, int tid) {   // S[row * SLD + col]
-    const double *li = P.Linv + pn.diag_off;
-    for (int idx = tid; idx < 4096; idx += 256) {
-        const int i = idx & 63, k = idx >> 6;
-        S[i * SLD + k] = (i < pn.w && k <= i) ? li[i + k * pn.w] : 0.0;
+// 1024 threads = 16 wavefronts, wavefront v forms the 16 x 16 piece (v >> 2, v & 3) of every product; the two operand tiles of a
+// product are fetched together (4 + 4 values per thread in flight) before they go to LDS.
+constexpr int kInvThreads = 1024;
+struct SbTileSrc {            // where a 64 x 64 operand comes from: value(i, k) = (i < ni && k < nk && (!lower || k <= i)) ? base[i * si + k * sk] : 0
+    const double *base;
+    int64_t si, sk;
+    int ni, nk;
+    bool lower, coherent;     // coherent: written earlier by this workgroup (read past the CU's L1)
+};
+__device__ __forceinline__ void sb_fetch(const SbTileSrc &T, double (&v)[4], int tid) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int idx = tid + kInvThreads * q, i = idx & 63, k = idx >> 6;
+        const bool in = i < T.ni && k < T.nk && (!T.lower || k <= i);
+        const double *p = T.base + i * T.si + k * T.sk;
+        v[q] = in ? (T.coherent ? front_ld(p) : *p) : 0.0;
     }
 }
-__device__ __forceinline__ void sb_mm(const double *A, const double *Bm, v4f64 (&c)[4], int wv, int l15, int lk) {
-    // c[sub] += A(rows 16 wv ..) * B(:, 16 sub ..); output layout: column 16 sub + l15, rows 16 wv + lk + 4 reg
-#pragma unroll 4
-    for (int kk = 0; kk < 16; kk++) {
-        const double a = A[(16 * wv + l15) * SLD + 4 * kk + lk];
+__device__ __forceinline__ void sb_put(double *S, const double (&v)[4], int tid) {      // S[row * SLD + col]
 #pragma unroll
-        for (int sub = 0; sub < 4; sub++)
-            c[sub] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Bm[(4 * kk + lk) * SLD + 16 * sub + l15], c[sub], 0, 0, 0);
+    for (int q = 0; q < 4; q++) {
+        const int idx = tid + kInvThreads * q;
+        S[(idx & 63) * SLD + (idx >> 6)] = v[q];
     }
+}
+// c += A(rows 16 ti ..) * B(:, 16 tj ..); output layout: column 16 tj + l15, rows 16 ti + lk + 4 reg
+__device__ __forceinline__ void sb_mm16(const double *A, const double *Bm, v4f64 &c, int ti, int tj, int l15, int lk) {
+#pragma unroll 4
+    for (int kk = 0; kk < 16; kk++)
+        c = __builtin_amdgcn_mfma_f64_16x16x4f64(A[(16 * ti + l15) * SLD + 4 * kk + lk], Bm[(4 * kk + lk) * SLD + 16 * tj + l15], c, 0, 0, 0);
 }
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(kInvThreads)
 k_invert_super(DevPlan P, FrontDesc F) {
     __shared__ double SA[64 * SLD], SB[64 * SLD];
     const int B = blockIdx.x / (kSbG - 1), cl = blockIdx.x % (kSbG - 1);
     const int nbB = min(kSbG, F.np - kSbG * B);
     if (cl + 1 >= nbB) return;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, lk = lane >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, lk = lane >> 4, ti = wv >> 2, tj = wv & 3;
     const FrontPanel *fps = P.front_panels + F.fp_off;
     const FrontPanel pc = fps[kSbG * B + cl];
+    const SbTileSrc linv_c = {P.Linv + pc.diag_off, 1, pc.w, pc.w, pc.w, true, false};
     for (int bl = cl + 1; bl < nbB; bl++) {
         const FrontPanel pb = fps[kSbG * B + bl];
-        v4f64 acc[4];
-#pragma unroll
-        for (int sub = 0; sub < 4; sub++) acc[sub] = (v4f64){0.0, 0.0, 0.0, 0.0};
+        v4f64 acc = {0.0, 0.0, 0.0, 0.0};
         for (int kl = cl; kl < bl; kl++) {
             const FrontPanel pk = fps[kSbG * B + kl];
-            const double *src = P.Lx + pk.panel_off + F.cw * (bl - kl);      // L[bl,kl]: rows of block bl inside panel kl
-            for (int idx = tid; idx < 4096; idx += 256) {
-                const int i = idx & 63, k = idx >> 6;
-                SA[i * SLD + k] = (i < pb.w && k < pk.w) ? src[i + (int64_t)k * pk.r] : 0.0;
-            }
-            if (kl == cl) {
-                sb_load_linv(P, pc, SB, tid);
-            } else {
-                const double *t = P.SbInv + sb_tile(F, B, kl, cl);           // written earlier by THIS workgroup (column-major)
-                for (int idx = tid; idx < 4096; idx += 256) SB[(idx & 63) * SLD + (idx >> 6)] = front_ld(t + idx);
-            }
+            // A = L[bl,kl]: rows of block bl inside panel kl (column-major, stride r);  B = Inv[kl,cl]
+            const SbTileSrc a_src = {P.Lx + pk.panel_off + F.cw * (bl - kl), 1, pk.r, pb.w, pk.w, false, false};
+            const SbTileSrc b_src = kl == cl ? linv_c : SbTileSrc{P.SbInv + sb_tile(F, B, kl, cl), 1, 64, 64, 64, false, true};
+            double va[4], vb[4];
+            sb_fetch(a_src, va, tid);
+            sb_fetch(b_src, vb, tid);
+            sb_put(SA, va, tid);
+            sb_put(SB, vb, tid);
             __syncthreads();
-            sb_mm(SA, SB, acc, wv, l15, lk);
+            sb_mm16(SA, SB, acc, ti, tj, l15, lk);
             __syncthreads();
         }
+        {   // Inv[bl,cl] = -Linv_bl * S
+            const SbTileSrc linv_b = {P.Linv + pb.diag_off, 1, pb.w, pb.w, pb.w, true, false};
+            double va[4];
+            sb_fetch(linv_b, va, tid);
 #pragma unroll
-        for (int sub = 0; sub < 4; sub++)
+            for (int reg = 0; reg < 4; reg++) SB[(16 * ti + lk + 4 * reg) * SLD + 16 * tj + l15] = acc[reg];
+            sb_put(SA, va, tid);
+            __syncthreads();
+            v4f64 o = {0.0, 0.0, 0.0, 0.0};
+            sb_mm16(SA, SB, o, ti, tj, l15, lk);
+            __syncthreads();
 #pragma unroll
-            for (int reg = 0; reg < 4; reg++) SB[(16 * wv + lk + 4 * reg) * SLD + 16 * sub + l15] = acc[sub][reg];
-        sb_load_linv(P, pb, SA, tid);
-        __syncthreads();
-        v4f64 o[4];
+            for (int reg = 0; reg < 4; reg++) SA[(16 * ti + lk + 4 * reg) * SLD + 16 * tj + l15] = -o[reg];
+            __syncthreads();
+            double *t = P.SbInv + sb_tile(F, B, bl, cl);
 #pragma unroll
-        for (int sub = 0; sub < 4; sub++) o[sub] = (v4f64){0.0, 0.0, 0.0, 0.0};
-        sb_mm(SA, SB, o, wv, l15, lk);
-        __syncthreads();
-#pragma unroll
-        for (int sub = 0; sub < 4; sub++)
-#pragma unroll
-            for (int reg = 0; reg < 4; reg++) SA[(16 * wv + lk + 4 * reg) * SLD + 16 * sub + l15] = -o[sub][reg];
-        __syncthreads();
-        double *t = P.SbInv + sb_tile(F, B, bl, cl);
-        for (int idx = tid; idx < 4096; idx += 256) front_st(t + idx, SA[(idx & 63) * SLD + (idx >> 6)]);            // [i + 64 k]
-        for (int idx = tid; idx < 4096; idx += 256) t[4096 + idx] = SA[(idx >> 6) * SLD + (idx & 63)];             // [64 i + k]
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+            for (int q = 0; q < 4; q++) {
+                const int idx = tid + kInvThreads * q;
+                front_st(t + idx, SA[(idx & 63) * SLD + (idx >> 6)]);            // column-major half [i + 64 k]
+                t[4096 + idx] = SA[(idx >> 6) * SLD + (idx & 63)];               // row-major half [64 i + k]
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
     }
 }
 
@@ -466,7 +479,7 @@ void launch_front_bwd_sb(hipStream_t st, const DevPlan &P, const FrontDesc &F, c
     hipLaunchKernelGGL(k_front_bwd_sb, dim3(F.np), dim3(kSbThreads), 0, st, P, F, z, x, xout);
 }
 void launch_invert_super(hipStream_t st, const DevPlan &P, const FrontDesc &F) {
-    if (F.sb_g > 0 && F.nsb > 0) hipLaunchKernelGGL(k_invert_super, dim3(F.nsb * (kSbG - 1)), dim3(256), 0, st, P, F);
+    if (F.sb_g > 0 && F.nsb > 0) hipLaunchKernelGGL(k_invert_super, dim3(F.nsb * (kSbG - 1)), dim3(kInvThreads), 0, st, P, F);
 }
 
 }  // namespace hipkkt

@@ -27,6 +27,14 @@ void hipkkt_default_opts(hipkkt_opts *o) {
     o->user_perm = nullptr;
 }
 
+// Gives the process-wide cache of device slabs (runtime_pool.h: up to 4 GiB per device, kept across handles so that a batch of small
+// problems does not pay hipMalloc / hipFree per handle) back to the driver -- for embedding hosts (Julia, torch) under memory pressure.
+int32_t hipkkt_trim_cache(int32_t device_id) {
+    if (hipSetDevice(device_id) != hipSuccess) return HIPKKT_ERR_DEVICE;
+    RuntimePool::get().trim(device_id);
+    return HIPKKT_OK;
+}
+
 int32_t hipkkt_is_available(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;

@@ -177,6 +177,7 @@ int32_t hipkkt_refactor(hipkkt_handle h, int32_t static_reg_enable, double eps_c
 static int32_t refactor_once(hipkkt_handle h, int32_t static_reg_enable, double eps_const, double eps_prop,
                              double *eps_used, int64_t *n_dynamic_reg) {
     HK_ENTER(h)
+    S->red_have_const = false;   // the resident constant-rhs solution (N2) belongs to the previous factorisation
     HK_CHECK(hipEventRecord(S->ev0, S->stream));
     if (S->profiling) {
         // eager, with the dense-update launches timed separately (adds event overhead)

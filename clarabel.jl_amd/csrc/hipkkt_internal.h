@@ -89,6 +89,7 @@ struct SolveCtx {
     double last_ms = 0;
     int64_t last_steps = 0;
     bool ir_used = false;
+    bool extra_steps = false;     // the last solve_finish ran refinement steps beyond the one inside the solve's graph
     const double *result() const { return (ir_used && h_rs->cur) ? d_x1 : d_x0; }
 };
 
@@ -99,7 +100,7 @@ struct hipkkt_solver {
     hipStream_t side = nullptr;          // far Schur updates run here, overlapped with the critical path
     std::vector<hipEvent_t> fork_events;
     bool use_side = true;
-    bool fork_gather = true;   // a stage's per-entry gather launch next to its big dense launch (hipkkt_factor.cpp enqueue_updates)
+    bool fork_gather = false;  // (measured r03b: no gain) a stage's per-entry gather launch next to its big dense launch (hipkkt_factor.cpp enqueue_updates)
     int far_wgs = 256;   // grid bound of the look-ahead (far) update launches; 0 = one workgroup per 4 tiles
     hipkkt_opts opts{};
     bool l1 = false;
@@ -175,6 +176,9 @@ struct hipkkt_solver {
     double *d_b = nullptr, *d_x = nullptr, *d_dx = nullptr, *d_e = nullptr;
     double *d_sin = nullptr, *d_sout = nullptr, *d_y = nullptr, *d_z = nullptr, *d_xp = nullptr;
     double *d_qb = nullptr, *d_res_in = nullptr, *d_res_out = nullptr, *d_res_part = nullptr;   // residuals_update! on the device (N4)
+    double *d_red = nullptr, *d_red_part = nullptr;   // reduced-system algebra of kkt_solve! (N2): [x1;z1] | [x2;z2] | step | variables.x | scalars
+    double *h_scal_red = nullptr;                     // pinned read-back of its ten scalars
+    bool red_have_const = false;                      // (x2, z2) of the current factorisation is resident
     double *d_stage = nullptr;   // staging for host-supplied values
     int64_t *d_stage_idx = nullptr;
     int64_t stage_cap = 0;

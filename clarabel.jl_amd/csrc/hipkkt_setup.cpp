@@ -21,7 +21,7 @@ void init_runtime(hipkkt_solver *S) {
         const char *ns = getenv("HIPKKT_SIDE_STREAM");
         S->use_side = ns && ns[0] == '1';
         const char *fg = getenv("HIPKKT_FORK_GATHER");
-        S->fork_gather = !(fg && fg[0] == '0');
+        S->fork_gather = fg && fg[0] == '1';
         const char *fw = getenv("HIPKKT_FAR_WGS");
         if (fw) S->far_wgs = atoi(fw);
     }
@@ -29,6 +29,8 @@ void init_runtime(hipkkt_solver *S) {
     for (hipEvent_t *e : {&S->ev0, &S->ev1, &S->ev2, &S->ev3}) *e = (hipEvent_t)need(rp.event_get(S->device));
     S->h_scal = (double *)need(rp.pinned_alloc(S->device));
     S->h_flags = (int *)need(rp.pinned_alloc(S->device));
+    S->h_scal_red = S->h_scal + 16;     // second half of the same pinned chunk (10 doubles; RuntimePool::kPinned = 256 bytes)
+    static_assert((16 + 10) * sizeof(double) <= RuntimePool::kPinned, "pinned chunk too small for the reduced-solve scalars");
     memset(S->h_scal, 0, SC_COUNT * sizeof(double));
     memset(S->h_flags, 0, FL_COUNT * sizeof(int));
     const char *ng = getenv("HIPKKT_NO_GRAPH");
@@ -72,6 +74,8 @@ void setup_device(hipkkt_solver *S) {
     S->nsoc = 0; S->soc_total = 0; S->wmax_all = 1;
     S->stage_cap = 0; S->d_stage = nullptr; S->d_stage_idx = nullptr;
     S->d_qb = S->d_res_in = S->d_res_out = S->d_res_part = nullptr;
+    S->d_red = S->d_red_part = nullptr;
+    S->red_have_const = false;
 
     HostPlan &P = S->plan;
     const int N = P.N;
@@ -364,7 +368,7 @@ void setup_device(hipkkt_solver *S) {
         const char *sl = getenv("HIPKKT_SPIN_LIMIT");      // tests force a sweep time-out with a tiny bound
         D.spin_limit = sl ? (unsigned)strtoul(sl, nullptr, 10) : (1u << 20);
         const char *pm = getenv("HIPKKT_PIVOT_MODE");
-        D.pivot_mode = pm ? atoi(pm) : 1;
+        D.pivot_mode = pm ? atoi(pm) : 0;   // measured (cfg 2a, r03b): mode 1 is 0.1 ms per factorisation SLOWER -- the 148 extra VALU issues per block cost more than the shorter chain saves
     }
     {
         const size_t nsync = seg_sync_ints(S->nseg, P.nsuper);

@@ -162,12 +162,14 @@ int32_t solve_finish(hipkkt_solver *S, SolveCtx &C, int64_t *ir_steps, double *o
     };
     readback();
     bool more = false;
+    C.extra_steps = false;
     while (C.ir_used && C.h_rs->active && !sweep_failed(C)) {   // rare: more than one step needed
         run_graphed(S, st, C.g_step, true, [&] { enqueue_refine_step(S, C, C.g_reltol, C.g_abstol, C.g_maxit, C.g_stop); });
         S->n_ldlsolves += 1;
         more = true;
         readback();
     }
+    C.extra_steps = more;
     if (more && out_dev) {   // the accepted iterate changed after the copy that solve_copy_out_dev enqueued
         solve_copy_out_dev(S, C, out_dev, nm);
         HK_CHECK(hipEventRecord(C.ev_b, st));
@@ -331,6 +333,111 @@ int32_t hipkkt_solve_multi_dev(hipkkt_handle h, int64_t nrhs, const double *rhs_
     HK_ENTER(h)
     if (!S->l1 || nrhs < 0 || (nrhs && !rhs_dev)) return HIPKKT_ERR_ARGUMENT;
     return solve_multi_impl(S, nrhs, nullptr, nullptr, rhs_dev, nullptr, nullptr, lhs_dev, ir_enable, reltol, abstol, max_iter, stop_ratio, ir_steps);
+    HK_LEAVE
+}
+
+// SURVEY section 8(f) row N2, second half: kkt_solve! (kktsystem.jl:135-215) between the caller's cone algebra and mul_Hs!.
+// Both solves are started before anything is waited for; the reduction (dots, dtau, axpys) and the copies of the step are
+// enqueued behind them speculatively; the host synchronises once.  Only if a solve needed more refinement steps than the one that
+// is part of its graph (rare) the reduction is repeated after those steps.
+static int32_t kkt_solve_reduced_impl(hipkkt_solver *S, const double *rhs_x, const double *workz, const double *var_x,
+                                      const double *in_dev, const double *scal_in, int32_t const_pending, double *lhs_x,
+                                      double *lhs_z, double *lhs_dev, double *scal_out, int32_t ir_enable, double reltol,
+                                      double abstol, int64_t max_iter, double stop_ratio, int64_t *ir_steps) {
+    const int64_t n = S->img.n, m = S->img.m, p = S->img.p;
+    const int nm = (int)(n + m);
+    if (!S->d_red) {
+        S->d_red = S->dalloc<double>(3 * (size_t)S->N + n + 16);                          // x1z1 | x2z2 | lhs | var_x | scalars
+        S->d_red_part = S->dalloc<double>(8 * (size_t)residual_blocks((int)n, (int)m) + 8);
+        S->red_have_const = false;
+    }
+    double *d_s1 = S->d_red, *d_s2 = d_s1 + S->N, *d_lhs = d_s2 + S->N, *d_xv = d_lhs + S->N, *d_sc = d_xv + n;
+    if (!const_pending && !S->red_have_const) { S->err = "kkt_solve_reduced: no constant-rhs solution resident (pass const_pending = 1 after a refactorisation)"; return HIPKKT_ERR_ARGUMENT; }
+    hipkkt_solver *T = solve_target(S);
+    const double tau = scal_in[0], kappa = scal_in[1], rhs_tau = scal_in[2], rhs_kappa = scal_in[3];
+    for (int attempt = 0; attempt < 2; attempt++) {
+        maybe_retry_persistent(T);
+        SolveCtx &A = T->ctx[0], &Bc = T->ctx[1];
+        // right-hand sides
+        if (in_dev) {
+            launch_set_rhs(A.stream, A.d_b, in_dev, nm, T->N);
+            HK_CHECK(hipMemcpyAsync(d_xv, in_dev + nm, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, A.stream));
+        } else {
+            if (n) HK_CHECK(hipMemcpyAsync(A.d_b, rhs_x, n * sizeof(double), hipMemcpyHostToDevice, A.stream));
+            if (m) HK_CHECK(hipMemcpyAsync(A.d_b + n, workz, m * sizeof(double), hipMemcpyHostToDevice, A.stream));
+            if (p) HK_CHECK(hipMemsetAsync(A.d_b + n + m, 0, p * sizeof(double), A.stream));
+            if (n) HK_CHECK(hipMemcpyAsync(d_xv, var_x, n * sizeof(double), hipMemcpyHostToDevice, A.stream));
+        }
+        solve_begin(T, A, ir_enable, reltol, abstol, max_iter, stop_ratio);
+        solve_copy_out_dev(T, A, d_s1, nm);
+        if (const_pending) {
+            launch_const_rhs(Bc.stream, Bc.d_b, S->d_qb, (int)n, nm, T->N);
+            solve_begin(T, Bc, ir_enable, reltol, abstol, max_iter, stop_ratio);
+            solve_copy_out_dev(T, Bc, d_s2, nm);
+            HK_CHECK(hipEventRecord(S->ev2, Bc.stream));
+            HK_CHECK(hipStreamWaitEvent(A.stream, S->ev2, 0));
+        }
+        auto reduce = [&]() {
+            launch_reduced(A.stream, S->dp, d_s1, d_s2, d_xv, S->d_qb, S->d_qb + n, tau, kappa, rhs_tau, rhs_kappa, S->d_red_part, d_sc,
+                           d_lhs, (int)n, (int)m);
+            if (lhs_dev) HK_CHECK(hipMemcpyAsync(lhs_dev, d_lhs, (size_t)nm * sizeof(double), hipMemcpyDeviceToDevice, A.stream));
+            if (lhs_x && n) HK_CHECK(hipMemcpyAsync(lhs_x, d_lhs, n * sizeof(double), hipMemcpyDeviceToHost, A.stream));
+            if (lhs_z && m) HK_CHECK(hipMemcpyAsync(lhs_z, d_lhs + n, m * sizeof(double), hipMemcpyDeviceToHost, A.stream));
+            HK_CHECK(hipMemcpyAsync(S->h_scal_red, d_sc, 10 * sizeof(double), hipMemcpyDeviceToHost, A.stream));
+        };
+        reduce();
+        int64_t st1 = 0, st2 = 0;
+        int32_t rc = solve_finish(T, A, &st1, d_s1, nm);
+        bool redo = A.extra_steps;
+        double ms = A.last_ms;
+        if (const_pending) {
+            const int32_t r2 = solve_finish(T, Bc, &st2, d_s2, nm);
+            redo = redo || Bc.extra_steps;
+            ms = std::max(ms, Bc.last_ms);
+            if (r2 < 0 || (r2 > 0 && rc == HIPKKT_OK)) rc = r2 < 0 ? r2 : (rc < 0 ? rc : r2);
+        }
+        bool timed_out = sweep_failed(A) || (const_pending && sweep_failed(Bc));
+        if (timed_out && recover_from_sweep_failure(T)) continue;   // repeat everything on the per-level kernels
+        if (timed_out) return HIPKKT_ERR_DEVICE;
+        if (redo && rc == HIPKKT_OK) {                              // the accepted iterates changed after the speculative reduction
+            if (const_pending) { HK_CHECK(hipEventRecord(S->ev2, Bc.stream)); HK_CHECK(hipStreamWaitEvent(A.stream, S->ev2, 0)); }
+            reduce();
+        }
+        HK_CHECK(hipStreamSynchronize(A.stream));
+        T->t_last_solve = ms; T->t_acc_solve += ms; T->n_solvecalls++; T->n_rhs_solved += const_pending ? 2 : 1;
+        if (T != S) { S->t_last_solve = ms; S->t_acc_solve += ms; S->n_solvecalls++; S->n_rhs_solved += const_pending ? 2 : 1; }
+        if (rc == HIPKKT_OK && const_pending) S->red_have_const = true;
+        if (ir_steps) { ir_steps[0] = st1; ir_steps[1] = st2; }
+        if (scal_out) memcpy(scal_out, S->h_scal_red, 10 * sizeof(double));
+        return rc;
+    }
+    return HIPKKT_ERR_DEVICE;
+}
+
+int32_t hipkkt_kkt_solve_reduced(hipkkt_handle h, const double *rhs_x, const double *workz, const double *var_x, const double *scal_in4,
+                                 int32_t const_pending, double *lhs_x, double *lhs_z, double *scal_out10, int32_t ir_enable,
+                                 double reltol, double abstol, int64_t max_iter, double stop_ratio, int64_t *ir_steps2) {
+    HK_ENTER(h)
+    const int64_t n = S->img.n, m = S->img.m;
+    if (!S->l1 || !S->d_qb || !scal_in4 || !scal_out10 || (n && (!rhs_x || !var_x)) || (m && !workz)) {
+        S->err = "kkt_solve_reduced: call hipkkt_set_qb first / bad arguments";
+        return HIPKKT_ERR_ARGUMENT;
+    }
+    return kkt_solve_reduced_impl(S, rhs_x, workz, var_x, nullptr, scal_in4, const_pending, lhs_x, lhs_z, nullptr, scal_out10, ir_enable,
+                                  reltol, abstol, max_iter, stop_ratio, ir_steps2);
+    HK_LEAVE
+}
+
+int32_t hipkkt_kkt_solve_reduced_dev(hipkkt_handle h, const double *in_dev, const double *scal_in4, int32_t const_pending,
+                                     double *lhs_dev, double *scal_out10, int32_t ir_enable, double reltol, double abstol,
+                                     int64_t max_iter, double stop_ratio, int64_t *ir_steps2) {
+    HK_ENTER(h)
+    if (!S->l1 || !S->d_qb || !scal_in4 || !scal_out10 || !in_dev) {
+        S->err = "kkt_solve_reduced_dev: call hipkkt_set_qb first / bad arguments";
+        return HIPKKT_ERR_ARGUMENT;
+    }
+    return kkt_solve_reduced_impl(S, nullptr, nullptr, nullptr, in_dev, scal_in4, const_pending, nullptr, nullptr, lhs_dev, scal_out10,
+                                  ir_enable, reltol, abstol, max_iter, stop_ratio, ir_steps2);
     HK_LEAVE
 }
 

@@ -61,6 +61,11 @@ int residual_blocks(int n, int m);
 int long_row_threshold();   // rows of the symmetric CSR view with more entries are taken by k_spmv_long
 void launch_residuals(hipStream_t st, const DevPlan &P, const double *x, const double *z, const double *s, const double *q,
                       const double *b, double tau, double kappa, double *out, double *part, double *scal, int n, int m);
+// N2: reduced-system algebra of kkt_solve! (part: 8 * residual_blocks(n, m) doubles, scal_out: 10 doubles)
+void launch_reduced(hipStream_t st, const DevPlan &P, const double *s1, const double *s2, const double *xv, const double *q,
+                    const double *b, double tau, double kappa, double rhs_tau, double rhs_kappa, double *part, double *scal_out,
+                    double *lhs, int n, int m);
+void launch_const_rhs(hipStream_t st, double *dst, const double *qb, int n, int nm, int N);
 void launch_norm_inf(hipStream_t st, const double *v, int n, unsigned long long *slot);
 void launch_add(hipStream_t st, double *dst, const double *a, int n);
 void launch_set_rhs(hipStream_t st, double *b, const double *rhs, int nm, int n);

@@ -2000,6 +2000,103 @@ k_residuals_finish(const double *__restrict__ part, int nblocks, double tau, dou
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// SURVEY section 8(f) row N2, second half: the reduced-system algebra of kkt_solve! (kktsystem.jl:170-196) on the device.
+// Given the two resident solutions  [x1; z1] (this step's right-hand side)  and  [x2; z2] (the constant right-hand side [-q; b]),
+// xi = x / tau and the resident q, b, P:
+//   tau_num = rhs.tau - rhs.kappa / tau + q.x1 + b.z1 + 2 xi'P x1
+//   tau_den = kappa / tau - q.x2 - b.z2 + (xi - x2)'P(xi - x2) - x2'P x2          (quad_form of mathutils.jl:299-337 = x'(P y), P symmetric)
+//   dtau = tau_num / tau_den ;  lhs = [x1; z1] + dtau [x2; z2]
+// Rows of the symmetric CSR view of K (4 lanes per row, like k_residuals); the seven dot products are reduced per workgroup into
+// part[blockIdx][8] and summed in block order by k_reduced_finish (deterministic).
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_reduced_rows(const int64_t *__restrict__ rowptr, const int *__restrict__ col, const int64_t *__restrict__ qidx,
+               const double *__restrict__ kval, const double *__restrict__ s1, const double *__restrict__ s2,
+               const double *__restrict__ xv, const double *__restrict__ q, const double *__restrict__ b, double tau,
+               double *__restrict__ part, int n, int m) {
+    __shared__ double red[4][8];
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int row = gid >> 2, sub = gid & 3;
+    double a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    if (row < n) {
+        const int64_t p0 = rowptr[row], p1 = rowptr[row + 1];
+        for (int64_t p = p0 + sub; p < p1; p += 4) {
+            const int c = col[p];
+            if (c < n) {
+                const double v = kval[qidx[p]];
+                a1 += v * s1[c];
+                a2 += v * s2[c];
+                a3 += v * (xv[c] / tau);
+            }
+        }
+    }
+    a1 += __shfl_xor(a1, 1, 64); a1 += __shfl_xor(a1, 2, 64);
+    a2 += __shfl_xor(a2, 1, 64); a2 += __shfl_xor(a2, 2, 64);
+    a3 += __shfl_xor(a3, 1, 64); a3 += __shfl_xor(a3, 2, 64);
+    double d[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};   // q.x1, b.z1, xi'P x1, q.x2, b.z2, (xi-x2)'P(xi-x2), x2'P x2
+    if (sub == 0 && row < n + m) {
+        if (row < n) {
+            const double xi = xv[row] / tau, x1 = s1[row], x2 = s2[row];
+            d[0] = q[row] * x1;
+            d[2] = xi * a1;
+            d[3] = q[row] * x2;
+            d[5] = (xi - x2) * (a3 - a2);
+            d[6] = x2 * a2;
+        } else {
+            const int j = row - n;
+            d[1] = b[j] * s1[row];
+            d[4] = b[j] * s2[row];
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 7; c++)
+        for (int off = 32; off > 0; off >>= 1) d[c] += __shfl_down(d[c], off, 64);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0)
+#pragma unroll
+        for (int c = 0; c < 8; c++) red[wave][c] = d[c];
+    __syncthreads();
+    if (threadIdx.x < 8)
+        part[(int64_t)blockIdx.x * 8 + threadIdx.x] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+}
+// scal_in = [tau, kappa, rhs.tau, rhs.kappa];  scal_out = [dtau, tau_num, tau_den, q.x1, b.z1, xi'Px1, q.x2, b.z2, (xi-x2)'P(xi-x2), x2'Px2]
+__global__ void __launch_bounds__(256)
+k_reduced_finish(const double *__restrict__ part, int nblocks, double tau, double kappa, double rhs_tau, double rhs_kappa,
+                 double *__restrict__ scal_out) {
+    __shared__ double buf[8][32];
+    const int which = threadIdx.x & 7, slot = threadIdx.x >> 3;       // 32 partial sums per dot product, fixed order
+    double a = 0.0;
+    for (int bq = slot; bq < nblocks; bq += 32) a += part[(int64_t)bq * 8 + which];
+    buf[which][slot] = a;
+    __syncthreads();
+    if (threadIdx.x < 8) {
+        double t = 0.0;
+        for (int i = 0; i < 32; i++) t += buf[threadIdx.x][i];
+        buf[threadIdx.x][0] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double qx1 = buf[0][0], bz1 = buf[1][0], xPx1 = buf[2][0], qx2 = buf[3][0], bz2 = buf[4][0], dPd = buf[5][0], x2Px2 = buf[6][0];
+        const double num = rhs_tau - rhs_kappa / tau + qx1 + bz1 + 2.0 * xPx1;         // kktsystem.jl:183
+        double den = kappa / tau - qx2 - bz2;                                           // :189
+        den += dPd - x2Px2;                                                             // :190
+        scal_out[0] = num / den; scal_out[1] = num; scal_out[2] = den;
+        scal_out[3] = qx1; scal_out[4] = bz1; scal_out[5] = xPx1; scal_out[6] = qx2; scal_out[7] = bz2; scal_out[8] = dPd; scal_out[9] = x2Px2;
+    }
+}
+// lhs = [x1; z1] + dtau [x2; z2]   (kktsystem.jl:195-196), dtau read from the device
+__global__ void k_reduced_axpy(const double *__restrict__ s1, const double *__restrict__ s2, const double *__restrict__ scal,
+                               double *__restrict__ lhs, int nm) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nm) lhs[i] = s1[i] + scal[0] * s2[i];
+}
+// the constant right-hand side of _kkt_solve_constant_rhs! (kktsystem.jl:80-92): [-q; b; 0]
+__global__ void k_const_rhs(double *__restrict__ dst, const double *__restrict__ qb, int n, int nm, int N) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N) dst[i] = i < n ? -qb[i] : (i < nm ? qb[i] : 0.0);
+}
+
 __global__ void __launch_bounds__(256)
 k_norm_inf(const double *__restrict__ v, int n, unsigned long long *__restrict__ slot) {
     double a = 0.0;
@@ -2308,6 +2405,18 @@ void launch_residuals(hipStream_t st, const DevPlan &P, const double *x, const d
     const int nb = residual_blocks(n, m);
     hipLaunchKernelGGL(k_residuals, dim3(nb), dim3(256), 0, st, P.sym_rowptr, P.sym_col, P.sym_q, P.kval, x, z, s, q, b, tau, out, part, n, m);
     hipLaunchKernelGGL(k_residuals_finish, dim3(1), dim3(256), 0, st, part, nb, tau, kappa, scal);
+}
+void launch_reduced(hipStream_t st, const DevPlan &P, const double *s1, const double *s2, const double *xv, const double *q,
+                    const double *b, double tau, double kappa, double rhs_tau, double rhs_kappa, double *part, double *scal_out,
+                    double *lhs, int n, int m) {
+    if (n + m <= 0) return;
+    const int nb = residual_blocks(n, m);
+    hipLaunchKernelGGL(k_reduced_rows, dim3(nb), dim3(256), 0, st, P.sym_rowptr, P.sym_col, P.sym_q, P.kval, s1, s2, xv, q, b, tau, part, n, m);
+    hipLaunchKernelGGL(k_reduced_finish, dim3(1), dim3(256), 0, st, part, nb, tau, kappa, rhs_tau, rhs_kappa, scal_out);
+    hipLaunchKernelGGL(k_reduced_axpy, dim3(nblk(n + m)), dim3(256), 0, st, s1, s2, scal_out, lhs, n + m);
+}
+void launch_const_rhs(hipStream_t st, double *dst, const double *qb, int n, int nm, int N) {
+    if (N > 0) hipLaunchKernelGGL(k_const_rhs, dim3(nblk(N)), dim3(256), 0, st, dst, qb, n, nm, N);
 }
 void launch_norm_inf(hipStream_t st, const double *v, int n, unsigned long long *slot) {
     if (n > 0) hipLaunchKernelGGL(k_norm_inf, dim3(min(nblk(n), 64u)), dim3(256), 0, st, v, n, slot);

@@ -44,8 +44,10 @@ public:
         }
         void *p = nullptr;
         if (hipMalloc(&p, bytes) != hipSuccess) {
+            (void)hipGetLastError();                       // the failed attempt must not linger as the thread's "last error": callers
+                                                           // that check hipGetLastError() after their launches would report it as theirs
             trim(device);                                  // give the cached blocks back and try once more
-            if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+            if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
         }
         *cap = bytes;
         return p;

@@ -117,8 +117,8 @@ struct PlanOptions {
     bool fuse_jit = false;     // apply the just-in-time updates of a front panel inside its panel kernel
                                // (measured slower on MI355X, DESIGN.md section 9: every workgroup repeats the diagonal tile)
     bool split_far = false;    // separate the far dense tiles of a stage (side-stream experiments)
-    int xcd_order = 2;         // order of the dense tiles of a big stage (performance only): 0 natural (target panel, row block),
-                               // 1 row blocks bucketed by XCD, 2 (default) 16 x 16 super-tiles dealt to the XCDs (symbolic.cpp)
+    int xcd_order = 0;         // order of the dense tiles of a big stage (performance only): 0 natural (target panel, row block),
+                               // 1 row blocks bucketed by XCD, 2 = 16 x 16 super-tiles dealt to the XCDs (symbolic.cpp; measured r03b: +0.05 ms per factorisation)
     int n_hold = 0;            // > 0: also try the "variables last" order (nodes < n_hold held back) and keep
                                // whichever order predicts fewer factor flops
     int front_block_min_width = 1024;   // supernodes at least this wide are cut into full 64-column panels (remainder last) so that

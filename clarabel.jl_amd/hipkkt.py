@@ -18,12 +18,12 @@ _f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
 
 # every symbol include/hipkkt.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
-    "hipkkt_default_opts", "hipkkt_is_available", "hipkkt_create", "hipkkt_create_from_parts", "hipkkt_destroy",
+    "hipkkt_default_opts", "hipkkt_is_available", "hipkkt_trim_cache", "hipkkt_create", "hipkkt_create_from_parts", "hipkkt_destroy",
     "hipkkt_get_dims", "hipkkt_info", "hipkkt_get_cost_model", "hipkkt_get_kkt", "hipkkt_get_perm",
     "hipkkt_get_dsigns", "hipkkt_get_map", "hipkkt_get_sparse_map", "hipkkt_update_values", "hipkkt_scale_values",
     "hipkkt_set_hs", "hipkkt_set_hs_dev", "hipkkt_set_hs_psd", "hipkkt_set_cone_types", "hipkkt_update_scaling", "hipkkt_update_scaling_dev", "hipkkt_block_products", "hipkkt_set_soc", "hipkkt_set_soc_batch", "hipkkt_set_genpow",
     "hipkkt_update_P", "hipkkt_update_A", "hipkkt_refactor", "hipkkt_setrhs", "hipkkt_setrhs_dev", "hipkkt_solve",
-    "hipkkt_solve_dev", "hipkkt_solve_multi", "hipkkt_solve_multi_dev", "hipkkt_ldl_solve", "hipkkt_get_timing", "hipkkt_reset_timing", "hipkkt_get_profile", "hipkkt_get_profile_launches", "hipkkt_set_profiling",
+    "hipkkt_solve_dev", "hipkkt_solve_multi", "hipkkt_solve_multi_dev", "hipkkt_kkt_solve_reduced", "hipkkt_kkt_solve_reduced_dev", "hipkkt_ldl_solve", "hipkkt_get_timing", "hipkkt_reset_timing", "hipkkt_get_profile", "hipkkt_get_profile_launches", "hipkkt_set_profiling",
     "hipkkt_get_counters", "hipkkt_debug_dump", "hipkkt_set_qb", "hipkkt_residuals", "hipkkt_residuals_dev",
     "hipkkt_selftest_mfma", "hipkkt_last_error",
 ]
@@ -93,6 +93,9 @@ def lib():
     L.hipkkt_ldl_solve.argtypes = [vp, _f64p, _f64p]
     L.hipkkt_solve_multi.argtypes = [vp, i64, _f64p, _f64p, vp, vp, i32, f64, f64, i64, f64, vp]
     L.hipkkt_solve_multi_dev.argtypes = [vp, i64, vp, vp, i32, f64, f64, i64, f64, vp]
+    L.hipkkt_kkt_solve_reduced.argtypes = [vp, _f64p, _f64p, _f64p, _f64p, i32, vp, vp, _f64p, i32, f64, f64, i64, f64, vp]
+    L.hipkkt_kkt_solve_reduced_dev.argtypes = [vp, vp, _f64p, i32, vp, _f64p, i32, f64, f64, i64, f64, vp]
+    L.hipkkt_trim_cache.argtypes = [i32]
     L.hipkkt_get_timing.argtypes = [vp, _f64p]
     L.hipkkt_reset_timing.argtypes = [vp]
     L.hipkkt_get_profile.argtypes = [vp, _f64p]
@@ -358,15 +361,49 @@ class Handle:
     def solve_multi(self, rhsx, rhsz, lhsx, lhsz, ir_enable=True, reltol=1e-13, abstol=1e-12, max_iter=10, stop_ratio=5.0):
         """nrhs right-hand sides on one factorisation (include/hipkkt.h hipkkt_solve_multi): rhsx [nrhs, n], rhsz [nrhs, m];
         lhsx / lhsz = writeable arrays of the same shapes (or None).  Returns (ok, steps[nrhs])."""
-        rhsx = np.ascontiguousarray(rhsx, dtype=np.float64).reshape(-1, self.n) if self.n else np.zeros((len(rhsz), 0))
-        rhsz = np.ascontiguousarray(rhsz, dtype=np.float64).reshape(-1, self.m) if self.m else np.zeros((len(rhsx), 0))
-        nrhs = max(rhsx.shape[0], rhsz.shape[0])
+        rhsx = np.ascontiguousarray(rhsx, dtype=np.float64)
+        rhsz = np.ascontiguousarray(rhsz, dtype=np.float64)
+        if self.n and self.m:
+            rhsx, rhsz = rhsx.reshape(-1, self.n), rhsz.reshape(-1, self.m)
+        elif self.n:
+            rhsx = rhsx.reshape(-1, self.n)
+            rhsz = np.zeros((rhsx.shape[0], 0))
+        else:
+            rhsz = rhsz.reshape(-1, self.m) if self.m else np.zeros((0, 0))
+            rhsx = np.zeros((rhsz.shape[0], 0))
+        if rhsx.shape[0] != rhsz.shape[0]:
+            raise HipKKTError(f"solve_multi: {rhsx.shape[0]} right-hand sides in rhsx but {rhsz.shape[0]} in rhsz")
+        nrhs = rhsx.shape[0]
         steps = np.zeros(max(nrhs, 1), dtype=np.int64)
         px = self._out_ptr(lhsx, nrhs * self.n, "lhsx")
         pz = self._out_ptr(lhsz, nrhs * self.m, "lhsz")
         rc = self._chk(self.L.hipkkt_solve_multi(self.h, nrhs, rhsx, rhsz, px, pz, int(ir_enable), reltol, abstol, max_iter,
                                                  stop_ratio, steps.ctypes.data), "solve_multi")
         return rc == 0, steps[:nrhs]
+
+    def kkt_solve_reduced(self, rhs_x, workz, var_x, tau, kappa, rhs_tau, rhs_kappa, const_pending, lhs_x, lhs_z, ir_enable=True,
+                          reltol=1e-13, abstol=1e-12, max_iter=10, stop_ratio=5.0):
+        """kkt_solve! between the caller's cone algebra and mul_Hs! (include/hipkkt.h hipkkt_kkt_solve_reduced; needs set_qb).
+        Returns (ok, dtau, scal[10], steps[2]); lhs_x / lhs_z = writeable arrays (or None)."""
+        f = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+        scal_in = np.array([tau, kappa, rhs_tau, rhs_kappa], dtype=np.float64)
+        scal = np.zeros(10)
+        steps = np.zeros(2, dtype=np.int64)
+        px = self._out_ptr(lhs_x, self.n, "lhs_x")
+        pz = self._out_ptr(lhs_z, self.m, "lhs_z")
+        rc = self._chk(self.L.hipkkt_kkt_solve_reduced(self.h, f(rhs_x), f(workz), f(var_x), scal_in, int(bool(const_pending)), px, pz, scal,
+                                                       int(ir_enable), reltol, abstol, max_iter, stop_ratio, steps.ctypes.data),
+                       "kkt_solve_reduced")
+        return rc == 0, float(scal[0]), scal, steps
+
+    def kkt_solve_reduced_dev(self, in_ptr, tau, kappa, rhs_tau, rhs_kappa, const_pending, out_ptr, ir_enable=True, reltol=1e-13,
+                              abstol=1e-12, max_iter=10, stop_ratio=5.0):
+        scal_in = np.array([tau, kappa, rhs_tau, rhs_kappa], dtype=np.float64)
+        scal = np.zeros(10)
+        steps = np.zeros(2, dtype=np.int64)
+        rc = self._chk(self.L.hipkkt_kkt_solve_reduced_dev(self.h, in_ptr, scal_in, int(bool(const_pending)), out_ptr, scal, int(ir_enable),
+                                                           reltol, abstol, max_iter, stop_ratio, steps.ctypes.data), "kkt_solve_reduced_dev")
+        return rc == 0, float(scal[0]), scal, steps
 
     def solve_multi_dev(self, nrhs, rhs_ptr, out_ptr, ir_enable=True, reltol=1e-13, abstol=1e-12, max_iter=10, stop_ratio=5.0):
         steps = np.zeros(max(nrhs, 1), dtype=np.int64)

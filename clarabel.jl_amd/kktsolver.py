@@ -126,6 +126,24 @@ class HipKKTSolver:
             print(f"[hipkkt] solve_multi ok={ok} ir_steps={list(steps)}")
         return ok
 
+    # SURVEY section 8(f) row N2, second half: kkt_solve! (kktsystem.jl:135-215) between the caller's cone algebra and mul_Hs! --
+    # the solve for (x1, z1), the d tau numerator / denominator (dots with q, b, quad_form with P) and dx, dz on the device.
+    # const_pending: the constant-rhs solve that kkt_update! left pending runs in the same call (its solution stays resident).
+    # Needs set_problem_vectors(q, b).  Returns (ok, dtau).
+    def kktsolver_kkt_solve_reduced(self, rhs_x, workz, var_x, tau, kappa, rhs_tau, rhs_kappa, const_pending, lhs_x, lhs_z):
+        st = self.settings
+        ok, dtau, scal, steps = self.h.kkt_solve_reduced(rhs_x, workz, var_x, tau, kappa, rhs_tau, rhs_kappa, const_pending, lhs_x, lhs_z,
+                                                         st.iterative_refinement_enable, st.iterative_refinement_reltol,
+                                                         st.iterative_refinement_abstol, st.iterative_refinement_max_iter,
+                                                         st.iterative_refinement_stop_ratio)
+        self.last_ir_steps = int(steps[0])
+        self.total_ir_steps += int(steps[0]) + (int(steps[1]) if const_pending else 0)
+        self.nsolves += 2 if const_pending else 1
+        self.last_reduced_scalars = scal
+        if _DEBUG:
+            print(f"[hipkkt] kkt_solve_reduced ok={ok} dtau={dtau:.6e} ir_steps={list(steps)}")
+        return ok, dtau
+
     # residuals_update!(residuals, variables, data) (residuals.jl:1-37) from the resident P, A
     def set_problem_vectors(self, q, b):
         self.h.set_qb(q, b)

@@ -52,4 +52,5 @@ class Settings:
     # SURVEY section 8(f) rows widened beyond the reference's plugin seam (all off by default = the reference's call pattern)
     device_residuals: bool = False            # N4: residuals_update! computed by the plugin from the resident P, A
     device_scaling: bool = False              # N1: update_scaling! / get_Hs! of the symmetric cones formed by the plugin from (s, z)
+    device_reduced: bool = False              # N2: the reduced-system algebra of kkt_solve! (d tau dots, quad_form, dx, dz) done by the plugin
     extra: dict = field(default_factory=dict)

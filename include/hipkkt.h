@@ -68,6 +68,9 @@ void hipkkt_default_opts(hipkkt_opts *opts);
 /* ref: ldlsolver_is_available(::Val{:hip}) (pattern: ext/directldl_pardiso.jl:144,148).
  * Number of usable HIP devices (0 = not available).  Never fails. */
 int32_t hipkkt_is_available(void);
+/* releases the process-wide cache of device memory blocks the library keeps between handles (not in the reference: an embedding
+ * host under memory pressure may call it at any time; live handles are unaffected) */
+int32_t hipkkt_trim_cache(int32_t device_id);
 
 /* ---- construction ------------------------------------------------------------------------ */
 
@@ -216,6 +219,26 @@ int32_t hipkkt_solve_multi(hipkkt_handle h, int64_t nrhs, const double *rhsx, co
 /* same with everything resident: rhs_dev / lhs_dev = nrhs x (n+m) doubles on the device */
 int32_t hipkkt_solve_multi_dev(hipkkt_handle h, int64_t nrhs, const double *rhs_dev, double *lhs_dev, int32_t ir_enable,
                                double reltol, double abstol, int64_t max_iter, double stop_ratio, int64_t *ir_steps);
+/* SURVEY section 8(f) row N2, second half.  ref: kkt_solve!(kktsystem, lhs, rhs, data, variables, cones, steptype),
+ * src/kktsystem.jl:135-215 -- everything between the caller's cone algebra (the vector c of  Hs dz + ds = -c, :152-163) and
+ * mul_Hs! (:203): the solve  K [x1; z1] = [rhs.x; c - rhs.z]  (:167-170), the numerator and denominator of d tau with
+ * quad_form(., P, .) (:176-190, mathutils.jl:299-337) from the q, b made resident by hipkkt_set_qb and the resident P values,
+ * and  dx = x1 + dtau x2,  dz = z1 + dtau z2  (:194-196).  ONE PCIe round trip and one host synchronisation per kkt_solve!.
+ *   rhs_x[n], workz[m] (= c - rhs.z), var_x[n] (= variables.x) in;  scal_in = {variables.tau, variables.kappa, rhs.tau, rhs.kappa}
+ *   const_pending != 0: the constant-rhs solve of _kkt_solve_constant_rhs! (:80-92), K [x2; z2] = [-q; b], left pending by
+ *     kkt_update!, runs here next to (x1, z1) on the second solve context and its solution becomes the resident (x2, z2);
+ *     const_pending == 0: (x2, z2) of the last such call (same factorisation) is used
+ *   lhs_x[n], lhs_z[m] out (host; either may be NULL);  scal_out[10] = {dtau, tau_num, tau_den, q.x1, b.z1, xi'P x1, q.x2, b.z2,
+ *     (xi - x2)'P(xi - x2), x2'P x2} (host, required);  ir_steps[2] = refinement steps of the (x1, z1) / (x2, z2) solve (may be NULL)
+ * The _dev form takes in_dev = [rhs_x | workz | var_x] (2n + m doubles) and writes lhs_dev = [dx | dz] (n + m doubles, may be NULL:
+ * the step then stays in the handle and only the scalars cross PCIe).  Returns 0, HIPKKT_NUMERICAL_FAILURE when a solve failed
+ * (the reference returns is_success = false), < 0 on usage / device errors (hipkkt_set_qb not called: HIPKKT_ERR_ARGUMENT). */
+int32_t hipkkt_kkt_solve_reduced(hipkkt_handle h, const double *rhs_x, const double *workz, const double *var_x, const double *scal_in4,
+                                 int32_t const_pending, double *lhs_x, double *lhs_z, double *scal_out10, int32_t ir_enable,
+                                 double reltol, double abstol, int64_t max_iter, double stop_ratio, int64_t *ir_steps2);
+int32_t hipkkt_kkt_solve_reduced_dev(hipkkt_handle h, const double *in_dev, const double *scal_in4, int32_t const_pending,
+                                     double *lhs_dev, double *scal_out10, int32_t ir_enable, double reltol, double abstol,
+                                     int64_t max_iter, double stop_ratio, int64_t *ir_steps2);
 /* seam L0.  ref: solve!(ldlsolver,K,x,b), directldl_qdldl.jl:85-96: x = K_fact^{-1} b, length N,
  * no refinement (the Julia-side DirectLDLKKTSolver refines).  x and b must not alias. */
 int32_t hipkkt_ldl_solve(hipkkt_handle h, double *x, const double *b);

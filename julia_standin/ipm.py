@@ -253,8 +253,12 @@ class KKTSystem:
         self.work_conic = np.zeros(m)
         self._multi = hasattr(kktsolver, "kktsolver_solve_multi") and getattr(kktsolver, "batch_constant_rhs", True)
         self._const_pending = False
+        self._have_const_dev = False      # the plugin holds (x2, z2) of the current factorisation (device_reduced)
         self._device_scaling = bool(getattr(getattr(kktsolver, "settings", None), "device_scaling", False)) and \
             hasattr(kktsolver, "kktsolver_update_scaled")
+        # SURVEY section 8(f) row N2, second half: d tau, dx, dz of kkt_solve! formed by the plugin (one PCIe round trip per kkt_solve!)
+        self._device_reduced = bool(getattr(getattr(kktsolver, "settings", None), "device_reduced", False)) and \
+            hasattr(kktsolver, "kktsolver_kkt_solve_reduced")
         self._rx2, self._rz2 = np.zeros((2, n)), np.zeros((2, m))
         self._lx2, self._lz2 = np.zeros((2, n)), np.zeros((2, m))
 
@@ -266,6 +270,7 @@ class KKTSystem:
             ok = self.kktsolver.kktsolver_update(cones)
         if not ok:
             return False
+        self._have_const_dev = False
         if self._multi:
             # the constant-rhs solve of :80-92 is left pending and batched with the first
             # kkt_solve of the iteration (both right-hand sides are known by then; INTEGRATION.md shows the Julia side)
@@ -310,6 +315,17 @@ class KKTSystem:
         else:
             cones.ds_from_dz_offset(ds_const, rhs.s, lhs.z, variables.z)
         workz[:] = ds_const - rhs.z
+        if self._device_reduced and (self._const_pending or self._have_const_dev):
+            ok, lhs.tau = self.kktsolver.kktsolver_kkt_solve_reduced(workx, workz, variables.x, variables.tau, variables.kappa, rhs.tau,
+                                                                    rhs.kappa, self._const_pending, lhs.x, lhs.z)
+            if not ok:
+                return False
+            self._have_const_dev = True
+            self._const_pending = False
+            cones.mul_Hs(lhs.s, lhs.z, workz)
+            lhs.s[:] = -(lhs.s + ds_const)
+            lhs.kappa = -(rhs.kappa + variables.kappa * lhs.tau) / variables.tau
+            return True
         if self._const_pending:      # [-q; b] and this step's right-hand side on one factorisation, concurrently
             self._rx2[0], self._rz2[0] = -data.q, data.b
             self._rx2[1], self._rz2[1] = workx, workz
@@ -368,7 +384,8 @@ class Solver:
         self.kktsystem = KKTSystem(kktsolver_factory(data.P, data.A, self.cones, m, n, st), m, n)
         ks = self.kktsystem.kktsolver
         self._device_residuals = bool(getattr(st, "device_residuals", False)) and hasattr(ks, "residuals_update")
-        if self._device_residuals:
+        self._needs_qb = self._device_residuals or (bool(getattr(st, "device_reduced", False)) and hasattr(ks, "kktsolver_kkt_solve_reduced"))
+        if self._needs_qb:               # q, b resident in the plugin (N4 residuals, N2 reduced-system algebra)
             ks.set_problem_vectors(data.q, data.b)
         self.info = Info()
         self.info.timers["kkt init"] = time.perf_counter() - t1
@@ -398,14 +415,14 @@ class Solver:
         data = self.data
         data.q[:] = np.asarray(q, dtype=np.float64) * data.d * data.c
         data.normq = None
-        if self._device_residuals:
+        if self._needs_qb:
             self.kktsystem.kktsolver.set_problem_vectors(data.q, data.b)
 
     def update_b(self, b):
         data = self.data
         data.b[:] = np.minimum(np.asarray(b, dtype=np.float64), INFINITY) * data.e
         data.normb = None
-        if self._device_residuals:
+        if self._needs_qb:
             self.kktsystem.kktsolver.set_problem_vectors(data.q, data.b)
 
     # ------------------------------------------------------------- residuals.jl:1-37

@@ -592,6 +592,60 @@ def test_residuals_update_on_device(name):
     assert abs(solr.obj_val - sold.obj_val) <= 1e-7 * max(1.0, abs(solr.obj_val))
 
 
+@pytest.mark.parametrize("name", ["qp_fixture", "lp_like", "cfg1", "portfolio_small", "sdp_small"])
+def test_kkt_solve_reduced_on_device(name):
+    """SURVEY section 8(f) row N2, second half: kkt_solve! (kktsystem.jl:135-215) between the caller's cone algebra and mul_Hs! done
+    by the plugin (hipkkt_kkt_solve_reduced): the seven dot products / quadratic forms against numpy on the very same (x1, z1),
+    (x2, z2) to 1e-13 of their term sums (fixed but different summation order), d tau, dx, dz from them, first with the pending
+    constant-rhs solve in the same call, then (combined step) with the resident one; and the whole IPM driven that way reaches the
+    same answer as with the host algebra."""
+    rng = np.random.default_rng(23)
+    if name == "lp_like":      # nnz(P) == 0: every quadratic form vanishes
+        P, q, A, b, cones = PROBLEMS["rand_uniform_300"]()
+        P = sp.csc_matrix(P.shape)
+    else:
+        P, q, A, b, cones = PROBLEMS[name]()
+    S = cl.Solver(P, q, A, b, cones, cl.Settings(device_reduced=True))
+    assert S.kktsystem._device_reduced and S._needs_qb
+    ks, data, v = S.kktsystem.kktsolver, S.data, S.variables
+    n, m = data.n, data.m
+    _scale_cones(S.cones, rng)
+    assert ks.kktsolver_update(S.cones)
+    Pfull = (data.P + sp.triu(data.P, 1).T).tocsr()
+    for step, pending in enumerate((True, False, False)):
+        rhs_x, workz = rng.standard_normal(n), rng.standard_normal(m)
+        v.x[:] = rng.standard_normal(n)
+        tau, kappa, rtau, rkappa = 0.8 + 0.1 * step, 0.4, rng.standard_normal(), rng.standard_normal()
+        lx, lz = np.zeros(n), np.zeros(m)
+        ok, dtau = ks.kktsolver_kkt_solve_reduced(rhs_x, workz, v.x, tau, kappa, rtau, rkappa, pending, lx, lz)
+        assert ok
+        sc = ks.last_reduced_scalars
+        # the same two solutions through the plain solve entry points (bit-identical contexts), then the reference's formulas in numpy
+        X, Z = np.zeros((2, n)), np.zeros((2, m))
+        assert ks.kktsolver_solve_multi(np.vstack([-data.q, rhs_x]), np.vstack([data.b, workz]), X, Z)
+        x2, z2, x1, z1 = X[0], Z[0], X[1], Z[1]
+        xi = v.x / tau
+        terms = [(data.q, x1), (data.b, z1), (xi, Pfull @ x1), (data.q, x2), (data.b, z2), (xi - x2, Pfull @ (xi - x2)), (x2, Pfull @ x2)]
+        for got, (a, c) in zip(sc[3:10], terms):
+            assert abs(got - float(a @ c)) <= 1e-13 * max(1.0, float(np.abs(a) @ np.abs(c))), (name, step)
+        num = rtau - rkappa / tau + sc[3] + sc[4] + 2.0 * sc[5]
+        den = kappa / tau - sc[6] - sc[7] + sc[8] - sc[9]
+        assert abs(sc[1] - num) <= 1e-15 * max(1.0, abs(num)) * 8 and abs(sc[2] - den) <= 1e-15 * max(1.0, abs(den)) * 8
+        assert dtau == sc[0] and abs(dtau - sc[1] / sc[2]) <= 1e-15 * abs(dtau) and abs(dtau - num / den) <= 1e-13 * max(1.0, abs(num / den))
+        assert np.max(np.abs(lx - (x1 + dtau * x2))) <= 1e-13 * max(1.0, np.max(np.abs(x1)) + abs(dtau) * np.max(np.abs(x2)))
+        assert np.max(np.abs(lz - (z1 + dtau * z2))) <= 1e-13 * max(1.0, np.max(np.abs(z1)) + abs(dtau) * np.max(np.abs(z2)))
+    assert ks._refactor()        # a new factorisation invalidates the resident (x2, z2): asking for it is a usage error
+    with pytest.raises(hipkkt.HipKKTError):
+        ks.kktsolver_kkt_solve_reduced(rhs_x, workz, v.x, 1.0, 1.0, 0.0, 0.0, False, None, None)
+    if name != "lp_like":
+        solr = cl.Solver(P, q, A, b, cones, cl.Settings()).solve()
+        sold = cl.Solver(P, q, A, b, cones, cl.Settings(device_reduced=True, device_residuals=True)).solve()
+        assert solr.status == sold.status == "SOLVED" and abs(solr.iterations - sold.iterations) <= 1
+        assert abs(solr.obj_val - sold.obj_val) <= 1e-7 * max(1.0, abs(solr.obj_val))
+        if solr.iterations == sold.iterations:
+            assert abs(solr.obj_val - sold.obj_val) <= 1e-9 * max(1.0, abs(solr.obj_val))
+
+
 def _image(h):
     colptr, rowval, nzval = h.kkt()
     maps = [h.map(w) for w in range(5)]
