@@ -27,7 +27,7 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 constexpr int SLD = 65;            // LDS row stride of a 64 x 64 tile
 constexpr int kSbThreads = 1024;   // 16 wavefronts: 4 values per tile and thread (two groups of 5 tiles = 80 VGPRs of the 128 available)
 constexpr int NW = kSbThreads / 64;  // wavefronts per workgroup
-constexpr int NT = 64 / NW;          // tile columns (forward) / rows (backward) per thread
+constexpr int NT = 2;                // values per (half) tile and thread: 32 x 64 / 1024
 static_assert(kSbMaxPanels * 16 <= 24 * 1024, "panel table of the sweeps must fit into LDS");
 
 __device__ __forceinline__ int64_t sb_tile(const FrontDesc &F, int B, int bl, int cl) {   // symbolic.h FrontDesc::sbinv_off
@@ -49,7 +49,7 @@ __device__ __forceinline__ double sum_waves(const double (*red)[64], int lane) {
     for (int c = 0; c < 4; c++) q[c] = (red[4 * c][lane] + red[4 * c + 1][lane]) + (red[4 * c + 2][lane] + red[4 * c + 3][lane]);
     return (q[0] + q[1]) + (q[2] + q[3]);
 }
-static_assert(NW == 16 && NT == 4, "sum_waves and the 4-way accumulators assume 16 wavefronts");
+static_assert(NW == 16 && NT == 2, "the half-tile thread map assumes 16 wavefronts");
 
 // ------------------------------------------------------------------------------------------
 // Inverse of the super-blocks' diagonal blocks: Inv[b,c] = -Linv_b * sum_{c <= k < b} L[b,k] Inv[k,c]  (Inv[c,c] = Linv_c, the
@@ -143,11 +143,30 @@ k_invert_super(DevPlan P, FrontDesc F) {
 }
 
 // ------------------------------------------------------------------------------------------
-// forward sweep
+// forward sweep.  One workgroup streams at most ~30 GB/s (measured, r03c: 160 KB per hop in 5.4 us), so every 64-row block is
+// shared by TWO workgroups: ticket t -> row block b = t / 2, half h = t % 2 = the rows 32 h .. 32 h + 31 of the block.  A half-tile
+// is 32 rows x 64 columns: lane -> row 32 h + (lane & 31), column phase lane >> 5; wave v -> the columns 2 v + phase + 32 t.
+// Both halves publish their 32 of the panel's 64 slots; the upper half (h = 1) also needs the lower half's r (lower ticket).
 // ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double sum_parts(const double (*red)[32], int lr) {      // fixed tree over the 32 partial sums of a row
+    double q[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+        q[0] += red[4 * c][lr];
+        q[1] += red[4 * c + 1][lr];
+        q[2] += red[4 * c + 2][lr];
+        q[3] += red[4 * c + 3][lr];
+    }
+    return (q[0] + q[1]) + (q[2] + q[3]);
+}
+// whole-wave wait for HALF a panel's slots (32 slots, both half-waves poll the same ones)
+__device__ __forceinline__ bool half_slot_wait(const FrontSlot *p32, int lane, double &v, int *err, int *failflag, unsigned lim) {
+    return front_slot_wait(p32 + (lane & 31), v, err, failflag, lim);
+}
+
 __global__ void __launch_bounds__(kSbThreads)
 k_front_fwd_sb(DevPlan P, FrontDesc F, double *__restrict__ y, double *__restrict__ z) {
-    __shared__ double red[NW][64];
+    __shared__ double red[32][32];
     __shared__ double ybuf[2][kSbG][64];
     __shared__ double rbuf[kSbG][64];
     __shared__ int64_t pn_off[kSbMaxPanels];   // panel table of the front in LDS: reading a record must not wait on the tile loads in flight
@@ -161,12 +180,14 @@ k_front_fwd_sb(DevPlan P, FrontDesc F, double *__restrict__ y, double *__restric
     }
     if (threadIdx.x == 0) { sb = atomicAdd(sync, 1); okflag = 1; }
     __syncthreads();
-    const int b = sb_rfl(sb);                   // wave-uniform for the compiler too: scalar branches, SGPR tile bases
+    const int tk = sb_rfl(sb);                  // wave-uniform for the compiler too: scalar branches, SGPR tile bases
+    const int b = tk >> 1, h = tk & 1;
     if (b >= F.nb) return;
     // re-arm the backward sweep's block (idle during this launch), every workgroup a share
-    for (int q = b * kSbThreads + threadIdx.x; q < F.sync_blk; q += F.nb * kSbThreads) sync[F.sync_blk + q] = 0;
+    for (int q = tk * kSbThreads + threadIdx.x; q < F.sync_blk; q += 2 * F.nb * kSbThreads) sync[F.sync_blk + q] = 0;
     FrontSlot *yslots = front_slots(sync, F.np), *rslots = yslots + (int64_t)F.np * 64;
     const int tid = threadIdx.x, lane = tid & 63, wv = sb_rfl(tid >> 6);
+    const int lr = lane & 31, ph = lane >> 5, ir = 32 * h + lr, k0 = 2 * wv + ph;      // row inside the block, first column
     const FrontPanel *fps = P.front_panels + F.fp_off;
     const int g = kSbG;
     const bool own = b < F.np;
@@ -178,20 +199,21 @@ k_front_fwd_sb(DevPlan P, FrontDesc F, double *__restrict__ y, double *__restric
     const int B = own ? b / g : F.nsb, bl = own ? b - g * B : 0;
     const int i0 = own ? F.cw * b : F.W + 64 * (b - F.np);
     const int nrows = own ? me.w : min(64, F.rF - i0);
-    const int i = i0 + lane;
-    const bool valid = lane < nrows;
+    const int i = i0 + ir;
+    const bool valid = ir < nrows;
+    const bool lead = wv == 0 && ph == 0;        // the 32 lanes that own this half's rows in the scalar parts
     // this row's start value: own rows  b_i - (external children), rows below the front  + (external children)
     double base = 0.0;
-    if (wv == 0 && valid) {
+    if (lead && valid) {
         double G = 0.0;
         const int64_t g0 = P.front_gptr[F.gptr_off + i], g1 = P.front_gptr[F.gptr_off + i + 1];
         for (int64_t gq = g0; gq < g1; gq++) G += P.ubuf[P.front_gidx[gq]];
-        base = own ? y[me.f + lane] - G : G;
+        base = own ? y[me.f + ir] - G : G;
     }
-    const double dinv_own = (own && valid && wv == 0) ? P.Dinv[me.f + lane] : 0.0;
+    const double dinv_own = (own && valid && lead) ? P.Dinv[me.f + ir] : 0.0;
     const int nQ = own ? B : F.nsb;            // super-blocks whose panels this row block accumulates
     double cur[kSbG][NT], nxt[kSbG][NT];       // the group being consumed and the one prefetched behind it
-    // the L tiles of super-block G on this row block
+    // the L tiles of super-block G on this half row block
     auto load_L = [&](int G, double (&dst)[kSbG][NT]) {
 #pragma unroll
         for (int p = 0; p < kSbG; p++) {
@@ -199,10 +221,10 @@ k_front_fwd_sb(DevPlan P, FrontDesc F, double *__restrict__ y, double *__restric
             const int qc = q < F.np ? q : F.np - 1;
             const int fq_r = sb_rfl(pn_r[qc]), fq_w = sb_rfl(pn_w[qc]);
             const double *pb = P.Lx + sb_rfl64(pn_off[qc]);
-            const unsigned o0 = (unsigned)(i - F.cw * q + wv * fq_r) * 8u, os = (unsigned)fq_r * (8u * NW);
+            const unsigned o0 = (unsigned)(i - F.cw * q + k0 * fq_r) * 8u, os = (unsigned)fq_r * (8u * 32u);
 #pragma unroll
             for (int t = 0; t < NT; t++) {
-                const int k = wv + NW * t;
+                const int k = k0 + 32 * t;
                 dst[p][t] = (q < F.np && valid && k < fq_w) ? sb_ld(pb, o0 + (unsigned)t * os) : 0.0;
             }
         }
@@ -214,13 +236,13 @@ k_front_fwd_sb(DevPlan P, FrontDesc F, double *__restrict__ y, double *__restric
             if (own && p < bl) {                 // (uniform) a full tile of the super-block inverse, column-major
                 const double *tl = P.SbInv + sb_tile(F, B, bl, p);
 #pragma unroll
-                for (int t = 0; t < NT; t++) dst[p][t] = valid ? sb_ld(tl, (unsigned)(lane + 64 * (wv + NW * t)) * 8u) : 0.0;
+                for (int t = 0; t < NT; t++) dst[p][t] = valid ? sb_ld(tl, (unsigned)(ir + 64 * (k0 + 32 * t)) * 8u) : 0.0;
             } else if (own && p == bl) {         // the panel's own inverse (lower triangular, w x w column-major)
                 const double *li = P.Linv + me.diag_off;
 #pragma unroll
                 for (int t = 0; t < NT; t++) {
-                    const int k = wv + NW * t;
-                    dst[p][t] = (valid && k <= lane) ? sb_ld(li, (unsigned)(lane + k * me.w) * 8u) : 0.0;
+                    const int k = k0 + 32 * t;
+                    dst[p][t] = (valid && k <= ir) ? sb_ld(li, (unsigned)(ir + k * me.w) * 8u) : 0.0;
                 }
             } else {
 #pragma unroll
@@ -228,10 +250,10 @@ k_front_fwd_sb(DevPlan P, FrontDesc F, double *__restrict__ y, double *__restric
             }
         }
     };
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    double a0 = 0.0, a1 = 0.0;
     // wait for the y of super-block Q's panels while the next group is prefetched into `nxt`, accumulate `cur`, cur <- nxt;
     // false = give up.  The polling waves issue their share of the prefetch AFTER their poll has succeeded: a wave's loads return
-    // in order, so a poll behind 20 tile loads could not see its slot before those have landed (they then have a whole hop to land).
+    // in order, so a poll behind its tile loads could not see its slot before those have landed (they then have a whole hop to land).
     auto consume = [&](int Q, auto &&prefetch) -> bool {
         double (*yb)[64] = ybuf[Q & 1];
         if (wv < kSbG) {                         // wave w polls the 64 slots of panel g Q + w (value and validity in one load per lane)
@@ -248,10 +270,8 @@ k_front_fwd_sb(DevPlan P, FrontDesc F, double *__restrict__ y, double *__restric
         if (!okflag) return false;
 #pragma unroll
         for (int p = 0; p < kSbG; p++) {
-            a0 = fma(cur[p][0], yb[p][wv], a0);
-            a1 = fma(cur[p][1], yb[p][wv + NW], a1);
-            a2 = fma(cur[p][2], yb[p][wv + 2 * NW], a2);
-            a3 = fma(cur[p][3], yb[p][wv + 3 * NW], a3);
+            a0 = fma(cur[p][0], yb[p][k0], a0);
+            a1 = fma(cur[p][1], yb[p][k0 + 32], a1);
         }
 #pragma unroll
         for (int p = 0; p < kSbG; p++)
@@ -267,53 +287,56 @@ k_front_fwd_sb(DevPlan P, FrontDesc F, double *__restrict__ y, double *__restric
     } else {
         load_inv(cur);
     }
-    red[wv][lane] = (a0 + a1) + (a2 + a3);
+    red[2 * wv + ph][lr] = a0 + a1;
     __syncthreads();
     if (!own) {
-        if (wv == 0 && valid && ok) P.ubuf[F.ubelow_off + (i - F.W)] = base + sum_waves(red, lane);
+        if (lead && valid && ok) P.ubuf[F.ubelow_off + (i - F.W)] = base + sum_parts(red, lr);
         return;
     }
-    if (wv == 0) {                               // partial right-hand side of this panel: to the later panels of the super-block
-        const double r = valid ? base - sum_waves(red, lane) : 0.0;
-        rbuf[bl][lane] = r;
-        if (ok) front_slot_st(rslots + b * 64 + lane, r);
-    } else if (wv <= bl) {                       // wave w polls r of panel g B + w - 1
+    if (wv == 0) {                               // partial right-hand side of this half panel: to the later panels of the super-block
+        if (ph == 0) {
+            const double r = valid ? base - sum_parts(red, lr) : 0.0;
+            rbuf[bl][ir] = r;
+            if (ok) front_slot_st(rslots + b * 64 + ir, r);
+        }
+    } else if (wv <= bl) {                       // wave w polls r of panel g B + w - 1 (both halves)
         const int c = wv - 1;
         double v = 0.0;
         const bool okw = ok && front_slot_wait(rslots + (g * B + c) * 64 + lane, v, sync + 1, P.flags + FL_FRONTFAIL, P.spin_limit);
         if (!okw) { v = 0.0; if (lane == 0) okflag = 0; }
         rbuf[c][lane] = v;
+    } else if (wv == bl + 1 && h == 1) {         // the upper half also needs the lower half's r of this very panel (ticket tk - 1)
+        double v = 0.0;
+        const bool okw = ok && half_slot_wait(rslots + b * 64, lane, v, sync + 1, P.flags + FL_FRONTFAIL, P.spin_limit);
+        if (!okw) { v = 0.0; if (lane == 0) okflag = 0; }
+        rbuf[bl][lane & 31] = v;
     }
     __syncthreads();
     if (!okflag) return;
     {   // y_b = sum_c Inv[b,c] r_c  (tiles of the panels after b in the super-block are zero)
-        auto gemv = [&](const double (&iv)[kSbG][NT]) {
-            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        double s0 = 0.0, s1 = 0.0;
 #pragma unroll
-            for (int p = 0; p < kSbG; p++) {
-                s0 = fma(iv[p][0], rbuf[p][wv], s0);
-                s1 = fma(iv[p][1], rbuf[p][wv + NW], s1);
-                s2 = fma(iv[p][2], rbuf[p][wv + 2 * NW], s2);
-                s3 = fma(iv[p][3], rbuf[p][wv + 3 * NW], s3);
-            }
-            red[wv][lane] = (s0 + s1) + (s2 + s3);
-        };
-        gemv(cur);                               // the inverse tiles were the last group prefetched
+        for (int p = 0; p < kSbG; p++) {
+            s0 = fma(cur[p][0], rbuf[p][k0], s0);
+            s1 = fma(cur[p][1], rbuf[p][k0 + 32], s1);
+        }
+        red[2 * wv + ph][lr] = s0 + s1;          // (the first reduction's reads finished before the barrier above)
     }
     __syncthreads();
-    if (wv == 0) {
-        const double v = valid ? sum_waves(red, lane) : 0.0;
-        front_slot_st(yslots + b * 64 + lane, v);            // first: the next super-block is waiting for it
-        if (valid) z[me.f + lane] = v * dinv_own;
+    if (lead) {
+        const double v = valid ? sum_parts(red, lr) : 0.0;
+        front_slot_st(yslots + b * 64 + ir, v);              // first: the next super-block is waiting for it
+        if (valid) z[me.f + ir] = v * dinv_own;
     }
 }
 
 // ------------------------------------------------------------------------------------------
-// backward sweep: ticket t owns panel p = np-1-t, lane = column k of the panel, wave v = the rows 4 v .. 4 v + 3 of every tile
+// backward sweep: ticket t -> panel p = np-1-t/2, half h = 1 - t % 2 (the UPPER column half first: the lower one needs its s).
+// lane -> column 32 h + (lane & 31) of the panel, row phase lane >> 5; wave v -> the rows 2 v + phase + 32 t of every tile
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kSbThreads)
 k_front_bwd_sb(DevPlan P, FrontDesc F, const double *__restrict__ z, double *__restrict__ x, double *__restrict__ xout) {
-    __shared__ double red[NW][64];
+    __shared__ double red[32][32];
     __shared__ double xbuf[2][kSbG][64];
     __shared__ double sbuf[kSbG][64];
     __shared__ int pn_w[kSbMaxPanels];          // panel widths in LDS (see k_front_fwd_sb)
@@ -324,40 +347,39 @@ k_front_bwd_sb(DevPlan P, FrontDesc F, const double *__restrict__ z, double *__r
     if (threadIdx.x == 0) { sb = atomicAdd(sync, 1); okflag = 1; }
     __syncthreads();
     const int tk = sb_rfl(sb);                  // wave-uniform for the compiler too
-    if (tk >= F.np) return;
+    if (tk >= 2 * F.np) return;
     // re-arm the forward sweep's block for the next solve (idle during this launch), every workgroup a share
-    for (int q = tk * kSbThreads + threadIdx.x; q < F.sync_blk; q += F.np * kSbThreads) sync[q - F.sync_blk] = 0;
+    for (int q = tk * kSbThreads + threadIdx.x; q < F.sync_blk; q += 2 * F.np * kSbThreads) sync[q - F.sync_blk] = 0;
     FrontSlot *xslots = front_slots(sync, F.np), *sslots = xslots + (int64_t)F.np * 64;
-    const int p = F.np - 1 - tk;
+    const int p = F.np - 1 - (tk >> 1), h = 1 - (tk & 1);
     const int tid = threadIdx.x, lane = tid & 63, wv = sb_rfl(tid >> 6);
+    const int kc = 32 * h + (lane & 31), ph = lane >> 5, j0 = 2 * wv + ph;       // column of the panel, first tile row
     const FrontPanel *fps = P.front_panels + F.fp_off;
     struct { int w, f; int64_t diag_off, lt_off; } me;
     me.w = sb_rfl(fps[p].w); me.f = sb_rfl(fps[p].f); me.diag_off = sb_rfl64(fps[p].diag_off); me.lt_off = sb_rfl64(fps[p].lt_off);
     const int w = me.w;
-    const bool cvalid = lane < w;
+    const bool cvalid = kc < w;
+    const bool lead = wv == 0 && ph == 0;
     const int g = kSbG;
     const int B = p / g, pl = p - g * B, nbB = min(g, F.np - g * B);
     const double *lt = P.LT + me.lt_off;            // row-major: lt[(j - w) * w + k], j = local panel row
-    const int perm_own = (cvalid && wv == 0) ? P.perm[me.f + lane] : 0;
-    const double zin = (cvalid && wv == 0) ? z[me.f + lane] : 0.0;
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    const int perm_own = (cvalid && lead) ? P.perm[me.f + kc] : 0;
+    const double zin = (cvalid && lead) ? z[me.f + kc] : 0.0;
+    double a0 = 0.0, a1 = 0.0;
     // (A) rows below the front: x is final
     {
         const int *rows = P.sn_rows + F.rows_off;
         for (int ib = F.W; ib < F.rF; ib += 64) {
-            const int lo = ib + NT * wv;
             double xv[NT], l[NT];
 #pragma unroll
             for (int t = 0; t < NT; t++) {
-                const int i = lo + t;
+                const int i = ib + j0 + 32 * t;
                 const bool in = i < F.rF;
                 xv[t] = in ? x[rows[in ? i : F.W]] : 0.0;
-                l[t] = (in && cvalid) ? lt[(int64_t)(i - F.cw * p - w) * w + lane] : 0.0;
+                l[t] = (in && cvalid) ? lt[(int64_t)(i - F.cw * p - w) * w + kc] : 0.0;
             }
             a0 = fma(l[0], xv[0], a0);
             a1 = fma(l[1], xv[1], a1);
-            a2 = fma(l[2], xv[2], a2);
-            a3 = fma(l[3], xv[3], a3);
         }
     }
     // (B) later super-blocks in descending order (groups 0 .. nG-1), then (group nG) the inverse tiles Inv[p .. , p]^T
@@ -369,10 +391,10 @@ k_front_bwd_sb(DevPlan P, FrontDesc F, const double *__restrict__ z, double *__r
         for (int pp = 0; pp < kSbG; pp++) {
             const int q = g * Q + pp;
             const int fq_w = sb_rfl(pn_w[q < F.np ? q : F.np - 1]);
-            const unsigned o0 = (unsigned)((F.cw * (q - p) + NT * wv - w) * w + lane) * 8u, os = (unsigned)w * 8u;
+            const unsigned o0 = (unsigned)((F.cw * (q - p) + j0 - w) * w + kc) * 8u, os = (unsigned)w * (8u * 32u);
 #pragma unroll
             for (int t = 0; t < NT; t++) {
-                const int jr = NT * wv + t;
+                const int jr = j0 + 32 * t;
                 dst[pp][t] = (q < F.np && cvalid && jr < fq_w) ? sb_ld(lt, o0 + (unsigned)t * os) : 0.0;
             }
         }
@@ -383,13 +405,13 @@ k_front_bwd_sb(DevPlan P, FrontDesc F, const double *__restrict__ z, double *__r
             if (cl > pl && cl < nbB) {           // (uniform) a full tile of the super-block inverse, row-major half
                 const double *tl = P.SbInv + sb_tile(F, B, cl, pl) + 4096;
 #pragma unroll
-                for (int t = 0; t < NT; t++) dst[cl][t] = cvalid ? sb_ld(tl, (unsigned)((NT * wv + t) * 64 + lane) * 8u) : 0.0;
+                for (int t = 0; t < NT; t++) dst[cl][t] = cvalid ? sb_ld(tl, (unsigned)((j0 + 32 * t) * 64 + kc) * 8u) : 0.0;
             } else if (cl == pl) {               // the panel's own inverse, transposed copy: Linv[i][k] at [k + i w]
                 const double *lit = P.LinvT + me.diag_off;
 #pragma unroll
                 for (int t = 0; t < NT; t++) {
-                    const int i2 = NT * wv + t;
-                    dst[cl][t] = (cvalid && i2 >= lane && i2 < w) ? sb_ld(lit, (unsigned)(lane + i2 * w) * 8u) : 0.0;
+                    const int i2 = j0 + 32 * t;
+                    dst[cl][t] = (cvalid && i2 >= kc && i2 < w) ? sb_ld(lit, (unsigned)(kc + i2 * w) * 8u) : 0.0;
                 }
             } else {
 #pragma unroll
@@ -414,10 +436,8 @@ k_front_bwd_sb(DevPlan P, FrontDesc F, const double *__restrict__ z, double *__r
         if (!okflag) return false;
 #pragma unroll
         for (int pp = 0; pp < kSbG; pp++) {
-            a0 = fma(cur[pp][0], xb[pp][NT * wv], a0);
-            a1 = fma(cur[pp][1], xb[pp][NT * wv + 1], a1);
-            a2 = fma(cur[pp][2], xb[pp][NT * wv + 2], a2);
-            a3 = fma(cur[pp][3], xb[pp][NT * wv + 3], a3);
+            a0 = fma(cur[pp][0], xb[pp][j0], a0);
+            a1 = fma(cur[pp][1], xb[pp][j0 + 32], a1);
         }
 #pragma unroll
         for (int pp = 0; pp < kSbG; pp++)
@@ -433,50 +453,52 @@ k_front_bwd_sb(DevPlan P, FrontDesc F, const double *__restrict__ z, double *__r
     } else {
         load_inv(cur);
     }
-    red[wv][lane] = (a0 + a1) + (a2 + a3);
+    red[2 * wv + ph][lane & 31] = a0 + a1;
     __syncthreads();
-    if (wv == 0) {                               // partial right-hand side of this panel: to the EARLIER panels of the super-block
-        const double s = cvalid ? zin - sum_waves(red, lane) : 0.0;
-        sbuf[pl][lane] = s;
-        if (ok) front_slot_st(sslots + p * 64 + lane, s);
-    } else if (pl + wv < nbB) {                  // wave v polls s of panel p + v
+    if (wv == 0) {                               // partial right-hand side of this half panel: to the EARLIER panels of the super-block
+        if (ph == 0) {
+            const double s = cvalid ? zin - sum_parts(red, lane & 31) : 0.0;
+            sbuf[pl][kc] = s;
+            if (ok) front_slot_st(sslots + p * 64 + kc, s);
+        }
+    } else if (pl + wv < nbB) {                  // wave v polls s of panel p + v (both halves)
         double v = 0.0;
         const bool okw = ok && front_slot_wait(sslots + (p + wv) * 64 + lane, v, sync + 1, P.flags + FL_FRONTFAIL, P.spin_limit);
         if (!okw) { v = 0.0; if (lane == 0) okflag = 0; }
         sbuf[pl + wv][lane] = v;
+    } else if (pl + wv == nbB && h == 0) {       // the lower half also needs the upper half's s of this very panel (ticket tk - 1)
+        double v = 0.0;
+        const bool okw = ok && half_slot_wait(sslots + p * 64 + 32, lane, v, sync + 1, P.flags + FL_FRONTFAIL, P.spin_limit);
+        if (!okw) { v = 0.0; if (lane == 0) okflag = 0; }
+        sbuf[pl][32 + (lane & 31)] = v;
     }
     __syncthreads();
     if (!okflag) return;
     {   // x_p = sum_{c >= p} Inv[c,p]^T s_c
-        auto gemv = [&](const double (&iv)[kSbG][NT]) {
-            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        double s0 = 0.0, s1 = 0.0;
 #pragma unroll
-            for (int cl = 0; cl < kSbG; cl++) {
-                s0 = fma(iv[cl][0], sbuf[cl][NT * wv], s0);
-                s1 = fma(iv[cl][1], sbuf[cl][NT * wv + 1], s1);
-                s2 = fma(iv[cl][2], sbuf[cl][NT * wv + 2], s2);
-                s3 = fma(iv[cl][3], sbuf[cl][NT * wv + 3], s3);
-            }
-            red[wv][lane] = (s0 + s1) + (s2 + s3);
-        };
-        gemv(cur);
+        for (int cl = 0; cl < kSbG; cl++) {
+            s0 = fma(cur[cl][0], sbuf[cl][j0], s0);
+            s1 = fma(cur[cl][1], sbuf[cl][j0 + 32], s1);
+        }
+        red[2 * wv + ph][lane & 31] = s0 + s1;
     }
     __syncthreads();
-    if (wv == 0) {
-        const double v = cvalid ? sum_waves(red, lane) : 0.0;
-        front_slot_st(xslots + p * 64 + lane, v);            // first: the previous super-block is waiting for it
+    if (lead) {
+        const double v = cvalid ? sum_parts(red, lane & 31) : 0.0;
+        front_slot_st(xslots + p * 64 + kc, v);              // first: the previous super-block is waiting for it
         if (cvalid) {
-            x[me.f + lane] = v;
+            x[me.f + kc] = v;
             xout[perm_own] = v;
         }
     }
 }
 
 void launch_front_fwd_sb(hipStream_t st, const DevPlan &P, const FrontDesc &F, double *y, double *z) {
-    hipLaunchKernelGGL(k_front_fwd_sb, dim3(F.nb), dim3(kSbThreads), 0, st, P, F, y, z);
+    hipLaunchKernelGGL(k_front_fwd_sb, dim3(2 * F.nb), dim3(kSbThreads), 0, st, P, F, y, z);
 }
 void launch_front_bwd_sb(hipStream_t st, const DevPlan &P, const FrontDesc &F, const double *z, double *x, double *xout) {
-    hipLaunchKernelGGL(k_front_bwd_sb, dim3(F.np), dim3(kSbThreads), 0, st, P, F, z, x, xout);
+    hipLaunchKernelGGL(k_front_bwd_sb, dim3(2 * F.np), dim3(kSbThreads), 0, st, P, F, z, x, xout);
 }
 void launch_invert_super(hipStream_t st, const DevPlan &P, const FrontDesc &F) {
     if (F.sb_g > 0 && F.nsb > 0) hipLaunchKernelGGL(k_invert_super, dim3(F.nsb * (kSbG - 1)), dim3(kInvThreads), 0, st, P, F);
