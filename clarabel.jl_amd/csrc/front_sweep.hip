@@ -1,8 +1,8 @@
 // K5 over a FRONT, super-block sweeps (round 3; VERDICT r2 task 1): the per-panel sweeps of kernels.hip (k_front_fwd / k_front_bwd)
 // pay one inter-workgroup hand-off per 64-column panel -- 88 dependent hops of ~1.7 us on the 5617-column root of a random sparse
-// QP, at 14 % of the HBM roofline.  Here the np panels of a front are grouped into super-blocks of kSbG = 5 consecutive panels and
-// the explicit inverse of every super-block's unit-lower diagonal block (5 x 5 tiles of 64 x 64, formed after each factorisation by
-// k_invert_super from the panels and the per-panel inverses) replaces the five dependent panel solves:
+// QP, at 14 % of the HBM roofline.  Here the np panels of a front are grouped into super-blocks of kSbG = 8 consecutive panels and
+// the explicit inverse of every super-block's unit-lower diagonal block (8 x 8 tiles of 64 x 64, formed after each factorisation by
+// k_invert_super from the panels and the per-panel inverses) replaces the eight dependent panel solves:
 //
 //   forward, workgroup b (row block b, super-block B = b / g):
 //       r_b = b_b - (external children) - sum_{q < gB} L[b,q] y_q          L tiles of a whole super-block per hop, prefetched
@@ -10,7 +10,7 @@
 //       y_b = sum_{gB <= c <= b} Inv[b,c] r_c                              Inv tiles prefetched like one more group of L tiles
 //   backward, ticket t -> panel p = np-1-t: the mirror image with L^T (row-major copy LT) and Inv^T.
 //
-// Two hand-offs per super-block instead of five: 18 x 2 hops on that root instead of 88.  The hand-off itself is unchanged
+// Two hand-offs per super-block instead of eight: 11 x 2 hops on that root instead of 88.  The hand-off itself is unchanged
 // (self-validating 16-byte slots, sweep_common.h); a second set of slots carries the partial right-hand sides r / s.  Workgroups
 // have 16 wavefronts: wave w < 5 polls panel w of the awaited super-block, thread (lane = row, wave v) owns the columns v + 16 t of
 // every tile (4 values per tile, two groups of 5 tiles in registers).  Same guarantees as the per-panel sweeps: tickets in arrival order
@@ -148,15 +148,16 @@ k_invert_super(DevPlan P, FrontDesc F) {
 // is 32 rows x 64 columns: lane -> row 32 h + (lane & 31), column phase lane >> 5; wave v -> the columns 2 v + phase + 32 t.
 // Both halves publish their 32 of the panel's 64 slots; the upper half (h = 1) also needs the lower half's r (lower ticket).
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ double sum_parts(const double (*red)[32], int lr) {      // fixed tree over the 32 partial sums of a row
-    double q[4] = {0.0, 0.0, 0.0, 0.0};
+// the two column / row phases of a wave are added inside the wave (lanes l and l + 32 hold the same row), the 16 per-wave partial
+// sums of a row go through LDS and are added in a fixed tree
+__device__ __forceinline__ void put_part(double (*red)[32], int wv, int lr, double v) {
+    v += __shfl_xor(v, 32, 64);
+    red[wv][lr] = v;                             // both half-waves store the same value
+}
+__device__ __forceinline__ double sum_parts(const double (*red)[32], int lr) {
+    double q[4];
 #pragma unroll
-    for (int c = 0; c < 8; c++) {
-        q[0] += red[4 * c][lr];
-        q[1] += red[4 * c + 1][lr];
-        q[2] += red[4 * c + 2][lr];
-        q[3] += red[4 * c + 3][lr];
-    }
+    for (int c = 0; c < 4; c++) q[c] = (red[4 * c][lr] + red[4 * c + 1][lr]) + (red[4 * c + 2][lr] + red[4 * c + 3][lr]);
     return (q[0] + q[1]) + (q[2] + q[3]);
 }
 // whole-wave wait for HALF a panel's slots (32 slots, both half-waves poll the same ones)
@@ -166,7 +167,7 @@ __device__ __forceinline__ bool half_slot_wait(const FrontSlot *p32, int lane, d
 
 __global__ void __launch_bounds__(kSbThreads)
 k_front_fwd_sb(DevPlan P, FrontDesc F, double *__restrict__ y, double *__restrict__ z) {
-    __shared__ double red[32][32];
+    __shared__ double red[NW][32];
     __shared__ double ybuf[2][kSbG][64];
     __shared__ double rbuf[kSbG][64];
     __shared__ int64_t pn_off[kSbMaxPanels];   // panel table of the front in LDS: reading a record must not wait on the tile loads in flight
@@ -287,7 +288,7 @@ k_front_fwd_sb(DevPlan P, FrontDesc F, double *__restrict__ y, double *__restric
     } else {
         load_inv(cur);
     }
-    red[2 * wv + ph][lr] = a0 + a1;
+    put_part(red, wv, lr, a0 + a1);
     __syncthreads();
     if (!own) {
         if (lead && valid && ok) P.ubuf[F.ubelow_off + (i - F.W)] = base + sum_parts(red, lr);
@@ -320,7 +321,7 @@ k_front_fwd_sb(DevPlan P, FrontDesc F, double *__restrict__ y, double *__restric
             s0 = fma(cur[p][0], rbuf[p][k0], s0);
             s1 = fma(cur[p][1], rbuf[p][k0 + 32], s1);
         }
-        red[2 * wv + ph][lr] = s0 + s1;          // (the first reduction's reads finished before the barrier above)
+        put_part(red, wv, lr, s0 + s1);          // (the first reduction's reads finished before the barrier above)
     }
     __syncthreads();
     if (lead) {
@@ -336,7 +337,7 @@ k_front_fwd_sb(DevPlan P, FrontDesc F, double *__restrict__ y, double *__restric
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kSbThreads)
 k_front_bwd_sb(DevPlan P, FrontDesc F, const double *__restrict__ z, double *__restrict__ x, double *__restrict__ xout) {
-    __shared__ double red[32][32];
+    __shared__ double red[NW][32];
     __shared__ double xbuf[2][kSbG][64];
     __shared__ double sbuf[kSbG][64];
     __shared__ int pn_w[kSbMaxPanels];          // panel widths in LDS (see k_front_fwd_sb)
@@ -453,7 +454,7 @@ k_front_bwd_sb(DevPlan P, FrontDesc F, const double *__restrict__ z, double *__r
     } else {
         load_inv(cur);
     }
-    red[2 * wv + ph][lane & 31] = a0 + a1;
+    put_part(red, wv, lane & 31, a0 + a1);
     __syncthreads();
     if (wv == 0) {                               // partial right-hand side of this half panel: to the EARLIER panels of the super-block
         if (ph == 0) {
@@ -481,7 +482,7 @@ k_front_bwd_sb(DevPlan P, FrontDesc F, const double *__restrict__ z, double *__r
             s0 = fma(cur[cl][0], sbuf[cl][j0], s0);
             s1 = fma(cur[cl][1], sbuf[cl][j0 + 32], s1);
         }
-        red[2 * wv + ph][lane & 31] = s0 + s1;
+        put_part(red, wv, lane & 31, s0 + s1);
     }
     __syncthreads();
     if (lead) {

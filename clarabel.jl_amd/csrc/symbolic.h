@@ -102,7 +102,7 @@ struct FrontDesc {
     int32_t sb_g, nsb;
     int64_t sbinv_off;
 };
-constexpr int kSbG = 5;           // panels per super-block of the front sweeps
+constexpr int kSbG = 8;           // panels per super-block of the front sweeps
 constexpr int kSbMinPanels = 10;  // fronts with fewer panels keep one hop per panel
 constexpr int kSbMaxPanels = 1024; // ... and so do fronts with more (the sweeps keep a panel table in LDS)
 
