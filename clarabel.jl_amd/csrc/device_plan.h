@@ -97,8 +97,8 @@ struct DevPlan {
     int *seg_sync;               // [0,nseg) forward tickets, [nseg,2nseg) backward tickets, then per-supernode counters:
     int seg_ticket;              // bit 0 / bit 1: forward / backward segment-sweep items are atomic tickets (default 3); 0: blockIdx
     unsigned spin_limit;         // bound of every spin loop of the persistent sweeps (default 2^20; HIPKKT_SPIN_LIMIT)
-    int pivot_mode;              // k_front_block's 8-pivot blocks: 1 (default) every lane eliminates the 8 x 8 diagonal piece itself,
-                                 // 0 the round-2 form with v_readlane on the pivot chain (HIPKKT_PIVOT_MODE, A/B timing)
+    int dbg;                     // timing experiments only (HIPKKT_DEBUG_FLAGS; results are WRONG when set): bit 0 = the super-block sweeps skip
+                                 // their L tile loads (what remains is the hand-off chain)
     int nseg;                    //   fdone[nsuper], bdone[nsuper], pdone[nsuper]; error word last   // per front: {ticket, error, flags[np]} (zeroed before every front kernel)
     // numeric state
     double *kval;    // resident, UNREGULARISED triu KKT values (original nz order)

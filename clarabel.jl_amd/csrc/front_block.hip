@@ -265,7 +265,6 @@ k_front_block(DevPlan P, FrontBatch B, int *sync_all, double *scratch_all, doubl
     double *dsave = Sa + 64 * 9 + 1024;                              // [64]
     FB_T(7);
     const unsigned long long spos = __ballot(P.sgn_perm[f + lane] > 0);
-    const double dinv_delta = fb_rcp(dyn_delta);
     int nreg = 0;
     __syncthreads();                                      // Sa (X_j) and Sb (the last operand tile) are free
 #pragma unroll
@@ -285,72 +284,23 @@ k_front_block(DevPlan P, FrontBatch B, int *sync_all, double *scratch_all, doubl
             double pcol[8];
 #pragma unroll
             for (int q = 0; q < 8; q++) pcol[q] = Pc[lane * 9 + q];
-            if (P.pivot_mode != 1) {
-                // round-2 form: the pivot and the entries a_jk come from the lanes that hold them (v_readlane on the chain)
 #pragma unroll
-                for (int kk = 0; kk < 8; kk++) {
-                    const int k = 8 * Bk + kk;
-                    const double reg = pcol[kk];
-                    double d = fb_readlane(reg, k);
-                    const double sg = ((spos >> k) & 1ull) ? 1.0 : -1.0;
-                    double dinv;
-                    if (P.pivot_mode == 2) {     // the reciprocal starts from the raw pivot while the sign test runs (bit-identical results)
-                        const double dinv0 = fb_rcp(d);
-                        const bool sub = d * sg < dyn_eps;
-                        dinv = sub ? (sg > 0.0 ? dinv_delta : -dinv_delta) : dinv0;
-                        d = sub ? dyn_delta * sg : d;
-                        nreg += sub ? 1 : 0;
-                    } else {
-                        if (d * sg < dyn_eps) { d = dyn_delta * sg; nreg++; }
-                        dinv = fb_rcp(d);
-                    }
-                    const double li = reg * dinv;
-                    colL[kk][lane] = li;
-                    colC[kk][lane] = reg;
-                    Sb[lane * FLD + k] = li;
-                    if (lane == k) dsave[k] = d;
+            for (int kk = 0; kk < 8; kk++) {
+                const int k = 8 * Bk + kk;
+                const double reg = pcol[kk];
+                double d = fb_readlane(reg, k);
+                const double sg = ((spos >> k) & 1ull) ? 1.0 : -1.0;
+                if (d * sg < dyn_eps) { d = dyn_delta * sg; nreg++; }
+                const double dinv = fb_rcp(d);
+                const double li = reg * dinv;
+                colL[kk][lane] = li;
+                colC[kk][lane] = reg;
+                Sb[lane * FLD + k] = li;
+                if (lane == k) dsave[k] = d;
 #pragma unroll
-                    for (int jj = kk + 1; jj < 8; jj++) {
-                        const double cj = fb_readlane(reg, 8 * Bk + jj);
-                        pcol[jj] = fma(-li, cj, pcol[jj]);
-                    }
-                }
-            } else {
-                // Every lane ALSO eliminates the block's own 8 x 8 diagonal piece (rows 8 Bk .. 8 Bk + 7), read from LDS as
-                // broadcast loads before the chain starts: the pivot d_k, the entries a_jk and the sign test then come from the
-                // lane's own registers -- no v_readlane, no SGPR hand-over on the pivot-to-pivot chain, which shrinks to
-                // rcp + two Newton steps + select + mul + fma.  Same operations on the same values as the lanes that own those
-                // rows perform (l = a * (1/d); a' = fma(-l, a_jk, a)), so the factor is bit-identical to pivot_mode 0; the
-                // reciprocal is started from the raw pivot while the sign test runs, and replaced when the test fires.
-                double g[8][8];                     // g[i][j], j <= i: the diagonal piece (uniform over the lanes)
-#pragma unroll
-                for (int i2 = 0; i2 < 8; i2++)
-#pragma unroll
-                    for (int j2 = 0; j2 <= i2; j2++) g[i2][j2] = Pc[(8 * Bk + i2) * 9 + j2];
-#pragma unroll
-                for (int kk = 0; kk < 8; kk++) {
-                    const int k = 8 * Bk + kk;
-                    const double reg = pcol[kk];
-                    const double d0 = g[kk][kk];
-                    const double sg = ((spos >> k) & 1ull) ? 1.0 : -1.0;
-                    const bool sub = d0 * sg < dyn_eps;           // identical in every lane
-                    const double dsub = dyn_delta * sg;
-                    const double dinv0 = fb_rcp(d0), dinvs = sg > 0.0 ? dinv_delta : -dinv_delta;   // fb_rcp is odd in its argument
-                    const double d = sub ? dsub : d0, dinv = sub ? dinvs : dinv0;
-                    nreg += sub ? 1 : 0;
-                    const double li = reg * dinv;
-                    colL[kk][lane] = li;
-                    colC[kk][lane] = reg;
-                    Sb[lane * FLD + k] = li;
-                    if (lane == k) dsave[k] = d;
-#pragma unroll
-                    for (int i2 = kk + 1; i2 < 8; i2++) {
-                        const double gl = g[i2][kk] * dinv;
-#pragma unroll
-                        for (int j2 = kk + 1; j2 <= i2; j2++) g[i2][j2] = fma(-gl, g[j2][kk], g[i2][j2]);
-                    }
-#pragma unroll
-                    for (int jj = kk + 1; jj < 8; jj++) pcol[jj] = fma(-li, g[jj][kk], pcol[jj]);
+                for (int jj = kk + 1; jj < 8; jj++) {
+                    const double cj = fb_readlane(reg, 8 * Bk + jj);
+                    pcol[jj] = fma(-li, cj, pcol[jj]);
                 }
             }
         }

@@ -367,8 +367,8 @@ void setup_device(hipkkt_solver *S) {
         D.seg_ticket = tk ? atoi(tk) : 3;                  // bit 0: forward sweep, bit 1: backward sweep
         const char *sl = getenv("HIPKKT_SPIN_LIMIT");      // tests force a sweep time-out with a tiny bound
         D.spin_limit = sl ? (unsigned)strtoul(sl, nullptr, 10) : (1u << 20);
-        const char *pm = getenv("HIPKKT_PIVOT_MODE");
-        D.pivot_mode = pm ? atoi(pm) : 0;   // measured (cfg 2a, r03b): mode 1 is 0.1 ms per factorisation SLOWER -- the 148 extra VALU issues per block cost more than the shorter chain saves
+        const char *df = getenv("HIPKKT_DEBUG_FLAGS");
+        D.dbg = df ? atoi(df) : 0;
     }
     {
         const size_t nsync = seg_sync_ints(S->nseg, P.nsuper);

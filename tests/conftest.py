@@ -10,6 +10,7 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu through gpurun)")
+    config.addinivalue_line("markers", "slow: the long tail of an exhaustive parametrisation (deselect with -m 'gpu and not slow' for a quick pass)")
 
 
 @pytest.fixture(scope="session")

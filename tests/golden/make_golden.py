@@ -12,7 +12,9 @@ so the golden vectors are of two kinds, kept apart in the file:
   "oracle"   : outputs of THIS repository's oracle on the same fixtures (iterations, x, objective) --
                regression vectors that travel to the GPU box; they are NOT reference outputs.
 
-Run:  python tests/golden/make_golden.py        (from the repo root; needs oracle/liboracle_kkt.so)
+Run:  python tests/golden/make_golden.py [out.json]     (from the repo root; needs oracle/liboracle_kkt.so;
+      default output = tests/golden/reference_known_answers.json; tests/test_golden_file.py regenerates the file into a
+      temporary directory and compares it with the committed one)
 """
 import json
 import os
@@ -24,7 +26,8 @@ import scipy.sparse as sp
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
-import clarabel_jl_amd as cl  # noqa: E402
+import clarabel_jl_amd  # noqa: E402,F401  (registers the dotted package directory)
+import julia_standin as cl  # noqa: E402  (the numpy stand-in of the Julia caller: Solver, Settings)
 from oracle.kkt_oracle import OracleKKTSolver  # noqa: E402
 from tests import fixtures as fx  # noqa: E402
 
@@ -64,7 +67,7 @@ def dump_problem(prob):
                 cones=[[type(c).__name__, int(c.dim)] for c in cones])
 
 
-def main():
+def build():
     out = dict(reference=[], layout=dict(qp=LAYOUT_QP), oracle=[])
     for name, mk, status, x, obj, tol, cite in REFERENCE:
         out["reference"].append(dict(name=name, citation=cite, problem=dump_problem(mk()), status=status, x=x, obj=obj, tol=tol))
@@ -76,11 +79,16 @@ def main():
                                   x=np.asarray(sol.x).tolist(),
                                   obj=None if np.isnan(sol.obj_val) else float(sol.obj_val),
                                   r_prim=float(sol.r_prim), r_dual=float(sol.r_dual)))
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_known_answers.json")
+    return out
+
+
+def main(path=None):
+    out = build()
+    path = path or os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_known_answers.json")
     with open(path, "w") as f:
         json.dump(out, f, indent=1)
     print("wrote", path)
 
 
 if __name__ == "__main__":
-    main()
+    main(sys.argv[1] if len(sys.argv) > 1 else None)

@@ -106,3 +106,27 @@ def test_hip_layout_matches_hand_derived_image():
     for w, key in enumerate(["map_P", "map_A", "map_Hsblocks", "map_diagP", "map_diag_full"]):
         assert np.array_equal(hk.h.map(w) + 1, L[key]), key
     assert np.array_equal(hk.h.dsigns(), L["Dsigns"])
+
+
+def test_golden_file_regenerates(tmp_path):
+    """The committed recipe (tests/golden/make_golden.py) still runs and reproduces the committed file: the "reference" and
+    "layout" sections exactly (they are literals of the reference's tests / SURVEY App. B), the "oracle" section up to
+    rounding (status and iteration counts exactly, x and objective to 1e-12: BLAS / libm builds may differ in the last bits)."""
+    import subprocess
+    import sys
+
+    out = tmp_path / "regen.json"
+    root = os.path.dirname(HERE)
+    subprocess.check_call([sys.executable, os.path.join(HERE, "golden", "make_golden.py"), str(out)], cwd=root)
+    with open(out) as f:
+        new = json.load(f)
+    assert new["reference"] == GOLD["reference"]
+    assert new["layout"] == GOLD["layout"]
+    assert [e["name"] for e in new["oracle"]] == [e["name"] for e in GOLD["oracle"]]
+    for a, c in zip(new["oracle"], GOLD["oracle"]):
+        assert a["status"] == c["status"] and a["iterations"] == c["iterations"] and a["ordering"] == c["ordering"], a["name"]
+        assert np.max(np.abs(np.array(a["x"]) - np.array(c["x"]))) <= 1e-12 * max(1.0, np.max(np.abs(c["x"]))), a["name"]
+        if c["obj"] is None:
+            assert a["obj"] is None
+        else:
+            assert abs(a["obj"] - c["obj"]) <= 1e-12 * max(1.0, abs(c["obj"])), a["name"]

@@ -95,12 +95,22 @@ def test_full_size_matches_oracle(name, oracle_factory):
     assert hk.kktsolver_update(cones) and ok_.kktsolver_update(cones)
     assert np.array_equal(hk.h.kkt()[2], o.nzval)
     assert abs(hk.diagonal_regularizer - ok_.diagonal_regularizer) <= 1e-16 * max(1.0, ok_.diagonal_regularizer)
-    in_twin = hk.h.counters()["in_twin"]      # cfg 5: a factorisation that broke down in the cheap order was repeated in
-    if not in_twin:                           # the robust one -- then only the refined results are comparable
+    in_twin = hk.h.counters()["in_twin"]      # cfg 5: a factorisation that broke down in the cheap order was repeated in the robust one
+    b = rng.standard_normal(o.N)
+    if not in_twin:
         assert hk.last_nreg == o.L.oracle_kkt_nreg(o.h)
-        b = rng.standard_normal(o.N)
         xg, xc = hk.h.ldl_solve(b), o.ldl_solve(b)
         assert np.max(np.abs(xg - xc)) <= 1e-9 * max(1.0, np.max(np.abs(xc)))
+    else:
+        # The oracle cannot follow into the robust order (minimum degree on K: 5e12 scalar flops for cfg 5, hours on a host core),
+        # so the twin's UNREFINED factorisation is held to the size-independent property instead: its solve is the exact solve of
+        # the regularised matrix up to a backward error at rounding level,  |(K + eps S) x - b| <= 1e-9 (|K| |x| + |b|)  row by
+        # row -- the same bound the same-order comparison above implies.
+        K = _sym_K(hk.h)
+        Kf = K + sp.diags(hk.diagonal_regularizer * hk.h.dsigns().astype(float))
+        xg = hk.h.ldl_solve(b)
+        bound = abs(Kf) @ np.abs(xg) + np.abs(b)
+        assert np.all(np.abs(Kf @ xg - b) <= 1e-9 * bound)
     for rep in range(2):
         rx, rz = rng.standard_normal(n), rng.standard_normal(m)
         lx_g, lz_g, lx_c, lz_c = np.zeros(n), np.zeros(m), np.zeros(n), np.zeros(m)
@@ -120,16 +130,63 @@ def test_full_size_ipm_end_to_end(name):
     assert sol.r_prim < 1e-8 and sol.r_dual < 1e-8
 
 
-@pytest.mark.parametrize("seed", [100, 113, 126, 137, 150, 168, 187, 201, 222, 240, 255, 271, 300, 318, 339, 355])   # 126 ends ALMOST_SOLVED on both paths
-def test_batch_config_sample_matches_oracle(seed, oracle_factory):
-    """cfg 4: seeds 100..355 are the 256 problems of the batch; a sample against the oracle (same order)"""
+BATCH_SAMPLE = (100, 113, 126, 137, 150, 168, 187, 201, 222, 240, 255, 271, 300, 318, 339, 355)   # 126 ends ALMOST_SOLVED on both paths
+
+
+def _trace_at(trace, it):
+    for rec in trace:
+        if rec["iter"] == it:
+            return rec
+    return None
+
+
+@pytest.mark.parametrize("seed", [pytest.param(s_, marks=() if s_ in BATCH_SAMPLE else pytest.mark.slow) for s_ in range(100, 356)])
+def test_batch_config_matches_oracle(seed, oracle_factory, capsys):
+    """cfg 4: seeds 100..355 are the 256 problems of the batch; EVERY one against the oracle on the same elimination order
+    (the 240 outside the original sample carry the `slow` marker: -m "gpu and not slow" skips them).
+    Gate: status equal, iterations equal or +-1, objective and residuals to 1e-10.  Where the plain 1e-10 is not met
+    the cause is measured, not assumed: the ORACLE is run on a second elimination order (SuperLU MMD) and what IT moves by between
+    the two orders (CPU vs CPU, the reference's own arithmetic) is added four-fold to the gate and logged -- these problems
+    carry column scalings of 10^U(-2,2), and the last IPM iterations of some are decided by digits no LDL^T reproduces across
+    orderings.  When the iteration counts differ by one, the two runs are compared at their last COMMON iterate instead."""
     P, q, A, b, cones = problems.batch_problem(seed)
     sg = cl.Solver(P, q, A, b, cones, cl.Settings())
+    sg.trace = []
     solg = sg.solve()
     perm = sg.kktsystem.kktsolver.h.perm()
-    solc = cl.Solver(P, q, A, b, cones, cl.Settings(), kktsolver_factory=lambda *a: oracle_factory(*a, ordering=perm)).solve()
+    sc = cl.Solver(P, q, A, b, cones, cl.Settings(), kktsolver_factory=lambda *a: oracle_factory(*a, ordering=perm))
+    sc.trace = []
+    solc = sc.solve()
     assert solg.status == solc.status
     assert abs(solg.iterations - solc.iterations) <= 1
-    if solg.status == "SOLVED" and solg.iterations == solc.iterations:
-        assert abs(solg.obj_val - solc.obj_val) <= 1e-8 * max(1.0, abs(solc.obj_val))
-        assert abs(solg.r_prim - solc.r_prim) <= 1e-9 and abs(solg.r_dual - solc.r_dual) <= 1e-9
+    if solg.status not in ("SOLVED", "ALMOST_SOLVED"):
+        return
+    itc = min(solg.iterations, solc.iterations)
+    tg, tc = _trace_at(sg.trace, itc), _trace_at(sc.trace, itc)
+    assert tg is not None and tc is not None
+    dobj = abs(tg["cost_primal"] - tc["cost_primal"]) / max(1.0, abs(tc["cost_primal"]))
+    dres = max(abs(tg["res_primal"] - tc["res_primal"]), abs(tg["res_dual"] - tc["res_dual"]))
+    if solg.iterations == solc.iterations:      # the final answers themselves
+        dobj = max(dobj, abs(solg.obj_val - solc.obj_val) / max(1.0, abs(solc.obj_val)))
+        dres = max(dres, abs(solg.r_prim - solc.r_prim), abs(solg.r_dual - solc.r_dual))
+    if dobj <= 1e-10 and dres <= 1e-10 and solg.iterations == solc.iterations:
+        return
+    # not within the plain gate: measure what the reference arithmetic itself does between two orderings on this problem
+    s2 = cl.Solver(P, q, A, b, cones, cl.Settings(), kktsolver_factory=lambda *a: oracle_factory(*a, ordering="mmd"))
+    s2.trace = []
+    sol2 = s2.solve()
+    it2 = min(itc, sol2.iterations)
+    t2, tc2 = _trace_at(s2.trace, it2), _trace_at(sc.trace, it2)
+    spread_obj = abs(t2["cost_primal"] - tc2["cost_primal"]) / max(1.0, abs(tc2["cost_primal"]))
+    spread_res = max(abs(t2["res_primal"] - tc2["res_primal"]), abs(t2["res_dual"] - tc2["res_dual"]))
+    if it2 == itc and sol2.iterations == solc.iterations:
+        spread_obj = max(spread_obj, abs(sol2.obj_val - solc.obj_val) / max(1.0, abs(solc.obj_val)))
+        spread_res = max(spread_res, abs(sol2.r_prim - solc.r_prim), abs(sol2.r_dual - solc.r_dual))
+    with capsys.disabled():
+        print(f"\n[batch-parity seed {seed}] {solg.status}: iterations hip/oracle/oracle(mmd) = {solg.iterations}/{solc.iterations}/"
+              f"{sol2.iterations}; at iterate {itc}: |dobj| {dobj:.2e}, |dres| {dres:.2e}; cause = the oracle's own spread between "
+              f"two elimination orders: obj {spread_obj:.2e}, res {spread_res:.2e}")
+    if solg.iterations != solc.iterations:      # a termination / step-length test decided below 1e-10: the oracle must show it too
+        assert abs(sol2.iterations - solc.iterations) <= 1
+    assert dobj <= 1e-10 + 4.0 * spread_obj
+    assert dres <= 1e-10 + 4.0 * spread_res
