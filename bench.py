@@ -43,31 +43,37 @@ def make_problem(cfg, seed_shift=0):
     raise SystemExit(f"unknown config {cfg}")
 
 
-def pmc_traffic(cfg):
-    """HBM bytes per launch of the dominant kernel (k_update_dense<4,4>) from the committed rocprofv3 PMC passes
-    (FETCH_SIZE and WRITE_SIZE collected in separate runs of this very command, tools/pmc_summary.py; read side
-    doubled = the gfx950 FETCH_SIZE correction).  The counters cannot be collected from inside the timed run,
-    so the figure is read from profiles/ for the workload it was measured on, else null."""
-    if cfg != "2a":
-        return None
+def kernel_sources_hash():
+    """sha1 over the HIP sources of the kernels the counters describe: a counter file measured on other sources is stale"""
+    import hashlib
+
+    h = hashlib.sha1()
+    for f in ("kernels.hip", "front_block.hip", "front_sweep.hip", "device_plan.h", "symbolic.cpp"):
+        with open(os.path.join(ROOT, "clarabel.jl_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:12]
+
+
+def pmc_counters(cfg):
+    """Hardware-counter figures of the dominant kernel family (the big dense updates) from the newest committed
+    profiles/r*_cfg<cfg>_counters.json (written by tools/pmc_to_json.py from SEPARATE rocprofv3 --pmc passes of this very command:
+    FETCH_SIZE, WRITE_SIZE, and the SQ matrix-core counters).  The counters cannot be collected from inside the timed run, so they
+    are read from profiles/ -- and only trusted when the file carries the hash of the kernel sources this run was built from;
+    otherwise (None, reason)."""
     import glob
 
-    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_cfg2a_pmc_hbm_traffic.txt")))
-    for path in reversed(cands):          # newest round / tag first
-        try:
-            # a big dense-update launch is ONE kernel: k_update_dense<4,4>, or its piece-wise variant k_update_dense_tail<P> when
-            # the tiles do not fill the chip's last round; the per-launch figure is the call-weighted mean over all of them
-            calls = rd = wr = 0.0
-            for line in open(path):
-                if "k_update_denseILi4" in line or "k_update_dense_tail" in line:
-                    f = line.split()
-                    calls += float(f[1]); rd += float(f[1]) * float(f[4]); wr += float(f[1]) * float(f[5])
-            if calls:
-                return {"bytes_per_launch": round((rd + wr) / calls * 1e6), "read_x2_MB": round(rd / calls, 3),
-                        "write_MB": round(wr / calls, 3), "launches_in_trace": int(calls), "source": os.path.relpath(path, ROOT)}
-        except OSError:
-            pass
-    return None
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_cfg{cfg}_counters.json")))
+    if not cands:
+        return None, "no counter file for this workload under profiles/"
+    try:
+        with open(cands[-1]) as fh:
+            d = json.load(fh)
+    except (OSError, ValueError):
+        return None, "unreadable counter file"
+    d["source"] = os.path.relpath(cands[-1], ROOT)
+    if d.get("kernel_sources_sha1") != kernel_sources_hash():
+        return None, f"{d['source']} was measured on other kernel sources ({d.get('kernel_sources_sha1')}); re-run tools/final_round.sh"
+    return d, None
 
 
 def _cpu_batch_worker(seed):
@@ -82,15 +88,25 @@ def _cpu_batch_worker(seed):
     t0 = _t.perf_counter()
     P, q, A, b, cones = pr_.batch_problem(seed)
     sol = cl_.Solver(P, q, A, b, cones, cl_.Settings(), kktsolver_factory=lambda *a: OracleKKTSolver(*a, ordering="mmd")).solve()
-    return sol.iterations, sol.status, _t.perf_counter() - t0
+    return sol.iterations, sol.status, _t.perf_counter() - t0, float(sol.obj_val), seed
 
 
-def _gpu_batch_init(device):
-    """worker process of the cfg-4 batch driver: one HIP context of its own on the rank's GPU, warmed up"""
+def _alg_bytes(S_, iterations):
+    """algorithmic HBM bytes of one solved problem (B_iter without PCIe): per iteration one factorisation and three
+    refined solves of two LDL solves + two SpMVs each, from the symbolic factor actually used"""
+    cm = S_.kktsystem.kktsolver.h.cost_model()
+    return float(iterations) * (cm["bytes_factor"] + 6.0 * (cm["bytes_solve"] + cm["bytes_spmv"]))
+
+
+def _gpu_batch_init(device, cpus=None):
+    """worker process of the cfg-4 batch driver: pinned to the cores next to the rank's GPU, one HIP context of its own on that GPU,
+    warmed up"""
     import clarabel_jl_amd  # noqa: F401
     import julia_standin as cl_
+    from clarabel_jl_amd import batch as b_
     from clarabel_jl_amd import problems as pr_
 
+    b_.pin_process(cpus)
     global _W
     _W = (cl_, pr_, device)
     P, q, A, b, cones = pr_.batch_problem(100)
@@ -105,8 +121,9 @@ def _gpu_batch_chunk(arg):
 
     def one(seed):
         P, q, A, b, cones = pr_.batch_problem(seed)
-        sol = cl_.Solver(P, q, A, b, cones, cl_.Settings(device_id=device)).solve()
-        return seed, sol.iterations, sol.status
+        S_ = cl_.Solver(P, q, A, b, cones, cl_.Settings(device_id=device))
+        sol = S_.solve()
+        return seed, sol.iterations, sol.status, float(sol.obj_val), _alg_bytes(S_, sol.iterations)
 
     return b_.run_concurrent(one, seeds, in_flight)
 
@@ -124,8 +141,9 @@ def bench_batch(args, cl, torch, dist, rank, world, local):
 
     def solve_one(k):
         P, q, A, b, cones = problems.batch_problem(100 + mine[k % len(mine)])
-        sol = cl.Solver(P, q, A, b, cones, cl.Settings(device_id=local)).solve()
-        return 100 + mine[k % len(mine)], sol.iterations, sol.status
+        S_ = cl.Solver(P, q, A, b, cones, cl.Settings(device_id=local))
+        sol = S_.solve()
+        return 100 + mine[k % len(mine)], sol.iterations, sol.status, float(sol.obj_val), _alg_bytes(S_, sol.iterations)
 
     res = []
     pool = None
@@ -134,7 +152,17 @@ def bench_batch(args, cl, torch, dist, rank, world, local):
         # mostly host-side (symbolic analysis, the numpy caller, call latencies), and Python threads alone stop scaling at ~2
         import multiprocessing as mp
 
-        pool = mp.get_context("spawn").Pool(args.workers, initializer=_gpu_batch_init, initargs=(local,))
+        # one BLAS / OpenMP thread per worker, workers pinned to the cores of the GPU's NUMA node (an even slice of the allowed cores
+        # where sysfs does not tell): 8 ranks x 6 workers must not fight over the same cores
+        batch.cap_host_threads(1)
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+        try:
+            pr = torch.cuda.get_device_properties(local)
+            bdf = f"{getattr(pr, 'pci_domain_id', 0):04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+        except Exception:
+            bdf = None
+        cpus = batch.gpu_numa_cpus(local, local_world, bdf)
+        pool = mp.get_context("spawn").Pool(args.workers, initializer=_gpu_batch_init, initargs=(local, cpus))
         pool.map(_gpu_batch_chunk, [([100 + mine[k % len(mine)]], 1) for k in range(args.workers)])      # warm-up: every worker once
         seeds = [100 + mine[(args.warmup + i) % len(mine)] for i in range(steps)]
         chunks = [(seeds[w::args.workers], args.in_flight) for w in range(args.workers)]
@@ -156,7 +184,9 @@ def bench_batch(args, cl, torch, dist, rank, world, local):
     total_solved = batch.gather_counts(sum(r[2] == "SOLVED" for r in res), dist, dev)
     total_probs = batch.gather_counts(steps, dist, dev)
     not_solved = [(r[0], r[2]) for r in res if r[2] != "SOLVED"]
+    total_bytes = batch.gather_counts(int(sum(r[4] for r in res)), dist, dev)
     cpu_baseline = None
+    parity = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # all-cores CPU baseline: the same problems, one per core, oracle KKT solver, bounded sample
         import multiprocessing as mp
@@ -177,6 +207,26 @@ def bench_batch(args, cl, torch, dist, rank, world, local):
                         "wall_s": round(t_cpu, 3), "sum_of_per_problem_s": round(sum(o[2] for o in out), 3),
                         "one_core_iterations_per_s": round(sum(o[0] for o in out) / sum(o[2] for o in out), 2),
                         "host_cores_available": os.cpu_count(), "pool_start_s": round(t_spawn, 2)}
+        # parity of the same run: the problems of the CPU sample, HIP path vs oracle (the oracle on ITS OWN ordering, SuperLU MMD):
+        # status, iteration counts (+-1), objective.  The IPM stops at 1e-8, and the two paths use different elimination orders, so
+        # the objective gate here is 1e-7 relative; the 1e-10 comparison on a common order is tests/test_gpu_fullsize.py
+        # (test_batch_config_matches_oracle, all 256 seeds).
+        by_seed = {r[0]: r for r in res}
+        st_eq = it_eq = it_pm1 = 0
+        max_dobj = 0.0
+        for o in out:
+            g_ = by_seed.get(o[4])
+            if g_ is None:
+                continue
+            st_eq += g_[2] == o[1]
+            it_eq += g_[1] == o[0]
+            it_pm1 += abs(g_[1] - o[0]) <= 1
+            if g_[2] == o[1] == "SOLVED":
+                max_dobj = max(max_dobj, abs(g_[3] - o[3]) / max(1.0, abs(o[3])))
+        parity = {"problems_compared": len(out), "status_equal": st_eq, "iterations_equal": it_eq, "iterations_within_1": it_pm1,
+                  "max_rel_dobj": float(f"{max_dobj:.3e}"), "tolerance": 1e-7,
+                  "pass": bool(st_eq == len(out) and it_pm1 == len(out) and max_dobj <= 1e-7),
+                  "note": "HIP path vs the oracle on its own ordering, whole IPM solves of the same problems in the same run"}
     if rank == 0:
         print(json.dumps({
             "metric": "IPM iterations/sec + KKT factor+solve ms, 10k-var sparse QP, 1/2/4/8 GPU",
@@ -187,8 +237,15 @@ def bench_batch(args, cl, torch, dist, rank, world, local):
                        "problems_solved": total_probs, "status_solved": total_solved, "not_solved": not_solved,
                        "in_flight_per_gpu": args.in_flight * max(1, args.workers), "host_processes_per_gpu": max(1, args.workers),
                        "threads_per_process": args.in_flight,
+                       "host_cores_kept_busy": batch.host_core_budget(world, args.workers, args.in_flight), "host_cores_available": os.cpu_count(),
                        "parallelism": f"{world} rank(s), {len(mine)} problems on rank 0"},
-            "problems_per_s": round(total_probs / elapsed, 3), "roofline": None, "cpu_baseline": cpu_baseline}))
+            "problems_per_s": round(total_probs / elapsed, 3),
+            "roofline": {"bound": "hbm", "achieved": round(total_bytes / elapsed / 1e9, 3), "peak": 8000.0 * world, "unit": "GB/s",
+                         "frac": round(total_bytes / elapsed / 1e9 / (8000.0 * world), 6), "traffic": None,
+                         "note": "algorithmic bytes of all solved problems (B_factor + 6 (B_solve + B_spmv) per IPM iteration, from each "
+                                 "problem's symbolic factor) / wall time: a batch of small problems is bound by host work and launch / "
+                                 "dependency latency, not by HBM -- the fraction says how far, it is not a kernel-quality figure"},
+            "cpu_baseline": cpu_baseline, "parity": parity}))
     if dist is not None:
         dist.destroy_process_group()
 
@@ -196,11 +253,13 @@ def bench_batch(args, cl, torch, dist, rank, world, local):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 20; cfg 4: the whole batch of 256 problems)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="2a")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-budget", type=float, default=30.0, help="seconds of CPU-oracle work allowed for cpu_baseline/parity")
+    ap.add_argument("--cpu-budget", type=float, default=75.0,
+                    help="seconds of CPU-oracle work allowed for cpu_baseline / parity (default: three KKT iteration units of the headline "
+                         "config, 23 s each on one host core: SURVEY section 8d asks for >= 3)")
     ap.add_argument("--update-policy", type=int, default=None)
     ap.add_argument("--update-batch", type=int, default=None, help="levels per update batch (default: automatic)")
     ap.add_argument("--in-flight", type=int, default=1, help="cfg 4: problems solved concurrently per host process (threads)")
@@ -208,6 +267,8 @@ def main():
     ap.add_argument("--device-scaling", action="store_true", help="also solve once end to end with N1 on (update_scaling!/get_Hs! on the device) and report it under end_to_end")
     ap.add_argument("--sequential-solves", action="store_true", help="three separate solve calls per unit instead of 2 concurrent + 1")
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 0 if args.config == "4" else 20
 
     import torch
 
@@ -385,8 +446,33 @@ def main():
             panels=p4["front_block_panels"], ms_per_refactor=round(p4["front_block_ms"], 4),
             us_per_panel=round(1e3 * p4["front_block_ms"] / max(1, p4["front_block_panels"]), 2),
             floor_note="wall-clock stamps (tools/fb_trace.py): 9.9 us pivots + 2.8 inverse + 2.8 hand-off + 4.2 two 64^3 products + rest per panel")
+    # algorithmic HBM bytes of one big dense-update launch, from the plan (every target tile read and written
+    # once, every source panel row once): T tiles of 64 x 64 doubles; a launch over T = R (R + 1) / 2 tiles of a front touches R
+    # row blocks of its K source columns (K = flops per tile / (2 * 64 * 64))
+    alg_bytes = None
+    if len(lms):
+        per = []
+        for m_, f_, t_ in zip(lms, lfl, ltl):
+            K_ = f_ / t_ / (2.0 * 64 * 64)
+            R_ = (np.sqrt(8.0 * t_ + 1.0) - 1.0) / 2.0
+            per.append(2.0 * t_ * 64 * 64 * 8 + R_ * 64 * K_ * 8)
+        alg_bytes = float(np.mean(per))
+    ctr, why = pmc_counters(args.config)
+    traffic = None
+    if ctr is not None:
+        traffic = dict(bytes_per_launch=ctr["bytes_per_launch"], read_x2_MB=ctr["read_x2_MB"], write_MB=ctr["write_MB"],
+                       launches_in_trace=ctr["launches_in_trace"], source=ctr["source"], kernel_sources_sha1=ctr["kernel_sources_sha1"],
+                       algorithmic_bytes_per_launch=None if alg_bytes is None else round(alg_bytes),
+                       ratio_to_algorithmic=None if not alg_bytes else round(ctr["bytes_per_launch"] / alg_bytes, 2),
+                       note="fabric-side bytes (L2 misses; Infinity-Cache hits are counted): FETCH_SIZE x2 (calibrated on this access shape, "
+                            "profiles/r03_a_traffic_calibration.txt) + WRITE_SIZE per launch")
+    cm_f = cm["flops_factor"]
     roofline = dict(bound="mfma", achieved=round(achieved, 3), peak=F64_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
-                    frac=round(achieved / F64_MFMA_PEAK_TFLOPS, 4), traffic=pmc_traffic(args.config),
+                    frac=round(achieved / F64_MFMA_PEAK_TFLOPS, 4), traffic=traffic, traffic_unavailable=why,
+                    mfma_busy_pct=None if ctr is None else ctr.get("mfma_busy_pct"),
+                    whole_factorisation=dict(note="SURVEY section 8(d)'s figure: F_factor / t_factor with F_factor = sum_j (c_j^2 + 3 c_j)",
+                                             flops=cm_f, ms=round(factor_ms, 4), achieved=round(cm_f / (factor_ms * 1e-3) / 1e12, 3),
+                                             frac=round(cm_f / (factor_ms * 1e-3) / 1e12 / F64_MFMA_PEAK_TFLOPS, 4)),
                     kernel=kern, **per_launch,
                     all_update_kernels=dict(achieved=round(agg, 3), ms_per_refactor=round(upd, 4),
                                             flops_per_refactor=flops_upd_kernels),

@@ -59,3 +59,66 @@ def run_concurrent(solve_one, items, in_flight: int):
 
     with ThreadPoolExecutor(max_workers=in_flight) as ex:
         return list(ex.map(solve_one, items))
+
+
+# ---- host placement of a rank's worker processes (bench.py --config 4 --gpus 8: 8 ranks x `--workers` processes on one node) ----------
+
+def cap_host_threads(n: int = 1):
+    """One BLAS / OpenMP thread per worker process: with 6 workers per GPU and 8 GPUs a node runs 48 problem-solving processes next to
+    8 rank processes; thread teams per process (OpenBLAS spins up one per 20k-element dot) would oversubscribe every core.  Must
+    run before the worker processes are spawned (they inherit the environment)."""
+    import os
+
+    for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS", "NUMEXPR_NUM_THREADS"):
+        os.environ[k] = str(n)
+
+
+def gpu_numa_cpus(device: int, local_world: int = 1, pci_bus_id: str | None = None):
+    """CPUs a rank's processes should run on: the cores of the NUMA node its GPU hangs off (sysfs), else an even slice of the
+    cores this process may use (one slice per local rank).  Returns a sorted list of CPU ids (never empty)."""
+    import os
+
+    allowed = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+    node = None
+    if pci_bus_id:
+        try:
+            with open(f"/sys/bus/pci/devices/{pci_bus_id.lower()}/numa_node") as f:
+                node = int(f.read().strip())
+        except (OSError, ValueError):
+            node = None
+    if node is not None and node >= 0:
+        try:
+            with open(f"/sys/devices/system/node/node{node}/cpulist") as f:
+                cpus = []
+                for part in f.read().strip().split(","):
+                    lo, _, hi = part.partition("-")
+                    cpus += list(range(int(lo), int(hi or lo) + 1))
+            cpus = [c for c in cpus if c in set(allowed)]
+            if cpus:
+                # (GPUs that share a NUMA node share its cores: the scheduler balances inside the node)
+                return cpus
+        except (OSError, ValueError):
+            pass
+    w = max(1, local_world)
+    per = max(1, len(allowed) // w)
+    lo = (device % w) * per
+    return allowed[lo:lo + per] or allowed
+
+
+def pin_process(cpus):
+    """restrict the calling process (and the threads it starts) to `cpus`; a no-op where the platform cannot"""
+    import os
+
+    if cpus and hasattr(os, "sched_setaffinity"):
+        try:
+            os.sched_setaffinity(0, set(cpus))
+            return True
+        except OSError:
+            return False
+    return False
+
+
+def host_core_budget(world: int, workers: int, in_flight: int = 1):
+    """host cores the batch driver keeps busy: per rank one driver process + `workers` solver processes (`in_flight` threads each hold
+    the GIL in turn, so a process is ~1 core); the analysis thread of a handle is short-lived and not counted"""
+    return world * (1 + max(1, workers))

@@ -88,10 +88,9 @@ __device__ __forceinline__ void sb_mm16(const double *A, const double *Bm, v4f64
         c = __builtin_amdgcn_mfma_f64_16x16x4f64(A[(16 * ti + l15) * SLD + 4 * kk + lk], Bm[(4 * kk + lk) * SLD + 16 * tj + l15], c, 0, 0, 0);
 }
 
-// The products of one workgroup form a chain ((bl, kl) for kl = cl .. bl-1, then the closing product with Linv_bl, for bl = cl+1 ..);
-// the operands of the NEXT product are fetched into registers before the current one runs on the matrix core, so the chain costs
-// one product + two barriers per link instead of a memory round trip (operands that this workgroup wrote itself are at least one
-// link old by the time they are fetched).
+// (Measured, r03f: fetching the next product's operands into registers while the current product runs does NOT help -- 148 us
+// instead of 129 us on cfg 2a: a 64 x 64 x 64 product is 1.7 us of matrix-core time on ONE compute unit, the chain of a super-block's
+// first column is 28 + 7 of them, and that, not the operand latency, is what the kernel costs.)
 __global__ void __launch_bounds__(kInvThreads)
 k_invert_super(DevPlan P, FrontDesc F) {
     __shared__ double SA[64 * SLD], SB[64 * SLD];
@@ -99,52 +98,39 @@ k_invert_super(DevPlan P, FrontDesc F) {
     const int nbB = min(kSbG, F.np - kSbG * B);
     if (cl + 1 >= nbB) return;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, lk = lane >> 4, ti = wv >> 2, tj = wv & 3;
-    const FrontPanel *fps = P.front_panels + F.fp_off + kSbG * B;
-    // operands of link (bl, kl): kl < bl: A = L[bl,kl] (rows of block bl inside panel kl), B = Inv[kl,cl];  kl == bl: A = Linv_bl, B = the sum
-    auto fetch = [&](int bl, int kl, double (&va)[4], double (&vb)[4]) {
-        const FrontPanel pb = fps[bl];
-        if (kl == bl) {
-            const SbTileSrc a_src = {P.Linv + pb.diag_off, 1, pb.w, pb.w, pb.w, true, false};
+    const FrontPanel *fps = P.front_panels + F.fp_off;
+    const FrontPanel pc = fps[kSbG * B + cl];
+    const SbTileSrc linv_c = {P.Linv + pc.diag_off, 1, pc.w, pc.w, pc.w, true, false};
+    for (int bl = cl + 1; bl < nbB; bl++) {
+        const FrontPanel pb = fps[kSbG * B + bl];
+        v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+        for (int kl = cl; kl < bl; kl++) {
+            const FrontPanel pk = fps[kSbG * B + kl];
+            // A = L[bl,kl]: rows of block bl inside panel kl (column-major, stride r);  B = Inv[kl,cl]
+            const SbTileSrc a_src = {P.Lx + pk.panel_off + F.cw * (bl - kl), 1, pk.r, pb.w, pk.w, false, false};
+            const SbTileSrc b_src = kl == cl ? linv_c : SbTileSrc{P.SbInv + sb_tile(F, B, kl, cl), 1, 64, 64, 64, false, true};
+            double va[4], vb[4];
             sb_fetch(a_src, va, tid);
-            return;
-        }
-        const FrontPanel pk = fps[kl];
-        const SbTileSrc a_src = {P.Lx + pk.panel_off + F.cw * (bl - kl), 1, pk.r, pb.w, pk.w, false, false};
-        sb_fetch(a_src, va, tid);
-        if (kl == cl) {
-            const SbTileSrc b_src = {P.Linv + pk.diag_off, 1, pk.w, pk.w, pk.w, true, false};
             sb_fetch(b_src, vb, tid);
-        } else {
-            const SbTileSrc b_src = {P.SbInv + sb_tile(F, B, kl, cl), 1, 64, 64, 64, false, true};
-            sb_fetch(b_src, vb, tid);
-        }
-    };
-    double va[4], vb[4], na[4], nb2[4];
-    int bl = cl + 1, kl = cl;
-    fetch(bl, kl, va, vb);
-    v4f64 acc = {0.0, 0.0, 0.0, 0.0};
-    while (bl < nbB) {
-        const bool closing = kl == bl;
-        int nbl = bl, nkl = kl + 1;               // the next link
-        if (closing) { nbl = bl + 1; nkl = cl; }
-        sb_put(SA, va, tid);
-        if (closing) {
-#pragma unroll
-            for (int reg = 0; reg < 4; reg++) SB[(16 * ti + lk + 4 * reg) * SLD + 16 * tj + l15] = acc[reg];
-        } else {
+            sb_put(SA, va, tid);
             sb_put(SB, vb, tid);
-        }
-        __syncthreads();
-        if (nbl < nbB) fetch(nbl, nkl, na, nb2);   // in flight while this link runs
-        if (!closing) {
+            __syncthreads();
             sb_mm16(SA, SB, acc, ti, tj, l15, lk);
             __syncthreads();
-        } else {
+        }
+        {   // Inv[bl,cl] = -Linv_bl * S
+            const SbTileSrc linv_b = {P.Linv + pb.diag_off, 1, pb.w, pb.w, pb.w, true, false};
+            double va[4];
+            sb_fetch(linv_b, va, tid);
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) SB[(16 * ti + lk + 4 * reg) * SLD + 16 * tj + l15] = acc[reg];
+            sb_put(SA, va, tid);
+            __syncthreads();
             v4f64 o = {0.0, 0.0, 0.0, 0.0};
             sb_mm16(SA, SB, o, ti, tj, l15, lk);
             __syncthreads();
 #pragma unroll
-            for (int reg = 0; reg < 4; reg++) SA[(16 * ti + lk + 4 * reg) * SLD + 16 * tj + l15] = -o[reg];   // Inv[bl,cl] = -Linv_bl * sum
+            for (int reg = 0; reg < 4; reg++) SA[(16 * ti + lk + 4 * reg) * SLD + 16 * tj + l15] = -o[reg];
             __syncthreads();
             double *t = P.SbInv + sb_tile(F, B, bl, cl);
 #pragma unroll
@@ -155,11 +141,7 @@ k_invert_super(DevPlan P, FrontDesc F) {
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            acc = (v4f64){0.0, 0.0, 0.0, 0.0};
         }
-#pragma unroll
-        for (int q = 0; q < 4; q++) { va[q] = na[q]; vb[q] = nb2[q]; }
-        bl = nbl; kl = nkl;
     }
 }
 

@@ -604,7 +604,8 @@ int32_t hipkkt_get_counters(hipkkt_handle h, int64_t *o) {
     if (!h || !o) return HIPKKT_ERR_ARGUMENT;
     o[0] = h->n_sweep_timeouts; o[1] = h->use_persist ? 1 : 0; o[2] = h->n_twin_refactors; o[3] = h->fallback ? 1 : 0;
     o[4] = h->using_fallback ? 1 : 0; o[5] = h->plan.ordering_used; o[6] = (int64_t)h->plan.fronts.size(); o[7] = h->nseg;
-    o[8] = (int64_t)h->fbatches.size(); o[9] = h->use_front_block ? 1 : 0; o[10] = o[11] = 0;
+    o[8] = (int64_t)h->fbatches.size(); o[9] = h->use_front_block ? 1 : 0;
+    plan_cache_counts(&o[10], &o[11]);   // process-wide: symbolic plans taken from / not found in the plan cache
     return HIPKKT_OK;
 }
 

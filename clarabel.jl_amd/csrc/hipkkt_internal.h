@@ -15,8 +15,10 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <future>
 #include <memory>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -285,6 +287,7 @@ namespace hipkkt_host {
 inline size_t seg_sync_ints(int nseg, int nsuper) { return (size_t)((2 * nseg + 31) & ~31) + 3 * (size_t)nsuper + 16; }
 
 // hipkkt_setup.cpp
+void plan_cache_counts(int64_t *hits, int64_t *misses);   // process-wide cache of symbolic plans (same pattern + options)
 void init_runtime(hipkkt_solver *S);
 void setup_device(hipkkt_solver *S);
 int32_t finish_create(hipkkt_solver *S, const hipkkt_opts *opts, hipkkt_handle *out);

@@ -6,6 +6,51 @@ using namespace hipkkt_host;
 
 namespace hipkkt_host {
 
+// Process-wide cache of symbolic plans keyed by the KKT pattern + the plan options: a batch of problems with
+// IDENTICAL structure (the same model re-solved with new data, MPC, parameter sweeps) pays the ordering + symbolic analysis once.
+// Patterns are compared exactly (hash first); a hit deep-copies the plan into the handle.  HIPKKT_PLAN_CACHE=0 disables it.
+namespace {
+struct PlanCache {
+    struct Entry {
+        uint64_t key;
+        std::string optkey;
+        std::vector<int64_t> colptr, rowval;
+        std::shared_ptr<const HostPlan> plan;
+    };
+    std::mutex mu;
+    std::deque<Entry> entries;
+    int64_t hits = 0, misses = 0;
+    static constexpr size_t kMaxEntries = 8;
+    static constexpr int64_t kMaxNnzL = 40000000;      // bigger plans (hundreds of MB of work lists) are not kept
+    static PlanCache &get() { static PlanCache c; return c; }
+    static bool enabled() { static const bool on = [] { const char *e = getenv("HIPKKT_PLAN_CACHE"); return !(e && e[0] == '0'); }(); return on; }
+    static uint64_t fnv(uint64_t h, const void *p, size_t n) {
+        const unsigned char *b = (const unsigned char *)p;
+        for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 1099511628211ull; }
+        return h;
+    }
+    std::shared_ptr<const HostPlan> find(uint64_t key, const std::string &optkey, const KKTImage &K) {
+        std::lock_guard<std::mutex> lk(mu);
+        for (const Entry &e : entries)
+            if (e.key == key && e.optkey == optkey && e.colptr == K.colptr && e.rowval == K.rowval) { hits++; return e.plan; }
+        misses++;
+        return nullptr;
+    }
+    void put(uint64_t key, const std::string &optkey, const KKTImage &K, const HostPlan &P) {
+        if (P.nnzL > kMaxNnzL) return;
+        Entry e{key, optkey, K.colptr, K.rowval, std::make_shared<const HostPlan>(P)};
+        std::lock_guard<std::mutex> lk(mu);
+        entries.push_front(std::move(e));
+        while (entries.size() > kMaxEntries) entries.pop_back();
+    }
+};
+}  // namespace
+void plan_cache_counts(int64_t *hits, int64_t *misses) {
+    PlanCache &c = PlanCache::get();
+    std::lock_guard<std::mutex> lk(c.mu);
+    *hits = c.hits; *misses = c.misses;
+}
+
 void init_runtime(hipkkt_solver *S) {
     { const char *pz = getenv("HIPKKT_POISON"); S->poison = pz && pz[0] == '1'; }
     HK_CHECK(hipSetDevice(S->device));
@@ -581,7 +626,29 @@ int32_t finish_create(hipkkt_solver *S, const hipkkt_opts *opts, hipkkt_handle *
             };
     }
     const auto t_a = std::chrono::steady_clock::now();
-    std::string err = build_plan((int)S->img.N, S->img.colptr.data(), S->img.rowval.data(), uperm, po, S->plan);
+    // plan cache: same pattern, same options => the same plan
+    uint64_t ckey = 0;
+    std::string optkey;
+    std::shared_ptr<const HostPlan> cached;
+    if (PlanCache::enabled()) {
+        char buf[256];
+        snprintf(buf, sizeof buf, "%d|%d|%d|%d|%.17g|%.17g|%d|%d|%d|%d|%d|%d|%d|%d|%d|%d", po.max_width, (int)po.relax, po.update_policy, po.update_batch,
+                 po.amd_dense_scale, po.dense_min_cover, (int)po.fuse_jit, (int)po.split_far, po.xcd_order, po.n_hold, po.front_block_min_width,
+                 po.front_min_panels, po.superhop, po.nd_mode, po.nd_leaf, uperm ? 1 : 0);
+        optkey = buf;
+        ckey = PlanCache::fnv(1469598103934665603ull, S->img.colptr.data(), S->img.colptr.size() * sizeof(int64_t));
+        ckey = PlanCache::fnv(ckey, S->img.rowval.data(), S->img.rowval.size() * sizeof(int64_t));
+        if (uperm) ckey = PlanCache::fnv(ckey, uperm, (size_t)S->img.N * sizeof(int64_t));
+        cached = PlanCache::get().find(ckey, optkey, S->img);
+    }
+    std::string err;
+    if (cached) {
+        S->plan = *cached;
+        S->plan.timing_note = "plan cache hit";
+    } else {
+        err = build_plan((int)S->img.N, S->img.colptr.data(), S->img.rowval.data(), uperm, po, S->plan);
+        if (err.empty() && PlanCache::enabled()) PlanCache::get().put(ckey, optkey, S->img, S->plan);
+    }
     po.on_alternative_order = nullptr;
     if (!err.empty()) { g_create_error = err; delete S; return HIPKKT_ERR_ARGUMENT; }
     if (S->plan.ordering_used != 1 && S->twin_cancel) S->twin_cancel->store(true);   // speculative twin not needed: the thread stops at its next phase

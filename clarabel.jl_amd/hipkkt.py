@@ -247,7 +247,7 @@ class Handle:
         self.L.hipkkt_get_counters(self.h, o)
         return dict(sweep_timeouts=int(o[0]), persistent=bool(o[1]), twin_refactors=int(o[2]), twin_exists=bool(o[3]),
                     in_twin=bool(o[4]), ordering=int(o[5]), fronts=int(o[6]), segments=int(o[7]), front_batches=int(o[8]),
-                    front_block=bool(o[9]))
+                    front_block=bool(o[9]), plan_cache_hits=int(o[10]), plan_cache_misses=int(o[11]))
 
     def profile_launches(self):
         n = C.c_int64(0)

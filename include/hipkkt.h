@@ -282,7 +282,9 @@ int32_t hipkkt_set_profiling(hipkkt_handle h, int32_t enable);
  * out[2] = factorisations repeated on the robust-order twin, out[3] = twin exists, out[4] = the current factorisation
  * lives in the twin, out[5] = ordering in use (0 minimum degree on K, 1 cone rows first, 2 user), out[6] = #fronts,
  * out[7] = #segments, out[8] = update batches of fronts factored by one launch each (front_block.hip), out[9] = that path is
- * enabled (0 after one of its hand-offs timed out: the handle then keeps one launch per panel), out[10..11] reserved (0) */
+ * enabled (0 after one of its hand-offs timed out: the handle then keeps one launch per panel), out[10] / out[11] = symbolic plans
+ * taken from / not found in the process-wide plan cache (same KKT pattern and options => the analysis of an earlier handle is reused;
+ * HIPKKT_PLAN_CACHE=0 disables it) */
 int32_t hipkkt_get_counters(hipkkt_handle h, int64_t *out12);
 
 /* developer diagnostic, not part of the plugin contract: copies an internal vector of the last LDL solve (what = 0 the

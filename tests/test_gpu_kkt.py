@@ -646,6 +646,31 @@ def test_kkt_solve_reduced_on_device(name):
             assert abs(solr.obj_val - sold.obj_val) <= 1e-9 * max(1.0, abs(solr.obj_val))
 
 
+def test_plan_cache_reuses_the_analysis_of_an_identical_pattern(oracle_factory):
+    """A second handle on the SAME KKT pattern and options takes its symbolic plan from the process-wide cache (DESIGN.md section 8:
+    batches of structurally identical problems) and behaves exactly like the first: same permutation, bit-identical solves."""
+    rng = np.random.default_rng(31)
+    Pt, A, cones = _prep(problems.random_sparse_qp(400, 700, 41, 3, 1))
+    m, n = A.shape
+    h1 = HipKKTSolver(Pt, A, cones, m, n, cl.Settings())
+    c1 = h1.h.counters()
+    Pt2 = Pt.copy()
+    Pt2.data *= 1.5                                   # new values, same pattern
+    h2 = HipKKTSolver(Pt2, A, cones, m, n, cl.Settings())
+    c2 = h2.h.counters()
+    assert c2["plan_cache_hits"] == c1["plan_cache_hits"] + 1 and c2["plan_cache_misses"] == c1["plan_cache_misses"]
+    assert np.array_equal(h1.h.perm(), h2.h.perm()) and h1.h.nnzL == h2.h.nnzL
+    h3 = HipKKTSolver(Pt, A, cones, m, n, cl.Settings())
+    _scale_cones(cones, rng)
+    assert h1.kktsolver_update(cones) and h3.kktsolver_update(cones)
+    b = rng.standard_normal(h1.h.N)
+    assert np.array_equal(h1.h.ldl_solve(b), h3.h.ldl_solve(b))
+    ok_ = oracle_factory(Pt, A, cones, m, n, cl.Settings(), ordering=h3.h.perm())
+    assert ok_.kktsolver_update(cones)
+    xc = ok_.k.ldl_solve(b)
+    assert np.max(np.abs(h3.h.ldl_solve(b) - xc)) <= 1e-9 * max(1.0, np.max(np.abs(xc)))
+
+
 def _image(h):
     colptr, rowval, nzval = h.kkt()
     maps = [h.map(w) for w in range(5)]

@@ -108,3 +108,87 @@ def test_run_concurrent_keeps_order_and_results():
     seq = batch.run_concurrent(solve, list(range(6)), 1)
     par = batch.run_concurrent(solve, list(range(6)), 3)
     assert seq == par and [r[0] for r in par] == list(range(6)) and all(r[1] == "SOLVED" for r in par)
+
+
+def _worker8(rank, world, port, nprob, nworkers, out):
+    """one rank of the cfg-4 batch driver on CPU: `nworkers` worker processes (bench.py --workers), pinned like the GPU run pins them"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import multiprocessing as pmp
+
+    batch.cap_host_threads(1)
+    cpus = batch.gpu_numa_cpus(rank, world, None)
+    mine = batch.shard(nprob, rank, world)
+    pool = pmp.get_context("spawn").Pool(nworkers, initializer=_pool_init, initargs=(cpus,))
+    chunks = [mine[w::nworkers] for w in range(nworkers)]
+    res = []
+
+    def timed(_):
+        for part in pool.map(_pool_chunk, chunks):
+            res.extend(part)
+
+    elapsed = batch.timed_steps(timed, steps=1, warmup=0, dist=dist)
+    pool.close()
+    pool.join()
+    total = batch.gather_counts(len(res), dist)
+    iters = batch.gather_counts(sum(r[2] for r in res), dist)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (rank, mine, res, elapsed, total, iters, cpus))
+    if rank == 0:
+        out.put(gathered)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _pool_init(cpus):
+    batch.pin_process(cpus)
+
+
+def _pool_chunk(seeds):
+    from oracle.kkt_oracle import OracleKKTSolver
+
+    outp = []
+    for k in seeds:
+        P, q, A, b, cones = problems.random_sparse_qp(20 + 3 * (k % 7), 30 + 5 * (k % 7), seed=300 + k, kA=3, kP=1)
+        sol = cl.Solver(P, q, A, b, cones, cl.Settings(), kktsolver_factory=lambda *a: OracleKKTSolver(*a)).solve()
+        outp.append((k, sol.status, sol.iterations, os.getpid(), sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else []))
+    return outp
+
+
+def test_eight_ranks_two_workers_each_solve_every_problem_once():
+    """bench.py --config 4 --gpus 8 on CPU: 8 gloo ranks x 2 worker processes, 40 problems sharded round-robin over the ranks and
+    then over each rank's workers.  Every problem is solved exactly once, the whole-job counts and the max-over-ranks time are common
+    to all ranks, and each rank's workers run on the cores the placement helper gave that rank."""
+    world, nprob, nworkers = 8, 40, 2
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker8, args=(r, world, port, nprob, nworkers, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    gathered = out.get(timeout=600)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    solved = sorted(r[0] for _, _, res, *_ in gathered for r in res)
+    assert solved == list(range(nprob))                              # every problem exactly once over ranks x workers
+    assert all(t == nprob for *_, t, _, _ in gathered)               # whole-job unit count agrees on all ranks
+    its = {i for *_, i, _ in gathered}
+    assert len(its) == 1 and its.pop() == sum(r[2] for _, _, res, *_ in gathered for r in res)
+    el = {e for _, _, _, e, *_ in gathered}
+    assert len(el) == 1 and el.pop() > 0                             # the max over ranks is common
+    for rank, mine, res, _, _, _, cpus in gathered:
+        assert sorted(r[0] for r in res) == sorted(mine)
+        assert all(r[1] == "SOLVED" for r in res)
+        assert len({r[3] for r in res}) <= nworkers                  # at most `nworkers` processes worked for this rank
+        for r in res:
+            assert set(r[4]) <= set(cpus) or not r[4]                 # ... on this rank's cores
+    assert batch.host_core_budget(8, 6) == 56                        # the figure DESIGN.md section 8 states for --gpus 8 --workers 6
+
+
+def test_gpu_numa_cpus_partitions_the_allowed_cores():
+    allowed = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+    parts = [batch.gpu_numa_cpus(r, 8, None) for r in range(8)]
+    assert all(parts) and all(set(p) <= set(allowed) for p in parts)
+    if len(allowed) >= 8:
+        assert sum(len(p) for p in parts) <= len(allowed) and len({c for p in parts for c in p}) == sum(len(p) for p in parts)
