@@ -37,7 +37,7 @@ struct PlanCache {
         return nullptr;
     }
     void put(uint64_t key, const std::string &optkey, const KKTImage &K, const HostPlan &P) {
-        if (P.nnzL > kMaxNnzL) return;
+        if (P.nnzL > kMaxNnzL || P.ordering_used == 1) return;   // ("cone rows first" plans come with a speculative twin analysis that a cache hit would skip)
         Entry e{key, optkey, K.colptr, K.rowval, std::make_shared<const HostPlan>(P)};
         std::lock_guard<std::mutex> lk(mu);
         entries.push_front(std::move(e));
