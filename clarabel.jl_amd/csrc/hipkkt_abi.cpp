@@ -383,6 +383,7 @@ int32_t hipkkt_set_cone_types(hipkkt_handle h, int64_t ncones, const int32_t *ki
     HK_ENTER(h)
     if (!S->l1 || ncones != (int64_t)S->cone_numel.size() || (ncones && !kinds)) { S->err = "set_cone_types: not an L1 handle / wrong number of cones"; return HIPKKT_ERR_ARGUMENT; }
     const int64_t m = S->img.m;
+    S->sc_ready = false;          // until this call has validated and uploaded its tables
     std::vector<signed char> kind((size_t)std::max<int64_t>(m, 1), 2);
     std::vector<int64_t> rowhs((size_t)std::max<int64_t>(m, 1), 0), socdesc;
     S->sc_psd_hs.clear(); S->sc_psd_n.clear(); S->sc_psd_total = 0; S->sc_nsoc = 0;
@@ -420,17 +421,26 @@ int32_t hipkkt_set_cone_types(hipkkt_handle h, int64_t ncones, const int32_t *ki
         row += numel;
         hs += blk;
     }
-    if (row != m || hs != S->img.nHs) { S->err = "set_cone_types: cone sizes do not add up to m / the Hs vector"; return HIPKKT_ERR_ARGUMENT; }
-    S->d_sc_kind = S->upload(kind);
-    S->d_sc_rowhs = S->upload(rowhs);
+    if (row != m || hs != S->img.nHs) { S->sc_ready = false; S->err = "set_cone_types: cone sizes do not add up to m / the Hs vector"; return HIPKKT_ERR_ARGUMENT; }
     if (socdesc.empty()) socdesc.assign(5, 0);
-    S->d_sc_socdesc = S->upload(socdesc);
-    S->d_sc_sz = S->dalloc<double>(2 * m);
-    S->d_sc_wl = S->dalloc<double>(2 * m);
-    S->d_sc_eta = S->dalloc<double>(S->sc_nsoc);
-    S->d_sc_R = S->dalloc<double>(S->sc_psd_total);
-    S->d_sc_W = S->dalloc<double>(S->sc_psd_total);
-    S->d_sc_fail = S->dalloc<int>(1);
+    // device buffers: allocated on the first call; a later call (same cone sizes, possibly other kinds) re-uses them when they are
+    // large enough -- slab memory is only returned when the handle is destroyed, so repeated calls must not allocate again
+    if (!S->d_sc_kind || (int64_t)socdesc.size() > S->sc_cap_socdesc || S->sc_psd_total > S->sc_cap_psd) {
+        S->d_sc_kind = S->dalloc<signed char>(kind.size());
+        S->d_sc_rowhs = S->dalloc<int64_t>(rowhs.size());
+        S->d_sc_socdesc = S->dalloc<int64_t>(socdesc.size());
+        S->d_sc_sz = S->dalloc<double>(2 * m);
+        S->d_sc_wl = S->dalloc<double>(2 * m);
+        S->d_sc_eta = S->dalloc<double>(socdesc.size() / 5);
+        S->d_sc_R = S->dalloc<double>(S->sc_psd_total);
+        S->d_sc_W = S->dalloc<double>(S->sc_psd_total);
+        S->d_sc_fail = S->dalloc<int>(1);
+        S->sc_cap_socdesc = (int64_t)socdesc.size();
+        S->sc_cap_psd = S->sc_psd_total;
+    }
+    copy_sync(S->stream, S->d_sc_kind, kind.data(), kind.size() * sizeof(signed char), hipMemcpyHostToDevice);
+    copy_sync(S->stream, S->d_sc_rowhs, rowhs.data(), rowhs.size() * sizeof(int64_t), hipMemcpyHostToDevice);
+    copy_sync(S->stream, S->d_sc_socdesc, socdesc.data(), socdesc.size() * sizeof(int64_t), hipMemcpyHostToDevice);
     S->sc_ready = true;
     return HIPKKT_OK;
     HK_LEAVE

@@ -169,6 +169,7 @@ struct hipkkt_solver {
     int sc_nsoc = 0;                                       // ALL second-order cones (sparse and dense), cone order
     std::vector<int64_t> sc_psd_hs, sc_psd_n;              // per PSD cone: first Hs entry, matrix dimension
     int64_t sc_psd_total = 0;                              // sum of n * n
+    int64_t sc_cap_socdesc = 0, sc_cap_psd = 0;            // capacities of the d_sc_* buffers (allocated once, re-used by later calls)
     signed char *d_sc_kind = nullptr;
     int64_t *d_sc_rowhs = nullptr, *d_sc_socdesc = nullptr;
     double *d_sc_sz = nullptr, *d_sc_wl = nullptr, *d_sc_eta = nullptr, *d_sc_R = nullptr, *d_sc_W = nullptr;

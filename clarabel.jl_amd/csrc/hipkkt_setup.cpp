@@ -120,6 +120,7 @@ void setup_device(hipkkt_solver *S) {
     S->stage_cap = 0; S->d_stage = nullptr; S->d_stage_idx = nullptr;
     S->d_qb = S->d_res_in = S->d_res_out = S->d_res_part = nullptr;
     S->d_red = S->d_red_part = nullptr;
+    S->d_sc_kind = nullptr; S->sc_cap_socdesc = S->sc_cap_psd = 0; S->sc_ready = false;   // (slab memory of an earlier set-up is gone)
     S->red_have_const = false;
 
     HostPlan &P = S->plan;

@@ -388,8 +388,9 @@ std::string build_plan(int N, const int64_t *Ap, const int64_t *Ai, const int64_
     //          (the dense PSD blocks of an SDP: 1.6e7 binary searches) it runs on a second host thread meanwhile.
     P.kmap.resize(P.nnzK);
     P.diag_dst.assign(N, -1);
-    auto kmap_job = [&P, N, Ap, Ai]() -> const char * {
-        for (int j = 0; j < N; j++)
+    auto kmap_job = [&P, N, Ap, Ai, &opt]() -> const char * {
+        for (int j = 0; j < N; j++) {
+            if ((j & 1023) == 0 && opt.cancel && opt.cancel->load(std::memory_order_relaxed)) return "cancelled";
             for (int64_t q = Ap[j]; q < Ap[j + 1]; q++) {
                 int pi = P.iperm[Ai[q]], pj = P.iperm[j];
                 int c = std::min(pi, pj), r = std::max(pi, pj);
@@ -402,6 +403,7 @@ std::string build_plan(int N, const int64_t *Ap, const int64_t *Ai, const int64_
                 P.kmap[q] = dest;
                 if (pi == pj) P.diag_dst[c] = dest;
             }
+        }
         for (int k = 0; k < N; k++)
             if (P.diag_dst[k] < 0) return "KKT matrix has a column without a diagonal entry";
         return nullptr;
@@ -450,6 +452,9 @@ std::string build_plan(int N, const int64_t *Ap, const int64_t *Ai, const int64_
             for (int64_t q = 0; q < max_r; q++) P.rel[q] = (int)q;     // the shared identity segment (see below)
         }
         for (int s = 0; s < S; s++) {
+            // the longest phase of a big analysis (1.2e7 tasks for the robust-order twin of an SDP): a cancelled speculation must not
+            // hold its owner's destructor for seconds -- poll the flag here too, not only at the phase boundaries
+            if ((s & 255) == 0 && opt.cancel && opt.cancel->load(std::memory_order_relaxed)) return "cancelled";
             int w = P.sn_first[s + 1] - P.sn_first[s];
             const int *rows = &P.sn_rows[P.sn_rowptr[s]];
             int r = (int)(P.sn_rowptr[s + 1] - P.sn_rowptr[s]);

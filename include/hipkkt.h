@@ -163,8 +163,10 @@ int32_t hipkkt_set_hs_psd(hipkkt_handle h, int64_t npsd, const int64_t *hs_off, 
  *                    device (:145-161, :502-540).  psd_R = NULL leaves the PSD blocks to hipkkt_set_hs_psd.
  *    Outputs (any may be NULL): w_out, lambda_out of length m in cone order (NN: w, lambda; SOC: the normalised w and lambda; zero
  *    on other rows) -- what the host loop needs for mul_Hs! / step directions; soc_eta_out[k] = eta of the k-th second-order cone;
- *    *scaling_ok = 0 when a second-order cone's s or z is not interior (update_scaling! returns false, coneops_socone.jl:88-90;
- *    that cone's entries are left untouched).
+ *    *scaling_ok = 0 when a second-order cone's s or z is not interior (update_scaling! returns false, coneops_socone.jl:88-90).
+ *    The resident KKT values, w_out, lambda_out and soc_eta_out are then UNSPECIFIED (the other cones have been rewritten, the
+ *    failing cone partly): like the reference, which never reaches get_Hs! in that case, the caller must not factor or read them
+ *    before a later call has succeeded.
  *   hipkkt_update_scaling_dev  the same with every pointer except scaling_ok in device memory (s, z resident: no PCIe at all). */
 int32_t hipkkt_set_cone_types(hipkkt_handle h, int64_t ncones, const int32_t *kinds);
 int32_t hipkkt_update_scaling(hipkkt_handle h, const double *s, const double *z, const double *psd_R, double *w_out,
