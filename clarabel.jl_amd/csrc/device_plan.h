@@ -42,7 +42,11 @@ struct FrontBatch {
     int64_t fp_off;               // front_panels[fp_off + q], q = 0 .. nb-1
     int64_t scratch_off;          // doubles: kFbMax x (64 x 64 inverse + 64 pivots), then the L tiles of the diagonal workgroups
     int32_t nb, nblk, r0;         // panels, 64-row blocks (= workgroups), rows of the first panel
-    int32_t sync_off;             // ints: {ticket, error} | 32: Minv flags | 64 + 8 k + j: L(k,j) flags   (128 ints per batch)
+    int32_t sync_off;             // ints: {ticket, error} | 16: second ticket | 32: Minv flags | 64 + 8 k + j: L(k,j) flags   (128 ints per batch)
+    // a launch handles the row blocks [i_base, i_end) and takes its tickets from sync[tick]: one launch = (0, nblk, 0); the look-ahead
+    // factorisation (hipkkt_factor.cpp) splits a batch into the launch of the row blocks the next batches need at once (0, R, 0) and
+    // the launch of the rest (R, nblk, 16), which finds every hand-off flag already set
+    int32_t i_base, i_end, tick, pad;
 };
 constexpr int64_t kFbScratch = (int64_t)kFbMax * 4160 + (int64_t)(kFbMax * (kFbMax - 1) / 2) * 4096;   // doubles per batch
 constexpr int kGathHeavy = 24;    // target entries with more pairs than this get a wavefront of their own

@@ -146,10 +146,10 @@ k_front_block(DevPlan P, FrontBatch B, int *sync_all, double *scratch_all, doubl
     double *scratch = scratch_all + B.scratch_off;
     double *ltiles = scratch + (int64_t)kFbMax * 4160;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, lk = lane >> 4;
-    if (tid == 0) sblk = atomicAdd(sync, 1);
+    if (tid == 0) sblk = atomicAdd(sync + B.tick, 1);
     __syncthreads();
-    const int i = sblk;                                   // row block of this workgroup
-    if (i >= B.nblk) return;
+    const int i = B.i_base + sblk;                        // row block of this workgroup
+    if (i >= B.i_end) return;
     FB_T(0);
     const FrontPanel *fp = P.front_panels + B.fp_off;
     const int nb = B.nb;
@@ -406,7 +406,7 @@ k_front_block(DevPlan P, FrontBatch B, int *sync_all, double *scratch_all, doubl
 
 void launch_front_block(hipStream_t st, const DevPlan &P, const FrontBatch &B, int *sync_all, double *scratch_all, double dyn_eps,
                         double dyn_delta, long long *trace) {
-    hipLaunchKernelGGL(k_front_block, dim3(B.nblk), dim3(256), 0, st, P, B, sync_all, scratch_all, dyn_eps, dyn_delta, trace);
+    if (B.i_end > B.i_base) hipLaunchKernelGGL(k_front_block, dim3(B.i_end - B.i_base), dim3(256), 0, st, P, B, sync_all, scratch_all, dyn_eps, dyn_delta, trace);
 }
 
 }  // namespace hipkkt

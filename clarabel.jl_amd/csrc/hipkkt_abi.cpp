@@ -431,6 +431,7 @@ int32_t hipkkt_set_cone_types(hipkkt_handle h, int64_t ncones, const int32_t *ki
         S->d_sc_socdesc = S->dalloc<int64_t>(socdesc.size());
         S->d_sc_sz = S->dalloc<double>(2 * m);
         S->d_sc_wl = S->dalloc<double>(2 * m);
+        fill_async(S->stream, S->d_sc_wl, 0, (size_t)std::max<int64_t>(2 * m, 1) * sizeof(double));   // w, lambda stay zero on the rows of cones the kernels do not write (PSD, others)
         S->d_sc_eta = S->dalloc<double>(socdesc.size() / 5);
         S->d_sc_R = S->dalloc<double>(S->sc_psd_total);
         S->d_sc_W = S->dalloc<double>(S->sc_psd_total);

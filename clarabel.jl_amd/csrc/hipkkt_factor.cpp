@@ -24,10 +24,14 @@ void enqueue_factor_level(hipkkt_solver *S, int l) {
 // Schur-complement updates applied after level l is factored: dense register tiles (matrix cores),
 // per-entry gather lists (tiny scattered contributions), relative-index scatter (whatever is left).
 // The three kinds own disjoint target tiles, so their order inside a stage is immaterial.
+// events of the fork / join pattern: created on first use, re-used by every later enqueue of the factorisation (an eager
+// look-ahead factorisation needs ~60 of them per call)
 static hipEvent_t new_fork_event(hipkkt_solver *S) {
+    if (S->fork_event_next < S->fork_events.size()) return S->fork_events[S->fork_event_next++];
     hipEvent_t e = nullptr;
     HK_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     S->fork_events.push_back(e);
+    S->fork_event_next = S->fork_events.size();
     return e;
 }
 
@@ -61,6 +65,7 @@ void enqueue_updates(hipkkt_solver *S, int l, bool split_far = false) {
 void enqueue_factor(hipkkt_solver *S, int static_enable, double eps_const, double eps_prop) {
     const HostPlan &P = S->plan;
     hipStream_t st = S->stream;
+    S->fork_event_next = 0;
     launch_zero_words(st, S->dp.scal, 2);                 // SC_MAXDIAG  (kernels.hip: why not hipMemsetAsync)
     launch_zero_words(st, S->dp.flags, FL_COUNT);
     launch_maxabs_gather(st, S->dp.kval, S->d_diag_full, S->N, (unsigned long long *)S->dp.scal + SC_MAXDIAG);
@@ -74,14 +79,65 @@ void enqueue_factor(hipkkt_solver *S, int static_enable, double eps_const, doubl
     int pending_level = -1;
     const bool fb = S->use_front_block && !S->fbatches.empty();
     if (fb) launch_zero_words(st, S->d_fb_sync, 128 * (int)S->fbatches.size());
+    // Look-ahead over a big front (HIPKKT_LOOKAHEAD=1; eager launches, two streams): the panel chain of batch t+1 runs on the main
+    // stream next to the far Schur updates of batch t on the CU-masked throughput stream `tb`, which leaves 16 compute units to the
+    // chain.  Per batch t of a look-ahead region (hipkkt_setup.cpp build_front_batches):
+    //    main:  [wait E(t-1)]  FB_crit(t) = k_front_block over the row blocks of batches t, t+1, t+2    U_crit(t)
+    //    tb:    [wait FB_crit(t)]  FB_rest(t) = k_front_block over the other row blocks    E(t) -> event    U_far(t)
+    // U_crit / E / U_far are the three parts of the batch's far stage (disjoint target tiles); E(t) holds exactly the tiles the chain
+    // needs from the throughput side (columns of t+1 x rows of t+3, columns of t+2 x rows of t+2, t+3), so the chain runs two batches
+    // ahead of the bulk of the far updates.
+    hipStream_t tb = S->la_stream;
+    const bool la = fb && S->lookahead && tb != nullptr;
+    bool la_active = false;
+    int cur_bi = -1;
+    std::vector<hipEvent_t> evE(S->fbatches.size(), nullptr);
     for (int l = 0; l < P.nlevels; l++) {
         if (fb && S->lvl_fb[l] != -1) {
             // a front's update batch: one launch for its panels and their just-in-time updates, then the batch's far stage
-            if (S->lvl_fb[l] >= 0)
-                launch_front_block(st, S->dp, S->fbatches[S->lvl_fb[l]], S->d_fb_sync, S->d_fb_scratch, S->opts.dynamic_reg_eps,
-                                   S->opts.dynamic_reg_delta, S->d_fb_trace);
+            if (S->lvl_fb[l] >= 0) {
+                cur_bi = S->lvl_fb[l];
+                const hipkkt_solver::LaBatch &A = S->la[(size_t)cur_bi];
+                if (la && A.on) {
+                    if (!la_active) {                     // entering a region: the throughput stream starts from everything done so far
+                        hipEvent_t e0 = new_event();
+                        HK_CHECK(hipEventRecord(e0, st));
+                        HK_CHECK(hipStreamWaitEvent(tb, e0, 0));
+                        la_active = true;
+                    }
+                    if (!A.first && evE[(size_t)cur_bi - 1]) HK_CHECK(hipStreamWaitEvent(st, evE[(size_t)cur_bi - 1], 0));
+                    FrontBatch Bc = S->fbatches[(size_t)cur_bi], Br = Bc;
+                    Bc.i_end = A.rc;
+                    Br.i_base = A.rc; Br.tick = 16;
+                    launch_front_block(st, S->dp, Bc, S->d_fb_sync, S->d_fb_scratch, S->opts.dynamic_reg_eps, S->opts.dynamic_reg_delta, S->d_fb_trace);
+                    hipEvent_t ec = new_event();
+                    HK_CHECK(hipEventRecord(ec, st));
+                    HK_CHECK(hipStreamWaitEvent(tb, ec, 0));
+                    launch_front_block(tb, S->dp, Br, S->d_fb_sync, S->d_fb_scratch, S->opts.dynamic_reg_eps, S->opts.dynamic_reg_delta, nullptr);
+                } else {
+                    launch_front_block(st, S->dp, S->fbatches[(size_t)cur_bi], S->d_fb_sync, S->d_fb_scratch, S->opts.dynamic_reg_eps,
+                                       S->opts.dynamic_reg_delta, S->d_fb_trace);
+                }
+            }
             const bool last = l + 1 >= P.nlevels || S->lvl_fb[l + 1] != -2;
             if (!last) continue;                          // the stages inside the batch are applied by the kernel itself
+            if (la_active && cur_bi >= 0 && S->la[(size_t)cur_bi].on) {
+                const hipkkt_solver::LaBatch &A = S->la[(size_t)cur_bi];
+                const int g0 = P.upd_stage_ptr[l], nd = P.upd_stage_ndense[l];
+                launch_update_dense(st, S->dp, g0, A.ncrit, 0, false);                                  // on the chain
+                launch_update_dense(tb, S->dp, g0 + A.ncrit, A.nE, 0, false);
+                evE[(size_t)cur_bi] = new_event();
+                HK_CHECK(hipEventRecord(evE[(size_t)cur_bi], tb));
+                const int nfar_ = nd - A.ncrit - A.nE;
+                launch_update_dense(tb, S->dp, g0 + A.ncrit + A.nE, nfar_, 0, nfar_ > 0 && P.upd_stage_flops_dense[l] >= 1.5e6 * nd);
+                if (A.last) {                             // leaving the region: everything back on the main stream
+                    hipEvent_t ej = new_event();
+                    HK_CHECK(hipEventRecord(ej, tb));
+                    HK_CHECK(hipStreamWaitEvent(st, ej, 0));
+                    la_active = false;
+                }
+                continue;
+            }
         } else {
             enqueue_factor_level(S, l);
         }
@@ -270,7 +326,8 @@ static int32_t refactor_once(hipkkt_handle h, int32_t static_reg_enable, double 
     } else {
         GraphSlot &g = S->g_factor;
         const bool same = g.static_enable == static_reg_enable && g.eps_const == eps_const && g.eps_prop == eps_prop;
-        run_graphed(S, S->stream, g, same, [&] { enqueue_factor(S, static_reg_enable, eps_const, eps_prop); });
+        if (S->lookahead && S->la_stream) enqueue_factor(S, static_reg_enable, eps_const, eps_prop);   // CU-masked stream: eager, not captured
+        else run_graphed(S, S->stream, g, same, [&] { enqueue_factor(S, static_reg_enable, eps_const, eps_prop); });
         g.static_enable = static_reg_enable; g.eps_const = eps_const; g.eps_prop = eps_prop;
     }
     HK_CHECK(hipEventRecord(S->ev1, S->stream));

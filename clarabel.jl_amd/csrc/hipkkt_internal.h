@@ -101,6 +101,7 @@ struct hipkkt_solver {
     hipStream_t stream = nullptr;
     hipStream_t side = nullptr;          // far Schur updates run here, overlapped with the critical path
     std::vector<hipEvent_t> fork_events;
+    size_t fork_event_next = 0;          // next pooled event of the current enqueue_factor
     bool use_side = true;
     bool fork_gather = false;  // (measured r03b: no gain) a stage's per-entry gather launch next to its big dense launch (hipkkt_factor.cpp enqueue_updates)
     int far_wgs = 256;   // grid bound of the look-ahead (far) update launches; 0 = one workgroup per 4 tiles
@@ -135,6 +136,16 @@ struct hipkkt_solver {
     std::vector<int> fb_last_level;      // per batch
     int *d_fb_sync = nullptr;
     double *d_fb_scratch = nullptr;
+    // look-ahead factorisation of a big front (hipkkt_factor.cpp enqueue_factor, HIPKKT_LOOKAHEAD=1): per front batch, the row blocks
+    // its crit launch covers (this batch's diagonal blocks + the rows of the next two batches) and the 3-way split of its far stage
+    struct LaBatch {
+        bool on = false, first = false, last = false;   // inside a look-ahead region / its first / its last batch
+        int rc = 0;                                     // row blocks of the crit launch
+        int ncrit = 0, nE = 0;                          // far stage: [crit | E | far] dense groups (setup reorders them)
+    };
+    std::vector<LaBatch> la;
+    bool lookahead = false;
+    hipStream_t la_stream = nullptr;     // throughput stream, CU-masked: leaves 2 compute units per XCD to the chain
     long long *d_fb_trace = nullptr;     // HIPKKT_FB_TRACE=1: wall-clock stamps of the first 8 workgroups of every batch (debug_dump 9)
     bool persist_allowed = true;         // false: HIPKKT_NO_PERSIST (never tried)
     int64_t persist_retry_at = -1;       // after a sweep time-out: the LDL-solve count at which the persistent kernels are tried again
@@ -276,6 +287,7 @@ struct hipkkt_solver {
         rp.pinned_free(device, h_flags);
         for (hipEvent_t e : {ev0, ev1, ev2, ev3}) rp.event_put(device, e);
         for (hipEvent_t e : fork_events) (void)hipEventDestroy(e);
+        if (la_stream) { (void)hipStreamSynchronize(la_stream); (void)hipStreamDestroy(la_stream); }
         rp.stream_put(device, 1, side);
         rp.stream_put(device, 0, stream);
     }

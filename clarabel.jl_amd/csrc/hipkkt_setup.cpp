@@ -67,6 +67,21 @@ void init_runtime(hipkkt_solver *S) {
         S->use_side = ns && ns[0] == '1';
         const char *fg = getenv("HIPKKT_FORK_GATHER");
         S->fork_gather = fg && fg[0] == '1';
+        const char *la = getenv("HIPKKT_LOOKAHEAD");
+        S->lookahead = la && la[0] == '1';
+        if (S->lookahead && !S->la_stream) {
+            // all compute units except the last two of every XCD (mask bits are interleaved over the XCDs: bit b -> XCD b % 8,
+            // tools/ubench_cumask.hip): the chain kernels on the handle's main stream always find those 16 free
+            int ncu = 0;
+            HK_CHECK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, S->device));
+            std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
+            for (int b = 0; b < ncu - 16; b++) mask[(size_t)b / 32] |= 1u << (b % 32);
+            if (ncu < 64 || hipExtStreamCreateWithCUMask(&S->la_stream, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
+                (void)hipGetLastError();
+                S->la_stream = nullptr;
+                S->lookahead = false;
+            }
+        }
         const char *fw = getenv("HIPKKT_FAR_WGS");
         if (fw) S->far_wgs = atoi(fw);
     }
@@ -541,6 +556,7 @@ static void build_front_batches(hipkkt_solver *S) {
             B.nb = H.nb;
             B.r0 = P.front_panels[F.fp_off + H.p0].r;
             B.nblk = (B.r0 + 63) / 64;
+            B.i_base = 0; B.i_end = B.nblk; B.tick = 0; B.pad = 0;
             B.sync_off = 128 * (int)S->fbatches.size();
             B.scratch_off = kFbScratch * (int64_t)S->fbatches.size();
             S->lvl_fb[H.level_first] = (int)S->fbatches.size();
@@ -548,6 +564,61 @@ static void build_front_batches(hipkkt_solver *S) {
             S->fbatches.push_back(B);
             S->fb_last_level.push_back(H.level_last);
         }
+    // ---- look-ahead regions: runs of >= 3 consecutive batches of one front whose far stages hold nothing but dense tiles.  The far
+    //      stage of batch t is reordered [crit | E | far]:
+    //        crit = tiles (columns of batch t+1) x (rows of batches t+1, t+2)            -> applied on the chain's stream
+    //        E    = (columns of t+1) x (rows of t+3)  and  (columns of t+2) x (rows of t+2, t+3)   -> first on the throughput stream;
+    //               the chain waits for them before the crit launch of batch t+1
+    //        far  = the rest
+    S->la.assign(S->fbatches.size(), hipkkt_solver::LaBatch());
+    if (S->lookahead && S->use_front_block) {
+        HostPlan &Pm = S->plan;
+        const auto hb = front_batches(P, S->plan_opts.update_policy, kFbMax);
+        const size_t nbh = hb.size();
+        std::vector<std::vector<int>> panel_batch(P.fronts.size());
+        for (size_t fi = 0; fi < P.fronts.size(); fi++) panel_batch[fi].assign((size_t)P.fronts[fi].np, -1);
+        for (size_t q = 0; q < nbh; q++)
+            for (int t = 0; t < hb[q].nb; t++) panel_batch[(size_t)hb[q].front][(size_t)(hb[q].p0 + t)] = (int)q;
+        auto dense_only = [&](int l) { return P.upd_stage_ptr[l + 1] - P.upd_stage_ptr[l] == P.upd_stage_ndense[l] && P.gath_stage_ptr[l + 1] == P.gath_stage_ptr[l]; };
+        size_t q = 0;
+        while (q < nbh) {
+            size_t e = q;
+            while (e + 1 < nbh && hb[e + 1].front == hb[q].front && hb[e + 1].p0 == hb[e].p0 + hb[e].nb && dense_only(hb[e].level_last)) e++;
+            if (e - q + 1 >= 3 && dense_only(hb[e].level_last)) {
+                for (size_t b = q; b <= e; b++) {
+                    hipkkt_solver::LaBatch &A = S->la[b];
+                    A.on = true; A.first = b == q; A.last = b == e;
+                    A.rc = 0;
+                    for (size_t c = b; c <= e && c < b + 3; c++) A.rc += hb[c].nb;
+                    A.rc = std::min(A.rc, S->fbatches[b].nblk);
+                    const int l = hb[b].level_last, g0 = P.upd_stage_ptr[l], nd = P.upd_stage_ndense[l];
+                    const FrontDesc &F = P.fronts[(size_t)hb[b].front];
+                    auto cls = [&](const UpdGroup &G) {
+                        if (P.sn_front[G.tgt] != hb[b].front) return 2;
+                        const int tb = panel_batch[(size_t)hb[b].front][(size_t)(G.tgt - F.s0)];
+                        const int row = P.sn_rows[P.sn_rowptr[G.tgt] + G.row_base], sr = P.sn_of_col[row];
+                        const int rb = P.sn_front[sr] == hb[b].front ? panel_batch[(size_t)hb[b].front][(size_t)(sr - F.s0)] : -1;
+                        if (tb < 0 || rb < 0 || tb > (int)e || rb > (int)e) return 2;
+                        const int dt = tb - (int)b, dr = rb - (int)b;
+                        if (dt == 1 && (dr == 1 || dr == 2)) return 0;
+                        if ((dt == 1 && dr == 3) || (dt == 2 && (dr == 2 || dr == 3))) return 1;
+                        return 2;
+                    };
+                    auto gb = Pm.upd_groups.begin() + g0, ge = gb + nd;
+                    auto m1 = std::stable_partition(gb, ge, [&](const UpdGroup &G) { return cls(G) == 0; });
+                    auto m2 = std::stable_partition(m1, ge, [&](const UpdGroup &G) { return cls(G) == 1; });
+                    A.ncrit = (int)(m1 - gb);
+                    A.nE = (int)(m2 - m1);
+                }
+            }
+            q = e + 1;
+        }
+    }
+    if (getenv("HIPKKT_VERBOSE")) {
+        int non = 0;
+        for (const auto &A : S->la) non += A.on;
+        fprintf(stderr, "hipkkt: look-ahead %s: %d of %zu front batches inside look-ahead regions\n", S->lookahead ? "on" : "off", non, S->la.size());
+    }
     if (getenv("HIPKKT_VERBOSE")) fprintf(stderr, "hipkkt: %zu front batch(es) factored by one launch each (fronts %zu, update batch %d)\n", S->fbatches.size(), P.fronts.size(), P.update_batch_used);
     const size_t nb_ = std::max<size_t>(S->fbatches.size(), 1);
     S->d_fb_sync = S->dalloc<int>(128 * nb_);
