@@ -111,6 +111,7 @@ void init_runtime(hipkkt_solver *S) {
 
 // (re)builds every device-resident structure from S->plan and S->img (values included)
 static void build_front_batches(hipkkt_solver *S);
+static void plan_lookahead(hipkkt_solver *S);
 void setup_device(hipkkt_solver *S) {
     HK_CHECK(hipSetDevice(S->device));
     for (GraphSlot *g : {&S->g_factor, &S->ctx[0].g_ldl, &S->ctx[0].g_first, &S->ctx[0].g_step, &S->ctx[1].g_ldl, &S->ctx[1].g_first,
@@ -138,6 +139,7 @@ void setup_device(hipkkt_solver *S) {
     S->d_sc_kind = nullptr; S->sc_cap_socdesc = S->sc_cap_psd = 0; S->sc_ready = false;   // (slab memory of an earlier set-up is gone)
     S->red_have_const = false;
 
+    plan_lookahead(S);
     HostPlan &P = S->plan;
     const int N = P.N;
     S->N = N;
@@ -541,40 +543,25 @@ void setup_device(hipkkt_solver *S) {
     HK_CHECK(hipStreamSynchronize(S->stream));
 }
 
-// One launch of k_front_block per qualifying update batch of a front (symbolic.cpp front_batches).  HIPKKT_FRONT_BLOCK=0: never.
-static void build_front_batches(hipkkt_solver *S) {
-    const HostPlan &P = S->plan;
-    S->fbatches.clear(); S->fb_last_level.clear();
-    S->lvl_fb.assign(std::max(P.nlevels, 1), -1);
-    const char *e = getenv("HIPKKT_FRONT_BLOCK");
-    if (e && e[0] == '0') S->use_front_block = false;
-    if (S->use_front_block)
-        for (const FrontBatchHost &H : front_batches(P, S->plan_opts.update_policy, kFbMax)) {
-            const FrontDesc &F = P.fronts[H.front];
-            FrontBatch B;
-            B.fp_off = F.fp_off + H.p0;
-            B.nb = H.nb;
-            B.r0 = P.front_panels[F.fp_off + H.p0].r;
-            B.nblk = (B.r0 + 63) / 64;
-            B.i_base = 0; B.i_end = B.nblk; B.tick = 0; B.pad = 0;
-            B.sync_off = 128 * (int)S->fbatches.size();
-            B.scratch_off = kFbScratch * (int64_t)S->fbatches.size();
-            S->lvl_fb[H.level_first] = (int)S->fbatches.size();
-            for (int l = H.level_first + 1; l <= H.level_last; l++) S->lvl_fb[l] = -2;
-            S->fbatches.push_back(B);
-            S->fb_last_level.push_back(H.level_last);
-        }
+// Look-ahead regions of the factorisation (HIPKKT_LOOKAHEAD=1) and the 3-way split of their far stages.  Runs BEFORE the work lists
+// go to the device: it reorders the dense groups of those stages inside S->plan.
+static void plan_lookahead(hipkkt_solver *S) {
     // ---- look-ahead regions: runs of >= 3 consecutive batches of one front whose far stages hold nothing but dense tiles.  The far
     //      stage of batch t is reordered [crit | E | far]:
     //        crit = tiles (columns of batch t+1) x (rows of batches t+1, t+2)            -> applied on the chain's stream
     //        E    = (columns of t+1) x (rows of t+3)  and  (columns of t+2) x (rows of t+2, t+3)   -> first on the throughput stream;
     //               the chain waits for them before the crit launch of batch t+1
     //        far  = the rest
-    S->la.assign(S->fbatches.size(), hipkkt_solver::LaBatch());
-    if (S->lookahead && S->use_front_block) {
-        HostPlan &Pm = S->plan;
-        const auto hb = front_batches(P, S->plan_opts.update_policy, kFbMax);
-        const size_t nbh = hb.size();
+    HostPlan &Pm = S->plan;
+    const HostPlan &P = S->plan;
+    const auto hb = front_batches(P, S->plan_opts.update_policy, kFbMax);
+    const size_t nbh = hb.size();
+    S->la.assign(nbh, hipkkt_solver::LaBatch());
+    {
+        const char *e = getenv("HIPKKT_FRONT_BLOCK");
+        if (!S->lookahead || (e && e[0] == '0')) return;
+    }
+    {
         std::vector<std::vector<int>> panel_batch(P.fronts.size());
         for (size_t fi = 0; fi < P.fronts.size(); fi++) panel_batch[fi].assign((size_t)P.fronts[fi].np, -1);
         for (size_t q = 0; q < nbh; q++)
@@ -590,7 +577,7 @@ static void build_front_batches(hipkkt_solver *S) {
                     A.on = true; A.first = b == q; A.last = b == e;
                     A.rc = 0;
                     for (size_t c = b; c <= e && c < b + 3; c++) A.rc += hb[c].nb;
-                    A.rc = std::min(A.rc, S->fbatches[b].nblk);
+                    A.rc = std::min(A.rc, (P.front_panels[P.fronts[(size_t)hb[b].front].fp_off + hb[b].p0].r + 63) / 64);
                     const int l = hb[b].level_last, g0 = P.upd_stage_ptr[l], nd = P.upd_stage_ndense[l];
                     const FrontDesc &F = P.fronts[(size_t)hb[b].front];
                     auto cls = [&](const UpdGroup &G) {
@@ -614,6 +601,31 @@ static void build_front_batches(hipkkt_solver *S) {
             q = e + 1;
         }
     }
+}
+
+// One launch of k_front_block per qualifying update batch of a front (symbolic.cpp front_batches).  HIPKKT_FRONT_BLOCK=0: never.
+static void build_front_batches(hipkkt_solver *S) {
+    const HostPlan &P = S->plan;
+    S->fbatches.clear(); S->fb_last_level.clear();
+    S->lvl_fb.assign(std::max(P.nlevels, 1), -1);
+    const char *e = getenv("HIPKKT_FRONT_BLOCK");
+    if (e && e[0] == '0') S->use_front_block = false;
+    if (S->use_front_block)
+        for (const FrontBatchHost &H : front_batches(P, S->plan_opts.update_policy, kFbMax)) {
+            const FrontDesc &F = P.fronts[H.front];
+            FrontBatch B;
+            B.fp_off = F.fp_off + H.p0;
+            B.nb = H.nb;
+            B.r0 = P.front_panels[F.fp_off + H.p0].r;
+            B.nblk = (B.r0 + 63) / 64;
+            B.i_base = 0; B.i_end = B.nblk; B.tick = 0; B.pad = 0;
+            B.sync_off = 128 * (int)S->fbatches.size();
+            B.scratch_off = kFbScratch * (int64_t)S->fbatches.size();
+            S->lvl_fb[H.level_first] = (int)S->fbatches.size();
+            for (int l = H.level_first + 1; l <= H.level_last; l++) S->lvl_fb[l] = -2;
+            S->fbatches.push_back(B);
+            S->fb_last_level.push_back(H.level_last);
+        }
     if (getenv("HIPKKT_VERBOSE")) {
         int non = 0;
         for (const auto &A : S->la) non += A.on;

@@ -129,3 +129,44 @@ def scale_cones(cones, rng):
             z[r] = rng.random(c.numel) + 0.2
     assert cones.update_scaling(s, z, 1.0)
     return s, z
+
+
+class ShadowKKT:
+    """Test infrastructure: the ORACLE drives an IPM run while the HIP solver is handed the very same inputs at every KKT call
+    (same elimination order); per solve the two solutions and refinement-step counts are recorded in `log` as
+    (iteration, rel_dx, ir_hip, ir_oracle).  Used to establish the CAUSE when two IPM trajectories part."""
+    batch_constant_rhs = False
+
+    def __init__(self, hip_cls, oracle_cls, *a):
+        import numpy as np
+
+        self.np = np
+        self.g = hip_cls(*a)
+        self.c = oracle_cls(*a, ordering=self.g.h.perm())
+        self.settings = self.c.settings
+        self.it = 0
+        self.log = []
+
+    def kktsolver_update(self, cones_):
+        self.it += 1
+        okc = self.c.kktsolver_update(cones_)
+        self.g.kktsolver_update(cones_)
+        return okc
+
+    def kktsolver_setrhs(self, rx, rz):
+        self.c.kktsolver_setrhs(rx, rz)
+        self.g.kktsolver_setrhs(rx, rz)
+
+    def kktsolver_solve(self, lx, lz):
+        np = self.np
+        n, m = self.g.n, self.g.m
+        gx, gz = np.zeros(n), np.zeros(m)
+        self.g.kktsolver_solve(gx, gz)
+        cx, cz = (lx if lx is not None else np.zeros(n)), (lz if lz is not None else np.zeros(m))
+        okc = self.c.kktsolver_solve(cx, cz)
+        xc, xg = np.concatenate([cx, cz]), np.concatenate([gx, gz])
+        self.log.append((self.it, float(np.max(np.abs(xg - xc)) / max(1.0, np.max(np.abs(xc)))), int(self.g.last_ir_steps), int(self.c.last_ir_steps)))
+        return okc
+
+    def __getattr__(self, k):
+        return getattr(self.c, k)
