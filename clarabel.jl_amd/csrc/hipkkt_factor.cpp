@@ -79,62 +79,44 @@ void enqueue_factor(hipkkt_solver *S, int static_enable, double eps_const, doubl
     int pending_level = -1;
     const bool fb = S->use_front_block && !S->fbatches.empty();
     if (fb) launch_zero_words(st, S->d_fb_sync, 128 * (int)S->fbatches.size());
-    // Look-ahead over a big front (HIPKKT_LOOKAHEAD=1; eager launches, two streams): the panel chain of batch t+1 runs on the main
-    // stream next to the far Schur updates of batch t on the CU-masked throughput stream `tb`, which leaves 16 compute units to the
-    // chain.  Per batch t of a look-ahead region (hipkkt_setup.cpp build_front_batches):
-    //    main:  [wait E(t-1)]  FB_crit(t) = k_front_block over the row blocks of batches t, t+1, t+2    U_crit(t)
-    //    tb:    [wait FB_crit(t)]  FB_rest(t) = k_front_block over the other row blocks    E(t) -> event    U_far(t)
-    // U_crit / E / U_far are the three parts of the batch's far stage (disjoint target tiles); E(t) holds exactly the tiles the chain
-    // needs from the throughput side (columns of t+1 x rows of t+3, columns of t+2 x rows of t+2, t+3), so the chain runs two batches
-    // ahead of the bulk of the far updates.
-    hipStream_t tb = S->la_stream;
-    const bool la = fb && S->lookahead && tb != nullptr;
-    bool la_active = false;
+    // Look-ahead over a big front (HIPKKT_LOOKAHEAD=1; eager launches): the far stage of batch t of a look-ahead region is split
+    // [chain | background] (hipkkt_setup.cpp plan_lookahead).  The chain part (columns of batch t+1) runs on the main stream, then the
+    // panel kernel of batch t+1; the background part runs NEXT TO that panel kernel on a CU-masked throughput stream that leaves the
+    // panel kernel its compute units, and is joined before the chain part of batch t+1.  What the background part holds was chosen
+    // by due date to fit the panel kernel's duration (symbolic.cpp step 14); nothing it writes is touched by the panel kernel
+    // (columns of batch t+2 and further right), and two background launches never overlap.
+    const bool la = fb && S->lookahead && S->la_streams[0] != nullptr;
     int cur_bi = -1;
-    std::vector<hipEvent_t> evE(S->fbatches.size(), nullptr);
+    hipEvent_t ev_bg = nullptr;                           // the background launch in flight
     for (int l = 0; l < P.nlevels; l++) {
         if (fb && S->lvl_fb[l] != -1) {
             // a front's update batch: one launch for its panels and their just-in-time updates, then the batch's far stage
             if (S->lvl_fb[l] >= 0) {
                 cur_bi = S->lvl_fb[l];
-                const hipkkt_solver::LaBatch &A = S->la[(size_t)cur_bi];
-                if (la && A.on) {
-                    if (!la_active) {                     // entering a region: the throughput stream starts from everything done so far
-                        hipEvent_t e0 = new_event();
-                        HK_CHECK(hipEventRecord(e0, st));
-                        HK_CHECK(hipStreamWaitEvent(tb, e0, 0));
-                        la_active = true;
-                    }
-                    if (!A.first && evE[(size_t)cur_bi - 1]) HK_CHECK(hipStreamWaitEvent(st, evE[(size_t)cur_bi - 1], 0));
-                    FrontBatch Bc = S->fbatches[(size_t)cur_bi], Br = Bc;
-                    Bc.i_end = A.rc;
-                    Br.i_base = A.rc; Br.tick = 16;
-                    launch_front_block(st, S->dp, Bc, S->d_fb_sync, S->d_fb_scratch, S->opts.dynamic_reg_eps, S->opts.dynamic_reg_delta, S->d_fb_trace);
-                    hipEvent_t ec = new_event();
-                    HK_CHECK(hipEventRecord(ec, st));
-                    HK_CHECK(hipStreamWaitEvent(tb, ec, 0));
-                    launch_front_block(tb, S->dp, Br, S->d_fb_sync, S->d_fb_scratch, S->opts.dynamic_reg_eps, S->opts.dynamic_reg_delta, nullptr);
-                } else {
-                    launch_front_block(st, S->dp, S->fbatches[(size_t)cur_bi], S->d_fb_sync, S->d_fb_scratch, S->opts.dynamic_reg_eps,
-                                       S->opts.dynamic_reg_delta, S->d_fb_trace);
-                }
+                launch_front_block(st, S->dp, S->fbatches[(size_t)cur_bi], S->d_fb_sync, S->d_fb_scratch, S->opts.dynamic_reg_eps,
+                                   S->opts.dynamic_reg_delta, S->d_fb_trace);
             }
             const bool last = l + 1 >= P.nlevels || S->lvl_fb[l + 1] != -2;
             if (!last) continue;                          // the stages inside the batch are applied by the kernel itself
-            if (la_active && cur_bi >= 0 && S->la[(size_t)cur_bi].on) {
+            if (la && cur_bi >= 0 && S->la[(size_t)cur_bi].on) {
                 const hipkkt_solver::LaBatch &A = S->la[(size_t)cur_bi];
-                const int g0 = P.upd_stage_ptr[l], nd = P.upd_stage_ndense[l];
-                launch_update_dense(st, S->dp, g0, A.ncrit, 0, false);                                  // on the chain
-                launch_update_dense(tb, S->dp, g0 + A.ncrit, A.nE, 0, false);
-                evE[(size_t)cur_bi] = new_event();
-                HK_CHECK(hipEventRecord(evE[(size_t)cur_bi], tb));
-                const int nfar_ = nd - A.ncrit - A.nE;
-                launch_update_dense(tb, S->dp, g0 + A.ncrit + A.nE, nfar_, 0, nfar_ > 0 && P.upd_stage_flops_dense[l] >= 1.5e6 * nd);
-                if (A.last) {                             // leaving the region: everything back on the main stream
-                    hipEvent_t ej = new_event();
-                    HK_CHECK(hipEventRecord(ej, tb));
-                    HK_CHECK(hipStreamWaitEvent(st, ej, 0));
-                    la_active = false;
+                const int g0 = P.upd_stage_ptr[l], nd = P.upd_stage_ndense[l], nbg = nd - A.ncrit;
+                if (ev_bg) { HK_CHECK(hipStreamWaitEvent(st, ev_bg, 0)); ev_bg = nullptr; }            // the background launch of the batch before
+                const bool big = P.upd_stage_flops_dense[l] >= 1.5e6 * nd;
+                launch_update_dense(st, S->dp, g0, A.ncrit, 0, big);                                    // chain part
+                static const double max_gf = [] { const char *e = getenv("HIPKKT_LA_MAXGF"); return e ? atof(e) : 1e30; }();
+                if (A.last || nbg <= 0 || P.upd_stage_flops_dense[l] > max_gf * 1e9) {
+                    launch_update_dense(st, S->dp, g0 + A.ncrit, nbg, 0, big);                          // leaving the region
+                } else {
+                    int k = 0;
+                    while (k + 1 < hipkkt_solver::kLaStreams && hipkkt_solver::la_keep(k) < A.next_blk + 2) k++;
+                    hipStream_t tb = S->la_streams[k];
+                    hipEvent_t e0 = new_event();
+                    HK_CHECK(hipEventRecord(e0, st));
+                    HK_CHECK(hipStreamWaitEvent(tb, e0, 0));
+                    launch_update_dense(tb, S->dp, g0 + A.ncrit, nbg, 0, big);
+                    ev_bg = new_event();
+                    HK_CHECK(hipEventRecord(ev_bg, tb));
                 }
                 continue;
             }
@@ -158,6 +140,7 @@ void enqueue_factor(hipkkt_solver *S, int static_enable, double eps_const, doubl
         }
     }
     if (pending) HK_CHECK(hipStreamWaitEvent(st, pending, 0));
+    if (ev_bg) HK_CHECK(hipStreamWaitEvent(st, ev_bg, 0));
     launch_invert_diag(st, S->dp, S->inv_nsmall, S->inv_wsmall, S->inv_nwide);
     for (const FrontDesc &F : P.fronts) launch_invert_super(st, S->dp, F);   // super-block inverses for the front sweeps
 }
@@ -326,7 +309,7 @@ static int32_t refactor_once(hipkkt_handle h, int32_t static_reg_enable, double 
     } else {
         GraphSlot &g = S->g_factor;
         const bool same = g.static_enable == static_reg_enable && g.eps_const == eps_const && g.eps_prop == eps_prop;
-        if (S->lookahead && S->la_stream) enqueue_factor(S, static_reg_enable, eps_const, eps_prop);   // CU-masked stream: eager, not captured
+        if (S->lookahead && S->la_streams[0]) enqueue_factor(S, static_reg_enable, eps_const, eps_prop);   // CU-masked stream: eager, not captured
         else run_graphed(S, S->stream, g, same, [&] { enqueue_factor(S, static_reg_enable, eps_const, eps_prop); });
         g.static_enable = static_reg_enable; g.eps_const = eps_const; g.eps_prop = eps_prop;
     }

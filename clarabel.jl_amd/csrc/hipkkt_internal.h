@@ -140,12 +140,14 @@ struct hipkkt_solver {
     // its crit launch covers (this batch's diagonal blocks + the rows of the next two batches) and the 3-way split of its far stage
     struct LaBatch {
         bool on = false, first = false, last = false;   // inside a look-ahead region / its first / its last batch
-        int rc = 0;                                     // row blocks of the crit launch
+        int next_blk = 0;                               // workgroups of the next batch's panel kernel
         int ncrit = 0, nE = 0;                          // far stage: [crit | E | far] dense groups (setup reorders them)
     };
     std::vector<LaBatch> la;
     bool lookahead = false;
-    hipStream_t la_stream = nullptr;     // throughput stream, CU-masked: leaves 2 compute units per XCD to the chain
+    static constexpr int kLaStreams = 4;
+    static int la_keep(int k) { return k == 0 ? 16 : k == 1 ? 32 : k == 2 ? 64 : 96; }   // compute units left to the panel kernel
+    hipStream_t la_streams[kLaStreams] = {nullptr, nullptr, nullptr, nullptr};            // throughput streams, CU-masked
     long long *d_fb_trace = nullptr;     // HIPKKT_FB_TRACE=1: wall-clock stamps of the first 8 workgroups of every batch (debug_dump 9)
     bool persist_allowed = true;         // false: HIPKKT_NO_PERSIST (never tried)
     int64_t persist_retry_at = -1;       // after a sweep time-out: the LDL-solve count at which the persistent kernels are tried again
@@ -287,7 +289,7 @@ struct hipkkt_solver {
         rp.pinned_free(device, h_flags);
         for (hipEvent_t e : {ev0, ev1, ev2, ev3}) rp.event_put(device, e);
         for (hipEvent_t e : fork_events) (void)hipEventDestroy(e);
-        if (la_stream) { (void)hipStreamSynchronize(la_stream); (void)hipStreamDestroy(la_stream); }
+        for (hipStream_t q : la_streams) if (q) { (void)hipStreamSynchronize(q); (void)hipStreamDestroy(q); }
         rp.stream_put(device, 1, side);
         rp.stream_put(device, 0, stream);
     }

@@ -69,17 +69,22 @@ void init_runtime(hipkkt_solver *S) {
         S->fork_gather = fg && fg[0] == '1';
         const char *la = getenv("HIPKKT_LOOKAHEAD");
         S->lookahead = la && la[0] == '1';
-        if (S->lookahead && !S->la_stream) {
-            // all compute units except the last two of every XCD (mask bits are interleaved over the XCDs: bit b -> XCD b % 8,
-            // tools/ubench_cumask.hip): the chain kernels on the handle's main stream always find those 16 free
+        if (S->lookahead && !S->la_streams[0]) {
+            // Throughput streams for the launches that run next to a panel kernel: all compute units except the last `keep / 8` of
+            // every XCD (mask bits are interleaved over the XCDs: bit b -> XCD b % 8, tools/ubench_cumask.hip), so that the panel
+            // kernel on the main stream finds those free whatever the other launch occupies.  k_front_block keeps one workgroup per
+            // compute unit (100 KB of LDS) and a batch has 2 ... 90 of them: one stream per size class.
             int ncu = 0;
             HK_CHECK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, S->device));
-            std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
-            for (int b = 0; b < ncu - 16; b++) mask[(size_t)b / 32] |= 1u << (b % 32);
-            if (ncu < 64 || hipExtStreamCreateWithCUMask(&S->la_stream, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
-                (void)hipGetLastError();
-                S->la_stream = nullptr;
-                S->lookahead = false;
+            for (int k = 0; k < hipkkt_solver::kLaStreams && S->lookahead; k++) {
+                const int keep = hipkkt_solver::la_keep(k);
+                std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
+                for (int b = 0; b < ncu - keep; b++) mask[(size_t)b / 32] |= 1u << (b % 32);
+                if (ncu < 2 * keep || hipExtStreamCreateWithCUMask(&S->la_streams[k], (uint32_t)mask.size(), mask.data()) != hipSuccess) {
+                    (void)hipGetLastError();
+                    S->la_streams[k] = nullptr;
+                    S->lookahead = false;
+                }
             }
         }
         const char *fw = getenv("HIPKKT_FAR_WGS");
@@ -547,11 +552,9 @@ void setup_device(hipkkt_solver *S) {
 // go to the device: it reorders the dense groups of those stages inside S->plan.
 static void plan_lookahead(hipkkt_solver *S) {
     // ---- look-ahead regions: runs of >= 3 consecutive batches of one front whose far stages hold nothing but dense tiles.  The far
-    //      stage of batch t is reordered [crit | E | far]:
-    //        crit = tiles (columns of batch t+1) x (rows of batches t+1, t+2)            -> applied on the chain's stream
-    //        E    = (columns of t+1) x (rows of t+3)  and  (columns of t+2) x (rows of t+2, t+3)   -> first on the throughput stream;
-    //               the chain waits for them before the crit launch of batch t+1
-    //        far  = the rest
+    //      stage of batch t (scheduled by due date: symbolic.cpp step 14) is reordered [chain | background]:
+    //        chain      = tiles of the columns of batch t+1: the next k_front_block needs them
+    //        background = everything further right (and targets outside the region): runs NEXT TO the k_front_block of batch t+1
     HostPlan &Pm = S->plan;
     const HostPlan &P = S->plan;
     const auto hb = front_batches(P, S->plan_opts.update_policy, kFbMax);
@@ -575,27 +578,19 @@ static void plan_lookahead(hipkkt_solver *S) {
                 for (size_t b = q; b <= e; b++) {
                     hipkkt_solver::LaBatch &A = S->la[b];
                     A.on = true; A.first = b == q; A.last = b == e;
-                    A.rc = 0;
-                    for (size_t c = b; c <= e && c < b + 3; c++) A.rc += hb[c].nb;
-                    A.rc = std::min(A.rc, (P.front_panels[P.fronts[(size_t)hb[b].front].fp_off + hb[b].p0].r + 63) / 64);
                     const int l = hb[b].level_last, g0 = P.upd_stage_ptr[l], nd = P.upd_stage_ndense[l];
                     const FrontDesc &F = P.fronts[(size_t)hb[b].front];
                     auto cls = [&](const UpdGroup &G) {
                         if (P.sn_front[G.tgt] != hb[b].front) return 2;
                         const int tb = panel_batch[(size_t)hb[b].front][(size_t)(G.tgt - F.s0)];
-                        const int row = P.sn_rows[P.sn_rowptr[G.tgt] + G.row_base], sr = P.sn_of_col[row];
-                        const int rb = P.sn_front[sr] == hb[b].front ? panel_batch[(size_t)hb[b].front][(size_t)(sr - F.s0)] : -1;
-                        if (tb < 0 || rb < 0 || tb > (int)e || rb > (int)e) return 2;
-                        const int dt = tb - (int)b, dr = rb - (int)b;
-                        if (dt == 1 && (dr == 1 || dr == 2)) return 0;
-                        if ((dt == 1 && dr == 3) || (dt == 2 && (dr == 2 || dr == 3))) return 1;
+                        if (tb == (int)b + 1 && tb <= (int)e) return 0;
                         return 2;
                     };
                     auto gb = Pm.upd_groups.begin() + g0, ge = gb + nd;
                     auto m1 = std::stable_partition(gb, ge, [&](const UpdGroup &G) { return cls(G) == 0; });
-                    auto m2 = std::stable_partition(m1, ge, [&](const UpdGroup &G) { return cls(G) == 1; });
                     A.ncrit = (int)(m1 - gb);
-                    A.nE = (int)(m2 - m1);
+                    A.nE = 0;
+                    A.next_blk = b < e ? (P.front_panels[P.fronts[(size_t)hb[b + 1].front].fp_off + hb[b + 1].p0].r + 63) / 64 : 0;
                 }
             }
             q = e + 1;
@@ -629,7 +624,7 @@ static void build_front_batches(hipkkt_solver *S) {
     if (getenv("HIPKKT_VERBOSE")) {
         int non = 0;
         for (const auto &A : S->la) non += A.on;
-        fprintf(stderr, "hipkkt: look-ahead %s: %d of %zu front batches inside look-ahead regions\n", S->lookahead ? "on" : "off", non, S->la.size());
+        fprintf(stderr, "hipkkt: look-ahead %s: %d of %zu front batches inside look-ahead regions, %lld update tasks rescheduled\n", S->lookahead ? "on" : "off", non, S->la.size(), (long long)P.la_sched_moved);
     }
     if (getenv("HIPKKT_VERBOSE")) fprintf(stderr, "hipkkt: %zu front batch(es) factored by one launch each (fronts %zu, update batch %d)\n", S->fbatches.size(), P.fronts.size(), P.update_batch_used);
     const size_t nb_ = std::max<size_t>(S->fbatches.size(), 1);
@@ -664,6 +659,14 @@ int32_t finish_create(hipkkt_solver *S, const hipkkt_opts *opts, hipkkt_handle *
         if (sh) po.superhop = atoi(sh);
         const char *nx = getenv("HIPKKT_XCD_ORDER");   // 0 / 1 / 2 (symbolic.h PlanOptions::xcd_order; default 2)
         if (nx) po.xcd_order = atoi(nx);
+    }
+    {
+        const char *la = getenv("HIPKKT_LOOKAHEAD");  // look-ahead factorisation of the fronts (hipkkt_factor.cpp): needs the due-date schedule
+        po.la_sched = la && la[0] == '1';
+        const char *ls = getenv("HIPKKT_LA_SCHED");   // 0: look-ahead without the due-date schedule (every batch's far stage as it is)
+        if (ls) po.la_sched = po.la_sched && atoi(ls) != 0;
+        const char *lr = getenv("HIPKKT_LA_RATE");
+        if (lr && atof(lr) > 0.0) po.la_rate_tf = atof(lr);
     }
     {
         const char *nh = getenv("HIPKKT_ORDERING");   // "amd": minimum degree on K only
@@ -716,7 +719,7 @@ int32_t finish_create(hipkkt_solver *S, const hipkkt_opts *opts, hipkkt_handle *
     std::shared_ptr<const HostPlan> cached;
     if (PlanCache::enabled()) {
         char buf[256];
-        snprintf(buf, sizeof buf, "%d|%d|%d|%d|%.17g|%.17g|%d|%d|%d|%d|%d|%d|%d|%d|%d|%d", po.max_width, (int)po.relax, po.update_policy, po.update_batch,
+        snprintf(buf, sizeof buf, "%d|%g|%d|%d|%d|%d|%.17g|%.17g|%d|%d|%d|%d|%d|%d|%d|%d|%d|%d", po.la_sched, po.la_rate_tf, po.max_width, (int)po.relax, po.update_policy, po.update_batch,
                  po.amd_dense_scale, po.dense_min_cover, (int)po.fuse_jit, (int)po.split_far, po.xcd_order, po.n_hold, po.front_block_min_width,
                  po.front_min_panels, po.superhop, po.nd_mode, po.nd_leaf, uperm ? 1 : 0);
         optkey = buf;

@@ -520,6 +520,81 @@ std::string build_plan(int N, const int64_t *Ap, const int64_t *Ai, const int64_
         }
         lap("ut:gen");
         if (cancelled) return "cancelled";
+        // ---- due-date schedule inside long panel chains (PlanOptions::la_sched).  A chain = consecutive supernodes, each
+        //      alone on its level, each the parent of the one before, rows nested (the panels of a front).  A "unit" = everything the
+        //      panels of batch bs (levels bs*B .. bs*B+B-1) contribute to target panel t of a LATER batch bt.  It may be applied at the
+        //      end of any batch sigma in [bs, bt-1] (stage = last level of sigma).  bt = sigma+1: the next panel kernel needs it (applied
+        //      on the chain).  bt > sigma+1: it runs NEXT TO the panel kernel of batch sigma+1, whose duration bounds what fits:
+        //      earliest due date first; what does not fit stays pending and ends up on the chain at its due date.
+        if (opt.la_sched && opt.update_policy == 2) {
+            const int B = update_batch;
+            std::vector<int> chain_first(S, -1);     // first supernode of the chain s belongs to
+            auto w_of = [&](int s) { return P.sn_first[s + 1] - P.sn_first[s]; };
+            auto r_of = [&](int s) { return (int)(P.sn_rowptr[s + 1] - P.sn_rowptr[s]); };
+            auto alone = [&](int s) { const int l = P.sn_level[s]; return P.lvl_ptr[l + 1] - P.lvl_ptr[l] == 1; };
+            for (int s = 0; s < S;) {
+                int e = s;
+                while (e + 1 < S && P.sn_parent[e] == e + 1 && P.sn_level[e + 1] == P.sn_level[e] + 1 && r_of(e + 1) == r_of(e) - w_of(e) &&
+                       alone(e) && alone(e + 1))
+                    e++;
+                if (e - s + 1 >= 4 * B)
+                    for (int q = s; q <= e; q++) chain_first[q] = s;
+                s = e + 1;
+            }
+            std::vector<double> cost;                // [panel of the chain][source batch]
+            std::vector<int> sigma;                  // the schedule, same shape
+            for (int s0 = 0; s0 < S; s0++) {
+                if (chain_first[s0] != s0) continue;
+                int np = 1;
+                while (s0 + np < S && chain_first[s0 + np] == s0) np++;
+                const int b0 = P.sn_level[s0] / B, b1 = P.sn_level[s0 + np - 1] / B, nbat = b1 - b0 + 1;
+                auto bat = [&](int s) { return P.sn_level[s] / B - b0; };
+                cost.assign((size_t)np * nbat, 0.0);
+                sigma.assign((size_t)np * nbat, -1);
+                for (const TaskKey &k : keys) {
+                    if (k.src < s0 || k.src >= s0 + np || k.tgt < s0 || k.tgt >= s0 + np || bat(k.tgt) <= bat(k.src)) continue;
+                    const UpdTask &T = P.upd_tasks[k.task];
+                    cost[(size_t)(k.tgt - s0) * nbat + bat(k.src)] += 2.0 * T.nrows * T.ncols * w_of(k.src);
+                }
+                std::vector<int> first_of(nbat + 1, np), nxt(np, 0);   // first panel of a batch; per target: next unscheduled source batch
+                for (int p = np - 1; p >= 0; p--) first_of[bat(s0 + p)] = p;
+                for (int b = nbat - 1; b >= 0; b--) first_of[b] = std::min(first_of[b], first_of[b + 1]);
+                for (int sg = 0; sg < nbat; sg++) {
+                    // due now: the columns of batch sg+1 (from every batch <= sg not applied yet)
+                    for (int p = first_of[std::min(sg + 1, nbat)]; p < first_of[std::min(sg + 2, nbat)]; p++)
+                        for (; nxt[p] <= sg; nxt[p]++) sigma[(size_t)p * nbat + nxt[p]] = sg;
+                    if (sg + 1 >= nbat) break;
+                    // next to the panel kernel of batch sg+1
+                    const int pn = first_of[sg + 1], npan = first_of[sg + 2] - pn;
+                    const double dur = 22e-6 * npan + 5e-6, nblk = r_of(s0 + pn) / 64.0;
+                    double cap = dur * opt.la_rate_tf * 1e12 * std::max(0.1, 1.0 - (nblk + 8.0) / 256.0);
+                    for (int p = first_of[std::min(sg + 2, nbat)]; p < np && cap > 0.0; p++)
+                        for (; nxt[p] <= sg && nxt[p] < bat(s0 + p) && cap > 0.0; nxt[p]++) {
+                            sigma[(size_t)p * nbat + nxt[p]] = sg;
+                            cap -= cost[(size_t)p * nbat + nxt[p]];
+                        }
+                }
+                if (getenv("HIPKKT_LA_VERBOSE")) {
+                    for (int sg = 0; sg < nbat; sg++) {
+                        double fc = 0.0, fbg = 0.0;
+                        for (int p = 0; p < np; p++)
+                            for (int bs = 0; bs < nbat; bs++)
+                                if (sigma[(size_t)p * nbat + bs] == sg) (bat(s0 + p) == sg + 1 ? fc : fbg) += cost[(size_t)p * nbat + bs];
+                        fprintf(stderr, "hipkkt: la_sched chain %d batch %d: on the chain %.2f GF, background %.2f GF\n", s0, sg, fc * 1e-9, fbg * 1e-9);
+                    }
+                }
+                int64_t moved = 0;
+                for (TaskKey &k : keys) {
+                    if (k.src < s0 || k.src >= s0 + np || k.tgt < s0 || k.tgt >= s0 + np || bat(k.tgt) <= bat(k.src)) continue;
+                    const int sg = sigma[(size_t)(k.tgt - s0) * nbat + bat(k.src)];
+                    if (sg < 0) continue;                                       // (cannot happen: every unit is due at some batch)
+                    const int st = std::min((b0 + sg) * B + B - 1, P.sn_level[k.tgt] - 1);
+                    moved += st != k.stage;
+                    k.stage = std::max(k.stage, st);
+                }
+                P.la_sched_moved += moved;
+            }
+        }
         // order: (stage, target, row block, source, task).  The keys are generated source by source, task by task, i.e. already in
         // (source, task) order: three stable counting sorts -- by row block, by target, by stage -- finish the job in O(n)
         // (a comparison sort of the 1.2e7 keys of an SDP twin took half a second).

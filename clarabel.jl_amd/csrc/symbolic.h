@@ -126,6 +126,11 @@ struct PlanOptions {
                                // cfg 1's 710-column root is 15 % slower to factor with 11 x 64 + 6 than with 12 x 60)
     int front_min_panels = 4;  // chains at least this long are solved by the persistent front kernels (0 = never)
     int superhop = 1;          // 1: fronts of >= kSbMinPanels panels are swept super-block by super-block (2 hand-offs per kSbG panels)
+    int la_sched = 0;          // 1: the Schur updates inside a long panel chain (a front) are scheduled by due date: what batch b
+                               // contributes to the columns of a batch further right than b+1 may be applied later, NEXT TO the panel
+                               // kernel of a following batch (hipkkt_factor.cpp look-ahead), merged per target tile with what other
+                               // batches contribute (symbolic.cpp step 14)
+    double la_rate_tf = 30.0;  // ... at this assumed matrix-core rate of the background launch (TFLOP/s on the whole device)
     int nd_mode = 1;           // nested dissection candidate: 0 never, 1 when the latency + throughput model predicts a
                                // >= 20 % cheaper KKT iteration than minimum degree, 2 always
     int nd_leaf = 256;         // subgraphs of at most this many nodes are ordered by minimum degree
@@ -142,6 +147,7 @@ struct HostPlan {
     int64_t nnzK = 0;
     std::vector<int> perm, iperm;  // perm[k] = original index eliminated k-th
 
+    int64_t la_sched_moved = 0;      // update tasks the due-date schedule moved to a later stage (PlanOptions::la_sched)
     int nsuper = 0;
     std::vector<int> sn_first;       // [nsuper+1] first (permuted) column
     std::vector<int> sn_of_col;      // [N]

@@ -27,6 +27,7 @@ if [ -n "$PROF" ]; then
   head -24 gpurun_out/prof_summary_$tag.txt
   find gpurun_out/prof_$tag -name "*.db" -size +40M -delete
 fi
+[ -n "$SKIP_BENCH" ] && exit 0
 timeout 400 python bench.py --no-cpu-baseline > gpurun_out/bench_2a_$tag.log 2>&1; tail -1 gpurun_out/bench_2a_$tag.log | python -c "
 import sys,json
 d=json.loads(sys.stdin.read()); r=d['roofline']
