@@ -617,6 +617,9 @@ int32_t hipkkt_get_counters(hipkkt_handle h, int64_t *o) {
     o[4] = h->using_fallback ? 1 : 0; o[5] = h->plan.ordering_used; o[6] = (int64_t)h->plan.fronts.size(); o[7] = h->nseg;
     o[8] = (int64_t)h->fbatches.size(); o[9] = h->use_front_block ? 1 : 0;
     plan_cache_counts(&o[10], &o[11]);   // process-wide: symbolic plans taken from / not found in the plan cache
+    o[12] = 0;
+    for (const auto &A : h->la) o[12] += A.on ? 1 : 0;
+    o[13] = h->plan.la_sched_moved;
     return HIPKKT_OK;
 }
 

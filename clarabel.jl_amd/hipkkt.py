@@ -243,11 +243,12 @@ class Handle:
                     n_solve_calls=int(o[5]), n_ldl_solves=int(o[6]), last_update_ms=o[7])
 
     def counters(self):
-        o = np.zeros(12, dtype=np.int64)
+        o = np.zeros(14, dtype=np.int64)
         self.L.hipkkt_get_counters(self.h, o)
         return dict(sweep_timeouts=int(o[0]), persistent=bool(o[1]), twin_refactors=int(o[2]), twin_exists=bool(o[3]),
                     in_twin=bool(o[4]), ordering=int(o[5]), fronts=int(o[6]), segments=int(o[7]), front_batches=int(o[8]),
-                    front_block=bool(o[9]), plan_cache_hits=int(o[10]), plan_cache_misses=int(o[11]))
+                    front_block=bool(o[9]), plan_cache_hits=int(o[10]), plan_cache_misses=int(o[11]), lookahead_batches=int(o[12]),
+                    lookahead_moved_tasks=int(o[13]))
 
     def profile_launches(self):
         n = C.c_int64(0)

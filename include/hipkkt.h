@@ -286,8 +286,9 @@ int32_t hipkkt_set_profiling(hipkkt_handle h, int32_t enable);
  * out[7] = #segments, out[8] = update batches of fronts factored by one launch each (front_block.hip), out[9] = that path is
  * enabled (0 after one of its hand-offs timed out: the handle then keeps one launch per panel), out[10] / out[11] = symbolic plans
  * taken from / not found in the process-wide plan cache (same KKT pattern and options => the analysis of an earlier handle is reused;
- * HIPKKT_PLAN_CACHE=0 disables it) */
-int32_t hipkkt_get_counters(hipkkt_handle h, int64_t *out12);
+ * HIPKKT_PLAN_CACHE=0 disables it), out[12] = front batches inside look-ahead regions (0 unless HIPKKT_LOOKAHEAD=1: their far updates
+ * run next to the next batch's panel kernel), out[13] = update tasks the due-date schedule of that mode moved to a later stage */
+int32_t hipkkt_get_counters(hipkkt_handle h, int64_t *out14);
 
 /* developer diagnostic, not part of the plugin contract: copies an internal vector of the last LDL solve (what = 0 the
  * permuted right-hand side, 1 z = D^-1 L^-1 b, 2 x in permuted order, 3 the forward update vectors, 4 the unregularised KKT values in nz order, 5 D and 6 1/D of the last factorisation, 7 / 8 the u / v vectors of the sparse second-order cones) or a plan table converted to doubles (10 supernode first

@@ -212,3 +212,43 @@ def test_batch_config_matches_oracle(seed, oracle_factory, capsys):
     assert log[first][0] <= itc                 # ... and it happens no later than the iterate where the runs are compared
     assert abs(solg.iterations - solc.iterations) <= 1
     assert dobj <= 1e-4 and dres <= 1e-8        # both runs end SOLVED at the IPM's own tolerances; this is how far apart that leaves them
+
+
+@pytest.mark.parametrize("name,sched", [("cfg2a", "1"), ("cfg2a", "0"), ("cfg3", "1")])
+def test_lookahead_factorisation_equals_serial_order(name, sched, monkeypatch):
+    """HIPKKT_LOOKAHEAD=1 (opt-in; DESIGN.md section 9: measured slower on MI355X, kept as a tested experiment): the far Schur updates of
+    a front batch are split [chain | background], the background part runs next to the next batch's panel kernel on a CU-masked stream,
+    and with the due-date schedule (HIPKKT_LA_SCHED, default on in that mode) updates are moved to later stages and merged per target
+    tile.  Same updates in another valid order: the unrefined LDL solve agrees with the serial order to rounding, the refined solve
+    meets the same stopping rule, and the run is deterministic."""
+    rng = np.random.default_rng(21)
+    Pt, A, cones = _prep(FULL[name]())
+    m, n = A.shape
+    scale_cones(cones, rng)
+    hk0 = HipKKTSolver(Pt, A, cones, m, n, cl.Settings())
+    assert hk0.kktsolver_update(cones)
+    assert hk0.h.counters()["lookahead_batches"] == 0
+    monkeypatch.setenv("HIPKKT_LOOKAHEAD", "1")
+    monkeypatch.setenv("HIPKKT_LA_SCHED", sched)
+    monkeypatch.setenv("HIPKKT_PLAN_CACHE", "0")
+    hk1 = HipKKTSolver(Pt, A, cones, m, n, cl.Settings())
+    assert hk1.kktsolver_update(cones)
+    c = hk1.h.counters()
+    assert c["lookahead_batches"] >= 3
+    if sched == "0":
+        assert c["lookahead_moved_tasks"] == 0
+    elif name == "cfg2a":      # (cfg 3's background parts all fit next to their panel kernels: nothing to move)
+        assert c["lookahead_moved_tasks"] > 0
+    b = rng.standard_normal(hk0.h.N)
+    x0, x1 = hk0.h.ldl_solve(b), hk1.h.ldl_solve(b)
+    assert np.max(np.abs(x1 - x0)) <= 1e-9 * max(1.0, np.max(np.abs(x0)))
+    rx, rz = rng.standard_normal(n), rng.standard_normal(m)
+    sols = []
+    for hk in (hk0, hk1):
+        lx, lz = np.zeros(n), np.zeros(m)
+        hk.kktsolver_setrhs(rx, rz)
+        assert hk.kktsolver_solve(lx, lz)
+        sols.append(np.concatenate([lx, lz]))
+    assert np.max(np.abs(sols[1] - sols[0])) <= 1e-9 * max(1.0, np.max(np.abs(sols[0])))
+    assert hk1.kktsolver_update(cones)
+    assert np.array_equal(hk1.h.ldl_solve(b), x1)
