@@ -655,7 +655,7 @@ int32_t finish_create(hipkkt_solver *S, const hipkkt_opts *opts, hipkkt_handle *
         if (dc && atof(dc) > 0) po.dense_min_cover = atof(dc);
         const char *nf = getenv("HIPKKT_FUSE_JIT");    // experiment: just-in-time updates inside the panel kernel
         if (nf && nf[0] == '1') po.fuse_jit = true;
-        const char *sh = getenv("HIPKKT_SUPERHOP");    // 0: one hop per panel in the front sweeps (round-2 kernels; A/B timing)
+        const char *sh = getenv("HIPKKT_SUPERHOP");    // 0: one hop per panel in the front sweeps (round-2 kernels; A/B timing); N: fronts of >= N panels
         if (sh) po.superhop = atoi(sh);
         const char *nx = getenv("HIPKKT_XCD_ORDER");   // 0 / 1 / 2 (symbolic.h PlanOptions::xcd_order; default 2)
         if (nx) po.xcd_order = atoi(nx);

@@ -956,7 +956,7 @@ std::string build_plan(int N, const int64_t *Ap, const int64_t *Ai, const int64_
             F.sync_blk = ((2 + np + 31) & ~31) + 2 * np * 64 * 4;   // multiple of 32 ints: the two blocks share no cache line
             sync_ints += 2 * F.sync_blk;
             F.sb_g = 0; F.nsb = 0; F.sbinv_off = 0;
-            if (opt.superhop && np >= kSbMinPanels && np <= kSbMaxPanels) {
+            if (opt.superhop > 0 && np >= std::max(opt.superhop, kSbMinPanels) && np <= kSbMaxPanels) {
                 F.sb_g = kSbG;
                 F.nsb = (np + kSbG - 1) / kSbG;
                 F.sbinv_off = P.sbinv_doubles;

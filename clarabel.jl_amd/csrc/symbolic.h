@@ -103,7 +103,7 @@ struct FrontDesc {
     int64_t sbinv_off;
 };
 constexpr int kSbG = 8;           // panels per super-block of the front sweeps
-constexpr int kSbMinPanels = 10;  // fronts with fewer panels keep one hop per panel
+constexpr int kSbMinPanels = 10;  // fronts with fewer panels always keep one hop per panel (a second super-block must exist)
 constexpr int kSbMaxPanels = 1024; // ... and so do fronts with more (the sweeps keep a panel table in LDS)
 
 struct PlanOptions {
@@ -125,7 +125,9 @@ struct PlanOptions {
                                // k_front_block can take their update batches; narrower ones keep balanced panel widths (measured:
                                // cfg 1's 710-column root is 15 % slower to factor with 11 x 64 + 6 than with 12 x 60)
     int front_min_panels = 4;  // chains at least this long are solved by the persistent front kernels (0 = never)
-    int superhop = 1;          // 1: fronts of >= kSbMinPanels panels are swept super-block by super-block (2 hand-offs per kSbG panels)
+    int superhop = 16;         // fronts of at least max(this, kSbMinPanels) panels are swept super-block by super-block (2 hand-offs per kSbG
+                               // panels); 0 = never.  Below ~14 panels the hops saved per unit (8 sweeps on the critical path) cost less than
+                               // the 0.11-0.13 ms of k_invert_super per factorisation (measured on cfg 1's 12-panel root: 917 -> 869 units/s)
     int la_sched = 0;          // 1: the Schur updates inside a long panel chain (a front) are scheduled by due date: what batch b
                                // contributes to the columns of a batch further right than b+1 may be applied later, NEXT TO the panel
                                // kernel of a following batch (hipkkt_factor.cpp look-ahead), merged per target tile with what other

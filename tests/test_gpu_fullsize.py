@@ -252,3 +252,27 @@ def test_lookahead_factorisation_equals_serial_order(name, sched, monkeypatch):
     assert np.max(np.abs(sols[1] - sols[0])) <= 1e-9 * max(1.0, np.max(np.abs(sols[0])))
     assert hk1.kktsolver_update(cones)
     assert np.array_equal(hk1.h.ldl_solve(b), x1)
+
+
+@pytest.mark.parametrize("name", ["cfg1", "cfg2a"])
+def test_super_block_sweeps_equal_panel_sweeps(name, monkeypatch):
+    """front_sweep.hip (two hand-offs per super-block of 8 panels, explicit inverse of the super-block's diagonal block) against the
+    panel-by-panel sweeps of round 2 (HIPKKT_SUPERHOP=0) on the same factorisation: cfg 1's 12-panel root (below the default threshold
+    of 16 panels, forced on with HIPKKT_SUPERHOP=1: partial second super-block) and cfg 2a's 88-panel root (default)."""
+    rng = np.random.default_rng(31)
+    prob = problems.random_sparse_qp(1000, 2000, 1, 4, 2) if name == "cfg1" else FULL[name]()
+    Pt, A, cones = _prep(prob)
+    m, n = A.shape
+    scale_cones(cones, rng)
+    monkeypatch.setenv("HIPKKT_PLAN_CACHE", "0")
+    sols = []
+    for sh in ("1", "0"):
+        monkeypatch.setenv("HIPKKT_SUPERHOP", sh)
+        hk = HipKKTSolver(Pt, A, cones, m, n, cl.Settings())
+        assert hk.kktsolver_update(cones)
+        b = np.random.default_rng(32).standard_normal(hk.h.N)
+        x = hk.h.ldl_solve(b)
+        assert np.array_equal(hk.h.ldl_solve(b), x)                      # deterministic
+        sols.append(x)
+        assert hk.h.counters()["sweep_timeouts"] == 0
+    assert np.max(np.abs(sols[0] - sols[1])) <= 1e-10 * max(1.0, np.max(np.abs(sols[1])))

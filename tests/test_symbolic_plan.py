@@ -102,7 +102,7 @@ def test_user_perm_and_dynamic_regularisation_count():
 
 
 @pytest.mark.parametrize("maxw", [8, 16, 64])
-def test_super_block_front_sweeps_reproduce_dense_solve(maxw, monkeypatch):
+def test_super_block_front_sweeps_reproduce_dense_solve(maxw, monkeypatch, capfd):
     """front_sweep.hip's super-block sweeps (k_invert_super / k_front_fwd_sb / k_front_bwd_sb) have a serial host twin in
     tests/support/plan_check.cpp with the same tile addresses, layouts (column-major / row-major halves of the inverse tiles,
     the row-major copy LT) and super-block structure.  Narrow panel widths turn the dense root of a small problem into a front of
@@ -116,8 +116,10 @@ def test_super_block_front_sweeps_reproduce_dense_solve(maxw, monkeypatch):
     K = sp.csc_matrix((nz, k.rowval, k.colptr), shape=(k.N, k.N)).toarray()
     K = K + K.T - np.diag(np.diag(K))
     xd = np.linalg.solve(K, b)
+    capfd.readouterr()
     rc, x, perm, st = ps.run(k.N, k.colptr, k.rowval, nz, ds, b, max_width=maxw, relax=1, policy=2 + 16 * 4)
     assert rc == 0 and st["nfronts"] >= 1
+    assert int(capfd.readouterr().err.split(" with super-block sweeps")[0].split()[-1]) >= 1     # (PLANCHECK_SUPERHOP=1: from kSbMinPanels panels on)
     assert np.linalg.norm(x - xd) <= 1e-9 * max(1.0, np.linalg.norm(xd))
     # and the same plan with one hop per panel gives the same answer (the two sweeps are interchangeable)
     monkeypatch.setenv("PLANCHECK_SUPERHOP", "0")
