@@ -435,7 +435,8 @@ def main():
     upd = float(np.median(upd_ms))
     p4 = sorted(d4, key=lambda p: p["dense4_ms"])[len(d4) // 2]
     # the just-in-time updates inside a front's update batches run inside k_front_block, not in the timed update kernels
-    flops_upd_kernels = cm["flops_update"] - p4.get("front_block_update_flops", 0.0)
+    # ... and so does the partial last round of a front batch's far updates (extra workgroups of the NEXT k_front_block launch)
+    flops_upd_kernels = cm["flops_update"] - p4.get("front_block_update_flops", 0.0) - p4.get("front_block_extra_flops", 0.0)
     agg = flops_upd_kernels / (upd * 1e-3) / 1e12 if upd > 0 else 0.0
     if p4["dense4_launches"] > 0 and p4["dense4_ms"] > 0:
         # dominant kernel alone: k_update_dense<4,4> (one wavefront per 64x64 tile), HIP events around each launch
@@ -463,7 +464,11 @@ def main():
             kernel="k_front_block", bound="dependency latency (pivot chain)", launches_per_refactor=p4["front_block_launches"],
             panels=p4["front_block_panels"], ms_per_refactor=round(p4["front_block_ms"], 4),
             us_per_panel=round(1e3 * p4["front_block_ms"] / max(1, p4["front_block_panels"]), 2),
-            floor_note="wall-clock stamps (tools/fb_trace.py): 9.9 us pivots + 2.8 inverse + 2.8 hand-off + 4.2 two 64^3 products + rest per panel")
+            floor_note="wall-clock stamps (tools/fb_trace.py): 9.9 us pivots + 2.8 inverse + 2.8 hand-off + 4.2 two 64^3 products + rest per panel",
+            extra_update_tiles=p4.get("front_block_extra_tiles", 0), extra_update_flops=p4.get("front_block_extra_flops", 0.0),
+            extra_note="dense update tiles of the partial last rounds of the far stages, executed by extra workgroups of these launches on compute "
+                       "units the panel chain leaves idle; their flops are NOT in roofline.achieved / all_update_kernels (those time the update "
+                       "kernels' own launches)")
     # algorithmic HBM bytes of one big dense-update launch, from the plan (every target tile read and written
     # once, every source panel row once): T tiles of 64 x 64 doubles; a launch over T = R (R + 1) / 2 tiles of a front touches R
     # row blocks of its K source columns (K = flops per tile / (2 * 64 * 64))

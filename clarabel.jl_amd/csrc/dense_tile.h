@@ -1,0 +1,215 @@
+// The dense Schur-update tile (k_update_dense, kernels.hip): one wavefront keeps NT x NR blocks of 16 x 16 of a target tile in FP64
+// matrix-core accumulators while it sweeps all contributing source panels.  In a header because two translation units run it: the
+// update kernels (kernels.hip) and the extra workgroups of a k_front_block launch (front_block.hip), which apply tiles of the previous
+// update stage on compute units the panel kernel leaves idle.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "device_plan.h"
+
+namespace hipkkt {
+
+#ifndef HIPKKT_V4F64_DEFINED
+#define HIPKKT_V4F64_DEFINED
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+#endif
+__device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+template <class T>
+__device__ __forceinline__ T *rfl_ptr(T *p) {
+    const unsigned long long u = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    return (T *)(((unsigned long long)hi << 32) | lo);
+}
+#define HK_GLOBAL __attribute__((address_space(1)))
+__device__ __forceinline__ double ld_off(const double *base, unsigned byte_off) {
+    // uniform base + 32-bit lane offset, explicitly in the global address space (global_load ... saddr)
+    return *(const HK_GLOBAL double *)((const HK_GLOBAL char *)base + byte_off);
+}
+__device__ __forceinline__ void st_off(double *base, unsigned byte_off, double v) {
+    *(HK_GLOBAL double *)((HK_GLOBAL char *)base + byte_off) = v;
+}
+
+// NT 16-column strips x NR 16-row blocks of a tile per wavefront
+template <int NT, int NR>
+struct DenseRaw {
+    double a[NT], b[NR], d;
+};
+
+// issue the loads of one k-step (4 k's): operand rows are contiguous for a fixed k
+template <int NT, int NR>
+__device__ __forceinline__ void dense_load(DenseRaw<NT, NR> &f, const double *sp, const double *dv, const unsigned (&coff)[NT],
+                                           const unsigned (&roff)[NR], unsigned r8, int K, int k0, int lk) {
+    int kk = k0 + lk;
+    kk = kk < K ? kk : K - 1;
+    const unsigned ko = (unsigned)kk * r8;
+#ifdef HIPKKT_EXPERIMENT_NOLOAD
+    f.d = 1.0 + ko * 1e-9;
+#pragma unroll
+    for (int t = 0; t < NT; t++) f.a[t] = 1e-3 * (coff[t] + 1);
+#pragma unroll
+    for (int t = 0; t < NR; t++) f.b[t] = 1e-3 * (roff[t] + 1);
+#else
+    f.d = ld_off(dv, (unsigned)kk * 8u);
+#pragma unroll
+    for (int t = 0; t < NT; t++) f.a[t] = ld_off(sp, coff[t] + ko);
+#pragma unroll
+    for (int t = 0; t < NR; t++) f.b[t] = ld_off(sp, roff[t] + ko);
+#endif
+}
+
+template <int NT, int NR>
+__device__ __forceinline__ void dense_mma(const DenseRaw<NT, NR> &f, v4f64 (&acc)[NT][NR], unsigned mbits, int K, int k0, int lk) {
+    const double dk = (k0 + lk < K) ? -f.d : 0.0;     // negated: acc = C - sum
+    double a[NT], b[NR];
+#pragma unroll
+    for (int t = 0; t < NT; t++)    // mbits: bit t = column operand t valid, bit 4+t = row operand t valid
+        a[t] = ((mbits >> t) & 1u) ? f.a[t] * dk : 0.0;
+#pragma unroll
+    for (int t = 0; t < NR; t++) b[t] = ((mbits >> (4 + t)) & 1u) ? f.b[t] : 0.0;
+#pragma unroll
+    for (int tj = 0; tj < NT; tj++)
+#pragma unroll
+        for (int ti = 0; ti < NR; ti++)
+            acc[tj][ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[tj], b[ti], acc[tj][ti], 0, 0, 0);
+}
+
+// NT = 4: one wavefront per tile (4 tiles per workgroup): highest operand reuse, for launches with
+//         thousands of tiles.   NT = 1: one wavefront per 16-column strip (one tile per workgroup):
+//         4x shorter critical path, for the just-in-time updates of the next panel (<= ~100 tiles); these may
+//         also split the tile's rows over 4/NR workgroups (NR 16-row blocks per wavefront).
+// LDS_OUT: the finished strip goes to lds_out[row * 65 + column] (the panel kernel's staging layout) instead of
+//          back to the panel -- used by k_factor_panel<true>, which applies a panel's pending updates itself.
+template <int NT, int NR, bool LDS_OUT>
+__device__ __forceinline__ void dense_tile_core(const DevPlan &P, double *tp, int rt, int nrt, int wt, int task_begin,
+                                                int task_end, int lane, int tj0, int ti0, double *lds_out) {
+    const int l15 = lane & 15, lk = lane >> 4;
+
+    // accumulators <- the target tile.  acc[tj][ti][reg]: column (tj0+tj)*16 + lk + 4*reg, row (ti0+ti)*16 + l15
+    v4f64 acc[NT][NR];
+#pragma unroll
+    for (int tj = 0; tj < NT; tj++)
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) {
+            const int jj = (tj0 + tj) * 16 + lk + 4 * reg;
+#pragma unroll
+            for (int ti = 0; ti < NR; ti++) {
+                const int ii = (ti0 + ti) * 16 + l15;
+                const bool ok = ii < nrt && jj < wt;
+                const double v = ld_off(tp, ok ? (unsigned)(ii + jj * rt) * 8u : 0u);
+                acc[tj][ti][reg] = ok ? v : 0.0;
+            }
+        }
+
+    // task records are 48-byte packed structs; the NEXT record is requested at the top of an iteration and only
+    // made wave-uniform (readfirstlane = the wait) at its end, so its latency hides under this task's MFMAs
+    DenseTask Tc = P.dtasks[task_begin];
+    for (int q = task_begin; q < task_end; q++) {
+        const DenseTask Tn = P.dtasks[q + 1 < task_end ? q + 1 : q];
+        const int row_lo = rfl(Tc.row_lo), nrows = rfl(Tc.nrows), col_lo = rfl(Tc.col_lo), ncols = rfl(Tc.ncols),
+                  geom = rfl(Tc.geom), K = rfl(Tc.K), tmap_idx = rfl(Tc.map);
+        const unsigned r8 = (unsigned)rfl(Tc.r8);
+        const double *sp = rfl_ptr(P.Lx + Tc.panel_off);
+        const double *dv = rfl_ptr(P.D + Tc.dfirst);
+        const int c_r = geom & 255, c_c = (geom >> 8) & 255;
+        unsigned roff[NR], coff[NT], mbits = 0;
+        if (geom & (1 << 17)) {      // wave-uniform: operands gathered through the task's tile maps
+            const int16_t *tm = P.upd_tmap + (int64_t)tmap_idx * 128;
+#pragma unroll
+            for (int x = 0; x < NR; x++) {
+                const int m = tm[(ti0 + x) * 16 + l15];
+                roff[x] = (unsigned)(row_lo + (m >= 0 ? m : 0)) * 8u;
+                mbits |= m >= 0 ? 16u << x : 0u;
+            }
+#pragma unroll
+            for (int x = 0; x < NT; x++) {
+                const int m = tm[64 + (tj0 + x) * 16 + l15];
+                coff[x] = (unsigned)(col_lo + (m >= 0 ? m : 0)) * 8u;
+                mbits |= m >= 0 ? 1u << x : 0u;
+            }
+        } else {
+#pragma unroll
+            for (int x = 0; x < NR; x++) {
+                const int ii = (ti0 + x) * 16 + l15 - c_r;
+                const bool okr = ii >= 0 && ii < nrows;
+                roff[x] = (unsigned)(row_lo + (okr ? ii : 0)) * 8u;
+                mbits |= okr ? 16u << x : 0u;
+            }
+#pragma unroll
+            for (int x = 0; x < NT; x++) {
+                const int jj = (tj0 + x) * 16 + l15 - c_c;
+                const bool okc = jj >= 0 && jj < ncols;
+                coff[x] = (unsigned)(col_lo + (okc ? jj : 0)) * 8u;
+                mbits |= okc ? 1u << x : 0u;
+            }
+        }
+        // register double buffering: the loads of step k+1 (clamped past the end) are in flight during
+        // the MFMAs of step k
+        if (NT == 1) {
+            // a 16-column strip has only 4 MFMAs (256 clocks) per k-step, less than one memory latency: keep FOUR
+            // k-steps of operands in flight (ring of 4 register buffers; steps past K contribute zeros)
+            DenseRaw<NT, NR> f0, f1, f2, f3;
+            dense_load<NT, NR>(f0, sp, dv, coff, roff, r8, K, 0, lk);
+            dense_load<NT, NR>(f1, sp, dv, coff, roff, r8, K, 4, lk);
+            dense_load<NT, NR>(f2, sp, dv, coff, roff, r8, K, 8, lk);
+            dense_load<NT, NR>(f3, sp, dv, coff, roff, r8, K, 12, lk);
+            for (int k0 = 0; k0 < K; k0 += 16) {
+                __builtin_amdgcn_sched_barrier(0);
+                dense_mma<NT, NR>(f0, acc, mbits, K, k0, lk);
+                dense_load<NT, NR>(f0, sp, dv, coff, roff, r8, K, k0 + 16, lk);
+                __builtin_amdgcn_sched_barrier(0);
+                dense_mma<NT, NR>(f1, acc, mbits, K, k0 + 4, lk);
+                dense_load<NT, NR>(f1, sp, dv, coff, roff, r8, K, k0 + 20, lk);
+                __builtin_amdgcn_sched_barrier(0);
+                dense_mma<NT, NR>(f2, acc, mbits, K, k0 + 8, lk);
+                dense_load<NT, NR>(f2, sp, dv, coff, roff, r8, K, k0 + 24, lk);
+                __builtin_amdgcn_sched_barrier(0);
+                dense_mma<NT, NR>(f3, acc, mbits, K, k0 + 12, lk);
+                dense_load<NT, NR>(f3, sp, dv, coff, roff, r8, K, k0 + 28, lk);
+            }
+        } else {
+            DenseRaw<NT, NR> fa, fb;
+            dense_load<NT, NR>(fa, sp, dv, coff, roff, r8, K, 0, lk);
+            for (int k0 = 0; k0 < K; k0 += 8) {     // steps past K contribute zeros (dk = 0)
+                dense_load<NT, NR>(fb, sp, dv, coff, roff, r8, K, k0 + 4, lk);
+                __builtin_amdgcn_sched_barrier(0);
+                dense_mma<NT, NR>(fa, acc, mbits, K, k0, lk);
+                __builtin_amdgcn_sched_barrier(0);
+                dense_load<NT, NR>(fa, sp, dv, coff, roff, r8, K, k0 + 8, lk);
+                __builtin_amdgcn_sched_barrier(0);
+                if (k0 + 4 < K) dense_mma<NT, NR>(fb, acc, mbits, K, k0 + 4, lk);   // narrow sources (K <= 4): one step
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        Tc = Tn;
+    }
+#pragma unroll
+    for (int tj = 0; tj < NT; tj++)
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) {
+            const int jj = (tj0 + tj) * 16 + lk + 4 * reg;
+#pragma unroll
+            for (int ti = 0; ti < NR; ti++) {
+                const int ii = (ti0 + ti) * 16 + l15;
+                if (LDS_OUT) lds_out[ii * 65 + jj] = acc[tj][ti][reg];
+                else if (ii < nrt && jj < wt) st_off(tp, (unsigned)(ii + jj * rt) * 8u, acc[tj][ti][reg]);
+            }
+        }
+}
+
+template <int NT, int NR>
+__device__ __forceinline__ void dense_tile(const DevPlan &P, const DenseGroup *Gp, int lane, int tj0, int ti0) {
+    // one self-contained record per tile (no group -> supernode tables -> panel chain of dependent loads)
+    const DenseGroup G = *Gp;
+    const int task_begin = rfl(G.task_begin), task_end = rfl(G.task_end);
+    const int wt = rfl(G.wt);
+    if (tj0 * 16 >= wt) return;
+    const int rt = rfl(G.rt);
+    double *tp = rfl_ptr(P.Lx + G.tile_off);
+    const int nrt = rfl(G.nrt);
+    if (ti0 * 16 >= nrt) return;
+    dense_tile_core<NT, NR, false>(P, tp, rt, nrt, wt, task_begin, task_end, lane, tj0, ti0, nullptr);
+}
+
+}  // namespace hipkkt

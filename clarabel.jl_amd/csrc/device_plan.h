@@ -47,6 +47,9 @@ struct FrontBatch {
     // factorisation (hipkkt_factor.cpp) splits a batch into the launch of the row blocks the next batches need at once (0, R, 0) and
     // the launch of the rest (R, nblk, 16), which finds every hand-off flag already set
     int32_t i_base, i_end, tick, pad;
+    // extra workgroups of the launch (blockIdx >= i_end - i_base): dense update tiles [x_begin, x_begin + x_count) of the PREVIOUS stage,
+    // four per workgroup (one wavefront each), on compute units the panel kernel leaves idle (hipkkt_factor.cpp)
+    int32_t x_begin, x_count;
 };
 constexpr int64_t kFbScratch = (int64_t)kFbMax * 4160 + (int64_t)(kFbMax * (kFbMax - 1) / 2) * 4096;   // doubles per batch
 constexpr int kGathHeavy = 24;    // target entries with more pairs than this get a wavefront of their own

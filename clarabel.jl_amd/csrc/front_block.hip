@@ -16,10 +16,10 @@
 #include <stdint.h>
 
 #include "kernels.h"
+#include "dense_tile.h"
 
 namespace hipkkt {
 
-typedef double v4f64 __attribute__((ext_vector_type(4)));
 constexpr int FLD = 65;   // LDS row stride of a 64 x 64 tile
 
 __device__ __forceinline__ int fb_ldi(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -133,6 +133,13 @@ __device__ __forceinline__ void fb_store_panel(const DevPlan &P, const FrontPane
     }
 }
 
+// kept out of line: the register allocation of the panel path must not depend on it
+__device__ __attribute__((noinline)) void fb_extra_tiles(const DevPlan &P, int begin, int count, int xb) {
+    const int lane = threadIdx.x & 63;
+    const int idx = rfl(xb * 4 + (int)(threadIdx.x >> 6));
+    if (idx < count) dense_tile<4, 4>(P, P.dgroups + begin + idx, lane, 0, 0);
+}
+
 #define FB_T(slot) do { if (trace && tid == 0 && i < 8) trace[(B.sync_off / 128 * 8 + i) * 16 + (slot)] = (long long)wall_clock64(); } while (0)
 __global__ void __launch_bounds__(256)
 k_front_block(DevPlan P, FrontBatch B, int *sync_all, double *scratch_all, double dyn_eps, double dyn_delta, long long *trace) {
@@ -146,6 +153,10 @@ k_front_block(DevPlan P, FrontBatch B, int *sync_all, double *scratch_all, doubl
     double *scratch = scratch_all + B.scratch_off;
     double *ltiles = scratch + (int64_t)kFbMax * 4160;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, lk = lane >> 4;
+    if ((int)blockIdx.x >= B.i_end - B.i_base) {          // extra workgroup: four tiles of the previous update stage (no hand-off, no LDS)
+        fb_extra_tiles(P, B.x_begin, B.x_count, (int)blockIdx.x - (B.i_end - B.i_base));
+        return;
+    }
     if (tid == 0) sblk = atomicAdd(sync + B.tick, 1);
     __syncthreads();
     const int i = B.i_base + sblk;                        // row block of this workgroup
@@ -406,7 +417,7 @@ k_front_block(DevPlan P, FrontBatch B, int *sync_all, double *scratch_all, doubl
 
 void launch_front_block(hipStream_t st, const DevPlan &P, const FrontBatch &B, int *sync_all, double *scratch_all, double dyn_eps,
                         double dyn_delta, long long *trace) {
-    if (B.i_end > B.i_base) hipLaunchKernelGGL(k_front_block, dim3(B.i_end - B.i_base), dim3(256), 0, st, P, B, sync_all, scratch_all, dyn_eps, dyn_delta, trace);
+    if (B.i_end > B.i_base) hipLaunchKernelGGL(k_front_block, dim3(B.i_end - B.i_base + (B.x_count + 3) / 4), dim3(256), 0, st, P, B, sync_all, scratch_all, dyn_eps, dyn_delta, trace);
 }
 
 }  // namespace hipkkt

@@ -596,6 +596,7 @@ int32_t hipkkt_get_profile(hipkkt_handle h, double *o) {
     if (!h || !o) return HIPKKT_ERR_ARGUMENT;
     o[0] = h->t_last_update; o[1] = h->prof_dense4_ms; o[2] = h->prof_dense4_flops; o[3] = (double)h->prof_dense4_launches;
     o[4] = h->prof_fb_ms; o[5] = (double)h->prof_fb_launches; o[6] = (double)h->prof_fb_panels; o[7] = h->prof_fb_flops;
+    o[8] = h->prof_extra_tiles; o[9] = h->prof_extra_flops;
     return HIPKKT_OK;
 }
 

@@ -35,7 +35,7 @@ static hipEvent_t new_fork_event(hipkkt_solver *S) {
     return e;
 }
 
-void enqueue_updates(hipkkt_solver *S, int l, bool split_far = false) {
+void enqueue_updates(hipkkt_solver *S, int l, bool split_far = false, int dense_skip_tail = 0) {
     const HostPlan &P = S->plan;
     hipStream_t st = S->stream;
     if (l + 1 < P.nlevels && P.lvl_fused[l + 1]) return;   // applied inside the next level's panel kernel
@@ -55,11 +55,36 @@ void enqueue_updates(hipkkt_solver *S, int l, bool split_far = false) {
         launch_update_gather(S->side, S->dp, P.gath_stage_ptr[l], ngath, S->gath_heavy_ptr[l], S->gath_heavy_ptr[l + 1] - S->gath_heavy_ptr[l]);
         HK_CHECK(hipEventRecord(joined, S->side));
     }
-    launch_update_dense(st, S->dp, g0, nd - (split_far ? P.upd_stage_nfar[l] : 0), 0, nd > 0 && P.upd_stage_flops_dense[l] >= 1.5e6 * nd);
+    launch_update_dense(st, S->dp, g0, nd - (split_far ? P.upd_stage_nfar[l] : 0) - dense_skip_tail, 0, nd > 0 && P.upd_stage_flops_dense[l] >= 1.5e6 * nd);
     if (!par)
         launch_update_gather(st, S->dp, P.gath_stage_ptr[l], ngath, S->gath_heavy_ptr[l], S->gath_heavy_ptr[l + 1] - S->gath_heavy_ptr[l]);
     launch_update_stage(st, S->dp, g0 + nd + ng, P.upd_stage_ptr[l + 1] - g0 - nd - ng);
     if (par) HK_CHECK(hipStreamWaitEvent(st, joined, 0));
+}
+
+// How many of a front batch's far tiles ride in the next k_front_block launch (HIPKKT_FB_EXTRA, enqueue_factor).  That launch has
+// `next_blk` workgroups of its own, one per compute unit (100 KB of LDS), and lasts ~115 us: every other compute unit can take one
+// extra workgroup = four tiles (one per SIMD, ~77 us each) for +5-10 us on the launch.  The stage's own launch then holds M = nd - r
+// tiles, and its cost is a step function of M (rounds of one tile per SIMD; measured on MI355X, K = 320: 1024 tiles 77 us, +<=256 as
+// strips 86, +<=512 as halves 94, 2048 tiles 129, 2304 145, 3072 194; <= 384 tiles 20 us + 0.065 per tile, <= 768 as strips 65): take as many
+// extras as fit, then give back what does not move M below the next step.  Never tiles of the next batch's columns (the first
+// `ncrit` groups of the stage).
+int fb_extra_tiles_of_stage(int nd, int ncrit, int next_blk) {
+    static const int cus = [] { const char *e = getenv("HIPKKT_FB_EXTRA_CUS"); return e ? atoi(e) : 254; }();
+    static const int rmin = [] { const char *e = getenv("HIPKKT_FB_EXTRA_MIN"); return e ? atoi(e) : 64; }();
+    const int rmax = std::min(nd - ncrit, std::max(0, 4 * (cus - next_blk)));
+    if (rmax < rmin) return 0;
+    const int mmin = nd - rmax;
+    int m;
+    if (mmin <= 384) m = mmin;            // the two-workgroups-per-tile launch of small stages costs ~20 us + 0.065 us per tile: no step
+    else if (mmin <= 768) m = 768;
+    else {
+        const int k = mmin / 1024, rem = mmin % 1024;
+        m = 1024 * k + (rem == 0 ? 0 : rem <= 256 ? 256 : rem <= 512 ? 512 : 1024);
+    }
+    m = std::max(std::min(m, nd), ncrit);
+    const int r = nd - m;
+    return r >= rmin ? r : 0;
 }
 
 void enqueue_factor(hipkkt_solver *S, int static_enable, double eps_const, double eps_prop) {
@@ -88,13 +113,16 @@ void enqueue_factor(hipkkt_solver *S, int static_enable, double eps_const, doubl
     const bool la = fb && S->lookahead && S->la_streams[0] != nullptr;
     int cur_bi = -1;
     hipEvent_t ev_bg = nullptr;                           // the background launch in flight
+    int extra_begin = 0, extra_count = 0;                 // dense tiles handed to the next k_front_block launch
     for (int l = 0; l < P.nlevels; l++) {
         if (fb && S->lvl_fb[l] != -1) {
             // a front's update batch: one launch for its panels and their just-in-time updates, then the batch's far stage
             if (S->lvl_fb[l] >= 0) {
                 cur_bi = S->lvl_fb[l];
-                launch_front_block(st, S->dp, S->fbatches[(size_t)cur_bi], S->d_fb_sync, S->d_fb_scratch, S->opts.dynamic_reg_eps,
-                                   S->opts.dynamic_reg_delta, S->d_fb_trace);
+                FrontBatch B = S->fbatches[(size_t)cur_bi];
+                B.x_begin = extra_begin; B.x_count = extra_count;      // the partial last round of the stage before (HIPKKT_FB_EXTRA)
+                extra_begin = extra_count = 0;
+                launch_front_block(st, S->dp, B, S->d_fb_sync, S->d_fb_scratch, S->opts.dynamic_reg_eps, S->opts.dynamic_reg_delta, S->d_fb_trace);
             }
             const bool last = l + 1 >= P.nlevels || S->lvl_fb[l + 1] != -2;
             if (!last) continue;                          // the stages inside the batch are applied by the kernel itself
@@ -128,7 +156,21 @@ void enqueue_factor(hipkkt_solver *S, int static_enable, double eps_const, doubl
             HK_CHECK(hipStreamWaitEvent(st, pending, 0));
             pending = nullptr;
         }
-        enqueue_updates(S, l, nfar > 0);
+        int skip = 0;
+        if (fb && S->fb_extra && !la && cur_bi >= 0 && S->lvl_fb[l] != -1 && S->la[(size_t)cur_bi].has_next && nfar == 0) {
+            // The far stage of a front batch runs in rounds of 1024 tiles (one per SIMD; 2048 with two co-resident wavefronts); what is
+            // left after the whole rounds keeps a fraction of the device busy for a full tile time.  Those tiles -- taken from the END
+            // of the [columns of the next batch | rest] order, so the next panel kernel does not need them -- ride in the next
+            // k_front_block launch as extra workgroups on the compute units it leaves idle.
+            const hipkkt_solver::LaBatch &A = S->la[(size_t)cur_bi];
+            const int r = fb_extra_tiles_of_stage(P.upd_stage_ndense[l], A.ncrit, A.next_blk);
+            if (r > 0 && P.upd_stage_flops_dense[l] >= 1.5e6 * P.upd_stage_ndense[l]) {
+                skip = r;
+                extra_begin = P.upd_stage_ptr[l] + P.upd_stage_ndense[l] - r;
+                extra_count = r;
+            }
+        }
+        enqueue_updates(S, l, nfar > 0, skip);
         if (nfar > 0) {   // forked AFTER the near updates: the far tiles must not compete with them for the CUs
             hipEvent_t e1 = new_event(), e2 = new_event();
             HK_CHECK(hipEventRecord(e1, st));
@@ -234,6 +276,19 @@ static int32_t refactor_once(hipkkt_handle h, int32_t static_reg_enable, double 
         std::vector<hipEvent_t> evf;        // around every k_front_block launch
         int fb_panels = 0;
         double fb_flops = 0;                // update flops of the stages inside the batches (executed by k_front_block)
+        int cur_bi = -1, extra_begin = 0, extra_count = 0;
+        std::vector<double> evd_flops;      // flops / tiles of the timed dense launches (a launch may have handed tiles to the next k_front_block)
+        std::vector<int> evd_tiles;
+        S->prof_extra_tiles = 0; S->prof_extra_flops = 0;
+        auto dense_flops = [&](int gb, int n) {
+            double f = 0;
+            for (int g = gb; g < gb + n; g++)
+                for (int q = P.upd_groups[g].task_begin; q < P.upd_groups[g].task_end; q++) {
+                    const UpdTask &T = P.upd_tasks[q];
+                    f += 2.0 * T.nrows * T.ncols * (P.sn_first[T.src + 1] - P.sn_first[T.src]);
+                }
+            return f;
+        };
         for (int l = 0; l < P.nlevels; l++) {
             if (fb && S->lvl_fb[l] != -1) {
                 if (S->lvl_fb[l] >= 0) {
@@ -241,8 +296,12 @@ static int32_t refactor_once(hipkkt_handle h, int32_t static_reg_enable, double 
                     HK_CHECK(hipEventCreate(&a));
                     HK_CHECK(hipEventCreate(&b));
                     HK_CHECK(hipEventRecord(a, st));
-                    launch_front_block(st, S->dp, S->fbatches[S->lvl_fb[l]], S->d_fb_sync, S->d_fb_scratch, S->opts.dynamic_reg_eps,
-                                       S->opts.dynamic_reg_delta, S->d_fb_trace);
+                    cur_bi = S->lvl_fb[l];
+                    FrontBatch B = S->fbatches[(size_t)cur_bi];
+                    B.x_begin = extra_begin; B.x_count = extra_count;
+                    extra_begin = extra_count = 0;
+                    launch_front_block(st, S->dp, B, S->d_fb_sync, S->d_fb_scratch, S->opts.dynamic_reg_eps, S->opts.dynamic_reg_delta,
+                                       S->d_fb_trace);
                     HK_CHECK(hipEventRecord(b, st));
                     evf.push_back(a);
                     evf.push_back(b);
@@ -259,13 +318,23 @@ static int32_t refactor_once(hipkkt_handle h, int32_t static_reg_enable, double 
                 HK_CHECK(hipEventCreate(&b));
                 HK_CHECK(hipEventRecord(a, st));
                 const int g0 = P.upd_stage_ptr[l], nd = P.upd_stage_ndense[l], ng = P.upd_stage_ngather[l];
-                launch_update_dense(st, S->dp, g0, nd, 0, nd > 0 && P.upd_stage_flops_dense[l] >= 1.5e6 * nd);
-                if (nd > 384) {   // the one-wavefront-per-tile variant (see launch_update_dense)
+                int skip = 0;                                              // (the same rule as enqueue_factor)
+                if (fb && S->fb_extra && !(S->lookahead && S->la_streams[0]) && cur_bi >= 0 && S->lvl_fb[l] != -1 && S->la[(size_t)cur_bi].has_next &&
+                    P.upd_stage_flops_dense[l] >= 1.5e6 * nd) {
+                    skip = fb_extra_tiles_of_stage(nd, S->la[(size_t)cur_bi].ncrit, S->la[(size_t)cur_bi].next_blk);
+                    if (skip > 0) { extra_begin = g0 + nd - skip; extra_count = skip; }
+                }
+                const double xf = skip > 0 ? dense_flops(g0 + nd - skip, skip) : 0.0;
+                S->prof_extra_tiles += skip; S->prof_extra_flops += xf;
+                launch_update_dense(st, S->dp, g0, nd - skip, 0, nd > 0 && P.upd_stage_flops_dense[l] >= 1.5e6 * nd);
+                if (nd - skip > 384) {   // the one-wavefront-per-tile variant (see launch_update_dense)
                     HK_CHECK(hipEventCreate(&c2));
                     HK_CHECK(hipEventRecord(c2, st));
                     evd.push_back(a);
                     evd.push_back(c2);
                     evd_level.push_back(l);
+                    evd_flops.push_back(P.upd_stage_flops_dense[l] - xf);
+                    evd_tiles.push_back(nd - skip);
                 }
                 launch_update_gather(st, S->dp, P.gath_stage_ptr[l], P.gath_stage_ptr[l + 1] - P.gath_stage_ptr[l], S->gath_heavy_ptr[l],
                          S->gath_heavy_ptr[l + 1] - S->gath_heavy_ptr[l]);
@@ -290,11 +359,11 @@ static int32_t refactor_once(hipkkt_handle h, int32_t static_reg_enable, double 
             float ms = 0;
             (void)hipEventElapsedTime(&ms, evd[i], evd[i + 1]);
             S->prof_dense4_ms += ms;
-            S->prof_dense4_flops += P.upd_stage_flops_dense[evd_level[i / 2]];
+            S->prof_dense4_flops += evd_flops[i / 2];
             S->prof_dense4_launches++;
             S->prof_launch_ms.push_back(ms);
-            S->prof_launch_flops.push_back(P.upd_stage_flops_dense[evd_level[i / 2]]);
-            S->prof_launch_tiles.push_back(P.upd_stage_ndense[evd_level[i / 2]]);
+            S->prof_launch_flops.push_back(evd_flops[i / 2]);
+            S->prof_launch_tiles.push_back(evd_tiles[i / 2]);
         }
         for (size_t i = 1; i < evd.size(); i += 2) (void)hipEventDestroy(evd[i]);
         for (hipEvent_t e : evs) (void)hipEventDestroy(e);

@@ -141,10 +141,12 @@ struct hipkkt_solver {
     struct LaBatch {
         bool on = false, first = false, last = false;   // inside a look-ahead region / its first / its last batch
         int next_blk = 0;                               // workgroups of the next batch's panel kernel
+        bool has_next = false;                          // the next batch of the same front follows at once: [chain | rest] order valid
         int ncrit = 0, nE = 0;                          // far stage: [crit | E | far] dense groups (setup reorders them)
     };
     std::vector<LaBatch> la;
     bool lookahead = false;
+    bool fb_extra = true;                // the partial last round of a batch's far updates rides in the next k_front_block launch (HIPKKT_FB_EXTRA=0: off)
     static constexpr int kLaStreams = 4;
     static int la_keep(int k) { return k == 0 ? 16 : k == 1 ? 32 : k == 2 ? 64 : 96; }   // compute units left to the panel kernel
     hipStream_t la_streams[kLaStreams] = {nullptr, nullptr, nullptr, nullptr};            // throughput streams, CU-masked
@@ -221,6 +223,7 @@ struct hipkkt_solver {
     double last_eps = 0;
     double prof_fb_flops = 0;
     double prof_fb_ms = 0;               // last profiled refactorisation: the k_front_block launches
+    double prof_extra_tiles = 0, prof_extra_flops = 0;   // ... dense update tiles / flops that rode in them (HIPKKT_FB_EXTRA)
     int prof_fb_launches = 0, prof_fb_panels = 0;
     double prof_dense4_ms = 0, prof_dense4_flops = 0;   // last profiled refactorisation: k_update_dense<4,4> alone
     int prof_dense4_launches = 0;

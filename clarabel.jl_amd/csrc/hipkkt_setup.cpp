@@ -87,6 +87,8 @@ void init_runtime(hipkkt_solver *S) {
                 }
             }
         }
+        const char *fx = getenv("HIPKKT_FB_EXTRA");   // 0: every far stage applies all of its tiles in its own launch (A/B timing)
+        S->fb_extra = !(fx && fx[0] == '0');
         const char *fw = getenv("HIPKKT_FAR_WGS");
         if (fw) S->far_wgs = atoi(fw);
     }
@@ -562,7 +564,7 @@ static void plan_lookahead(hipkkt_solver *S) {
     S->la.assign(nbh, hipkkt_solver::LaBatch());
     {
         const char *e = getenv("HIPKKT_FRONT_BLOCK");
-        if (!S->lookahead || (e && e[0] == '0')) return;
+        if ((!S->lookahead && !S->fb_extra) || (e && e[0] == '0')) return;
     }
     {
         std::vector<std::vector<int>> panel_batch(P.fronts.size());
@@ -570,6 +572,29 @@ static void plan_lookahead(hipkkt_solver *S) {
         for (size_t q = 0; q < nbh; q++)
             for (int t = 0; t < hb[q].nb; t++) panel_batch[(size_t)hb[q].front][(size_t)(hb[q].p0 + t)] = (int)q;
         auto dense_only = [&](int l) { return P.upd_stage_ptr[l + 1] - P.upd_stage_ptr[l] == P.upd_stage_ndense[l] && P.gath_stage_ptr[l + 1] == P.gath_stage_ptr[l]; };
+        // [columns of the next batch | rest] for every batch whose successor follows at once (dense groups only; stable)
+        auto part = [&](size_t b, size_t e) {
+            hipkkt_solver::LaBatch &A = S->la[b];
+            const int l = hb[b].level_last, g0 = P.upd_stage_ptr[l], nd = P.upd_stage_ndense[l];
+            const FrontDesc &F = P.fronts[(size_t)hb[b].front];
+            auto near = [&](const UpdGroup &G) {
+                if (P.sn_front[G.tgt] != hb[b].front) return false;
+                const int tb = panel_batch[(size_t)hb[b].front][(size_t)(G.tgt - F.s0)];
+                return tb == (int)b + 1 && tb <= (int)e;
+            };
+            auto gb = Pm.upd_groups.begin() + g0, ge = gb + nd;
+            A.ncrit = (int)(std::stable_partition(gb, ge, near) - gb);
+            A.nE = 0;
+            A.has_next = b < e;
+            A.next_blk = b < e ? (P.front_panels[P.fronts[(size_t)hb[b + 1].front].fp_off + hb[b + 1].p0].r + 63) / 64 : 0;
+        };
+        if (S->fb_extra && !S->lookahead) {
+            for (size_t b = 0; b < nbh; b++) {
+                const bool next = b + 1 < nbh && hb[b + 1].front == hb[b].front && hb[b + 1].p0 == hb[b].p0 + hb[b].nb;
+                part(b, next ? b + 1 : b);
+            }
+            return;
+        }
         size_t q = 0;
         while (q < nbh) {
             size_t e = q;
@@ -613,7 +638,7 @@ static void build_front_batches(hipkkt_solver *S) {
             B.nb = H.nb;
             B.r0 = P.front_panels[F.fp_off + H.p0].r;
             B.nblk = (B.r0 + 63) / 64;
-            B.i_base = 0; B.i_end = B.nblk; B.tick = 0; B.pad = 0;
+            B.i_base = 0; B.i_end = B.nblk; B.tick = 0; B.pad = 0; B.x_begin = 0; B.x_count = 0;
             B.sync_off = 128 * (int)S->fbatches.size();
             B.scratch_off = kFbScratch * (int64_t)S->fbatches.size();
             S->lvl_fb[H.level_first] = (int)S->fbatches.size();

@@ -265,10 +265,11 @@ class Handle:
         return out[: ln.value]
 
     def profile(self):
-        o = np.zeros(8)
+        o = np.zeros(10)
         self.L.hipkkt_get_profile(self.h, o)
         return dict(update_ms=o[0], dense4_ms=o[1], dense4_flops=o[2], dense4_launches=int(o[3]), front_block_ms=o[4],
-                    front_block_launches=int(o[5]), front_block_panels=int(o[6]), front_block_update_flops=o[7])
+                    front_block_launches=int(o[5]), front_block_panels=int(o[6]), front_block_update_flops=o[7],
+                    front_block_extra_tiles=int(o[8]), front_block_extra_flops=o[9])
 
     # ---- numeric
     def update_values(self, index, values):

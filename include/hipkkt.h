@@ -271,8 +271,10 @@ int32_t hipkkt_reset_timing(hipkkt_handle h);
 /* last refactorisation run with profiling enabled: out[0] = ms of all Schur-update kernels, out[1] = ms of the
  * k_update_dense<4,4> launches alone (one wavefront per 64x64 tile), out[2] = their algorithmic flops, out[3] = their
  * number; out[4] = ms of the k_front_block launches (one per update batch of a front), out[5] = their number, out[6] = the panels
- * they factor, out[7] = the Schur-update flops of the stages they absorb (not part of out[0]'s kernels) */
-int32_t hipkkt_get_profile(hipkkt_handle h, double *out8);
+ * they factor, out[7] = the Schur-update flops of the stages they absorb (not part of out[0]'s kernels), out[8] / out[9] = dense update
+ * tiles / their flops that rode in those launches as extra workgroups instead of in their stage's own launch (the partial last round
+ * of a front batch's far updates; not part of out[0] .. out[2] either) */
+int32_t hipkkt_get_profile(hipkkt_handle h, double *out10);
 /* the k_update_dense<4,4> launches of that refactorisation one by one: ms[i], algorithmic flops[i], target tiles[i]
  * (any array may be NULL; at most cap entries are written, *count receives the number of launches) */
 int32_t hipkkt_get_profile_launches(hipkkt_handle h, double *ms, double *flops, double *tiles, int64_t cap, int64_t *count);

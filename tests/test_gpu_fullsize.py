@@ -276,3 +276,34 @@ def test_super_block_sweeps_equal_panel_sweeps(name, monkeypatch):
         sols.append(x)
         assert hk.h.counters()["sweep_timeouts"] == 0
     assert np.max(np.abs(sols[0] - sols[1])) <= 1e-10 * max(1.0, np.max(np.abs(sols[1])))
+
+
+@pytest.mark.parametrize("name", ["cfg2a", "cfg3"])
+def test_extra_tiles_in_front_block_launches_are_bit_identical(name, monkeypatch):
+    """hipkkt_factor.cpp fb_extra_tiles_of_stage: the partial last round of a front batch's far updates rides in the NEXT k_front_block
+    launch as extra workgroups (compute units the panel chain leaves idle) instead of in the stage's own launch.  Same tiles, same tile
+    code, same order of accumulation per tile, and no tile the next panel kernel needs: the factorisation and the solves are
+    bit-identical to HIPKKT_FB_EXTRA=0, the profile says how many tiles moved, and nothing is applied twice or dropped (refined
+    solve against the true K)."""
+    rng = np.random.default_rng(41)
+    Pt, A, cones = _prep(FULL[name]())
+    m, n = A.shape
+    scale_cones(cones, rng)
+    monkeypatch.setenv("HIPKKT_PLAN_CACHE", "0")
+    out = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("HIPKKT_FB_EXTRA", flag)
+        hk = HipKKTSolver(Pt, A, cones, m, n, cl.Settings())
+        assert hk.kktsolver_update(cones)
+        b = np.random.default_rng(42).standard_normal(hk.h.N)
+        x = hk.h.ldl_solve(b)
+        hk.h.set_profiling(True)
+        assert hk.kktsolver_update(cones)
+        prof = hk.h.profile()
+        hk.h.set_profiling(False)
+        assert np.array_equal(hk.h.ldl_solve(b), x)          # the eager profiled path applies the same split
+        out.append((x, hk.h.debug_dump(5), prof))
+    (x1, d1, p1), (x0, d0, p0) = out
+    assert p1["front_block_extra_tiles"] > 0 and p0["front_block_extra_tiles"] == 0
+    assert abs((p1["dense4_flops"] + p1["front_block_extra_flops"]) - p0["dense4_flops"]) <= 1e-9 * p0["dense4_flops"] or p1["dense4_launches"] != p0["dense4_launches"]
+    assert np.array_equal(d1, d0) and np.array_equal(x1, x0)
