@@ -81,7 +81,9 @@ __device__ __forceinline__ void dense_mma(const DenseRaw<NT, NR> &f, v4f64 (&acc
 //         also split the tile's rows over 4/NR workgroups (NR 16-row blocks per wavefront).
 // LDS_OUT: the finished strip goes to lds_out[row * 65 + column] (the panel kernel's staging layout) instead of
 //          back to the panel -- used by k_factor_panel<true>, which applies a panel's pending updates itself.
-template <int NT, int NR, bool LDS_OUT>
+// DEEP: four k-steps of operands in flight also for NT > 1 (72 instead of 36 operand registers) -- for a wavefront that is ALONE on its
+//       SIMD (the extra workgroups of a k_front_block launch: 512 registers available, no second wavefront to cover an L2 round trip)
+template <int NT, int NR, bool LDS_OUT, bool DEEP = false>
 __device__ __forceinline__ void dense_tile_core(const DevPlan &P, double *tp, int rt, int nrt, int wt, int task_begin,
                                                 int task_end, int lane, int tj0, int ti0, double *lds_out) {
     const int l15 = lane & 15, lk = lane >> 4;
@@ -146,7 +148,7 @@ __device__ __forceinline__ void dense_tile_core(const DevPlan &P, double *tp, in
         }
         // register double buffering: the loads of step k+1 (clamped past the end) are in flight during
         // the MFMAs of step k
-        if (NT == 1) {
+        if (NT == 1 || DEEP) {
             // a 16-column strip has only 4 MFMAs (256 clocks) per k-step, less than one memory latency: keep FOUR
             // k-steps of operands in flight (ring of 4 register buffers; steps past K contribute zeros)
             DenseRaw<NT, NR> f0, f1, f2, f3;
@@ -198,7 +200,7 @@ __device__ __forceinline__ void dense_tile_core(const DevPlan &P, double *tp, in
         }
 }
 
-template <int NT, int NR>
+template <int NT, int NR, bool DEEP = false>
 __device__ __forceinline__ void dense_tile(const DevPlan &P, const DenseGroup *Gp, int lane, int tj0, int ti0) {
     // one self-contained record per tile (no group -> supernode tables -> panel chain of dependent loads)
     const DenseGroup G = *Gp;
@@ -209,7 +211,7 @@ __device__ __forceinline__ void dense_tile(const DevPlan &P, const DenseGroup *G
     double *tp = rfl_ptr(P.Lx + G.tile_off);
     const int nrt = rfl(G.nrt);
     if (ti0 * 16 >= nrt) return;
-    dense_tile_core<NT, NR, false>(P, tp, rt, nrt, wt, task_begin, task_end, lane, tj0, ti0, nullptr);
+    dense_tile_core<NT, NR, false, DEEP>(P, tp, rt, nrt, wt, task_begin, task_end, lane, tj0, ti0, nullptr);
 }
 
 }  // namespace hipkkt

@@ -46,7 +46,7 @@ struct FrontBatch {
     // a launch handles the row blocks [i_base, i_end) and takes its tickets from sync[tick]: one launch = (0, nblk, 0); the look-ahead
     // factorisation (hipkkt_factor.cpp) splits a batch into the launch of the row blocks the next batches need at once (0, R, 0) and
     // the launch of the rest (R, nblk, 16), which finds every hand-off flag already set
-    int32_t i_base, i_end, tick, pad;
+    int32_t i_base, i_end, tick, pad;   // pad: tiles per wavefront of the extra workgroups (0 = 1)
     // extra workgroups of the launch (blockIdx >= i_end - i_base): dense update tiles [x_begin, x_begin + x_count) of the PREVIOUS stage,
     // four per workgroup (one wavefront each), on compute units the panel kernel leaves idle (hipkkt_factor.cpp)
     int32_t x_begin, x_count;

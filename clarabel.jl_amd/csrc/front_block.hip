@@ -134,10 +134,12 @@ __device__ __forceinline__ void fb_store_panel(const DevPlan &P, const FrontPane
 }
 
 // kept out of line: the register allocation of the panel path must not depend on it
-__device__ __attribute__((noinline)) void fb_extra_tiles(const DevPlan &P, int begin, int count, int xb) {
+// Each wavefront is alone on its SIMD (100 KB of LDS per workgroup): tiles with four k-steps of operands in flight, kFbExtraPerWave
+// of them one after the other -- the launch lasts as long as its panel chain anyway.
+__device__ __attribute__((noinline)) void fb_extra_tiles(const DevPlan &P, int begin, int count, int xb, int per_wave) {
     const int lane = threadIdx.x & 63;
-    const int idx = rfl(xb * 4 + (int)(threadIdx.x >> 6));
-    if (idx < count) dense_tile<4, 4>(P, P.dgroups + begin + idx, lane, 0, 0);
+    int idx = rfl((xb * 4 + (int)(threadIdx.x >> 6)) * per_wave);
+    for (int q = 0; q < per_wave && idx < count; q++, idx++) dense_tile<4, 4, true>(P, P.dgroups + begin + idx, lane, 0, 0);
 }
 
 #define FB_T(slot) do { if (trace && tid == 0 && i < 8) trace[(B.sync_off / 128 * 8 + i) * 16 + (slot)] = (long long)wall_clock64(); } while (0)
@@ -154,7 +156,7 @@ k_front_block(DevPlan P, FrontBatch B, int *sync_all, double *scratch_all, doubl
     double *ltiles = scratch + (int64_t)kFbMax * 4160;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, lk = lane >> 4;
     if ((int)blockIdx.x >= B.i_end - B.i_base) {          // extra workgroup: four tiles of the previous update stage (no hand-off, no LDS)
-        fb_extra_tiles(P, B.x_begin, B.x_count, (int)blockIdx.x - (B.i_end - B.i_base));
+        fb_extra_tiles(P, B.x_begin, B.x_count, (int)blockIdx.x - (B.i_end - B.i_base), B.pad > 0 ? B.pad : 1);
         return;
     }
     if (tid == 0) sblk = atomicAdd(sync + B.tick, 1);
@@ -417,7 +419,7 @@ k_front_block(DevPlan P, FrontBatch B, int *sync_all, double *scratch_all, doubl
 
 void launch_front_block(hipStream_t st, const DevPlan &P, const FrontBatch &B, int *sync_all, double *scratch_all, double dyn_eps,
                         double dyn_delta, long long *trace) {
-    if (B.i_end > B.i_base) hipLaunchKernelGGL(k_front_block, dim3(B.i_end - B.i_base + (B.x_count + 3) / 4), dim3(256), 0, st, P, B, sync_all, scratch_all, dyn_eps, dyn_delta, trace);
+    if (B.i_end > B.i_base) hipLaunchKernelGGL(k_front_block, dim3(B.i_end - B.i_base + (B.x_count + 4 * std::max(B.pad, 1) - 1) / (4 * std::max(B.pad, 1))), dim3(256), 0, st, P, B, sync_all, scratch_all, dyn_eps, dyn_delta, trace);
 }
 
 }  // namespace hipkkt

@@ -62,29 +62,51 @@ void enqueue_updates(hipkkt_solver *S, int l, bool split_far = false, int dense_
     if (par) HK_CHECK(hipStreamWaitEvent(st, joined, 0));
 }
 
-// How many of a front batch's far tiles ride in the next k_front_block launch (HIPKKT_FB_EXTRA, enqueue_factor).  That launch has
-// `next_blk` workgroups of its own, one per compute unit (100 KB of LDS), and lasts ~115 us: every other compute unit can take one
-// extra workgroup = four tiles (one per SIMD, ~77 us each) for +5-10 us on the launch.  The stage's own launch then holds M = nd - r
-// tiles, and its cost is a step function of M (rounds of one tile per SIMD; measured on MI355X, K = 320: 1024 tiles 77 us, +<=256 as
-// strips 86, +<=512 as halves 94, 2048 tiles 129, 2304 145, 3072 194; <= 384 tiles 20 us + 0.065 per tile, <= 768 as strips 65): take as many
-// extras as fit, then give back what does not move M below the next step.  Never tiles of the next batch's columns (the first
-// `ncrit` groups of the stage).
-int fb_extra_tiles_of_stage(int nd, int ncrit, int next_blk) {
+// How many of a front batch's far tiles ride in the next k_front_block launch (enqueue_factor; HIPKKT_FB_EXTRA=0: none).  That launch
+// has `next_blk` workgroups of its own, one per compute unit (100 KB of LDS), and lasts ~112 us: every other compute unit can take one
+// extra workgroup = four wavefronts, each alone on its SIMD, with one tile (launch +10 us) or two tiles one after the other (+28 us)
+// per wavefront.  The stage's own launch then holds M = nd - r tiles; its cost is a step function of M (rounds of one tile per SIMD;
+// measured on MI355X at K = 320: 1024 tiles 77 us, 2048 130, 3072 194; a remainder of <= 256 tiles as strips +13, <= 512 as halves
+// +20; <= 384 tiles in all: 20 us + 0.065 per tile; <= 768: 66 us).  Choose tiles per wavefront and M to minimise the sum; M sits
+// on a step (what would not move it below the next one is given back).  Never tiles of the next batch's columns (the first `ncrit`
+// groups of the stage).
+static double dense_stage_cost_us(int m) {
+    if (m <= 0) return 0.0;
+    if (m <= 384) return 20.0 + 0.065 * m;
+    if (m <= 768) return 66.0;
+    const int k = m / 1024, rem = m % 1024;
+    const double base = k == 0 ? 0.0 : k == 1 ? 77.0 : 65.0 * k;
+    if (rem == 0) return base;
+    if (rem <= 256) return base + 13.0;
+    if (rem <= 512) return base + 20.0;
+    return k == 0 ? 77.0 : 65.0 * (k + 1);
+}
+int fb_extra_tiles_of_stage(int nd, int ncrit, int next_blk, int *per_wave_out) {
     static const int cus = [] { const char *e = getenv("HIPKKT_FB_EXTRA_CUS"); return e ? atoi(e) : 254; }();
     static const int rmin = [] { const char *e = getenv("HIPKKT_FB_EXTRA_MIN"); return e ? atoi(e) : 64; }();
-    const int rmax = std::min(nd - ncrit, std::max(0, 4 * (cus - next_blk)));
-    if (rmax < rmin) return 0;
-    const int mmin = nd - rmax;
-    int m;
-    if (mmin <= 384) m = mmin;            // the two-workgroups-per-tile launch of small stages costs ~20 us + 0.065 us per tile: no step
-    else if (mmin <= 768) m = 768;
-    else {
-        const int k = mmin / 1024, rem = mmin % 1024;
-        m = 1024 * k + (rem == 0 ? 0 : rem <= 256 ? 256 : rem <= 512 ? 512 : 1024);
+    static const int pw_max = [] { const char *e = getenv("HIPKKT_FB_EXTRA_PER_WAVE"); return e ? std::max(1, std::min(2, atoi(e))) : 2; }();
+    static const double pen[3] = {0.0, 10.0, 28.0};       // what the panel launch gains in duration
+    double best = dense_stage_cost_us(nd);
+    int best_r = 0, best_pw = 1;
+    for (int pw = 1; pw <= pw_max; pw++) {
+        const int rmax = std::min(nd - ncrit, std::max(0, 4 * pw * (cus - next_blk)));
+        if (rmax < rmin) continue;
+        const int mmin = nd - rmax;
+        int m;
+        if (mmin <= 384) m = mmin;
+        else if (mmin <= 768) m = 768;
+        else {
+            const int k = mmin / 1024, rem = mmin % 1024;
+            m = 1024 * k + (rem == 0 ? 0 : rem <= 256 ? 256 : rem <= 512 ? 512 : 1024);
+        }
+        m = std::max(std::min(m, nd), ncrit);
+        const int r = nd - m;
+        if (r < rmin) continue;
+        const double c = dense_stage_cost_us(m) + pen[pw];
+        if (c < best - 1.0) { best = c; best_r = r; best_pw = pw; }
     }
-    m = std::max(std::min(m, nd), ncrit);
-    const int r = nd - m;
-    return r >= rmin ? r : 0;
+    *per_wave_out = best_pw;
+    return best_r;
 }
 
 void enqueue_factor(hipkkt_solver *S, int static_enable, double eps_const, double eps_prop) {
@@ -113,14 +135,14 @@ void enqueue_factor(hipkkt_solver *S, int static_enable, double eps_const, doubl
     const bool la = fb && S->lookahead && S->la_streams[0] != nullptr;
     int cur_bi = -1;
     hipEvent_t ev_bg = nullptr;                           // the background launch in flight
-    int extra_begin = 0, extra_count = 0;                 // dense tiles handed to the next k_front_block launch
+    int extra_begin = 0, extra_count = 0, extra_pw = 1;   // dense tiles handed to the next k_front_block launch, tiles per wavefront there
     for (int l = 0; l < P.nlevels; l++) {
         if (fb && S->lvl_fb[l] != -1) {
             // a front's update batch: one launch for its panels and their just-in-time updates, then the batch's far stage
             if (S->lvl_fb[l] >= 0) {
                 cur_bi = S->lvl_fb[l];
                 FrontBatch B = S->fbatches[(size_t)cur_bi];
-                B.x_begin = extra_begin; B.x_count = extra_count;      // the partial last round of the stage before (HIPKKT_FB_EXTRA)
+                B.x_begin = extra_begin; B.x_count = extra_count; B.pad = extra_pw;     // far tiles of the stage before (fb_extra_tiles_of_stage)
                 extra_begin = extra_count = 0;
                 launch_front_block(st, S->dp, B, S->d_fb_sync, S->d_fb_scratch, S->opts.dynamic_reg_eps, S->opts.dynamic_reg_delta, S->d_fb_trace);
             }
@@ -163,7 +185,7 @@ void enqueue_factor(hipkkt_solver *S, int static_enable, double eps_const, doubl
             // of the [columns of the next batch | rest] order, so the next panel kernel does not need them -- ride in the next
             // k_front_block launch as extra workgroups on the compute units it leaves idle.
             const hipkkt_solver::LaBatch &A = S->la[(size_t)cur_bi];
-            const int r = fb_extra_tiles_of_stage(P.upd_stage_ndense[l], A.ncrit, A.next_blk);
+            const int r = fb_extra_tiles_of_stage(P.upd_stage_ndense[l], A.ncrit, A.next_blk, &extra_pw);
             if (r > 0 && P.upd_stage_flops_dense[l] >= 1.5e6 * P.upd_stage_ndense[l]) {
                 skip = r;
                 extra_begin = P.upd_stage_ptr[l] + P.upd_stage_ndense[l] - r;
@@ -276,7 +298,7 @@ static int32_t refactor_once(hipkkt_handle h, int32_t static_reg_enable, double 
         std::vector<hipEvent_t> evf;        // around every k_front_block launch
         int fb_panels = 0;
         double fb_flops = 0;                // update flops of the stages inside the batches (executed by k_front_block)
-        int cur_bi = -1, extra_begin = 0, extra_count = 0;
+        int cur_bi = -1, extra_begin = 0, extra_count = 0, extra_pw = 1;
         std::vector<double> evd_flops;      // flops / tiles of the timed dense launches (a launch may have handed tiles to the next k_front_block)
         std::vector<int> evd_tiles;
         S->prof_extra_tiles = 0; S->prof_extra_flops = 0;
@@ -298,7 +320,7 @@ static int32_t refactor_once(hipkkt_handle h, int32_t static_reg_enable, double 
                     HK_CHECK(hipEventRecord(a, st));
                     cur_bi = S->lvl_fb[l];
                     FrontBatch B = S->fbatches[(size_t)cur_bi];
-                    B.x_begin = extra_begin; B.x_count = extra_count;
+                    B.x_begin = extra_begin; B.x_count = extra_count; B.pad = extra_pw;
                     extra_begin = extra_count = 0;
                     launch_front_block(st, S->dp, B, S->d_fb_sync, S->d_fb_scratch, S->opts.dynamic_reg_eps, S->opts.dynamic_reg_delta,
                                        S->d_fb_trace);
@@ -321,7 +343,7 @@ static int32_t refactor_once(hipkkt_handle h, int32_t static_reg_enable, double 
                 int skip = 0;                                              // (the same rule as enqueue_factor)
                 if (fb && S->fb_extra && !(S->lookahead && S->la_streams[0]) && cur_bi >= 0 && S->lvl_fb[l] != -1 && S->la[(size_t)cur_bi].has_next &&
                     P.upd_stage_flops_dense[l] >= 1.5e6 * nd) {
-                    skip = fb_extra_tiles_of_stage(nd, S->la[(size_t)cur_bi].ncrit, S->la[(size_t)cur_bi].next_blk);
+                    skip = fb_extra_tiles_of_stage(nd, S->la[(size_t)cur_bi].ncrit, S->la[(size_t)cur_bi].next_blk, &extra_pw);
                     if (skip > 0) { extra_begin = g0 + nd - skip; extra_count = skip; }
                 }
                 const double xf = skip > 0 ? dense_flops(g0 + nd - skip, skip) : 0.0;

@@ -262,9 +262,6 @@ __device__ __forceinline__ double pivot_rcp(double d) {
 // wave applies the rank-8 update to its own live blocks; the chunk rows (group O) follow with the published
 // values and a second barrier.  16 barriers per 64-column panel instead of 64, and only the 8x8 triangle of the
 // current block sits on the pivot-to-pivot critical path.
-template <int NT, int NR, bool LDS_OUT>
-__device__ __forceinline__ void dense_tile_core(const DevPlan &P, double *tp, int rt, int nrt, int wt, int task_begin,
-                                                int task_end, int lane, int tj0, int ti0, double *lds_out);
 
 // FUSED (experiment, off by default: symbolic.h PlanOptions::fuse_jit): the panel's pending just-in-time updates
 // (FacJit) are applied here first, on the matrix cores: waves 0-3 take the diagonal tile, waves 4-7 the workgroup's
