@@ -88,40 +88,55 @@ __device__ __forceinline__ void sb_mm16(const double *A, const double *Bm, v4f64
         c = __builtin_amdgcn_mfma_f64_16x16x4f64(A[(16 * ti + l15) * SLD + 4 * kk + lk], Bm[(4 * kk + lk) * SLD + 16 * tj + l15], c, 0, 0, 0);
 }
 
-// (Measured, r03f: fetching the next product's operands into registers while the current product runs does NOT help -- 148 us
-// instead of 129 us on cfg 2a: a 64 x 64 x 64 product is 1.7 us of matrix-core time on ONE compute unit, the chain of a super-block's
-// first column is 28 + 7 of them, and that, not the operand latency, is what the kernel costs.)
+// The chain of a super-block's first column is 28 + 7 dependent 64 x 64 x 64 products.  What a product costs on it: the A operand
+// L[bl,kl] (fetched one product ahead, into registers), two LDS stores, two barriers and 16 matrix-core instructions per wavefront.
+// The B operands Inv[kl,cl] are the workgroup's own earlier results: they stay in registers (7 tiles x 4 values per thread) instead of
+// being read back from memory past the L1 -- that round trip was half of the 3.7 us per product of the first version (129 us per
+// launch on cfg 2a; prefetching both operands of the next product WITHOUT keeping the results: 148 us).
 __global__ void __launch_bounds__(kInvThreads)
 k_invert_super(DevPlan P, FrontDesc F) {
     __shared__ double SA[64 * SLD], SB[64 * SLD];
+    __shared__ int64_t s_off[kSbG];
+    __shared__ int s_r[kSbG], s_w[kSbG];
+    __shared__ int64_t s_diag[kSbG];
     const int B = blockIdx.x / (kSbG - 1), cl = blockIdx.x % (kSbG - 1);
     const int nbB = min(kSbG, F.np - kSbG * B);
     if (cl + 1 >= nbB) return;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, lk = lane >> 4, ti = wv >> 2, tj = wv & 3;
     const FrontPanel *fps = P.front_panels + F.fp_off;
-    const FrontPanel pc = fps[kSbG * B + cl];
-    const SbTileSrc linv_c = {P.Linv + pc.diag_off, 1, pc.w, pc.w, pc.w, true, false};
-    for (int bl = cl + 1; bl < nbB; bl++) {
-        const FrontPanel pb = fps[kSbG * B + bl];
-        v4f64 acc = {0.0, 0.0, 0.0, 0.0};
-        for (int kl = cl; kl < bl; kl++) {
-            const FrontPanel pk = fps[kSbG * B + kl];
-            // A = L[bl,kl]: rows of block bl inside panel kl (column-major, stride r);  B = Inv[kl,cl]
-            const SbTileSrc a_src = {P.Lx + pk.panel_off + F.cw * (bl - kl), 1, pk.r, pb.w, pk.w, false, false};
-            const SbTileSrc b_src = kl == cl ? linv_c : SbTileSrc{P.SbInv + sb_tile(F, B, kl, cl), 1, 64, 64, 64, false, true};
-            double va[4], vb[4];
-            sb_fetch(a_src, va, tid);
-            sb_fetch(b_src, vb, tid);
-            sb_put(SA, va, tid);
-            sb_put(SB, vb, tid);
-            __syncthreads();
-            sb_mm16(SA, SB, acc, ti, tj, l15, lk);
-            __syncthreads();
-        }
-        {   // Inv[bl,cl] = -Linv_bl * S
-            const SbTileSrc linv_b = {P.Linv + pb.diag_off, 1, pb.w, pb.w, pb.w, true, false};
-            double va[4];
-            sb_fetch(linv_b, va, tid);
+    if (tid < nbB) {
+        const FrontPanel q = fps[kSbG * B + tid];
+        s_off[tid] = q.panel_off; s_r[tid] = q.r; s_w[tid] = q.w; s_diag[tid] = q.diag_off;
+    }
+    __syncthreads();
+    auto a_src = [&](int bl, int kl) {   // L[bl,kl]: rows of block bl inside panel kl (column-major, stride r)
+        return SbTileSrc{P.Lx + s_off[kl] + F.cw * (bl - kl), 1, s_r[kl], s_w[bl], s_w[kl], false, false};
+    };
+    auto linv_src = [&](int b) { return SbTileSrc{P.Linv + s_diag[b], 1, s_w[b], s_w[b], s_w[b], true, false}; };
+    double inv[kSbG - 1][4];              // Inv[cl + j, cl] in the thread layout of sb_put (value (i, k) at idx = tid + 1024 q: i = idx & 63, k = idx >> 6)
+    sb_fetch(linv_src(cl), inv[0], tid);
+#pragma unroll
+    for (int jb = 1; jb < kSbG; jb++) {
+        const int bl = cl + jb;
+        if (bl < nbB) {                  // workgroup-uniform
+            v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+            double va[4], vn[4];
+            sb_fetch(a_src(bl, cl), va, tid);
+#pragma unroll
+            for (int jk = 0; jk < kSbG - 1; jk++) {
+                if (jk < jb) {
+                    if (jk + 1 < jb) sb_fetch(a_src(bl, cl + jk + 1), vn, tid);      // the next product's A operand ...
+                    else sb_fetch(linv_src(bl), vn, tid);                            // ... or the panel inverse of the last step
+                    sb_put(SA, va, tid);
+                    sb_put(SB, inv[jk], tid);
+                    __syncthreads();
+                    sb_mm16(SA, SB, acc, ti, tj, l15, lk);
+                    __syncthreads();
+#pragma unroll
+                    for (int q = 0; q < 4; q++) va[q] = vn[q];
+                }
+            }
+            // Inv[bl,cl] = -Linv_bl * S
 #pragma unroll
             for (int reg = 0; reg < 4; reg++) SB[(16 * ti + lk + 4 * reg) * SLD + 16 * tj + l15] = acc[reg];
             sb_put(SA, va, tid);
@@ -136,10 +151,11 @@ k_invert_super(DevPlan P, FrontDesc F) {
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const int idx = tid + kInvThreads * q;
-                front_st(t + idx, SA[(idx & 63) * SLD + (idx >> 6)]);            // column-major half [i + 64 k]
+                const double v = SA[(idx & 63) * SLD + (idx >> 6)];
+                t[idx] = v;                                                      // column-major half [i + 64 k]
                 t[4096 + idx] = SA[(idx >> 6) * SLD + (idx & 63)];               // row-major half [64 i + k]
+                if (jb < kSbG - 1) inv[jb][q] = v;
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         }
     }
