@@ -136,7 +136,7 @@ __device__ __forceinline__ void fb_store_panel(const DevPlan &P, const FrontPane
 // kept out of line: the register allocation of the panel path must not depend on it
 // Each wavefront is alone on its SIMD (100 KB of LDS per workgroup): tiles with four k-steps of operands in flight, kFbExtraPerWave
 // of them one after the other -- the launch lasts as long as its panel chain anyway.
-__device__ __attribute__((noinline)) void fb_extra_tiles(const DevPlan &P, int begin, int count, int xb, int per_wave) {
+__device__ __forceinline__ void fb_extra_tiles(const DevPlan &P, int begin, int count, int xb, int per_wave) {
     const int lane = threadIdx.x & 63;
     int idx = rfl((xb * 4 + (int)(threadIdx.x >> 6)) * per_wave);
     for (int q = 0; q < per_wave && idx < count; q++, idx++) dense_tile<4, 4, true>(P, P.dgroups + begin + idx, lane, 0, 0);
