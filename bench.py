@@ -431,6 +431,16 @@ def main():
         upd_ms.append(h.timing()["last_update_ms"])
         d4.append(h.profile())
         launches = h.profile_launches()
+    # the same launches with every far tile kept in its stage's own launch (none riding in the next k_front_block launch): what the
+    # dominant kernel's launches looked like before round 3's extra workgroups, for comparison
+    h.set_profiling(2)
+    d4n = []
+    for i in range(3):
+        t = units[i % len(units)]
+        h.set_hs_dev(t["hs_d"].data_ptr(), h.nHs)
+        h.refactor(st.static_regularization_enable, st.static_regularization_constant, st.static_regularization_proportional)
+        d4n.append(h.profile())
+    p4n = sorted(d4n, key=lambda p: p["dense4_ms"])[len(d4n) // 2]
     h.set_profiling(False)
     upd = float(np.median(upd_ms))
     p4 = sorted(d4, key=lambda p: p["dense4_ms"])[len(d4) // 2]
@@ -496,6 +506,15 @@ def main():
                     whole_factorisation=dict(note="SURVEY section 8(d)'s figure: F_factor / t_factor with F_factor = sum_j (c_j^2 + 3 c_j)",
                                              flops=cm_f, ms=round(factor_ms, 4), achieved=round(cm_f / (factor_ms * 1e-3) / 1e12, 3),
                                              frac=round(cm_f / (factor_ms * 1e-3) / 1e12 / F64_MFMA_PEAK_TFLOPS, 4)),
+                    frac_note=("achieved = algorithmic flops of the k_update_dense<4,4> / k_update_dense_tail launches / their HIP-event time.  Since round 3 "
+                               "the far tiles that would form a stage's partial last rounds ride in the next k_front_block launch instead "
+                               "(critical_path_kernel.extra_update_*): the stage launches that remain are whole rounds plus the sparse-tree launch, so this "
+                               "fraction describes fewer, smaller launches than `all_tiles_in_own_launches` (the same refactorisation with that mechanism off)"),
+                    all_tiles_in_own_launches=(None if not (p4n["dense4_launches"] > 0 and p4n["dense4_ms"] > 0) else dict(
+                        achieved=round(p4n["dense4_flops"] / (p4n["dense4_ms"] * 1e-3) / 1e12, 3),
+                        frac=round(p4n["dense4_flops"] / (p4n["dense4_ms"] * 1e-3) / 1e12 / F64_MFMA_PEAK_TFLOPS, 4),
+                        launches_per_refactor=p4n["dense4_launches"], ms_per_refactor=round(p4n["dense4_ms"], 4),
+                        front_block_ms_per_refactor=round(p4n["front_block_ms"], 4))),
                     kernel=kern, **per_launch,
                     all_update_kernels=dict(achieved=round(agg, 3), ms_per_refactor=round(upd, 4),
                                             flops_per_refactor=flops_upd_kernels),

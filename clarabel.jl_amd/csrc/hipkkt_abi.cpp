@@ -674,6 +674,7 @@ int32_t hipkkt_reset_timing(hipkkt_handle h) {
 int32_t hipkkt_set_profiling(hipkkt_handle h, int32_t enable) {
     if (!h) return HIPKKT_ERR_ARGUMENT;
     h->profiling = enable != 0;
+    h->profiling_no_extra = enable == 2;
     return HIPKKT_OK;
 }
 

@@ -341,7 +341,7 @@ static int32_t refactor_once(hipkkt_handle h, int32_t static_reg_enable, double 
                 HK_CHECK(hipEventRecord(a, st));
                 const int g0 = P.upd_stage_ptr[l], nd = P.upd_stage_ndense[l], ng = P.upd_stage_ngather[l];
                 int skip = 0;                                              // (the same rule as enqueue_factor)
-                if (fb && S->fb_extra && !(S->lookahead && S->la_streams[0]) && cur_bi >= 0 && S->lvl_fb[l] != -1 && S->la[(size_t)cur_bi].has_next &&
+                if (fb && S->fb_extra && !S->profiling_no_extra && !(S->lookahead && S->la_streams[0]) && cur_bi >= 0 && S->lvl_fb[l] != -1 && S->la[(size_t)cur_bi].has_next &&
                     P.upd_stage_flops_dense[l] >= 1.5e6 * nd) {
                     skip = fb_extra_tiles_of_stage(nd, S->la[(size_t)cur_bi].ncrit, S->la[(size_t)cur_bi].next_blk, &extra_pw);
                     if (skip > 0) { extra_begin = g0 + nd - skip; extra_count = skip; }

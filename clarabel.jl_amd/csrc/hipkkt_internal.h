@@ -217,6 +217,7 @@ struct hipkkt_solver {
     std::shared_ptr<std::atomic<bool>> twin_cancel;   // set when the twin turns out not to be needed
     bool using_fallback = false;
     bool profiling = false;
+    bool profiling_no_extra = false;     // hipkkt_set_profiling(h, 2): the profiled refactorisations keep every far tile in its stage's own launch
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
     double t_last_factor = 0, t_last_solve = 0, t_acc_factor = 0, t_acc_solve = 0, t_last_update = 0;
     int64_t n_factor = 0, n_solvecalls = 0, n_ldlsolves = 0, n_rhs_solved = 0;

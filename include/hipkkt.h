@@ -278,7 +278,9 @@ int32_t hipkkt_get_profile(hipkkt_handle h, double *out10);
 /* the k_update_dense<4,4> launches of that refactorisation one by one: ms[i], algorithmic flops[i], target tiles[i]
  * (any array may be NULL; at most cap entries are written, *count receives the number of launches) */
 int32_t hipkkt_get_profile_launches(hipkkt_handle h, double *ms, double *flops, double *tiles, int64_t cap, int64_t *count);
-/* 1 = time the update (MFMA) kernels separately inside refactor (adds event overhead) */
+/* 1 = time the update (MFMA) kernels and the k_front_block launches separately inside refactor (eager launches, adds event overhead);
+ * 2 = the same with every far update tile kept in its stage's own launch (none riding in the next k_front_block launch): the
+ * comparison figure for out[8] / out[9] of hipkkt_get_profile; 0 = off */
 int32_t hipkkt_set_profiling(hipkkt_handle h, int32_t enable);
 
 /* robustness counters: out[0] = persistent sweep time-outs seen so far (each one repeats the solve on the per-level

@@ -300,8 +300,11 @@ def test_extra_tiles_in_front_block_launches_are_bit_identical(name, monkeypatch
         hk.h.set_profiling(True)
         assert hk.kktsolver_update(cones)
         prof = hk.h.profile()
-        hk.h.set_profiling(False)
         assert np.array_equal(hk.h.ldl_solve(b), x)          # the eager profiled path applies the same split
+        hk.h.set_profiling(2)                                # ... and mode 2 keeps every tile in its stage's own launch
+        assert hk.kktsolver_update(cones)
+        assert hk.h.profile()["front_block_extra_tiles"] == 0 and np.array_equal(hk.h.ldl_solve(b), x)
+        hk.h.set_profiling(False)
         out.append((x, hk.h.debug_dump(5), prof))
     (x1, d1, p1), (x0, d0, p0) = out
     assert p1["front_block_extra_tiles"] > 0 and p0["front_block_extra_tiles"] == 0
