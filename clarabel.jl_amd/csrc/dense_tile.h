@@ -200,6 +200,104 @@ __device__ __forceinline__ void dense_tile_core(const DevPlan &P, double *tp, in
         }
 }
 
+// FULL tiles (DenseGroup::pad & 1, set when the plan is uploaded: a 64 x 64 tile whose every task covers all 64 rows and columns
+// contiguously with K a multiple of 8 -- all but the edge tiles of a front's big launches): nothing to mask, the lane offsets are
+// loop-invariant, and the k-steps advance the UNIFORM base pointers in scalar registers: 9 loads + 4 multiplies per 16 matrix-core
+// instructions instead of 9 + 35 vector instructions (address arithmetic with a clamp and a 32-bit multiply, 18 selects), which
+// cost matrix-core time one for one (the two pipes of a SIMD do not overlap for FP64).  Same products, same order of accumulation
+// as dense_tile_core: bit-identical.  A function of its own (not a branch inside the task loop of dense_tile_core: that spilled
+// 227 registers) so that its live ranges and the general path's are allocated separately.
+__device__ __forceinline__ void dense_tile_core_full(const DevPlan &P, double *tp, int rt, int task_begin, int task_end, int lane) {
+    const int l15 = lane & 15, lk = lane >> 4;
+    v4f64 acc[4][4];
+#pragma unroll
+    for (int tj = 0; tj < 4; tj++)
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) {
+            const int jj = tj * 16 + lk + 4 * reg;
+#pragma unroll
+            for (int ti = 0; ti < 4; ti++) acc[tj][ti][reg] = ld_off(tp, (unsigned)(ti * 16 + l15 + jj * rt) * 8u);
+        }
+    // One stream of k-steps over ALL tasks of the tile: the first operands of task q+1 are requested before the last matrix-core
+    // instructions of task q (a task is one 64-column source panel = 16 k-steps; restarting the load pipeline per task exposed a
+    // memory round trip five times per tile).  The record of task q+2 is requested at the same point.
+    const double *sp, *dv;
+    unsigned ca[4], rb[4], dl, step;
+    int K;
+    auto setup = [&](const DenseTask &T) {
+        const int row_lo = rfl(T.row_lo), col_lo = rfl(T.col_lo);
+        const unsigned r8 = (unsigned)rfl(T.r8);
+        K = rfl(T.K);
+        sp = rfl_ptr(P.Lx + T.panel_off);      // wave-uniform bases (scalar registers) + 32-bit lane offsets
+        dv = rfl_ptr(P.D + T.dfirst);
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            ca[t] = (unsigned)(col_lo + t * 16 + l15) * 8u + (unsigned)lk * r8;
+            rb[t] = (unsigned)(row_lo + t * 16 + l15) * 8u + (unsigned)lk * r8;
+        }
+        dl = (unsigned)lk * 8u;
+        step = 4u * r8;
+    };
+    DenseRaw<4, 4> fa, fb;
+    auto load = [&](DenseRaw<4, 4> &f) {
+        f.d = ld_off(dv, dl);
+#pragma unroll
+        for (int t = 0; t < 4; t++) f.a[t] = ld_off(sp, ca[t]);
+#pragma unroll
+        for (int t = 0; t < 4; t++) f.b[t] = ld_off(sp, rb[t]);
+    };
+    auto advance = [&]() {          // the lane offsets move on by one k-step (4 columns of the source panel): 9 adds
+        dl += 32u;
+#pragma unroll
+        for (int t = 0; t < 4; t++) { ca[t] += step; rb[t] += step; }
+    };
+    auto mma = [&](const DenseRaw<4, 4> &f) {
+        const double nd = -f.d;
+        double a[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) a[t] = f.a[t] * nd;
+#pragma unroll
+        for (int tj = 0; tj < 4; tj++)
+#pragma unroll
+            for (int ti = 0; ti < 4; ti++) acc[tj][ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[tj], f.b[ti], acc[tj][ti], 0, 0, 0);
+    };
+    DenseTask Tn = P.dtasks[task_begin + 1 < task_end ? task_begin + 1 : task_begin];
+    setup(P.dtasks[task_begin]);
+    load(fa);
+    advance();
+    for (int q = task_begin; q < task_end; q++) {
+        const int Kq = K;
+        for (int k0 = 0; k0 < Kq; k0 += 8) {
+            load(fb);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(fa);
+            __builtin_amdgcn_sched_barrier(0);
+            if (k0 + 8 < Kq) {
+                advance();
+                load(fa);
+                advance();
+            } else if (q + 1 < task_end) {                       // the next task's first k-step, and the record after it
+                const DenseTask Tc = Tn;
+                Tn = P.dtasks[q + 2 < task_end ? q + 2 : q + 1];
+                setup(Tc);
+                load(fa);
+                advance();
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mma(fb);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#pragma unroll
+    for (int tj = 0; tj < 4; tj++)
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) {
+            const int jj = tj * 16 + lk + 4 * reg;
+#pragma unroll
+            for (int ti = 0; ti < 4; ti++) st_off(tp, (unsigned)(ti * 16 + l15 + jj * rt) * 8u, acc[tj][ti][reg]);
+        }
+}
+
 template <int NT, int NR, bool DEEP = false>
 __device__ __forceinline__ void dense_tile(const DevPlan &P, const DenseGroup *Gp, int lane, int tj0, int ti0) {
     // one self-contained record per tile (no group -> supernode tables -> panel chain of dependent loads)
@@ -211,6 +309,10 @@ __device__ __forceinline__ void dense_tile(const DevPlan &P, const DenseGroup *G
     double *tp = rfl_ptr(P.Lx + G.tile_off);
     const int nrt = rfl(G.nrt);
     if (ti0 * 16 >= nrt) return;
+    if (NT == 4 && NR == 4 && (rfl(G.pad) & 1)) {       // wave-uniform
+        dense_tile_core_full(P, tp, rt, task_begin, task_end, lane);
+        return;
+    }
     dense_tile_core<NT, NR, false, DEEP>(P, tp, rt, nrt, wt, task_begin, task_end, lane, tj0, ti0, nullptr);
 }
 

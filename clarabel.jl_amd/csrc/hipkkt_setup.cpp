@@ -366,12 +366,20 @@ void setup_device(hipkkt_solver *S) {
     D.upd_groups = S->upload(P.upd_groups);
     {
         std::vector<DenseGroup> dg(P.upd_groups.size());
+        const bool no_full_tiles = [] { const char *e = getenv("HIPKKT_FULL_TILES"); return e && e[0] == '0'; }();   // A/B timing
         for (size_t q = 0; q < dg.size(); q++) {
             const UpdGroup &G = P.upd_groups[q];
             const int t = G.tgt;
             const int rt = (int)(P.sn_rowptr[t + 1] - P.sn_rowptr[t]);
+            // pad bit 0: a FULL tile (dense_tile.h dense_tile_core_full): 64 x 64, every task lands contiguously on all of it
+            bool full = G.dense == 1 && rt - G.row_base >= kUpdRows && P.sn_first[t + 1] - P.sn_first[t] == 64 && !no_full_tiles;
+            for (int u = G.task_begin; u < G.task_end && full; u++) {
+                const UpdTask &T = P.upd_tasks[u];
+                const int K = P.sn_first[T.src + 1] - P.sn_first[T.src];
+                full = !(T.geom & (1 << 17)) && (T.geom & 0xFFFF) == 0 && T.nrows >= 64 && T.ncols >= 64 && K >= 8 && (K & 7) == 0;
+            }
             dg[q] = {P.sn_panel[t] + G.row_base, rt, std::min(kUpdRows, rt - G.row_base), P.sn_first[t + 1] - P.sn_first[t],
-                     G.task_begin, G.task_end, 0};
+                     G.task_begin, G.task_end, full ? 1 : 0};
         }
         D.dgroups = S->upload(dg);
     }
