@@ -85,7 +85,8 @@ int fb_extra_tiles_of_stage(int nd, int ncrit, int next_blk, int *per_wave_out) 
     static const int cus = [] { const char *e = getenv("HIPKKT_FB_EXTRA_CUS"); return e ? atoi(e) : 254; }();
     static const int rmin = [] { const char *e = getenv("HIPKKT_FB_EXTRA_MIN"); return e ? atoi(e) : 64; }();
     static const int pw_max = [] { const char *e = getenv("HIPKKT_FB_EXTRA_PER_WAVE"); return e ? std::max(1, std::min(2, atoi(e))) : 2; }();
-    static const double pen[3] = {0.0, 10.0, 28.0};       // what the panel launch gains in duration
+    static const double pen[3] = {0.0, [] { const char *e = getenv("HIPKKT_FB_EXTRA_PEN1"); return e ? atof(e) : 10.0; }(),
+                                  [] { const char *e = getenv("HIPKKT_FB_EXTRA_PEN2"); return e ? atof(e) : 28.0; }()};   // what the panel launch gains in duration (us)
     double best = dense_stage_cost_us(nd);
     int best_r = 0, best_pw = 1;
     for (int pw = 1; pw <= pw_max; pw++) {
