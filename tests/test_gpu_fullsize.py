@@ -307,6 +307,12 @@ def test_extra_tiles_in_front_block_launches_are_bit_identical(name, monkeypatch
         hk.h.set_profiling(False)
         out.append((x, hk.h.debug_dump(5), prof))
     (x1, d1, p1), (x0, d0, p0) = out
+    # ... and so is the mask-free core of the full tiles (dense_tile.h dense_tile_core_full) against the general tile code
+    monkeypatch.setenv("HIPKKT_FB_EXTRA", "1")
+    monkeypatch.setenv("HIPKKT_FULL_TILES", "0")
+    hk = HipKKTSolver(Pt, A, cones, m, n, cl.Settings())
+    assert hk.kktsolver_update(cones)
+    assert np.array_equal(hk.h.ldl_solve(np.random.default_rng(42).standard_normal(hk.h.N)), x1) and np.array_equal(hk.h.debug_dump(5), d1)
     assert p1["front_block_extra_tiles"] > 0 and p0["front_block_extra_tiles"] == 0
     assert abs((p1["dense4_flops"] + p1["front_block_extra_flops"]) - p0["dense4_flops"]) <= 1e-9 * p0["dense4_flops"] or p1["dense4_launches"] != p0["dense4_launches"]
     assert np.array_equal(d1, d0) and np.array_equal(x1, x0)
