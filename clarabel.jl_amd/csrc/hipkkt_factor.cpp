@@ -214,6 +214,13 @@ void enqueue_factor(hipkkt_solver *S, int static_enable, double eps_const, doubl
 
 extern "C" {
 
+int32_t hipkkt_debug_extra_tiles(int32_t nd, int32_t ncrit, int32_t next_blk, int32_t *per_wave) {
+    int pw = 1;
+    const int r = fb_extra_tiles_of_stage(nd, ncrit, next_blk, &pw);
+    if (per_wave) *per_wave = pw;
+    return r;
+}
+
 // ---- factor ------------------------------------------------------------------------------------
 
 static int32_t refactor_once(hipkkt_handle h, int32_t static_reg_enable, double eps_const, double eps_prop,

@@ -24,7 +24,7 @@ SYMBOLS = [
     "hipkkt_set_hs", "hipkkt_set_hs_dev", "hipkkt_set_hs_psd", "hipkkt_set_cone_types", "hipkkt_update_scaling", "hipkkt_update_scaling_dev", "hipkkt_block_products", "hipkkt_set_soc", "hipkkt_set_soc_batch", "hipkkt_set_genpow",
     "hipkkt_update_P", "hipkkt_update_A", "hipkkt_refactor", "hipkkt_setrhs", "hipkkt_setrhs_dev", "hipkkt_solve",
     "hipkkt_solve_dev", "hipkkt_solve_multi", "hipkkt_solve_multi_dev", "hipkkt_kkt_solve_reduced", "hipkkt_kkt_solve_reduced_dev", "hipkkt_ldl_solve", "hipkkt_get_timing", "hipkkt_reset_timing", "hipkkt_get_profile", "hipkkt_get_profile_launches", "hipkkt_set_profiling",
-    "hipkkt_get_counters", "hipkkt_debug_dump", "hipkkt_set_qb", "hipkkt_residuals", "hipkkt_residuals_dev",
+    "hipkkt_get_counters", "hipkkt_debug_dump", "hipkkt_debug_extra_tiles", "hipkkt_set_qb", "hipkkt_residuals", "hipkkt_residuals_dev",
     "hipkkt_selftest_mfma", "hipkkt_last_error",
 ]
 
@@ -106,6 +106,8 @@ def lib():
     L.hipkkt_residuals.argtypes = [vp, _f64p, _f64p, _f64p, f64, f64, vp, vp, vp, vp, vp, _f64p]
     L.hipkkt_residuals_dev.argtypes = [vp, vp, f64, f64, vp, _f64p]
     L.hipkkt_debug_dump.argtypes = [vp, i32, vp, i64, C.POINTER(i64)]
+    L.hipkkt_debug_extra_tiles.argtypes = [i32, i32, i32, C.POINTER(i32)]
+    L.hipkkt_debug_extra_tiles.restype = i32
     L.hipkkt_selftest_mfma.argtypes = [i32, C.POINTER(f64)]
     L.hipkkt_last_error.argtypes = [vp]
     L.hipkkt_last_error.restype = C.c_char_p

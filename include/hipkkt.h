@@ -299,6 +299,10 @@ int32_t hipkkt_get_counters(hipkkt_handle h, int64_t *out14);
  * columns, 11 levels, 12 rows per supernode, 13 parents, 14 membership in the persistent sweeps); *len receives the
  * length, nothing is copied when cap is too small */
 int32_t hipkkt_debug_dump(hipkkt_handle h, int32_t what, double *out, int64_t cap, int64_t *len);
+/* developer diagnostic, host logic only (no device needed): how many of the `nd` dense tiles of a front batch's far stage -- the
+ * first `ncrit` of them belong to the next batch's columns -- ride in the next k_front_block launch, which has `next_blk` workgroups
+ * of its own; *per_wave receives the tiles per wavefront there (hipkkt_factor.cpp fb_extra_tiles_of_stage) */
+int32_t hipkkt_debug_extra_tiles(int32_t nd, int32_t ncrit, int32_t next_blk, int32_t *per_wave);
 
 /* diagnostic: checks the FP64 matrix-core operand/result lane maps used by the update kernel
  * against a host product with an asymmetric B (returns 0 when they agree to 1e-12) */

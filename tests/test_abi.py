@@ -46,3 +46,28 @@ def test_product_never_imports_oracle_or_the_caller_standin():
                 else:
                     assert "oracle" not in src.lower() and "julia_standin" not in src, f
     assert not os.path.exists(os.path.join(pkg, "ipm.py")) and not os.path.exists(os.path.join(pkg, "cones.py"))
+
+
+def test_extra_tile_choice_is_consistent():
+    """hipkkt_factor.cpp fb_extra_tiles_of_stage (host logic, no device): the far tiles of a front batch that ride in the next
+    k_front_block launch never include tiles of the next batch's columns, fit the compute units that launch leaves idle, and leave
+    the stage's own launch on a step of its cost function (or as small as it can be)."""
+    import ctypes as C
+
+    L = hipkkt.lib()
+    seen_two = False
+    for nd in list(range(0, 600, 37)) + list(range(600, 4200, 101)):
+        for ncrit in (0, nd // 8, nd // 3, nd):
+            for next_blk in (2, 37, 87, 200, 254):
+                pw = C.c_int32(0)
+                r = L.hipkkt_debug_extra_tiles(nd, ncrit, next_blk, C.byref(pw))
+                assert 0 <= r <= nd - ncrit
+                assert pw.value in (1, 2)
+                seen_two = seen_two or (r > 0 and pw.value == 2)
+                assert r <= 4 * pw.value * max(0, 254 - next_blk)
+                if r > 0:
+                    m = nd - r
+                    assert r >= 64
+                    assert m <= 384 or m == ncrit or m == 768 or m % 1024 in (0, 256, 512), (nd, ncrit, next_blk, r)
+    assert seen_two
+    assert L.hipkkt_debug_extra_tiles(3403, 435, 82, None) > 0 and L.hipkkt_debug_extra_tiles(50, 10, 10, None) == 0
