@@ -79,13 +79,11 @@ __device__ __forceinline__ void dense_mma(const DenseRaw<NT, NR> &f, v4f64 (&acc
 //         thousands of tiles.   NT = 1: one wavefront per 16-column strip (one tile per workgroup):
 //         4x shorter critical path, for the just-in-time updates of the next panel (<= ~100 tiles); these may
 //         also split the tile's rows over 4/NR workgroups (NR 16-row blocks per wavefront).
-// LDS_OUT: the finished strip goes to lds_out[row * 65 + column] (the panel kernel's staging layout) instead of
-//          back to the panel -- used by k_factor_panel<true>, which applies a panel's pending updates itself.
 // DEEP: four k-steps of operands in flight also for NT > 1 (72 instead of 36 operand registers) -- for a wavefront that is ALONE on its
 //       SIMD (the extra workgroups of a k_front_block launch: 512 registers available, no second wavefront to cover an L2 round trip)
-template <int NT, int NR, bool LDS_OUT, bool DEEP = false>
+template <int NT, int NR, bool DEEP = false>
 __device__ __forceinline__ void dense_tile_core(const DevPlan &P, double *tp, int rt, int nrt, int wt, int task_begin,
-                                                int task_end, int lane, int tj0, int ti0, double *lds_out) {
+                                                int task_end, int lane, int tj0, int ti0) {
     const int l15 = lane & 15, lk = lane >> 4;
 
     // accumulators <- the target tile.  acc[tj][ti][reg]: column (tj0+tj)*16 + lk + 4*reg, row (ti0+ti)*16 + l15
@@ -194,8 +192,7 @@ __device__ __forceinline__ void dense_tile_core(const DevPlan &P, double *tp, in
 #pragma unroll
             for (int ti = 0; ti < NR; ti++) {
                 const int ii = (ti0 + ti) * 16 + l15;
-                if (LDS_OUT) lds_out[ii * 65 + jj] = acc[tj][ti][reg];
-                else if (ii < nrt && jj < wt) st_off(tp, (unsigned)(ii + jj * rt) * 8u, acc[tj][ti][reg]);
+                if (ii < nrt && jj < wt) st_off(tp, (unsigned)(ii + jj * rt) * 8u, acc[tj][ti][reg]);
             }
         }
 }
@@ -313,7 +310,7 @@ __device__ __forceinline__ void dense_tile(const DevPlan &P, const DenseGroup *G
         dense_tile_core_full(P, tp, rt, task_begin, task_end, lane);
         return;
     }
-    dense_tile_core<NT, NR, false, DEEP>(P, tp, rt, nrt, wt, task_begin, task_end, lane, tj0, ti0, nullptr);
+    dense_tile_core<NT, NR, DEEP>(P, tp, rt, nrt, wt, task_begin, task_end, lane, tj0, ti0);
 }
 
 }  // namespace hipkkt

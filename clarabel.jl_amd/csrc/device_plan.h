@@ -41,6 +41,7 @@ constexpr int kFbMax = 5;         // panels per launch (= the longest update bat
 struct FrontBatch {
     int64_t fp_off;               // front_panels[fp_off + q], q = 0 .. nb-1
     int64_t scratch_off;          // doubles: kFbMax x (64 x 64 inverse + 64 pivots), then the L tiles of the diagonal workgroups
+    int64_t stream_off;           // doubles: records of the streamed pivot chain, (8 j + Bk) * kFbRec for block Bk of the batch's panel j
     int32_t nb, nblk, r0;         // panels, 64-row blocks (= workgroups), rows of the first panel
     int32_t sync_off;             // ints: {ticket, error} | 16: second ticket | 32: Minv flags | 64 + 8 k + j: L(k,j) flags   (128 ints per batch)
     // a launch handles the row blocks [i_base, i_end) and takes its tickets from sync[tick]: one launch = (0, nblk, 0); the look-ahead
@@ -52,6 +53,8 @@ struct FrontBatch {
     int32_t x_begin, x_count;
 };
 constexpr int64_t kFbScratch = (int64_t)kFbMax * 4160 + (int64_t)(kFbMax * (kFbMax - 1) / 2) * 4096;   // doubles per batch
+constexpr int kFbRec = 528;       // one streamed block of 8 pivots: [8][64] raw columns a_rk = d_k l_rk, 8 pivots d_k, 8 reciprocals
+constexpr int64_t kFbStream = (int64_t)kFbMax * 8 * kFbRec;   // doubles per batch
 constexpr int kGathHeavy = 24;    // target entries with more pairs than this get a wavefront of their own
 
 struct DevPlan {
@@ -70,7 +73,6 @@ struct DevPlan {
     const signed char *sgn_perm;
     const FacItem *fac_items;
     const FacRec *fac_recs;      // [fac_items] the same items, self-contained (k_factor_panel)
-    const FacJit *fac_jit;       // [fac_items] pending updates applied by k_factor_panel<true> (symbolic.h)
     const FacItem *slv_items;
     const FacItem *bwd_items;
     const int *rel;

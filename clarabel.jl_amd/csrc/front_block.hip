@@ -10,8 +10,18 @@
 // poll, one agent acquire, sc1 loads -- MI355X_MICROARCH.md "inter-workgroup visibility").  Nothing another workgroup reads is read
 // before its flag, no scratch line is shared between producers, and a workgroup only ever waits for lower tickets (already running):
 // no deadlock at any grid size; every spin is bounded and aborts the whole factorisation through FL_FACFAIL (the host then repeats it
-// with one launch per panel).  Cost per panel on the critical path: pivots + inverse + one tile hand-off + two 64x64x64 products,
-// instead of two dependent launches in which every workgroup repeats the diagonal tile.
+// with one launch per panel).
+//
+// STREAMED PIVOT CHAIN (round 4, template parameter STREAM).  The critical path of a front is the chain of its diagonal tiles.  In the
+// round-3 form the diagonal workgroup i waited for ALL 64 pivots of tile i-1, its explicit inverse and the publish before it could form
+// X = A(i,i-1) L^-T D^-1, update its own tile and start its pivots: 22.7 us per panel of which 9.9 us are pivots.  Streamed: workgroup
+// i-1 publishes every finished block of 8 pivots (the raw columns a_rk = d_k l_rk of its tile, d_k, 1/d_k: one 528-double record,
+// write-through stores, no flag -- the record area is filled with a NaN sentinel before every factorisation and the consumer polls the
+// data itself) and workgroup i treats its rows of panel i-1 as what they are, 64 more rows of that panel: per record it eliminates the
+// block's 8 columns of A(i,i-1) by substitution (lane = row, the arithmetic of k_factor_panel's chunk rows), then applies the rank-8
+// update to the rest of A(i,i-1) and to its own diagonal tile on the matrix core.  It trails the producer by one hand-off and starts
+// its own pivots one block time after the producer's last pivot: the inverse, its publish and both 64^3 products leave the chain
+// (the inverse is still formed and published, for the workgroups below the diagonal, while the next tile is already being eliminated).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -59,6 +69,36 @@ __device__ __forceinline__ void fb_st16(double *p, double a, double b) {
     const unsigned long long ua = (unsigned long long)__double_as_longlong(a), ub = (unsigned long long)__double_as_longlong(b);
     v4u r = {(unsigned)ua, (unsigned)(ua >> 32), (unsigned)ub, (unsigned)(ub >> 32)};
     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 2" : : "v"(p), "v"(r) : "memory");
+}
+// LDS-only workgroup barrier: __syncthreads() also waits for this wave's outstanding global stores (vmcnt), which would put the
+// write-through latency of every streamed record on the pivot chain.  Nothing in the loops that use it communicates through global
+// memory inside the workgroup.
+__device__ __forceinline__ void fb_bar() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// "not written yet" in a stream record: a NaN no arithmetic produces (both halves equal, so a 32-bit fill pattern would do too)
+constexpr unsigned kFbSentHalf = 0xFFFFDEADu;
+constexpr unsigned long long kFbSentinel = 0xFFFFDEADFFFFDEADull;
+__device__ __forceinline__ bool fb_fresh(v4u r) {
+    return !(r[0] == kFbSentHalf && r[1] == kFbSentHalf) && !(r[2] == kFbSentHalf && r[3] == kFbSentHalf);
+}
+// polls two 16-byte chunks of a stream record until all four doubles have been written (per lane; bounded)
+__device__ __forceinline__ bool fb_poll2(const double *p0, const double *p1, double2 &d0, double2 &d1, int *err, int *failflag, unsigned lim) {
+    for (unsigned spins = 0;; spins++) {
+        v4u r0, r1;
+        asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
+                     : "=&v"(r0), "=&v"(r1)
+                     : "v"(p0), "v"(p1)
+                     : "memory");
+        if (fb_fresh(r0) && fb_fresh(r1)) { d0 = fb_unpack(r0); d1 = fb_unpack(r1); return true; }
+        if ((spins & 63u) == 63u || lim < 64u) {
+            if (spins > lim) {
+                __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                atomicOr(failflag, 1);
+                return false;
+            }
+            if (fb_ldi(err) != 0) return false;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
 }
 // a 64 x 64 row-major scratch tile <-> an LDS tile [row * FLD + col]: 8 chunks of 16 bytes per thread
 __device__ __forceinline__ void fb_tile_load(const double *tl, double *S, int tid) {
@@ -143,8 +183,10 @@ __device__ __forceinline__ void fb_extra_tiles(const DevPlan &P, int begin, int 
 }
 
 #define FB_T(slot) do { if (trace && tid == 0 && i < 8) trace[(B.sync_off / 128 * 8 + i) * 16 + (slot)] = (long long)wall_clock64(); } while (0)
+template <bool STREAM>
 __global__ void __launch_bounds__(256)
-k_front_block(DevPlan P, FrontBatch B, int *sync_all, double *scratch_all, double dyn_eps, double dyn_delta, long long *trace) {
+k_front_block(DevPlan P, FrontBatch B, int *sync_all, double *scratch_all, double *stream_all, double dyn_eps, double dyn_delta,
+              long long *trace) {
     __shared__ double Sa[64 * FLD];     // this workgroup's 64 x 64 strip: A_j, then X_j; the pivot loop's small buffers; the inverse
     __shared__ double Sb[64 * FLD];     // the other operand: Minv_j, then L(k,j); the pivot loop's result L11
     __shared__ double St[64 * FLD];     // products of the blocked inverse
@@ -154,6 +196,7 @@ k_front_block(DevPlan P, FrontBatch B, int *sync_all, double *scratch_all, doubl
     int *err = sync + 1, *fl_minv = sync + 32, *fl_L = sync + 64;
     double *scratch = scratch_all + B.scratch_off;
     double *ltiles = scratch + (int64_t)kFbMax * 4160;
+    double *stream = stream_all + B.stream_off;            // STREAM: record (panel j, block Bk) at ((8 j + Bk) * kFbRec)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, lk = lane >> 4;
     if ((int)blockIdx.x >= B.i_end - B.i_base) {          // extra workgroup: four tiles of the previous update stage (no hand-off, no LDS)
         fb_extra_tiles(P, B.x_begin, B.x_count, (int)blockIdx.x - (B.i_end - B.i_base), B.pad > 0 ? B.pad : 1);
@@ -168,8 +211,12 @@ k_front_block(DevPlan P, FrontBatch B, int *sync_all, double *scratch_all, doubl
     const int nb = B.nb;
     const bool diag = i < nb;
     const int ncb = diag ? i + 1 : nb;                    // column blocks held here
-    const int nsteps = diag ? i : nb;
+    // STREAM: a diagonal workgroup's last step (the panel just left of its own tile) is the streamed one after this loop
+    const int nsteps = diag ? (STREAM ? i - 1 : i) : nb;
     const int nr = min(64, B.r0 - 64 * i);
+    // expected pivot signs of this workgroup's own columns: requested now, used by the pivots (a diagonal workgroup's critical path)
+    const int f = diag ? fp[i].f : 0;
+    const signed char sgn_l = diag ? P.sgn_perm[f + lane] : (signed char)0;
     v4f64 acc[kFbMax][4];
     // ---- load the row block (coalesced over rows, through LDS into the accumulator layout: lane (col l15, row lk + 4 reg))
 #pragma unroll
@@ -195,7 +242,7 @@ k_front_block(DevPlan P, FrontBatch B, int *sync_all, double *scratch_all, doubl
 #pragma unroll
     for (int j = 0; j < kFbMax; j++) {
         if (j < nsteps) {                                  // workgroup-uniform
-            const bool last = diag && j == nsteps - 1;     // next: this workgroup's own diagonal tile (critical path of the front)
+            const bool last = !STREAM && diag && j == nsteps - 1;     // next: this workgroup's own diagonal tile (critical path of the front)
             if (!fb_wait(fl_minv + j, err, P.flags + FL_FACFAIL, P.spin_limit, &sres)) return;
             if (j == nsteps - 1) FB_T(2);
             const double *mv = scratch + (int64_t)j * 4160;
@@ -257,12 +304,7 @@ k_front_block(DevPlan P, FrontBatch B, int *sync_all, double *scratch_all, doubl
             }
         }
     }
-    FB_T(6);
-    if (!diag) return;
-    // ---- the diagonal tile stays in the accumulators (rows 16 wv + lk + 4 reg, columns 16 sub + l15).  Per block of 8 pivots: the
-    //      waves hand the block's 8 columns to wave 0 through LDS, wave 0 eliminates them without leaving the wavefront (lane = row;
-    //      the pivot rule and arithmetic of k_factor_panel, kernels.hip), and every wave applies the rank-8 update to its 16 rows
-    //      on the matrix core.  L11 is collected in Sb for the inverse and the solves.
+    // ---- the diagonal tile stays in the accumulators (rows 16 wv + lk + 4 reg, columns 16 sub + l15).
     v4f64 tacc[4];
 #pragma unroll
     for (int sub = 0; sub < 4; sub++) {
@@ -270,16 +312,99 @@ k_front_block(DevPlan P, FrontBatch B, int *sync_all, double *scratch_all, doubl
 #pragma unroll
         for (int k = 0; k < kFbMax; k++) if (k == i) tacc[sub] = acc[k][sub];
     }
-    const FrontPanel pi = fp[i];
-    const int f = pi.f;
     double *Pc = Sa;                                                 // [64][9]   the block's columns, by row
     double (*colL)[64] = (double (*)[64])(Sa + 64 * 9);              // [8][64]   l_ik
     double (*colC)[64] = (double (*)[64])(Sa + 64 * 9 + 512);        // [8][64]   raw a_ik = d_k l_ik
     double *dsave = Sa + 64 * 9 + 1024;                              // [64]
+    double *dinvs = Sa + 64 * 9 + 1024 + 64;                         // [64]      1/d_k as used on the chain (fb_rcp)
+    if (STREAM && diag && i > 0) {
+        // ---- streamed step: this workgroup's rows of panel i-1, block by block behind the workgroup that eliminates tile i-1
+        v4f64 xacc[4];
+#pragma unroll
+        for (int sub = 0; sub < 4; sub++) {
+            xacc[sub] = (v4f64){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int k = 0; k < kFbMax; k++) if (k == i - 1) xacc[sub] = acc[k][sub];
+        }
+        const double *rec0 = stream + (int64_t)(i - 1) * 8 * kFbRec;
+        double *ltile = ltiles + (int64_t)(i * (i - 1) / 2 + i - 1) * 4096;       // L(i, i-1), row-major, for the workgroups below
+        if (tid == 0) sres = 1;
+        __syncthreads();                                   // Sa / Sb (operands of the last regular step) are free
+#pragma unroll
+        for (int Bk = 0; Bk < 8; Bk++) {
+            {
+                const int sub = Bk >> 1, c0 = 8 * (Bk & 1);
+                if (l15 >= c0 && l15 < c0 + 8) {
+#pragma unroll
+                    for (int reg = 0; reg < 4; reg++) Pc[(16 * wv + lk + 4 * reg) * 9 + l15 - c0] = xacc[sub][reg];
+                }
+            }
+            double *CR = Sb + (Bk & 1) * kFbRec;           // the record: [8][64] raw columns of tile i-1, 8 pivots, 8 reciprocals
+            if (wv < 2) {                                  // waves 0, 1 poll (wave 3 has write-through stores in flight: it must not wait)
+                const double *rec = rec0 + (int64_t)Bk * kFbRec;
+                double2 d0, d1;
+                const bool ok = fb_poll2(rec + 2 * tid, rec + 2 * (tid + 128), d0, d1, err, P.flags + FL_FACFAIL, P.spin_limit);
+                CR[2 * tid] = d0.x; CR[2 * tid + 1] = d0.y;
+                CR[2 * tid + 256] = d1.x; CR[2 * tid + 257] = d1.y;
+                bool ok2 = true;
+                if (tid >= 64 && tid < 72) {
+                    double2 e0, e1;
+                    ok2 = fb_poll2(rec + 512 + 2 * (tid - 64), rec + 512 + 2 * (tid - 64), e0, e1, err, P.flags + FL_FACFAIL, P.spin_limit);
+                    CR[512 + 2 * (tid - 64)] = e0.x; CR[513 + 2 * (tid - 64)] = e0.y;
+                }
+                if (!(ok && ok2)) sres = 0;
+            }
+            fb_bar();
+            if (sres == 0) return;                         // (uniform: nobody writes sres after this point)
+            if (Bk == 0) FB_T(12);
+            if (wv == 0) {
+                double p[8], cr[28], dv[8];
+#pragma unroll
+                for (int q = 0; q < 8; q++) { p[q] = Pc[lane * 9 + q]; dv[q] = CR[520 + q]; }
+#pragma unroll
+                for (int kk = 0, t = 0; kk < 8; kk++)
+#pragma unroll
+                    for (int jj = kk + 1; jj < 8; jj++, t++) cr[t] = CR[kk * 64 + 8 * Bk + jj];       // a_{jj,kk} of tile i-1 (wave-uniform)
+#pragma unroll
+                for (int kk = 0, t = 0; kk < 8; kk++) {
+                    const double li = p[kk] * dv[kk];
+                    colL[kk][lane] = li;
+                    colC[kk][lane] = p[kk];
+#pragma unroll
+                    for (int jj = kk + 1; jj < 8; jj++, t++) p[jj] = fma(-li, cr[t], p[jj]);
+                }
+            }
+            fb_bar();
+            if (wv == 3) {                                 // L(i, i-1)[row][8 Bk .. 8 Bk + 7] = l, 64 contiguous bytes per lane
+#pragma unroll
+                for (int q = 0; q < 4; q++) fb_st16(ltile + lane * 64 + 8 * Bk + 2 * q, colL[2 * q][lane], colL[2 * q + 1][lane]);
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++) {
+                const double av = -colL[4 * ks + lk][16 * wv + l15];
+#pragma unroll
+                for (int sub = 0; sub < 4; sub++)
+                    if (sub >= ((8 * Bk + 8) >> 4))
+                        xacc[sub] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, CR[(4 * ks + lk) * 64 + 16 * sub + l15], xacc[sub], 0, 0, 0);
+#pragma unroll
+                for (int sub = 0; sub < 4; sub++)
+                    tacc[sub] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, colC[4 * ks + lk][16 * sub + l15], tacc[sub], 0, 0, 0);
+            }
+            // Pc is rewritten at once (only wave 0 read it, before the barrier above); colL / colC by wave 0 after the next
+            // iteration's first barrier; the record buffer alternates
+        }
+        FB_T(13);
+    }
+    FB_T(6);
+    if (!diag) return;
+    // ---- Per block of 8 pivots: the waves hand the block's 8 columns to wave 0 through LDS, wave 0 eliminates them without leaving
+    //      the wavefront (lane = row; the pivot rule and arithmetic of k_factor_panel, kernels.hip), and every wave applies the rank-8
+    //      update to its 16 rows on the matrix core.  L11 is collected in Sb for the inverse and the solves.  STREAM: waves 1 and 2
+    //      publish the block's record for the diagonal workgroup that follows in this launch; the loop's barriers are LDS-only.
     FB_T(7);
-    const unsigned long long spos = __ballot(P.sgn_perm[f + lane] > 0);
+    const unsigned long long spos = __ballot(sgn_l > 0);
     int nreg = 0;
-    __syncthreads();                                      // Sa (X_j) and Sb (the last operand tile) are free
+    if (STREAM) fb_bar(); else __syncthreads();           // Sa (X_j) and Sb (the last operand tile / record) are free
 #pragma unroll
     for (int Bk = 0; Bk < 8; Bk++) {
         {
@@ -289,10 +414,18 @@ k_front_block(DevPlan P, FrontBatch B, int *sync_all, double *scratch_all, doubl
                 for (int reg = 0; reg < 4; reg++) Pc[(16 * wv + lk + 4 * reg) * 9 + l15 - c0] = tacc[sub][reg];
             }
         }
-        if (Bk == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the L tile stores issued before the pivots have drained ...
-        __syncthreads();
-        if (Bk == 0 && i > 0 && tid == 0)                                // ... for every thread: hand the tile over
-            __hip_atomic_store(fl_L + 8 * i + (i - 1), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (STREAM) {
+            if (Bk == 2 && i > 0 && wv == 3) {            // wave 3 wrote L(i, i-1) during the streamed step: long drained by now
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0) __hip_atomic_store(fl_L + 8 * i + (i - 1), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            fb_bar();
+        } else {
+            if (Bk == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the L tile stores issued before the pivots have drained ...
+            __syncthreads();
+            if (Bk == 0 && i > 0 && tid == 0)                                // ... for every thread: hand the tile over
+                __hip_atomic_store(fl_L + 8 * i + (i - 1), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         if (wv == 0) {
             double pcol[8];
 #pragma unroll
@@ -309,7 +442,7 @@ k_front_block(DevPlan P, FrontBatch B, int *sync_all, double *scratch_all, doubl
                 colL[kk][lane] = li;
                 colC[kk][lane] = reg;
                 Sb[lane * FLD + k] = li;
-                if (lane == k) dsave[k] = d;
+                if (lane == k) { dsave[k] = d; if (STREAM) dinvs[k] = dinv; }
 #pragma unroll
                 for (int jj = kk + 1; jj < 8; jj++) {
                     const double cj = fb_readlane(reg, 8 * Bk + jj);
@@ -317,7 +450,18 @@ k_front_block(DevPlan P, FrontBatch B, int *sync_all, double *scratch_all, doubl
                 }
             }
         }
-        __syncthreads();
+        if (STREAM) fb_bar(); else __syncthreads();
+        if (STREAM && i + 1 < nb) {                       // the block's record for the next diagonal workgroup (write-through, no flag)
+            double *rec = stream + ((int64_t)i * 8 + Bk) * kFbRec;
+            const double *flat = &colC[0][0];
+            if (wv == 1 || wv == 2) {
+                const int c = tid - 64;
+                fb_st16(rec + 2 * c, flat[2 * c], flat[2 * c + 1]);
+                fb_st16(rec + 2 * c + 256, flat[2 * c + 256], flat[2 * c + 257]);
+                if (c >= 64 && c < 68) fb_st16(rec + 512 + 2 * (c - 64), dsave[8 * Bk + 2 * (c - 64)], dsave[8 * Bk + 2 * (c - 64) + 1]);
+                if (c >= 68 && c < 72) fb_st16(rec + 520 + 2 * (c - 68), dinvs[8 * Bk + 2 * (c - 68)], dinvs[8 * Bk + 2 * (c - 68) + 1]);
+            }
+        }
         if (Bk < 7) {
             // a_ij -= sum_k l_ik a_jk over the block's 8 pivots, for the 16-column strips that still hold live columns
 #pragma unroll
@@ -396,7 +540,7 @@ k_front_block(DevPlan P, FrontBatch B, int *sync_all, double *scratch_all, doubl
     FB_T(10);
     // ---- off the critical path: the factored block for the solves' explicit inverses, D and 1/D (exact division), the last X_j
     {
-        double *ld = P.Ldiag + pi.diag_off;
+        double *ld = P.Ldiag + fp[i].diag_off;
         for (int idx = tid; idx < 4096; idx += 256) {
             const int r_ = idx & 63, k = idx >> 6;
             ld[idx] = r_ > k ? Sb[r_ * FLD + k] : (r_ == k ? 1.0 : 0.0);
@@ -417,9 +561,25 @@ k_front_block(DevPlan P, FrontBatch B, int *sync_all, double *scratch_all, doubl
     FB_T(11);
 }
 
-void launch_front_block(hipStream_t st, const DevPlan &P, const FrontBatch &B, int *sync_all, double *scratch_all, double dyn_eps,
-                        double dyn_delta, long long *trace) {
-    if (B.i_end > B.i_base) hipLaunchKernelGGL(k_front_block, dim3(B.i_end - B.i_base + (B.x_count + 4 * std::max(B.pad, 1) - 1) / (4 * std::max(B.pad, 1))), dim3(256), 0, st, P, B, sync_all, scratch_all, dyn_eps, dyn_delta, trace);
+void launch_front_block(hipStream_t st, const DevPlan &P, const FrontBatch &B, int *sync_all, double *scratch_all, double *stream_all,
+                        double dyn_eps, double dyn_delta, bool streamed, long long *trace) {
+    if (B.i_end <= B.i_base) return;
+    const dim3 grid(B.i_end - B.i_base + (B.x_count + 4 * std::max(B.pad, 1) - 1) / (4 * std::max(B.pad, 1)));
+    if (streamed) hipLaunchKernelGGL(k_front_block<true>, grid, dim3(256), 0, st, P, B, sync_all, scratch_all, stream_all, dyn_eps, dyn_delta, trace);
+    else hipLaunchKernelGGL(k_front_block<false>, grid, dim3(256), 0, st, P, B, sync_all, scratch_all, stream_all, dyn_eps, dyn_delta, trace);
+}
+
+// before every factorisation: the sync words of all front batches to zero, the stream records to "not written yet"
+__global__ void k_fb_reset(int *sync_all, int nsync, unsigned long long *stream_all, long long nstream) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x, step = (long long)gridDim.x * blockDim.x;
+    for (long long q = t; q < nsync; q += step) sync_all[q] = 0;
+    for (long long q = t; q < nstream; q += step) stream_all[q] = kFbSentinel;
+}
+void launch_fb_reset(hipStream_t st, int *sync_all, int nsync, double *stream_all, int64_t nstream) {
+    const long long n = std::max<long long>(nsync, nstream);
+    if (n <= 0) return;
+    const int blocks = (int)std::min<long long>((n + 255) / 256, 1024);
+    hipLaunchKernelGGL(k_fb_reset, dim3(blocks), dim3(256), 0, st, sync_all, nsync, (unsigned long long *)stream_all, (long long)nstream);
 }
 
 }  // namespace hipkkt

@@ -592,11 +592,13 @@ int32_t hipkkt_get_timing(hipkkt_handle h, double *o) {
     return HIPKKT_OK;
 }
 
-int32_t hipkkt_get_profile(hipkkt_handle h, double *o) {
-    if (!h || !o) return HIPKKT_ERR_ARGUMENT;
-    o[0] = h->t_last_update; o[1] = h->prof_dense4_ms; o[2] = h->prof_dense4_flops; o[3] = (double)h->prof_dense4_launches;
-    o[4] = h->prof_fb_ms; o[5] = (double)h->prof_fb_launches; o[6] = (double)h->prof_fb_panels; o[7] = h->prof_fb_flops;
-    o[8] = h->prof_extra_tiles; o[9] = h->prof_extra_flops;
+int32_t hipkkt_abi_version(void) { return HIPKKT_ABI_VERSION; }
+
+int32_t hipkkt_get_profile(hipkkt_handle h, double *out, int64_t cap) {
+    if (!h || !out || cap < 0) return HIPKKT_ERR_ARGUMENT;
+    const double o[10] = {h->t_last_update, h->prof_dense4_ms, h->prof_dense4_flops, (double)h->prof_dense4_launches, h->prof_fb_ms,
+                          (double)h->prof_fb_launches, (double)h->prof_fb_panels, h->prof_fb_flops, h->prof_extra_tiles, h->prof_extra_flops};
+    for (int64_t i = 0; i < cap && i < 10; i++) out[i] = o[i];   // never more than the caller's buffer holds
     return HIPKKT_OK;
 }
 
@@ -612,15 +614,16 @@ int32_t hipkkt_get_profile_launches(hipkkt_handle h, double *ms, double *flops, 
     return HIPKKT_OK;
 }
 
-int32_t hipkkt_get_counters(hipkkt_handle h, int64_t *o) {
-    if (!h || !o) return HIPKKT_ERR_ARGUMENT;
+int32_t hipkkt_get_counters(hipkkt_handle h, int64_t *out, int64_t cap) {
+    if (!h || !out || cap < 0) return HIPKKT_ERR_ARGUMENT;
+    int64_t o[14];
     o[0] = h->n_sweep_timeouts; o[1] = h->use_persist ? 1 : 0; o[2] = h->n_twin_refactors; o[3] = h->fallback ? 1 : 0;
     o[4] = h->using_fallback ? 1 : 0; o[5] = h->plan.ordering_used; o[6] = (int64_t)h->plan.fronts.size(); o[7] = h->nseg;
     o[8] = (int64_t)h->fbatches.size(); o[9] = h->use_front_block ? 1 : 0;
     plan_cache_counts(&o[10], &o[11]);   // process-wide: symbolic plans taken from / not found in the plan cache
-    o[12] = 0;
-    for (const auto &A : h->la) o[12] += A.on ? 1 : 0;
-    o[13] = h->plan.la_sched_moved;
+    o[12] = h->fb_streamed ? 1 : 0;
+    o[13] = 0;
+    for (int64_t i = 0; i < cap && i < 14; i++) out[i] = o[i];
     return HIPKKT_OK;
 }
 

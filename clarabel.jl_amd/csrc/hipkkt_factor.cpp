@@ -17,49 +17,21 @@ void enqueue_factor_level(hipkkt_solver *S, int l) {
         launch_factor_level(S->stream, S->dp, P.fac_lvl_ptr[l], n, P.fac_lvl_maxw[l], S->opts.dynamic_reg_eps,
                             S->opts.dynamic_reg_delta);
     else
-        launch_factor_panel(S->stream, S->dp, P.fac_lvl_ptr[l], n, S->opts.dynamic_reg_eps, S->opts.dynamic_reg_delta,
-                            P.lvl_fused[l] != 0);
+        launch_factor_panel(S->stream, S->dp, P.fac_lvl_ptr[l], n, S->opts.dynamic_reg_eps, S->opts.dynamic_reg_delta);
 }
 
 // Schur-complement updates applied after level l is factored: dense register tiles (matrix cores),
 // per-entry gather lists (tiny scattered contributions), relative-index scatter (whatever is left).
 // The three kinds own disjoint target tiles, so their order inside a stage is immaterial.
-// events of the fork / join pattern: created on first use, re-used by every later enqueue of the factorisation (an eager
-// look-ahead factorisation needs ~60 of them per call)
-static hipEvent_t new_fork_event(hipkkt_solver *S) {
-    if (S->fork_event_next < S->fork_events.size()) return S->fork_events[S->fork_event_next++];
-    hipEvent_t e = nullptr;
-    HK_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    S->fork_events.push_back(e);
-    S->fork_event_next = S->fork_events.size();
-    return e;
-}
-
-void enqueue_updates(hipkkt_solver *S, int l, bool split_far = false, int dense_skip_tail = 0) {
+// dense_skip_tail: the last tiles of the stage's dense list ride in the next k_front_block launch instead.
+void enqueue_updates(hipkkt_solver *S, int l, int dense_skip_tail = 0) {
     const HostPlan &P = S->plan;
     hipStream_t st = S->stream;
-    if (l + 1 < P.nlevels && P.lvl_fused[l + 1]) return;   // applied inside the next level's panel kernel
     const int g0 = P.upd_stage_ptr[l], nd = P.upd_stage_ndense[l], ng = P.upd_stage_ngather[l];
-    const int64_t ngath = P.gath_stage_ptr[l + 1] - P.gath_stage_ptr[l];
-    // A stage that carries the sparse part of the tree into a big front has a long matrix-core launch (thousands of low-fill
-    // tiles) AND a long per-entry gather launch (latency-bound: dependent record -> operand loads per thread); they own disjoint
-    // targets and only read their sources, so the gather runs on the side stream next to the tile launch (cfg 2a: 0.32 + 0.37 ms
-    // back to back in round 2).  HIPKKT_FORK_GATHER=0: one after the other.
-    const bool par = S->fork_gather && nd > 384 && ngath >= 65536;
-    hipEvent_t joined = nullptr;
-    if (par) {
-        hipEvent_t e1 = new_fork_event(S);
-        joined = new_fork_event(S);
-        HK_CHECK(hipEventRecord(e1, st));
-        HK_CHECK(hipStreamWaitEvent(S->side, e1, 0));
-        launch_update_gather(S->side, S->dp, P.gath_stage_ptr[l], ngath, S->gath_heavy_ptr[l], S->gath_heavy_ptr[l + 1] - S->gath_heavy_ptr[l]);
-        HK_CHECK(hipEventRecord(joined, S->side));
-    }
-    launch_update_dense(st, S->dp, g0, nd - (split_far ? P.upd_stage_nfar[l] : 0) - dense_skip_tail, 0, nd > 0 && P.upd_stage_flops_dense[l] >= 1.5e6 * nd);
-    if (!par)
-        launch_update_gather(st, S->dp, P.gath_stage_ptr[l], ngath, S->gath_heavy_ptr[l], S->gath_heavy_ptr[l + 1] - S->gath_heavy_ptr[l]);
+    launch_update_dense(st, S->dp, g0, nd - dense_skip_tail, nd > 0 && P.upd_stage_flops_dense[l] >= 1.5e6 * nd);
+    launch_update_gather(st, S->dp, P.gath_stage_ptr[l], P.gath_stage_ptr[l + 1] - P.gath_stage_ptr[l], S->gath_heavy_ptr[l],
+                         S->gath_heavy_ptr[l + 1] - S->gath_heavy_ptr[l]);
     launch_update_stage(st, S->dp, g0 + nd + ng, P.upd_stage_ptr[l + 1] - g0 - nd - ng);
-    if (par) HK_CHECK(hipStreamWaitEvent(st, joined, 0));
 }
 
 // How many of a front batch's far tiles ride in the next k_front_block launch (enqueue_factor; HIPKKT_FB_EXTRA=0: none).  That launch
@@ -82,9 +54,7 @@ static double dense_stage_cost_us(int m) {
     return k == 0 ? 77.0 : 65.0 * (k + 1);
 }
 int fb_extra_tiles_of_stage(int nd, int ncrit, int next_blk, int *per_wave_out) {
-    static const int cus = [] { const char *e = getenv("HIPKKT_FB_EXTRA_CUS"); return e ? atoi(e) : 254; }();
-    static const int rmin = [] { const char *e = getenv("HIPKKT_FB_EXTRA_MIN"); return e ? atoi(e) : 64; }();
-    static const int pw_max = [] { const char *e = getenv("HIPKKT_FB_EXTRA_PER_WAVE"); return e ? std::max(1, std::min(2, atoi(e))) : 2; }();
+    constexpr int cus = 254, rmin = 64, pw_max = 2;
     static const double pen[3] = {0.0, [] { const char *e = getenv("HIPKKT_FB_EXTRA_PEN1"); return e ? atof(e) : 10.0; }(),
                                   [] { const char *e = getenv("HIPKKT_FB_EXTRA_PEN2"); return e ? atof(e) : 28.0; }()};   // what the panel launch gains in duration (us)
     double best = dense_stage_cost_us(nd);
@@ -113,29 +83,14 @@ int fb_extra_tiles_of_stage(int nd, int ncrit, int next_blk, int *per_wave_out) 
 void enqueue_factor(hipkkt_solver *S, int static_enable, double eps_const, double eps_prop) {
     const HostPlan &P = S->plan;
     hipStream_t st = S->stream;
-    S->fork_event_next = 0;
     launch_zero_words(st, S->dp.scal, 2);                 // SC_MAXDIAG  (kernels.hip: why not hipMemsetAsync)
     launch_zero_words(st, S->dp.flags, FL_COUNT);
     launch_maxabs_gather(st, S->dp.kval, S->d_diag_full, S->N, (unsigned long long *)S->dp.scal + SC_MAXDIAG);
     HK_CHECK(hipMemsetAsync(S->dp.Lx, 0, (size_t)P.panel_doubles * sizeof(double), st));
     launch_init_panels(st, S->dp, S->nnzK, static_enable, eps_const, eps_prop);
-    // Far updates (targets more than `lookahead` levels ahead) are forked to the side stream right after the
-    // level's factorisation and joined before the next batch end touches the same targets (symbolic.h).
-    auto new_event = [&]() { return new_fork_event(S); };
-    const bool fork = S->use_side && P.lookahead > 0;
-    hipEvent_t pending = nullptr;
-    int pending_level = -1;
     const bool fb = S->use_front_block && !S->fbatches.empty();
-    if (fb) launch_zero_words(st, S->d_fb_sync, 128 * (int)S->fbatches.size());
-    // Look-ahead over a big front (HIPKKT_LOOKAHEAD=1; eager launches): the far stage of batch t of a look-ahead region is split
-    // [chain | background] (hipkkt_setup.cpp plan_lookahead).  The chain part (columns of batch t+1) runs on the main stream, then the
-    // panel kernel of batch t+1; the background part runs NEXT TO that panel kernel on a CU-masked throughput stream that leaves the
-    // panel kernel its compute units, and is joined before the chain part of batch t+1.  What the background part holds was chosen
-    // by due date to fit the panel kernel's duration (symbolic.cpp step 14); nothing it writes is touched by the panel kernel
-    // (columns of batch t+2 and further right), and two background launches never overlap.
-    const bool la = fb && S->lookahead && S->la_streams[0] != nullptr;
+    if (fb) launch_fb_reset(st, S->d_fb_sync, 128 * (int)S->fbatches.size(), S->d_fb_stream, S->fb_stream_doubles);
     int cur_bi = -1;
-    hipEvent_t ev_bg = nullptr;                           // the background launch in flight
     int extra_begin = 0, extra_count = 0, extra_pw = 1;   // dense tiles handed to the next k_front_block launch, tiles per wavefront there
     for (int l = 0; l < P.nlevels; l++) {
         if (fb && S->lvl_fb[l] != -1) {
@@ -145,47 +100,21 @@ void enqueue_factor(hipkkt_solver *S, int static_enable, double eps_const, doubl
                 FrontBatch B = S->fbatches[(size_t)cur_bi];
                 B.x_begin = extra_begin; B.x_count = extra_count; B.pad = extra_pw;     // far tiles of the stage before (fb_extra_tiles_of_stage)
                 extra_begin = extra_count = 0;
-                launch_front_block(st, S->dp, B, S->d_fb_sync, S->d_fb_scratch, S->opts.dynamic_reg_eps, S->opts.dynamic_reg_delta, S->d_fb_trace);
+                launch_front_block(st, S->dp, B, S->d_fb_sync, S->d_fb_scratch, S->d_fb_stream, S->opts.dynamic_reg_eps,
+                                   S->opts.dynamic_reg_delta, S->fb_streamed, S->d_fb_trace);
             }
             const bool last = l + 1 >= P.nlevels || S->lvl_fb[l + 1] != -2;
             if (!last) continue;                          // the stages inside the batch are applied by the kernel itself
-            if (la && cur_bi >= 0 && S->la[(size_t)cur_bi].on) {
-                const hipkkt_solver::LaBatch &A = S->la[(size_t)cur_bi];
-                const int g0 = P.upd_stage_ptr[l], nd = P.upd_stage_ndense[l], nbg = nd - A.ncrit;
-                if (ev_bg) { HK_CHECK(hipStreamWaitEvent(st, ev_bg, 0)); ev_bg = nullptr; }            // the background launch of the batch before
-                const bool big = P.upd_stage_flops_dense[l] >= 1.5e6 * nd;
-                launch_update_dense(st, S->dp, g0, A.ncrit, 0, big);                                    // chain part
-                static const double max_gf = [] { const char *e = getenv("HIPKKT_LA_MAXGF"); return e ? atof(e) : 1e30; }();
-                if (A.last || nbg <= 0 || P.upd_stage_flops_dense[l] > max_gf * 1e9) {
-                    launch_update_dense(st, S->dp, g0 + A.ncrit, nbg, 0, big);                          // leaving the region
-                } else {
-                    int k = 0;
-                    while (k + 1 < hipkkt_solver::kLaStreams && hipkkt_solver::la_keep(k) < A.next_blk + 2) k++;
-                    hipStream_t tb = S->la_streams[k];
-                    hipEvent_t e0 = new_event();
-                    HK_CHECK(hipEventRecord(e0, st));
-                    HK_CHECK(hipStreamWaitEvent(tb, e0, 0));
-                    launch_update_dense(tb, S->dp, g0 + A.ncrit, nbg, 0, big);
-                    ev_bg = new_event();
-                    HK_CHECK(hipEventRecord(ev_bg, tb));
-                }
-                continue;
-            }
         } else {
             enqueue_factor_level(S, l);
         }
-        const int nfar = fork ? P.upd_stage_nfar[l] : 0;
-        if (pending && (nfar > 0 || l >= pending_level + P.lookahead)) {
-            HK_CHECK(hipStreamWaitEvent(st, pending, 0));
-            pending = nullptr;
-        }
         int skip = 0;
-        if (fb && S->fb_extra && !la && cur_bi >= 0 && S->lvl_fb[l] != -1 && S->la[(size_t)cur_bi].has_next && nfar == 0) {
+        if (fb && S->fb_extra && cur_bi >= 0 && S->lvl_fb[l] != -1 && S->next_batch[(size_t)cur_bi].has_next) {
             // The far stage of a front batch runs in rounds of 1024 tiles (one per SIMD; 2048 with two co-resident wavefronts); what is
             // left after the whole rounds keeps a fraction of the device busy for a full tile time.  Those tiles -- taken from the END
             // of the [columns of the next batch | rest] order, so the next panel kernel does not need them -- ride in the next
             // k_front_block launch as extra workgroups on the compute units it leaves idle.
-            const hipkkt_solver::LaBatch &A = S->la[(size_t)cur_bi];
+            const hipkkt_solver::NextBatch &A = S->next_batch[(size_t)cur_bi];
             const int r = fb_extra_tiles_of_stage(P.upd_stage_ndense[l], A.ncrit, A.next_blk, &extra_pw);
             if (r > 0 && P.upd_stage_flops_dense[l] >= 1.5e6 * P.upd_stage_ndense[l]) {
                 skip = r;
@@ -193,19 +122,8 @@ void enqueue_factor(hipkkt_solver *S, int static_enable, double eps_const, doubl
                 extra_count = r;
             }
         }
-        enqueue_updates(S, l, nfar > 0, skip);
-        if (nfar > 0) {   // forked AFTER the near updates: the far tiles must not compete with them for the CUs
-            hipEvent_t e1 = new_event(), e2 = new_event();
-            HK_CHECK(hipEventRecord(e1, st));
-            HK_CHECK(hipStreamWaitEvent(S->side, e1, 0));
-            launch_update_dense(S->side, S->dp, P.upd_stage_ptr[l] + P.upd_stage_ndense[l] - nfar, nfar, S->far_wgs);
-            HK_CHECK(hipEventRecord(e2, S->side));
-            pending = e2;
-            pending_level = l;
-        }
+        enqueue_updates(S, l, skip);
     }
-    if (pending) HK_CHECK(hipStreamWaitEvent(st, pending, 0));
-    if (ev_bg) HK_CHECK(hipStreamWaitEvent(st, ev_bg, 0));
     launch_invert_diag(st, S->dp, S->inv_nsmall, S->inv_wsmall, S->inv_nwide);
     for (const FrontDesc &F : P.fronts) launch_invert_super(st, S->dp, F);   // super-block inverses for the front sweeps
 }
@@ -302,7 +220,7 @@ static int32_t refactor_once(hipkkt_handle h, int32_t static_reg_enable, double 
         std::vector<hipEvent_t> evs, evd;   // evs: all update kernels of a stage; evd: its k_update_dense<4,4> launch alone
         std::vector<int> evd_level;
         const bool fb = S->use_front_block && !S->fbatches.empty();
-        if (fb) launch_zero_words(st, S->d_fb_sync, 128 * (int)S->fbatches.size());
+        if (fb) launch_fb_reset(st, S->d_fb_sync, 128 * (int)S->fbatches.size(), S->d_fb_stream, S->fb_stream_doubles);
         std::vector<hipEvent_t> evf;        // around every k_front_block launch
         int fb_panels = 0;
         double fb_flops = 0;                // update flops of the stages inside the batches (executed by k_front_block)
@@ -330,8 +248,8 @@ static int32_t refactor_once(hipkkt_handle h, int32_t static_reg_enable, double 
                     FrontBatch B = S->fbatches[(size_t)cur_bi];
                     B.x_begin = extra_begin; B.x_count = extra_count; B.pad = extra_pw;
                     extra_begin = extra_count = 0;
-                    launch_front_block(st, S->dp, B, S->d_fb_sync, S->d_fb_scratch, S->opts.dynamic_reg_eps, S->opts.dynamic_reg_delta,
-                                       S->d_fb_trace);
+                    launch_front_block(st, S->dp, B, S->d_fb_sync, S->d_fb_scratch, S->d_fb_stream, S->opts.dynamic_reg_eps,
+                                       S->opts.dynamic_reg_delta, S->fb_streamed, S->d_fb_trace);
                     HK_CHECK(hipEventRecord(b, st));
                     evf.push_back(a);
                     evf.push_back(b);
@@ -341,22 +259,21 @@ static int32_t refactor_once(hipkkt_handle h, int32_t static_reg_enable, double 
             } else {
                 enqueue_factor_level(S, l);
             }
-            const bool fused_next = l + 1 < P.nlevels && P.lvl_fused[l + 1];   // applied by the next panel kernel
-            if (P.upd_stage_ptr[l + 1] > P.upd_stage_ptr[l] && !fused_next) {
+            if (P.upd_stage_ptr[l + 1] > P.upd_stage_ptr[l]) {
                 hipEvent_t a, b, c2;
                 HK_CHECK(hipEventCreate(&a));
                 HK_CHECK(hipEventCreate(&b));
                 HK_CHECK(hipEventRecord(a, st));
                 const int g0 = P.upd_stage_ptr[l], nd = P.upd_stage_ndense[l], ng = P.upd_stage_ngather[l];
                 int skip = 0;                                              // (the same rule as enqueue_factor)
-                if (fb && S->fb_extra && !S->profiling_no_extra && !(S->lookahead && S->la_streams[0]) && cur_bi >= 0 && S->lvl_fb[l] != -1 && S->la[(size_t)cur_bi].has_next &&
+                if (fb && S->fb_extra && !S->profiling_no_extra && cur_bi >= 0 && S->lvl_fb[l] != -1 && S->next_batch[(size_t)cur_bi].has_next &&
                     P.upd_stage_flops_dense[l] >= 1.5e6 * nd) {
-                    skip = fb_extra_tiles_of_stage(nd, S->la[(size_t)cur_bi].ncrit, S->la[(size_t)cur_bi].next_blk, &extra_pw);
+                    skip = fb_extra_tiles_of_stage(nd, S->next_batch[(size_t)cur_bi].ncrit, S->next_batch[(size_t)cur_bi].next_blk, &extra_pw);
                     if (skip > 0) { extra_begin = g0 + nd - skip; extra_count = skip; }
                 }
                 const double xf = skip > 0 ? dense_flops(g0 + nd - skip, skip) : 0.0;
                 S->prof_extra_tiles += skip; S->prof_extra_flops += xf;
-                launch_update_dense(st, S->dp, g0, nd - skip, 0, nd > 0 && P.upd_stage_flops_dense[l] >= 1.5e6 * nd);
+                launch_update_dense(st, S->dp, g0, nd - skip, nd > 0 && P.upd_stage_flops_dense[l] >= 1.5e6 * nd);
                 if (nd - skip > 384) {   // the one-wavefront-per-tile variant (see launch_update_dense)
                     HK_CHECK(hipEventCreate(&c2));
                     HK_CHECK(hipEventRecord(c2, st));
@@ -408,8 +325,7 @@ static int32_t refactor_once(hipkkt_handle h, int32_t static_reg_enable, double 
     } else {
         GraphSlot &g = S->g_factor;
         const bool same = g.static_enable == static_reg_enable && g.eps_const == eps_const && g.eps_prop == eps_prop;
-        if (S->lookahead && S->la_streams[0]) enqueue_factor(S, static_reg_enable, eps_const, eps_prop);   // CU-masked stream: eager, not captured
-        else run_graphed(S, S->stream, g, same, [&] { enqueue_factor(S, static_reg_enable, eps_const, eps_prop); });
+        run_graphed(S, S->stream, g, same, [&] { enqueue_factor(S, static_reg_enable, eps_const, eps_prop); });
         g.static_enable = static_reg_enable; g.eps_const = eps_const; g.eps_prop = eps_prop;
     }
     HK_CHECK(hipEventRecord(S->ev1, S->stream));

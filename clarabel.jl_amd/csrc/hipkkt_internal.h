@@ -99,12 +99,6 @@ struct hipkkt_solver {
     int device = 0;
     SolveCtx ctx[kNumCtx];
     hipStream_t stream = nullptr;
-    hipStream_t side = nullptr;          // far Schur updates run here, overlapped with the critical path
-    std::vector<hipEvent_t> fork_events;
-    size_t fork_event_next = 0;          // next pooled event of the current enqueue_factor
-    bool use_side = true;
-    bool fork_gather = false;  // (measured r03b: no gain) a stage's per-entry gather launch next to its big dense launch (hipkkt_factor.cpp enqueue_updates)
-    int far_wgs = 256;   // grid bound of the look-ahead (far) update launches; 0 = one workgroup per 4 tiles
     hipkkt_opts opts{};
     bool l1 = false;
     KKTImage img;      // L1: assembled image; L0: colptr/rowval/nzval/dsigns copied in
@@ -136,24 +130,24 @@ struct hipkkt_solver {
     std::vector<int> fb_last_level;      // per batch
     int *d_fb_sync = nullptr;
     double *d_fb_scratch = nullptr;
-    // look-ahead factorisation of a big front (hipkkt_factor.cpp enqueue_factor, HIPKKT_LOOKAHEAD=1): per front batch, the row blocks
-    // its crit launch covers (this batch's diagonal blocks + the rows of the next two batches) and the 3-way split of its far stage
-    struct LaBatch {
-        bool on = false, first = false, last = false;   // inside a look-ahead region / its first / its last batch
+    // streamed pivot chain of k_front_block (front_block.hip): per (batch, panel, 8-pivot block) one record of 528 doubles that the
+    // diagonal workgroup publishes as it eliminates and the next diagonal workgroup polls (sentinel-filled before every factorisation)
+    double *d_fb_stream = nullptr;
+    int64_t fb_stream_doubles = 0;
+    bool fb_streamed = true;             // HIPKKT_FB_STREAM=0: the round-3 chain (hand-off of the explicit inverse after all 64 pivots)
+    // per front batch: what the next batch of the same front needs from this batch's far stage ([columns of the next batch | rest]
+    // order of the stage's dense tiles, hipkkt_setup.cpp order_far_stages) -- the rest may ride in the next k_front_block launch
+    struct NextBatch {
         int next_blk = 0;                               // workgroups of the next batch's panel kernel
         bool has_next = false;                          // the next batch of the same front follows at once: [chain | rest] order valid
-        int ncrit = 0, nE = 0;                          // far stage: [crit | E | far] dense groups (setup reorders them)
+        int ncrit = 0;                                  // far stage: the first ncrit dense groups are the next batch's columns
     };
-    std::vector<LaBatch> la;
-    bool lookahead = false;
+    std::vector<NextBatch> next_batch;
     bool fb_extra = true;                // the partial last round of a batch's far updates rides in the next k_front_block launch (HIPKKT_FB_EXTRA=0: off)
-    static constexpr int kLaStreams = 4;
-    static int la_keep(int k) { return k == 0 ? 16 : k == 1 ? 32 : k == 2 ? 64 : 96; }   // compute units left to the panel kernel
-    hipStream_t la_streams[kLaStreams] = {nullptr, nullptr, nullptr, nullptr};            // throughput streams, CU-masked
     long long *d_fb_trace = nullptr;     // HIPKKT_FB_TRACE=1: wall-clock stamps of the first 8 workgroups of every batch (debug_dump 9)
     bool persist_allowed = true;         // false: HIPKKT_NO_PERSIST (never tried)
     int64_t persist_retry_at = -1;       // after a sweep time-out: the LDL-solve count at which the persistent kernels are tried again
-    int64_t persist_backoff = 0;         // doubles with every time-out (64, 128, ...); HIPKKT_PERSIST_RETRY=0 disables the retry
+    int64_t persist_backoff = 0;         // doubles with every time-out (64, 128, ...)
     int64_t n_sweep_timeouts = 0;
     int64_t n_twin_refactors = 0;        // factorisations repeated on the robust-order twin
     int nseg = 0;
@@ -206,7 +200,6 @@ struct hipkkt_solver {
     hipkkt_host::GraphSlot g_factor;
     bool use_graph = true;
     bool runtime_ready = false;   // init_runtime done (streams, events, pinned areas)
-    bool poison = false;
     PlanOptions plan_opts;       // as used for the current plan
     // robust-order twin (minimum degree on K), created on the first factorisation that fails in the
     // "variables last" order; every later factorisation still tries the fast order first
@@ -251,7 +244,6 @@ struct hipkkt_solver {
         void *p = slab_cur;
         slab_cur += bytes;
         slab_left -= bytes;
-        if (poison) (void)hipMemsetAsync(p, 0xFF, n * sizeof(T), stream);   // debugging aid (HIPKKT_POISON=1): NaNs in every fresh buffer
         return (T *)p;
     }
     template <class T>
@@ -276,7 +268,6 @@ struct hipkkt_solver {
         // everything below goes back to the process-wide cache (runtime_pool.h): the streams must be idle first
         RuntimePool &rp = RuntimePool::get();
         if (stream) (void)hipStreamSynchronize(stream);
-        if (side) (void)hipStreamSynchronize(side);
         for (SolveCtx &C : ctx)
             if (C.own_stream && C.stream) (void)hipStreamSynchronize(C.stream);
         if (g_factor.exec) (void)hipGraphExecDestroy(g_factor.exec);
@@ -292,9 +283,6 @@ struct hipkkt_solver {
         rp.pinned_free(device, h_scal);
         rp.pinned_free(device, h_flags);
         for (hipEvent_t e : {ev0, ev1, ev2, ev3}) rp.event_put(device, e);
-        for (hipEvent_t e : fork_events) (void)hipEventDestroy(e);
-        for (hipStream_t q : la_streams) if (q) { (void)hipStreamSynchronize(q); (void)hipStreamDestroy(q); }
-        rp.stream_put(device, 1, side);
         rp.stream_put(device, 0, stream);
     }
 };

@@ -52,45 +52,15 @@ void plan_cache_counts(int64_t *hits, int64_t *misses) {
 }
 
 void init_runtime(hipkkt_solver *S) {
-    { const char *pz = getenv("HIPKKT_POISON"); S->poison = pz && pz[0] == '1'; }
     HK_CHECK(hipSetDevice(S->device));
     RuntimePool &rp = RuntimePool::get();
     auto need = [&](void *p) { if (!p) throw DeviceError{"creating a stream / event / pinned buffer failed"}; return p; };
+    S->stream = (hipStream_t)need(rp.stream_get(S->device, 0));
     {
-        // the critical path (panel factorisations) gets the higher priority
-        S->stream = (hipStream_t)need(rp.stream_get(S->device, 0));
-        S->side = (hipStream_t)need(rp.stream_get(S->device, 1));
-        // measured on MI355X (cfg 2a): forking the far updates gives no net gain inside a hipGraph -- the far
-        // kernel fills every CU and the panel kernels on the critical path slow down by what the overlap
-        // saves -- so the fork is opt-in (HIPKKT_SIDE_STREAM=1)
-        const char *ns = getenv("HIPKKT_SIDE_STREAM");
-        S->use_side = ns && ns[0] == '1';
-        const char *fg = getenv("HIPKKT_FORK_GATHER");
-        S->fork_gather = fg && fg[0] == '1';
-        const char *la = getenv("HIPKKT_LOOKAHEAD");
-        S->lookahead = la && la[0] == '1';
-        if (S->lookahead && !S->la_streams[0]) {
-            // Throughput streams for the launches that run next to a panel kernel: all compute units except the last `keep / 8` of
-            // every XCD (mask bits are interleaved over the XCDs: bit b -> XCD b % 8, tools/ubench_cumask.hip), so that the panel
-            // kernel on the main stream finds those free whatever the other launch occupies.  k_front_block keeps one workgroup per
-            // compute unit (100 KB of LDS) and a batch has 2 ... 90 of them: one stream per size class.
-            int ncu = 0;
-            HK_CHECK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, S->device));
-            for (int k = 0; k < hipkkt_solver::kLaStreams && S->lookahead; k++) {
-                const int keep = hipkkt_solver::la_keep(k);
-                std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
-                for (int b = 0; b < ncu - keep; b++) mask[(size_t)b / 32] |= 1u << (b % 32);
-                if (ncu < 2 * keep || hipExtStreamCreateWithCUMask(&S->la_streams[k], (uint32_t)mask.size(), mask.data()) != hipSuccess) {
-                    (void)hipGetLastError();
-                    S->la_streams[k] = nullptr;
-                    S->lookahead = false;
-                }
-            }
-        }
-        const char *fx = getenv("HIPKKT_FB_EXTRA");   // 0: every far stage applies all of its tiles in its own launch (A/B timing)
+        const char *fx = getenv("HIPKKT_FB_EXTRA");   // 0: every far stage applies all of its tiles in its own launch (A/B timing, bit-identity test)
         S->fb_extra = !(fx && fx[0] == '0');
-        const char *fw = getenv("HIPKKT_FAR_WGS");
-        if (fw) S->far_wgs = atoi(fw);
+        const char *fs = getenv("HIPKKT_FB_STREAM");  // 0: the pivot chain of k_front_block hands over L11^-T D^-1 after all 64 pivots (round-3 form)
+        S->fb_streamed = !(fs && fs[0] == '0');
     }
     static_assert(SC_COUNT * sizeof(double) <= RuntimePool::kPinned && sizeof(RefineState) <= RuntimePool::kPinned, "pinned chunk too small");
     for (hipEvent_t *e : {&S->ev0, &S->ev1, &S->ev2, &S->ev3}) *e = (hipEvent_t)need(rp.event_get(S->device));
@@ -118,7 +88,7 @@ void init_runtime(hipkkt_solver *S) {
 
 // (re)builds every device-resident structure from S->plan and S->img (values included)
 static void build_front_batches(hipkkt_solver *S);
-static void plan_lookahead(hipkkt_solver *S);
+static void order_far_stages(hipkkt_solver *S);
 void setup_device(hipkkt_solver *S) {
     HK_CHECK(hipSetDevice(S->device));
     for (GraphSlot *g : {&S->g_factor, &S->ctx[0].g_ldl, &S->ctx[0].g_first, &S->ctx[0].g_step, &S->ctx[1].g_ldl, &S->ctx[1].g_first,
@@ -146,7 +116,7 @@ void setup_device(hipkkt_solver *S) {
     S->d_sc_kind = nullptr; S->sc_cap_socdesc = S->sc_cap_psd = 0; S->sc_ready = false;   // (slab memory of an earlier set-up is gone)
     S->red_have_const = false;
 
-    plan_lookahead(S);
+    order_far_stages(S);
     HostPlan &P = S->plan;
     const int N = P.N;
     S->N = N;
@@ -162,8 +132,7 @@ void setup_device(hipkkt_solver *S) {
         S->p_off[s + 1] = S->p_off[s] + nb * w;
     }
     S->reg_lvl_ptr.assign(P.nlevels + 1, 0);
-    const char *nn = getenv("HIPKKT_NO_NARROW");
-    const bool allow_narrow = !(nn && nn[0] == '1');
+    const bool allow_narrow = true;
     // ---- segments of the persistent sweeps = level ranges between two front kernels; inside a segment the wide bottom
     //      levels (thousands of leaf supernodes) are cheaper as one launch per level, the persistent kernels take over
     //      from the first level with fewer than kPersistMaxItems items (seg_lstar)
@@ -359,14 +328,13 @@ void setup_device(hipkkt_solver *S) {
         }
         D.fac_recs = S->upload(recs);
     }
-    D.fac_jit = S->upload(P.fac_jit);
     D.slv_items = S->upload(S->slv_items);
     D.rel = S->upload(P.rel);
     D.upd_tasks = S->upload(P.upd_tasks);
     D.upd_groups = S->upload(P.upd_groups);
     {
         std::vector<DenseGroup> dg(P.upd_groups.size());
-        const bool no_full_tiles = [] { const char *e = getenv("HIPKKT_FULL_TILES"); return e && e[0] == '0'; }();   // A/B timing
+        const bool no_full_tiles = [] { const char *e = getenv("HIPKKT_FULL_TILES"); return e && e[0] == '0'; }();   // bit-identity test of the full-tile core
         for (size_t q = 0; q < dg.size(); q++) {
             const UpdGroup &G = P.upd_groups[q];
             const int t = G.tgt;
@@ -441,12 +409,10 @@ void setup_device(hipkkt_solver *S) {
     D.sn_bparent = S->upload(sn_bparent);
     D.nseg = S->nseg;
     {
-        const char *tk = getenv("HIPKKT_SEG_TICKET");      // 0: item = blockIdx (A/B timing of the ticket's cost)
-        D.seg_ticket = tk ? atoi(tk) : 3;                  // bit 0: forward sweep, bit 1: backward sweep
+        D.seg_ticket = 3;                                  // bit 0: forward sweep, bit 1: backward sweep take their items by atomic ticket
         const char *sl = getenv("HIPKKT_SPIN_LIMIT");      // tests force a sweep time-out with a tiny bound
         D.spin_limit = sl ? (unsigned)strtoul(sl, nullptr, 10) : (1u << 20);
-        const char *df = getenv("HIPKKT_DEBUG_FLAGS");
-        D.dbg = df ? atoi(df) : 0;
+        D.dbg = 0;
     }
     {
         const size_t nsync = seg_sync_ints(S->nseg, P.nsuper);
@@ -558,76 +524,37 @@ void setup_device(hipkkt_solver *S) {
     HK_CHECK(hipStreamSynchronize(S->stream));
 }
 
-// Look-ahead regions of the factorisation (HIPKKT_LOOKAHEAD=1) and the 3-way split of their far stages.  Runs BEFORE the work lists
-// go to the device: it reorders the dense groups of those stages inside S->plan.
-static void plan_lookahead(hipkkt_solver *S) {
-    // ---- look-ahead regions: runs of >= 3 consecutive batches of one front whose far stages hold nothing but dense tiles.  The far
-    //      stage of batch t (scheduled by due date: symbolic.cpp step 14) is reordered [chain | background]:
-    //        chain      = tiles of the columns of batch t+1: the next k_front_block needs them
-    //        background = everything further right (and targets outside the region): runs NEXT TO the k_front_block of batch t+1
+// Far stage of every front batch whose successor (the next batch of the same front) follows at once: its dense tiles are reordered
+// [columns of the next batch | rest] (stable).  The next k_front_block launch needs only the first part before it starts; tiles from
+// the END of the rest may ride in that launch as extra workgroups (hipkkt_factor.cpp fb_extra_tiles_of_stage).  Runs BEFORE the
+// work lists go to the device: it reorders the dense groups of those stages inside S->plan.
+static void order_far_stages(hipkkt_solver *S) {
     HostPlan &Pm = S->plan;
     const HostPlan &P = S->plan;
     const auto hb = front_batches(P, S->plan_opts.update_policy, kFbMax);
     const size_t nbh = hb.size();
-    S->la.assign(nbh, hipkkt_solver::LaBatch());
+    S->next_batch.assign(nbh, hipkkt_solver::NextBatch());
     {
         const char *e = getenv("HIPKKT_FRONT_BLOCK");
-        if ((!S->lookahead && !S->fb_extra) || (e && e[0] == '0')) return;
+        if (!S->fb_extra || (e && e[0] == '0')) return;
     }
-    {
-        std::vector<std::vector<int>> panel_batch(P.fronts.size());
-        for (size_t fi = 0; fi < P.fronts.size(); fi++) panel_batch[fi].assign((size_t)P.fronts[fi].np, -1);
-        for (size_t q = 0; q < nbh; q++)
-            for (int t = 0; t < hb[q].nb; t++) panel_batch[(size_t)hb[q].front][(size_t)(hb[q].p0 + t)] = (int)q;
-        auto dense_only = [&](int l) { return P.upd_stage_ptr[l + 1] - P.upd_stage_ptr[l] == P.upd_stage_ndense[l] && P.gath_stage_ptr[l + 1] == P.gath_stage_ptr[l]; };
-        // [columns of the next batch | rest] for every batch whose successor follows at once (dense groups only; stable)
-        auto part = [&](size_t b, size_t e) {
-            hipkkt_solver::LaBatch &A = S->la[b];
-            const int l = hb[b].level_last, g0 = P.upd_stage_ptr[l], nd = P.upd_stage_ndense[l];
-            const FrontDesc &F = P.fronts[(size_t)hb[b].front];
-            auto near = [&](const UpdGroup &G) {
-                if (P.sn_front[G.tgt] != hb[b].front) return false;
-                const int tb = panel_batch[(size_t)hb[b].front][(size_t)(G.tgt - F.s0)];
-                return tb == (int)b + 1 && tb <= (int)e;
-            };
-            auto gb = Pm.upd_groups.begin() + g0, ge = gb + nd;
-            A.ncrit = (int)(std::stable_partition(gb, ge, near) - gb);
-            A.nE = 0;
-            A.has_next = b < e;
-            A.next_blk = b < e ? (P.front_panels[P.fronts[(size_t)hb[b + 1].front].fp_off + hb[b + 1].p0].r + 63) / 64 : 0;
+    std::vector<std::vector<int>> panel_batch(P.fronts.size());
+    for (size_t fi = 0; fi < P.fronts.size(); fi++) panel_batch[fi].assign((size_t)P.fronts[fi].np, -1);
+    for (size_t q = 0; q < nbh; q++)
+        for (int t = 0; t < hb[q].nb; t++) panel_batch[(size_t)hb[q].front][(size_t)(hb[q].p0 + t)] = (int)q;
+    for (size_t b = 0; b < nbh; b++) {
+        const bool next = b + 1 < nbh && hb[b + 1].front == hb[b].front && hb[b + 1].p0 == hb[b].p0 + hb[b].nb;
+        hipkkt_solver::NextBatch &A = S->next_batch[b];
+        const int l = hb[b].level_last, g0 = P.upd_stage_ptr[l], nd = P.upd_stage_ndense[l];
+        const FrontDesc &F = P.fronts[(size_t)hb[b].front];
+        auto near = [&](const UpdGroup &G) {
+            if (!next || P.sn_front[G.tgt] != hb[b].front) return false;
+            return panel_batch[(size_t)hb[b].front][(size_t)(G.tgt - F.s0)] == (int)b + 1;
         };
-        if (S->fb_extra && !S->lookahead) {
-            for (size_t b = 0; b < nbh; b++) {
-                const bool next = b + 1 < nbh && hb[b + 1].front == hb[b].front && hb[b + 1].p0 == hb[b].p0 + hb[b].nb;
-                part(b, next ? b + 1 : b);
-            }
-            return;
-        }
-        size_t q = 0;
-        while (q < nbh) {
-            size_t e = q;
-            while (e + 1 < nbh && hb[e + 1].front == hb[q].front && hb[e + 1].p0 == hb[e].p0 + hb[e].nb && dense_only(hb[e].level_last)) e++;
-            if (e - q + 1 >= 3 && dense_only(hb[e].level_last)) {
-                for (size_t b = q; b <= e; b++) {
-                    hipkkt_solver::LaBatch &A = S->la[b];
-                    A.on = true; A.first = b == q; A.last = b == e;
-                    const int l = hb[b].level_last, g0 = P.upd_stage_ptr[l], nd = P.upd_stage_ndense[l];
-                    const FrontDesc &F = P.fronts[(size_t)hb[b].front];
-                    auto cls = [&](const UpdGroup &G) {
-                        if (P.sn_front[G.tgt] != hb[b].front) return 2;
-                        const int tb = panel_batch[(size_t)hb[b].front][(size_t)(G.tgt - F.s0)];
-                        if (tb == (int)b + 1 && tb <= (int)e) return 0;
-                        return 2;
-                    };
-                    auto gb = Pm.upd_groups.begin() + g0, ge = gb + nd;
-                    auto m1 = std::stable_partition(gb, ge, [&](const UpdGroup &G) { return cls(G) == 0; });
-                    A.ncrit = (int)(m1 - gb);
-                    A.nE = 0;
-                    A.next_blk = b < e ? (P.front_panels[P.fronts[(size_t)hb[b + 1].front].fp_off + hb[b + 1].p0].r + 63) / 64 : 0;
-                }
-            }
-            q = e + 1;
-        }
+        auto gb = Pm.upd_groups.begin() + g0, ge = gb + nd;
+        A.ncrit = (int)(std::stable_partition(gb, ge, near) - gb);
+        A.has_next = next;
+        A.next_blk = next ? (P.front_panels[P.fronts[(size_t)hb[b + 1].front].fp_off + hb[b + 1].p0].r + 63) / 64 : 0;
     }
 }
 
@@ -649,21 +576,19 @@ static void build_front_batches(hipkkt_solver *S) {
             B.i_base = 0; B.i_end = B.nblk; B.tick = 0; B.pad = 0; B.x_begin = 0; B.x_count = 0;
             B.sync_off = 128 * (int)S->fbatches.size();
             B.scratch_off = kFbScratch * (int64_t)S->fbatches.size();
+            B.stream_off = kFbStream * (int64_t)S->fbatches.size();
             S->lvl_fb[H.level_first] = (int)S->fbatches.size();
             for (int l = H.level_first + 1; l <= H.level_last; l++) S->lvl_fb[l] = -2;
             S->fbatches.push_back(B);
             S->fb_last_level.push_back(H.level_last);
         }
-    if (getenv("HIPKKT_VERBOSE")) {
-        int non = 0;
-        for (const auto &A : S->la) non += A.on;
-        fprintf(stderr, "hipkkt: look-ahead %s: %d of %zu front batches inside look-ahead regions, %lld update tasks rescheduled\n", S->lookahead ? "on" : "off", non, S->la.size(), (long long)P.la_sched_moved);
-    }
     if (getenv("HIPKKT_VERBOSE")) fprintf(stderr, "hipkkt: %zu front batch(es) factored by one launch each (fronts %zu, update batch %d)\n", S->fbatches.size(), P.fronts.size(), P.update_batch_used);
     const size_t nb_ = std::max<size_t>(S->fbatches.size(), 1);
     S->d_fb_sync = S->dalloc<int>(128 * nb_);
     S->d_fb_scratch = S->dalloc<double>((size_t)kFbScratch * nb_);
     fill_async(S->stream, S->d_fb_sync, 0, 128 * nb_ * sizeof(int));
+    S->fb_stream_doubles = S->fb_streamed ? (int64_t)kFbStream * (int64_t)nb_ : 0;
+    S->d_fb_stream = S->dalloc<double>((size_t)std::max<int64_t>(S->fb_stream_doubles, 1));
     if (getenv("HIPKKT_FB_TRACE")) {
         S->d_fb_trace = (long long *)S->dalloc<double>(nb_ * 128);
         fill_async(S->stream, S->d_fb_trace, 0, nb_ * 128 * sizeof(double));
@@ -680,26 +605,10 @@ int32_t finish_create(hipkkt_solver *S, const hipkkt_opts *opts, hipkkt_handle *
     po.front_min_panels = opts->front_min_panels == 0 ? 4 : std::max(0, opts->front_min_panels);
     po.n_hold = S->l1 ? (int)S->img.n : 0;
     {
-        const char *ns = getenv("HIPKKT_SIDE_STREAM");
-        po.split_far = ns && ns[0] == '1';
         const char *mr = getenv("HIPKKT_FRONT_BLOCK_MIN_ROWS");   // tests: 0, so that small fronts take the front-batch kernel too
         if (mr) po.front_block_min_width = atoi(mr);
-        const char *dc = getenv("HIPKKT_DENSE_COVER");   // A/B: threshold between the tile path and the gather lists
-        if (dc && atof(dc) > 0) po.dense_min_cover = atof(dc);
-        const char *nf = getenv("HIPKKT_FUSE_JIT");    // experiment: just-in-time updates inside the panel kernel
-        if (nf && nf[0] == '1') po.fuse_jit = true;
-        const char *sh = getenv("HIPKKT_SUPERHOP");    // 0: one hop per panel in the front sweeps (round-2 kernels; A/B timing); N: fronts of >= N panels
+        const char *sh = getenv("HIPKKT_SUPERHOP");    // 0: one hop per panel in the front sweeps; N: fronts of >= N panels go super-block by super-block
         if (sh) po.superhop = atoi(sh);
-        const char *nx = getenv("HIPKKT_XCD_ORDER");   // 0 / 1 / 2 (symbolic.h PlanOptions::xcd_order; default 2)
-        if (nx) po.xcd_order = atoi(nx);
-    }
-    {
-        const char *la = getenv("HIPKKT_LOOKAHEAD");  // look-ahead factorisation of the fronts (hipkkt_factor.cpp): needs the due-date schedule
-        po.la_sched = la && la[0] == '1';
-        const char *ls = getenv("HIPKKT_LA_SCHED");   // 0: look-ahead without the due-date schedule (every batch's far stage as it is)
-        if (ls) po.la_sched = po.la_sched && atoi(ls) != 0;
-        const char *lr = getenv("HIPKKT_LA_RATE");
-        if (lr && atof(lr) > 0.0) po.la_rate_tf = atof(lr);
     }
     {
         const char *nh = getenv("HIPKKT_ORDERING");   // "amd": minimum degree on K only
@@ -722,9 +631,8 @@ int32_t finish_create(hipkkt_solver *S, const hipkkt_opts *opts, hipkkt_handle *
         // then repeated on a twin handle in the minimum-degree order.  Its symbolic analysis is seconds of host work on the
         // problems that take this path (dense PSD blocks), so it starts on a host thread as soon as the minimum-degree order is
         // known and the cheap order is about to be evaluated against it -- speculatively: if the cheap order is not chosen the
-        // thread is cancelled at its next phase boundary (HIPKKT_TWIN_AHEAD=0: analysed only when it is needed).
-        const char *ta = getenv("HIPKKT_TWIN_AHEAD");
-        if (!(ta && ta[0] == '0') && S->l1)
+        // thread is cancelled at its next phase boundary.
+        if (S->l1)
             po.on_alternative_order = [S, &po](const std::vector<int> &perm_md) {
                 std::unique_ptr<hipkkt_solver> T(new hipkkt_solver());
                 T->device = S->device;
@@ -752,9 +660,9 @@ int32_t finish_create(hipkkt_solver *S, const hipkkt_opts *opts, hipkkt_handle *
     std::shared_ptr<const HostPlan> cached;
     if (PlanCache::enabled()) {
         char buf[256];
-        snprintf(buf, sizeof buf, "%d|%g|%d|%d|%d|%d|%.17g|%.17g|%d|%d|%d|%d|%d|%d|%d|%d|%d|%d", po.la_sched, po.la_rate_tf, po.max_width, (int)po.relax, po.update_policy, po.update_batch,
-                 po.amd_dense_scale, po.dense_min_cover, (int)po.fuse_jit, (int)po.split_far, po.xcd_order, po.n_hold, po.front_block_min_width,
-                 po.front_min_panels, po.superhop, po.nd_mode, po.nd_leaf, uperm ? 1 : 0);
+        snprintf(buf, sizeof buf, "%d|%d|%d|%d|%.17g|%.17g|%d|%d|%d|%d|%d|%d|%d", po.max_width, (int)po.relax, po.update_policy, po.update_batch,
+                 po.amd_dense_scale, po.dense_min_cover, po.n_hold, po.front_block_min_width, po.front_min_panels, po.superhop, po.nd_mode,
+                 po.nd_leaf, uperm ? 1 : 0);
         optkey = buf;
         ckey = PlanCache::fnv(1469598103934665603ull, S->img.colptr.data(), S->img.colptr.size() * sizeof(int64_t));
         ckey = PlanCache::fnv(ckey, S->img.rowval.data(), S->img.rowval.size() * sizeof(int64_t));

@@ -12,17 +12,18 @@ void launch_soc_batch(hipStream_t st, double *kval, const int64_t *uidx, const i
 void launch_maxabs_gather(hipStream_t st, const double *v, const int64_t *idx, int64_t n, unsigned long long *slot);
 void launch_init_panels(hipStream_t st, const DevPlan &P, int64_t nnz, int static_enable, double eps_const, double eps_prop);
 void launch_factor_level(hipStream_t st, const DevPlan &P, int item_begin, int nitems, int wmax, double dyn_eps, double dyn_delta);
-void launch_factor_panel(hipStream_t st, const DevPlan &P, int item_begin, int nitems, double dyn_eps, double dyn_delta,
-                         bool fused = false);
+void launch_factor_panel(hipStream_t st, const DevPlan &P, int item_begin, int nitems, double dyn_eps, double dyn_delta);
 void launch_update_stage(hipStream_t st, const DevPlan &P, int group_begin, int ngroups);
 // full_k: the tiles of this launch carry whole panels of sources (>= 1.5 MFLOP per tile): a partial last round is cut into pieces
-void launch_update_dense(hipStream_t st, const DevPlan &P, int group_begin, int ngroups, int max_wgs = 0, bool full_k = false);
+void launch_update_dense(hipStream_t st, const DevPlan &P, int group_begin, int ngroups, bool full_k = false);
 void launch_fwd_narrow(hipStream_t st, const DevPlan &P, int sn_begin, int n, int wmax, double *y, double *z);
 void launch_bwd_narrow(hipStream_t st, const DevPlan &P, int sn_begin, int n, int wmax, const double *z, double *x, double *xout);
 void launch_psd_hs(hipStream_t st, double *kval, const int64_t *map_hs, int64_t hs_off, const double *W, int n);
 // front_block.hip
-void launch_front_block(hipStream_t st, const DevPlan &P, const FrontBatch &B, int *sync_all, double *scratch_all, double dyn_eps,
-                        double dyn_delta, long long *trace = nullptr);
+void launch_front_block(hipStream_t st, const DevPlan &P, const FrontBatch &B, int *sync_all, double *scratch_all, double *stream_all,
+                        double dyn_eps, double dyn_delta, bool streamed, long long *trace = nullptr);
+// zeroes the sync words of all front batches and fills the stream records of the streamed pivot chain with the "not yet written" sentinel
+void launch_fb_reset(hipStream_t st, int *sync_all, int nsync, double *stream_all, int64_t nstream);
 // front_sweep.hip: super-block sweeps over a front (FrontDesc::sb_g > 0) and the super-block inverses they need
 void launch_front_fwd_sb(hipStream_t st, const DevPlan &P, const FrontDesc &F, double *y, double *z);
 void launch_front_bwd_sb(hipStream_t st, const DevPlan &P, const FrontDesc &F, const double *z, double *x, double *xout);

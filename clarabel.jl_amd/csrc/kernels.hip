@@ -263,11 +263,6 @@ __device__ __forceinline__ double pivot_rcp(double d) {
 // values and a second barrier.  16 barriers per 64-column panel instead of 64, and only the 8x8 triangle of the
 // current block sits on the pivot-to-pivot critical path.
 
-// FUSED (experiment, off by default: symbolic.h PlanOptions::fuse_jit): the panel's pending just-in-time updates
-// (FacJit) are applied here first, on the matrix cores: waves 0-3 take the diagonal tile, waves 4-7 the workgroup's
-// row chunk, one 16-column strip each (the code of k_update_dense<1,4>), and hand the updated rows over through the
-// staging buffer instead of through the panel.
-template <bool FUSED>
 __global__ void __launch_bounds__(512)
 k_factor_panel(DevPlan P, int item_begin, double dyn_eps, double dyn_delta) {
     __shared__ double colL[2][8][64];     // l_ik of the diagonal-block rows of block B          (parity B & 1)
@@ -288,24 +283,10 @@ k_factor_panel(DevPlan P, int item_begin, double dyn_eps, double dyn_delta) {
     const int prow = grp ? lo + lane : lane;              // panel row of this lane
     const bool rvalid = grp ? lane < nr : lane < w;
     double a[16];                                         // a[8*h + jj] = column 8*(v + 4h) + jj of this lane's row
-    if (FUSED) {
-        const FacJit J = P.fac_jit[item_begin + blockIdx.x];
-        if (grp == 0 || nr > 0)                           // wave-uniform
-            dense_tile_core<1, 4, true>(P, pan + (grp ? lo : 0), r, grp ? nr : w, w, rfl(grp ? J.c_begin : J.d_begin),
-                                        rfl(grp ? J.c_end : J.d_end), lane, v, 0, Yt[grp]);
-        __syncthreads();
 #pragma unroll
-        for (int c = 0; c < 16; c++) {
-            const int j = 8 * (v + 4 * (c >> 3)) + (c & 7);
-            a[c] = (rvalid && j < w) ? Yt[grp][lane * 65 + j] : 0.0;
-        }
-        __syncthreads();                                  // the pivot loop stages its results in Yt
-    } else {
-#pragma unroll
-        for (int c = 0; c < 16; c++) {
-            const int j = 8 * (v + 4 * (c >> 3)) + (c & 7);
-            a[c] = (rvalid && j < w) ? pan[prow + (int64_t)j * r] : 0.0;
-        }
+    for (int c = 0; c < 16; c++) {
+        const int j = 8 * (v + 4 * (c >> 3)) + (c & 7);
+        a[c] = (rvalid && j < w) ? pan[prow + (int64_t)j * r] : 0.0;
     }
     const unsigned long long spos = __ballot(lane < w && P.sgn_perm[f + (lane < w ? lane : 0)] > 0);
     double *myY = &Yt[grp][lane * 65];
@@ -2019,43 +2000,28 @@ void launch_factor_level(hipStream_t st, const DevPlan &P, int item_begin, int n
         hipLaunchKernelGGL(k_factor_level, dim3(nitems), dim3(256), factor_lds_bytes(wmax), st, P, item_begin, wmax, dyn_eps,
                            dyn_delta);
 }
-void launch_factor_panel(hipStream_t st, const DevPlan &P, int item_begin, int nitems, double dyn_eps, double dyn_delta, bool fused) {
-    if (nitems <= 0) return;
-    if (fused) hipLaunchKernelGGL(k_factor_panel<true>, dim3(nitems), dim3(512), 0, st, P, item_begin, dyn_eps, dyn_delta);
-    else hipLaunchKernelGGL(k_factor_panel<false>, dim3(nitems), dim3(512), 0, st, P, item_begin, dyn_eps, dyn_delta);
+void launch_factor_panel(hipStream_t st, const DevPlan &P, int item_begin, int nitems, double dyn_eps, double dyn_delta) {
+    if (nitems > 0) hipLaunchKernelGGL(k_factor_panel, dim3(nitems), dim3(512), 0, st, P, item_begin, dyn_eps, dyn_delta);
 }
 void launch_update_stage(hipStream_t st, const DevPlan &P, int group_begin, int ngroups) {
     if (ngroups > 0) hipLaunchKernelGGL(k_update_stage, dim3(ngroups), dim3(kUpdWaves * 64), 0, st, P, group_begin);
 }
-// 16-row blocks per wavefront in the just-in-time launches (4: one workgroup per tile; 2 / 1: two / four workgroups).
-// Measured on cfg 2a (factorisation): 5.81 ms / 5.65 ms / 5.65 ms for 4 / 2 / 1.
-static const int g_tail_split = [] { const char *e = getenv("HIPKKT_TAIL_SPLIT"); return e ? atoi(e) : 1; }();   // 0: whole tiles only (A/B)
-static const int g_jit_nr = [] { const char *e = getenv("HIPKKT_JIT_NR"); return e ? atoi(e) : 2; }();
-#ifndef HIPKKT_DENSE_BIG_NT
-#define HIPKKT_DENSE_BIG_NT 4
-#endif
-void launch_update_dense(hipStream_t st, const DevPlan &P, int group_begin, int ngroups, int max_wgs, bool full_k) {
+// Few tiles (<= 384: the just-in-time updates on the critical path): 16-column strips x 32 rows per wavefront, two workgroups per tile
+// (measured on cfg 2a, factorisation: 5.81 / 5.65 / 5.65 ms with 64 / 32 / 16 rows per wavefront).  Plenty of tiles: one wavefront per
+// tile; full_k launches (whole panels of sources, >= 1.5 MFLOP per tile) cut the tiles of a partial last round into strips / halves.
+void launch_update_dense(hipStream_t st, const DevPlan &P, int group_begin, int ngroups, bool full_k) {
     if (ngroups <= 0) return;
-    if (max_wgs > 0) {   // look-ahead launch: a bounded grid that strides over the tiles
-        hipLaunchKernelGGL((k_update_dense<4, 4>), dim3(std::min((ngroups + 3) / 4, max_wgs)), dim3(256), 0, st, P, group_begin, ngroups);
-        return;
-    }
-    if (ngroups > 384) {   // plenty of tiles: one wavefront per tile, the tiles of a partial last round in pieces
+    if (ngroups > 384) {
         const int round = 1024, r = ngroups % round, nfull = ngroups - r;   // nfull: multiple of 1024, hence of 4
-        if (g_tail_split && full_k && r > 0 && (r <= 256 || (nfull == 0 && r <= 768)))   // (a lone partial round: three strip sub-rounds still beat it)
+        if (full_k && r > 0 && (r <= 256 || (nfull == 0 && r <= 768)))      // (a lone partial round: three strip sub-rounds still beat it)
             hipLaunchKernelGGL(k_update_dense_tail<4>, dim3(nfull / 4 + r), dim3(256), 0, st, P, group_begin, nfull, ngroups);
-        else if (g_tail_split && full_k && r > 0 && r <= 512)
+        else if (full_k && r > 0 && r <= 512)
             hipLaunchKernelGGL(k_update_dense_tail<2>, dim3(nfull / 4 + (r + 1) / 2), dim3(256), 0, st, P, group_begin, nfull, ngroups);
         else
-            hipLaunchKernelGGL((k_update_dense<HIPKKT_DENSE_BIG_NT, 4>), dim3((ngroups + HIPKKT_DENSE_BIG_NT - 1) / HIPKKT_DENSE_BIG_NT),
-                               dim3(256), 0, st, P, group_begin, ngroups);
+            hipLaunchKernelGGL((k_update_dense<4, 4>), dim3((ngroups + 3) / 4), dim3(256), 0, st, P, group_begin, ngroups);
+    } else {
+        hipLaunchKernelGGL((k_update_dense<1, 2>), dim3(ngroups * 2), dim3(256), 0, st, P, group_begin, ngroups);
     }
-    else                 // few tiles (just-in-time updates): split every tile over 4 wavefronts
-        switch (g_jit_nr) {
-        case 1: hipLaunchKernelGGL((k_update_dense<1, 1>), dim3(ngroups * 4), dim3(256), 0, st, P, group_begin, ngroups); break;
-        case 2: hipLaunchKernelGGL((k_update_dense<1, 2>), dim3(ngroups * 2), dim3(256), 0, st, P, group_begin, ngroups); break;
-        default: hipLaunchKernelGGL((k_update_dense<1, 4>), dim3(ngroups), dim3(256), 0, st, P, group_begin, ngroups);
-        }
 }
 void launch_fwd_narrow(hipStream_t st, const DevPlan &P, int sn_begin, int n, int wmax, double *y, double *z) {
     if (n <= 0) return;

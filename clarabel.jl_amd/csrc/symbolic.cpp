@@ -520,81 +520,6 @@ std::string build_plan(int N, const int64_t *Ap, const int64_t *Ai, const int64_
         }
         lap("ut:gen");
         if (cancelled) return "cancelled";
-        // ---- due-date schedule inside long panel chains (PlanOptions::la_sched).  A chain = consecutive supernodes, each
-        //      alone on its level, each the parent of the one before, rows nested (the panels of a front).  A "unit" = everything the
-        //      panels of batch bs (levels bs*B .. bs*B+B-1) contribute to target panel t of a LATER batch bt.  It may be applied at the
-        //      end of any batch sigma in [bs, bt-1] (stage = last level of sigma).  bt = sigma+1: the next panel kernel needs it (applied
-        //      on the chain).  bt > sigma+1: it runs NEXT TO the panel kernel of batch sigma+1, whose duration bounds what fits:
-        //      earliest due date first; what does not fit stays pending and ends up on the chain at its due date.
-        if (opt.la_sched && opt.update_policy == 2) {
-            const int B = update_batch;
-            std::vector<int> chain_first(S, -1);     // first supernode of the chain s belongs to
-            auto w_of = [&](int s) { return P.sn_first[s + 1] - P.sn_first[s]; };
-            auto r_of = [&](int s) { return (int)(P.sn_rowptr[s + 1] - P.sn_rowptr[s]); };
-            auto alone = [&](int s) { const int l = P.sn_level[s]; return P.lvl_ptr[l + 1] - P.lvl_ptr[l] == 1; };
-            for (int s = 0; s < S;) {
-                int e = s;
-                while (e + 1 < S && P.sn_parent[e] == e + 1 && P.sn_level[e + 1] == P.sn_level[e] + 1 && r_of(e + 1) == r_of(e) - w_of(e) &&
-                       alone(e) && alone(e + 1))
-                    e++;
-                if (e - s + 1 >= 4 * B)
-                    for (int q = s; q <= e; q++) chain_first[q] = s;
-                s = e + 1;
-            }
-            std::vector<double> cost;                // [panel of the chain][source batch]
-            std::vector<int> sigma;                  // the schedule, same shape
-            for (int s0 = 0; s0 < S; s0++) {
-                if (chain_first[s0] != s0) continue;
-                int np = 1;
-                while (s0 + np < S && chain_first[s0 + np] == s0) np++;
-                const int b0 = P.sn_level[s0] / B, b1 = P.sn_level[s0 + np - 1] / B, nbat = b1 - b0 + 1;
-                auto bat = [&](int s) { return P.sn_level[s] / B - b0; };
-                cost.assign((size_t)np * nbat, 0.0);
-                sigma.assign((size_t)np * nbat, -1);
-                for (const TaskKey &k : keys) {
-                    if (k.src < s0 || k.src >= s0 + np || k.tgt < s0 || k.tgt >= s0 + np || bat(k.tgt) <= bat(k.src)) continue;
-                    const UpdTask &T = P.upd_tasks[k.task];
-                    cost[(size_t)(k.tgt - s0) * nbat + bat(k.src)] += 2.0 * T.nrows * T.ncols * w_of(k.src);
-                }
-                std::vector<int> first_of(nbat + 1, np), nxt(np, 0);   // first panel of a batch; per target: next unscheduled source batch
-                for (int p = np - 1; p >= 0; p--) first_of[bat(s0 + p)] = p;
-                for (int b = nbat - 1; b >= 0; b--) first_of[b] = std::min(first_of[b], first_of[b + 1]);
-                for (int sg = 0; sg < nbat; sg++) {
-                    // due now: the columns of batch sg+1 (from every batch <= sg not applied yet)
-                    for (int p = first_of[std::min(sg + 1, nbat)]; p < first_of[std::min(sg + 2, nbat)]; p++)
-                        for (; nxt[p] <= sg; nxt[p]++) sigma[(size_t)p * nbat + nxt[p]] = sg;
-                    if (sg + 1 >= nbat) break;
-                    // next to the panel kernel of batch sg+1
-                    const int pn = first_of[sg + 1], npan = first_of[sg + 2] - pn;
-                    const double dur = 22e-6 * npan + 5e-6, nblk = r_of(s0 + pn) / 64.0;
-                    double cap = dur * opt.la_rate_tf * 1e12 * std::max(0.1, 1.0 - (nblk + 8.0) / 256.0);
-                    for (int p = first_of[std::min(sg + 2, nbat)]; p < np && cap > 0.0; p++)
-                        for (; nxt[p] <= sg && nxt[p] < bat(s0 + p) && cap > 0.0; nxt[p]++) {
-                            sigma[(size_t)p * nbat + nxt[p]] = sg;
-                            cap -= cost[(size_t)p * nbat + nxt[p]];
-                        }
-                }
-                if (getenv("HIPKKT_LA_VERBOSE")) {
-                    for (int sg = 0; sg < nbat; sg++) {
-                        double fc = 0.0, fbg = 0.0;
-                        for (int p = 0; p < np; p++)
-                            for (int bs = 0; bs < nbat; bs++)
-                                if (sigma[(size_t)p * nbat + bs] == sg) (bat(s0 + p) == sg + 1 ? fc : fbg) += cost[(size_t)p * nbat + bs];
-                        fprintf(stderr, "hipkkt: la_sched chain %d batch %d: on the chain %.2f GF, background %.2f GF\n", s0, sg, fc * 1e-9, fbg * 1e-9);
-                    }
-                }
-                int64_t moved = 0;
-                for (TaskKey &k : keys) {
-                    if (k.src < s0 || k.src >= s0 + np || k.tgt < s0 || k.tgt >= s0 + np || bat(k.tgt) <= bat(k.src)) continue;
-                    const int sg = sigma[(size_t)(k.tgt - s0) * nbat + bat(k.src)];
-                    if (sg < 0) continue;                                       // (cannot happen: every unit is due at some batch)
-                    const int st = std::min((b0 + sg) * B + B - 1, P.sn_level[k.tgt] - 1);
-                    moved += st != k.stage;
-                    k.stage = std::max(k.stage, st);
-                }
-                P.la_sched_moved += moved;
-            }
-        }
         // order: (stage, target, row block, source, task).  The keys are generated source by source, task by task, i.e. already in
         // (source, task) order: three stable counting sorts -- by row block, by target, by stage -- finish the job in O(n)
         // (a comparison sort of the 1.2e7 keys of an SDP twin took half a second).
@@ -689,7 +614,6 @@ std::string build_plan(int N, const int64_t *Ap, const int64_t *Ai, const int64_
         lap("ut:classify");
         if (cancelled) return "cancelled";
         P.upd_stage_ngather.assign(P.nlevels, 0);
-        P.upd_stage_nfar.assign(P.nlevels, 0);
         P.gath_stage_ptr.assign(P.nlevels + 1, 0);
         P.gath_pptr.push_back(0);
         P.gath_src.reserve(gather_pairs_bound); P.gath_dj.reserve(gather_pairs_bound); P.gath_sn.reserve(gather_pairs_bound);
@@ -698,82 +622,6 @@ std::string build_plan(int N, const int64_t *Ap, const int64_t *Ai, const int64_
         for (int l = 0; l < P.nlevels; l++) {
             auto b = P.upd_groups.begin() + P.upd_stage_ptr[l], e = P.upd_groups.begin() + P.upd_stage_ptr[l + 1];
             auto mid = std::stable_partition(b, e, [](const UpdGroup &g) { return g.dense == 1; });
-            if (opt.xcd_order == 2 && mid - b >= 1024) {
-                // 2-D blocked XCD order (performance only; the groups own disjoint tiles, any order is correct).  Workgroup k of
-                // k_update_dense<4,4> takes 4 consecutive tiles and is observed to run on XCD k % 8; an XCD holds 64 such
-                // workgroups = 256 tiles at a time, and they walk their sources' columns roughly in step.  In the natural order
-                // (row blocks of one target panel after the other) the 256 tiles of an XCD share their COLUMN operand and fetch
-                // 256 different row operands through that XCD's L2 (measured: 2.4x the algorithmic bytes at the fabric side,
-                // profiles/r03_a_traffic_calibration.txt).  Here the tiles are cut into 16 x 16 super-tiles of (row block,
-                // column block) space, each XCD is dealt whole super-tiles, and the eight streams are interleaved 4 tiles at a
-                // time: the 256 concurrent tiles of an XCD then touch 16 + 16 operand blocks instead of 1 + 256.
-                constexpr int T = 16;
-                struct Key { int sk, si, gk, gi; UpdGroup g; };
-                std::vector<Key> ks;
-                ks.reserve((size_t)(mid - b));
-                for (auto it = b; it != mid; ++it) {
-                    const int gi = P.sn_rows[P.sn_rowptr[it->tgt] + it->row_base] / kUpdRows, gk = P.sn_first[it->tgt] / kMaxSnWidth;
-                    ks.push_back({gk / T, gi / T, gk, gi, *it});
-                }
-                std::stable_sort(ks.begin(), ks.end(), [](const Key &x, const Key &y) {
-                    if (x.sk != y.sk) return x.sk < y.sk;
-                    if (x.si != y.si) return x.si < y.si;
-                    if (x.gk != y.gk) return x.gk < y.gk;
-                    return x.gi < y.gi;
-                });
-                std::vector<std::vector<UpdGroup>> stream(8);
-                for (size_t q = 0; q < ks.size();) {          // whole super-tiles to the least loaded stream
-                    size_t e2 = q;
-                    while (e2 < ks.size() && ks[e2].sk == ks[q].sk && ks[e2].si == ks[q].si) e2++;
-                    int best = 0;
-                    for (int x = 1; x < 8; x++)
-                        if (stream[x].size() < stream[best].size()) best = x;
-                    for (size_t p = q; p < e2; p++) stream[best].push_back(ks[p].g);
-                    q = e2;
-                }
-                std::vector<size_t> pos(8, 0);
-                auto out = b;
-                size_t remaining = (size_t)(mid - b);
-                while (remaining > 0)
-                    for (int x = 0; x < 8 && remaining > 0; x++) {
-                        int src = x;
-                        if (pos[src] >= stream[src].size()) {   // this stream is exhausted: borrow from the fullest one
-                            size_t best = 0;
-                            for (int y = 0; y < 8; y++)
-                                if (stream[y].size() - pos[y] > best) { best = stream[y].size() - pos[y]; src = y; }
-                        }
-                        for (int c = 0; c < 4 && pos[src] < stream[src].size(); c++) { *out++ = stream[src][pos[src]++]; remaining--; }
-                    }
-            } else if (opt.xcd_order == 1 && mid - b >= 256) {
-                // XCD-aware order (performance only): workgroup k of k_update_dense<4,4> takes 4 consecutive tiles and is
-                // observed to run on XCD k % 8.  Tiles are bucketed by (global row block) % 8 and the buckets are
-                // interleaved 4 tiles at a time, so one XCD's L2 keeps re-using 1/8 of the source panels' rows (its A
-                // operands) while the 64-row column operands stream through.
-                std::vector<std::vector<UpdGroup>> bucket(8);
-                for (auto it = b; it != mid; ++it) {
-                    const int grow = P.sn_rows[P.sn_rowptr[it->tgt] + it->row_base];
-                    bucket[(grow / kUpdRows) & 7].push_back(*it);
-                }
-                std::vector<size_t> pos(8, 0);
-                auto out = b;
-                size_t remaining = (size_t)(mid - b);
-                while (remaining > 0)
-                    for (int x = 0; x < 8 && remaining > 0; x++) {
-                        int src = x;
-                        if (pos[src] >= bucket[src].size()) {   // this bucket is exhausted: borrow from the fullest one
-                            size_t best = 0;
-                            for (int y = 0; y < 8; y++)
-                                if (bucket[y].size() - pos[y] > best) { best = bucket[y].size() - pos[y]; src = y; }
-                        }
-                        for (int c = 0; c < 4 && pos[src] < bucket[src].size(); c++) { *out++ = bucket[src][pos[src]++]; remaining--; }
-                    }
-            }
-            if (opt.update_policy == 2 && opt.split_far) {   // dense tiles: near targets first, far targets last
-                const int B = update_batch;
-                auto midf = std::stable_partition(b, mid, [&](const UpdGroup &g) { return P.sn_level[g.tgt] <= l + B; });
-                P.upd_stage_nfar[l] = (int)(mid - midf);
-                P.lookahead = B;
-            }
             auto mid2 = std::stable_partition(mid, e, [](const UpdGroup &g) { return g.dense == 2; });
             P.upd_stage_ndense[l] = (int)(mid - b);
             P.upd_stage_ngather[l] = (int)(mid2 - mid);
@@ -840,41 +688,6 @@ std::string build_plan(int N, const int64_t *Ap, const int64_t *Ai, const int64_
     lap("ut:lists");
 
     if (cancelled) return "cancelled";
-    // ---- 14b. fused just-in-time updates: inside a front, the stage before panel p+1 holds nothing but the dense
-    //           tiles of that one panel (sources: the batch-mates factored just before it).  The panel kernel of
-    //           p+1 then applies them to the rows it owns (every workgroup: the diagonal tile, redundantly, and
-    //           its own row chunk) and the stage needs no kernel of its own -- one launch and one store/reload of
-    //           the panel less on the critical path of the factorisation.
-    P.fac_jit.assign(P.fac_items.size(), FacJit{0, 0, 0, 0});
-    P.lvl_fused.assign(P.nlevels, 0);
-    if (opt.fuse_jit && kFacRows == kUpdRows)
-        for (int l = 1; l < P.nlevels; l++) {
-            if (P.lvl_ptr[l + 1] - P.lvl_ptr[l] != 1) continue;
-            const int s = P.lvl_sn[P.lvl_ptr[l]];
-            if (P.sn_first[s + 1] - P.sn_first[s] != kUpdRows) continue;
-            const int g0 = P.upd_stage_ptr[l - 1], g1 = P.upd_stage_ptr[l];
-            if (g1 == g0 || P.upd_stage_ndense[l - 1] != g1 - g0 || P.upd_stage_nfar[l - 1] != 0) continue;
-            bool ok = true;
-            for (int g = g0; g < g1 && ok; g++)
-                ok = P.upd_groups[g].tgt == s && P.upd_groups[g].dense == 1 && P.upd_groups[g].row_base % kUpdRows == 0;
-            if (!ok) continue;
-            const int64_t r = P.sn_rowptr[s + 1] - P.sn_rowptr[s];
-            std::vector<int> by_tile((size_t)((r + kUpdRows - 1) / kUpdRows), -1);
-            for (int g = g0; g < g1; g++) by_tile[P.upd_groups[g].row_base / kUpdRows] = g;
-            for (int i = P.fac_lvl_ptr[l]; i < P.fac_lvl_ptr[l + 1]; i++) {
-                const FacItem &it = P.fac_items[i];
-                FacJit J{0, 0, 0, 0};
-                if (by_tile[0] >= 0) { J.d_begin = P.upd_groups[by_tile[0]].task_begin; J.d_end = P.upd_groups[by_tile[0]].task_end; }
-                const size_t ct = (size_t)it.blk + 1;
-                if (ct < by_tile.size() && by_tile[ct] >= 0) {
-                    J.c_begin = P.upd_groups[by_tile[ct]].task_begin;
-                    J.c_end = P.upd_groups[by_tile[ct]].task_end;
-                }
-                P.fac_jit[i] = J;
-            }
-            P.lvl_fused[l] = 1;
-        }
-
     lap("ut:jit");
 
     if (cancelled) return "cancelled";
@@ -1039,7 +852,7 @@ std::vector<FrontBatchHost> front_batches(const HostPlan &P, int update_policy, 
                 const FrontPanel &fp = P.front_panels[F.fp_off + t];
                 const int l = F.level_first + t;
                 ok = fp.w == 64 && P.sn_level[fp.sn] == l && P.lvl_ptr[l + 1] - P.lvl_ptr[l] == 1 && P.lvl_sn[P.lvl_ptr[l]] == fp.sn &&
-                     fp.r == P.front_panels[F.fp_off + p].r - 64 * (t - p) && !P.lvl_fused[l];
+                     fp.r == P.front_panels[F.fp_off + p].r - 64 * (t - p);
                 // stage l (between panel t and t + 1): only contributions of this batch's panels to panel t + 1, all dense tiles
                 if (ok && t + 1 < q) {
                     const int tgt = P.front_panels[F.fp_off + t + 1].sn, smin = P.front_panels[F.fp_off + p].sn;

@@ -70,13 +70,6 @@ struct FacRec {
     int32_t f, w, r, blk;                  // first column, width, rows, row-chunk index
 };
 
-// Pending (just-in-time) updates of one factor item, applied by the panel kernel itself before it eliminates:
-// task ranges (into upd_tasks) of the item's diagonal tile and of its row chunk.  Used for the panels of a front
-// whose only pending updates come from the batch-mates factored just before them (lvl_fused).
-struct FacJit {
-    int32_t d_begin, d_end, c_begin, c_end;
-};
-
 // A "front" = one wide (fundamental) supernode that the width cap split into a chain of np panels of
 // cw columns (the last may be narrower).  Its panels have nested row structures (panel p holds the
 // front rows [cw*p, rF)), so the triangular solves over the chain are done by ONE persistent kernel
@@ -114,11 +107,6 @@ struct PlanOptions {
     double amd_dense_scale = 1.5;
     double dense_min_cover = 64.0;   // a target tile takes the matrix-core path when its sources cover at least this
                                      // many entries each on average (else: per-entry gather lists)
-    bool fuse_jit = false;     // apply the just-in-time updates of a front panel inside its panel kernel
-                               // (measured slower on MI355X, DESIGN.md section 9: every workgroup repeats the diagonal tile)
-    bool split_far = false;    // separate the far dense tiles of a stage (side-stream experiments)
-    int xcd_order = 0;         // order of the dense tiles of a big stage (performance only): 0 natural (target panel, row block),
-                               // 1 row blocks bucketed by XCD, 2 = 16 x 16 super-tiles dealt to the XCDs (symbolic.cpp; measured r03b: +0.05 ms per factorisation)
     int n_hold = 0;            // > 0: also try the "variables last" order (nodes < n_hold held back) and keep
                                // whichever order predicts fewer factor flops
     int front_block_min_width = 1024;   // supernodes at least this wide are cut into full 64-column panels (remainder last) so that
@@ -128,11 +116,6 @@ struct PlanOptions {
     int superhop = 16;         // fronts of at least max(this, kSbMinPanels) panels are swept super-block by super-block (2 hand-offs per kSbG
                                // panels); 0 = never.  Below ~14 panels the hops saved per unit (8 sweeps on the critical path) cost less than
                                // the 0.11-0.13 ms of k_invert_super per factorisation (measured on cfg 1's 12-panel root: 917 -> 869 units/s)
-    int la_sched = 0;          // 1: the Schur updates inside a long panel chain (a front) are scheduled by due date: what batch b
-                               // contributes to the columns of a batch further right than b+1 may be applied later, NEXT TO the panel
-                               // kernel of a following batch (hipkkt_factor.cpp look-ahead), merged per target tile with what other
-                               // batches contribute (symbolic.cpp step 14)
-    double la_rate_tf = 30.0;  // ... at this assumed matrix-core rate of the background launch (TFLOP/s on the whole device)
     int nd_mode = 1;           // nested dissection candidate: 0 never, 1 when the latency + throughput model predicts a
                                // >= 20 % cheaper KKT iteration than minimum degree, 2 always
     int nd_leaf = 256;         // subgraphs of at most this many nodes are ordered by minimum degree
@@ -149,7 +132,6 @@ struct HostPlan {
     int64_t nnzK = 0;
     std::vector<int> perm, iperm;  // perm[k] = original index eliminated k-th
 
-    int64_t la_sched_moved = 0;      // update tasks the due-date schedule moved to a later stage (PlanOptions::la_sched)
     int nsuper = 0;
     std::vector<int> sn_first;       // [nsuper+1] first (permuted) column
     std::vector<int> sn_of_col;      // [N]
@@ -167,9 +149,6 @@ struct HostPlan {
     std::vector<FacItem> fac_items;
     std::vector<int> fac_lvl_ptr;  // [nlevels+1]
     std::vector<int> fac_lvl_maxw; // [nlevels] widest supernode of the level (LDS sizing)
-    std::vector<FacJit> fac_jit;   // [fac_items] see FacJit (all-zero ranges where unused)
-    std::vector<char> lvl_fused;   // [nlevels] 1: stage l-1's updates all land on level l's single 64-column panel and
-                                   // are applied inside its panel kernel; the stage has no launch of its own
 
     std::vector<int> rel;
     std::vector<UpdTask> upd_tasks;
@@ -178,11 +157,7 @@ struct HostPlan {
     std::vector<int16_t> upd_tmap;
     std::vector<int> upd_stage_ndense;  // [nlevels] the first ndense groups of a stage are dense tiles,
     std::vector<int> upd_stage_ngather; // [nlevels] the next ngather groups go through the per-entry gather lists
-    std::vector<int> upd_stage_nfar;    // [nlevels] the LAST nfar dense groups of a stage update targets more than
-                                        // `update_batch` levels ahead: nothing needs them before the next batch end,
-                                        // so they run on a side stream concurrently with the next panels' critical path
     int update_batch_used = 4;          // the batch length the schedule was built with
-    int lookahead = 0;                  // = update_batch when far groups were separated, else 0
     // per-entry gather lists (groups of kind 2): entries of one stage are contiguous
     std::vector<int64_t> gath_stage_ptr;   // [nlevels+1] into gath_tgt
     std::vector<int64_t> gath_tgt;         // Lx offset of the target entry

@@ -16,9 +16,11 @@ _i64p = np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
 _i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
 _f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
 
+ABI_VERSION = 4   # include/hipkkt.h HIPKKT_ABI_VERSION (checked when the library is loaded)
+
 # every symbol include/hipkkt.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
-    "hipkkt_default_opts", "hipkkt_is_available", "hipkkt_trim_cache", "hipkkt_create", "hipkkt_create_from_parts", "hipkkt_destroy",
+    "hipkkt_default_opts", "hipkkt_is_available", "hipkkt_abi_version", "hipkkt_trim_cache", "hipkkt_create", "hipkkt_create_from_parts", "hipkkt_destroy",
     "hipkkt_get_dims", "hipkkt_info", "hipkkt_get_cost_model", "hipkkt_get_kkt", "hipkkt_get_perm",
     "hipkkt_get_dsigns", "hipkkt_get_map", "hipkkt_get_sparse_map", "hipkkt_update_values", "hipkkt_scale_values",
     "hipkkt_set_hs", "hipkkt_set_hs_dev", "hipkkt_set_hs_psd", "hipkkt_set_cone_types", "hipkkt_update_scaling", "hipkkt_update_scaling_dev", "hipkkt_block_products", "hipkkt_set_soc", "hipkkt_set_soc_batch", "hipkkt_set_genpow",
@@ -56,6 +58,10 @@ def lib():
     L.hipkkt_default_opts.argtypes = [C.POINTER(Opts)]
     L.hipkkt_default_opts.restype = None
     L.hipkkt_is_available.restype = i32
+    L.hipkkt_abi_version.restype = i32
+    if L.hipkkt_abi_version() != ABI_VERSION:       # signatures change between versions: never call through a mismatch
+        raise HipKKTError(f"{LIB_PATH} implements ABI version {L.hipkkt_abi_version()}, this binding was written against "
+                          f"{ABI_VERSION} (include/hipkkt.h HIPKKT_ABI_VERSION): rebuild the library")
     L.hipkkt_create.restype = i32
     L.hipkkt_create.argtypes = [i32, i64, _i64p, _i64p, _f64p, _i64p, C.POINTER(Opts), C.POINTER(vp)]
     L.hipkkt_create_from_parts.restype = i32
@@ -98,10 +104,10 @@ def lib():
     L.hipkkt_trim_cache.argtypes = [i32]
     L.hipkkt_get_timing.argtypes = [vp, _f64p]
     L.hipkkt_reset_timing.argtypes = [vp]
-    L.hipkkt_get_profile.argtypes = [vp, _f64p]
+    L.hipkkt_get_profile.argtypes = [vp, _f64p, i64]
     L.hipkkt_set_profiling.argtypes = [vp, i32]
     L.hipkkt_get_profile_launches.argtypes = [vp, vp, vp, vp, i64, C.POINTER(i64)]
-    L.hipkkt_get_counters.argtypes = [vp, _i64p]
+    L.hipkkt_get_counters.argtypes = [vp, _i64p, i64]
     L.hipkkt_set_qb.argtypes = [vp, _f64p, _f64p]
     L.hipkkt_residuals.argtypes = [vp, _f64p, _f64p, _f64p, f64, f64, vp, vp, vp, vp, vp, _f64p]
     L.hipkkt_residuals_dev.argtypes = [vp, vp, f64, f64, vp, _f64p]
@@ -246,11 +252,10 @@ class Handle:
 
     def counters(self):
         o = np.zeros(14, dtype=np.int64)
-        self.L.hipkkt_get_counters(self.h, o)
+        self.L.hipkkt_get_counters(self.h, o, len(o))
         return dict(sweep_timeouts=int(o[0]), persistent=bool(o[1]), twin_refactors=int(o[2]), twin_exists=bool(o[3]),
                     in_twin=bool(o[4]), ordering=int(o[5]), fronts=int(o[6]), segments=int(o[7]), front_batches=int(o[8]),
-                    front_block=bool(o[9]), plan_cache_hits=int(o[10]), plan_cache_misses=int(o[11]), lookahead_batches=int(o[12]),
-                    lookahead_moved_tasks=int(o[13]))
+                    front_block=bool(o[9]), plan_cache_hits=int(o[10]), plan_cache_misses=int(o[11]), streamed_chain=bool(o[12]))
 
     def profile_launches(self):
         n = C.c_int64(0)
@@ -268,7 +273,7 @@ class Handle:
 
     def profile(self):
         o = np.zeros(10)
-        self.L.hipkkt_get_profile(self.h, o)
+        self.L.hipkkt_get_profile(self.h, o, len(o))
         return dict(update_ms=o[0], dense4_ms=o[1], dense4_flops=o[2], dense4_launches=int(o[3]), front_block_ms=o[4],
                     front_block_launches=int(o[5]), front_block_panels=int(o[6]), front_block_update_flops=o[7],
                     front_block_extra_tiles=int(o[8]), front_block_extra_flops=o[9])

@@ -68,6 +68,11 @@ void hipkkt_default_opts(hipkkt_opts *opts);
 /* ref: ldlsolver_is_available(::Val{:hip}) (pattern: ext/directldl_pardiso.jl:144,148).
  * Number of usable HIP devices (0 = not available).  Never fails. */
 int32_t hipkkt_is_available(void);
+/* Version of THIS interface.  A binding compares it with the HIPKKT_ABI_VERSION it was written against when it loads the library
+ * and refuses a mismatch (the Julia glue and the ctypes mirror do): signatures may change between versions, never within one.
+ * 4: hipkkt_get_profile / hipkkt_get_counters take the capacity of the caller's buffer (they wrote a fixed, growing number of values). */
+#define HIPKKT_ABI_VERSION 4
+int32_t hipkkt_abi_version(void);
 /* releases the process-wide cache of device memory blocks the library keeps between handles (not in the reference: an embedding
  * host under memory pressure may call it at any time; live handles are unaffected) */
 int32_t hipkkt_trim_cache(int32_t device_id);
@@ -274,7 +279,7 @@ int32_t hipkkt_reset_timing(hipkkt_handle h);
  * they factor, out[7] = the Schur-update flops of the stages they absorb (not part of out[0]'s kernels), out[8] / out[9] = dense update
  * tiles / their flops that rode in those launches as extra workgroups instead of in their stage's own launch (the partial last round
  * of a front batch's far updates; not part of out[0] .. out[2] either) */
-int32_t hipkkt_get_profile(hipkkt_handle h, double *out10);
+int32_t hipkkt_get_profile(hipkkt_handle h, double *out, int64_t cap);   /* writes min(cap, 10) values */
 /* the k_update_dense<4,4> launches of that refactorisation one by one: ms[i], algorithmic flops[i], target tiles[i]
  * (any array may be NULL; at most cap entries are written, *count receives the number of launches) */
 int32_t hipkkt_get_profile_launches(hipkkt_handle h, double *ms, double *flops, double *tiles, int64_t cap, int64_t *count);
@@ -290,9 +295,9 @@ int32_t hipkkt_set_profiling(hipkkt_handle h, int32_t enable);
  * out[7] = #segments, out[8] = update batches of fronts factored by one launch each (front_block.hip), out[9] = that path is
  * enabled (0 after one of its hand-offs timed out: the handle then keeps one launch per panel), out[10] / out[11] = symbolic plans
  * taken from / not found in the process-wide plan cache (same KKT pattern and options => the analysis of an earlier handle is reused;
- * HIPKKT_PLAN_CACHE=0 disables it), out[12] = front batches inside look-ahead regions (0 unless HIPKKT_LOOKAHEAD=1: their far updates
- * run next to the next batch's panel kernel), out[13] = update tasks the due-date schedule of that mode moved to a later stage */
-int32_t hipkkt_get_counters(hipkkt_handle h, int64_t *out14);
+ * HIPKKT_PLAN_CACHE=0 disables it), out[12] = the pivot chain of the front batches is streamed block by block (front_block.hip; 0 with
+ * HIPKKT_FB_STREAM=0), out[13] = reserved (0).  Writes min(cap, 14) values. */
+int32_t hipkkt_get_counters(hipkkt_handle h, int64_t *out, int64_t cap);
 
 /* developer diagnostic, not part of the plugin contract: copies an internal vector of the last LDL solve (what = 0 the
  * permuted right-hand side, 1 z = D^-1 L^-1 b, 2 x in permuted order, 3 the forward update vectors, 4 the unregularised KKT values in nz order, 5 D and 6 1/D of the last factorisation, 7 / 8 the u / v vectors of the sparse second-order cones) or a plan table converted to doubles (10 supernode first

@@ -183,8 +183,6 @@ int plan_check_run(int64_t N, const int64_t *Ap, const int64_t *Ai, const double
     opt.max_width = max_width; opt.relax = relax != 0; opt.update_policy = policy & 15; if (policy >> 4) opt.update_batch = policy >> 4;
     { const char *sh = getenv("PLANCHECK_SUPERHOP"); if (sh) opt.superhop = atoi(sh); }
     { const char *fm = getenv("PLANCHECK_FRONT_MIN"); if (fm) opt.front_min_panels = atoi(fm); }
-    { const char *ls = getenv("PLANCHECK_LA_SCHED"); if (ls) opt.la_sched = atoi(ls); }
-    { const char *lr = getenv("PLANCHECK_LA_RATE"); if (lr) opt.la_rate_tf = atof(lr); }
     std::string err = build_plan((int)N, Ap, Ai, user_perm, opt, P);
     if (!err.empty()) { fprintf(stderr, "build_plan: %s\n", err.c_str()); return -1; }
     if (perm_out) for (int k = 0; k < N; k++) perm_out[k] = P.perm[k];
@@ -199,7 +197,7 @@ int plan_check_run(int64_t N, const int64_t *Ap, const int64_t *Ai, const double
         for (auto &g : P.upd_groups) ndense += g.dense == 1;
         int nsbf = 0;
         for (auto &F : P.fronts) nsbf += F.sb_g > 0;
-        if (getenv("PLANCHECK_VERBOSE")) fprintf(stderr, "plan_check: %zu fronts, %d with super-block sweeps, %lld update tasks rescheduled by due date\n", P.fronts.size(), nsbf, (long long)P.la_sched_moved);
+        if (getenv("PLANCHECK_VERBOSE")) fprintf(stderr, "plan_check: %zu fronts, %d with super-block sweeps\n", P.fronts.size(), nsbf);
         stats[12] = (double)P.fronts.size(); stats[13] = (double)P.gath_tgt.size(); stats[14] = (double)ndense; stats[15] = (double)nmapped;
     }
     if (symbolic_only) return 0;

@@ -214,31 +214,33 @@ def test_batch_config_matches_oracle(seed, oracle_factory, capsys):
     assert dobj <= 1e-4 and dres <= 1e-8        # both runs end SOLVED at the IPM's own tolerances; this is how far apart that leaves them
 
 
-@pytest.mark.parametrize("name,sched", [("cfg2a", "1"), ("cfg2a", "0"), ("cfg3", "1")])
-def test_lookahead_factorisation_equals_serial_order(name, sched, monkeypatch):
-    """HIPKKT_LOOKAHEAD=1 (opt-in; DESIGN.md section 9: measured slower on MI355X, kept as a tested experiment): the far Schur updates of
-    a front batch are split [chain | background], the background part runs next to the next batch's panel kernel on a CU-masked stream,
-    and with the due-date schedule (HIPKKT_LA_SCHED, default on in that mode) updates are moved to later stages and merged per target
-    tile.  Same updates in another valid order: the unrefined LDL solve agrees with the serial order to rounding, the refined solve
-    meets the same stopping rule, and the run is deterministic."""
+@pytest.mark.parametrize("name", ["cfg2a", "cfg3", "cfg5"])
+def test_streamed_pivot_chain_equals_whole_tile_handoff(name, monkeypatch):
+    """front_block.hip, round 4: the diagonal workgroups of a front batch hand their tile over block by block (8 pivots at a time, the
+    next diagonal workgroup eliminates its rows of that panel by substitution behind the producer) instead of as one explicit inverse
+    after all 64 pivots (HIPKKT_FB_STREAM=0, the round-3 chain).  Different rounding of L(i, i-1) (substitution vs product with the
+    inverse), same factorisation: D, the dynamic-regularisation count and the unrefined LDL solve agree to rounding, the refined solve
+    meets the same stopping rule, and the streamed run is deterministic (bit-identical when repeated)."""
     rng = np.random.default_rng(21)
     Pt, A, cones = _prep(FULL[name]())
     m, n = A.shape
     scale_cones(cones, rng)
+    monkeypatch.setenv("HIPKKT_PLAN_CACHE", "0")
+    monkeypatch.setenv("HIPKKT_FB_STREAM", "0")
     hk0 = HipKKTSolver(Pt, A, cones, m, n, cl.Settings())
     assert hk0.kktsolver_update(cones)
-    assert hk0.h.counters()["lookahead_batches"] == 0
-    monkeypatch.setenv("HIPKKT_LOOKAHEAD", "1")
-    monkeypatch.setenv("HIPKKT_LA_SCHED", sched)
-    monkeypatch.setenv("HIPKKT_PLAN_CACHE", "0")
+    assert not hk0.h.counters()["streamed_chain"]
+    monkeypatch.setenv("HIPKKT_FB_STREAM", "1")
     hk1 = HipKKTSolver(Pt, A, cones, m, n, cl.Settings())
     assert hk1.kktsolver_update(cones)
     c = hk1.h.counters()
-    assert c["lookahead_batches"] >= 3
-    if sched == "0":
-        assert c["lookahead_moved_tasks"] == 0
-    elif name == "cfg2a":      # (cfg 3's background parts all fit next to their panel kernels: nothing to move)
-        assert c["lookahead_moved_tasks"] > 0
+    assert c["streamed_chain"] and c["front_block"] and c["front_batches"] >= 1 and c["sweep_timeouts"] == 0
+    if c["in_twin"] or hk0.h.counters()["in_twin"]:
+        pytest.skip("this iterate broke down in the cheap order on one of the two chains: the twins are compared by the oracle tests")
+    assert hk0.last_nreg == hk1.last_nreg
+    d0, d1 = hk0.h.debug_dump(5), hk1.h.debug_dump(5)
+    assert np.all(np.sign(d0) == np.sign(d1))
+    assert np.max(np.abs(d1 - d0) / np.maximum(np.abs(d0), 1e-300)) <= 1e-6      # pivots of an ill-conditioned K: rounding, amplified
     b = rng.standard_normal(hk0.h.N)
     x0, x1 = hk0.h.ldl_solve(b), hk1.h.ldl_solve(b)
     assert np.max(np.abs(x1 - x0)) <= 1e-9 * max(1.0, np.max(np.abs(x0)))
@@ -252,6 +254,7 @@ def test_lookahead_factorisation_equals_serial_order(name, sched, monkeypatch):
     assert np.max(np.abs(sols[1] - sols[0])) <= 1e-9 * max(1.0, np.max(np.abs(sols[0])))
     assert hk1.kktsolver_update(cones)
     assert np.array_equal(hk1.h.ldl_solve(b), x1)
+    assert np.array_equal(hk1.h.debug_dump(5), d1)
 
 
 @pytest.mark.parametrize("name", ["cfg1", "cfg2a"])

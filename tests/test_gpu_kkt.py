@@ -146,9 +146,8 @@ def test_plan_variants_agree(policy, maxw, oracle_factory):
     {"HIPKKT_NO_GRAPH": "1"},
     {"HIPKKT_NO_PERSIST": "1"},
     {"HIPKKT_NO_FRONT": "1"},
-    {"HIPKKT_NO_NARROW": "1"},
-    {"HIPKKT_FUSE_JIT": "1"},
-    {"HIPKKT_SIDE_STREAM": "1", "HIPKKT_FAR_WGS": "64"},
+    {"HIPKKT_FB_STREAM": "0", "HIPKKT_FRONT_BLOCK_MIN_ROWS": "0"},
+    {"HIPKKT_FRONT_BLOCK_MIN_ROWS": "0"},
     {"HIPKKT_ORDERING": "amd"},
     {"HIPKKT_FRONT_BLOCK": "0"},
 ])

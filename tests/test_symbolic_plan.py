@@ -128,31 +128,3 @@ def test_super_block_front_sweeps_reproduce_dense_solve(maxw, monkeypatch, capfd
     assert np.linalg.norm(x - x0) <= 1e-10 * max(1.0, np.linalg.norm(x0))
 
 
-@pytest.mark.parametrize("rate", [0.02, 0.0005, 1e4])
-def test_due_date_schedule_of_front_updates_reproduces_dense_solve(rate, monkeypatch, capfd):
-    """PlanOptions::la_sched (look-ahead factorisation, hipkkt_factor.cpp): inside a long panel chain the Schur updates of a batch
-    into columns further right than the next batch are moved to later stages by due date and merged per target tile.  Any such
-    schedule is a valid order of the same updates: the host interpreter of the plan must still reproduce the dense solve, and the
-    front's batches must still qualify for k_front_block (their inner stages hold nothing but their own just-in-time updates).
-    rate = the assumed throughput of the background launches: small -> almost everything stays pending until it is due (left-looking
-    limit), huge -> everything is applied at the first opportunity (the unscheduled plan)."""
-    rng = np.random.default_rng(12)
-    k, nz, ds = _kkt(problems.random_sparse_qp(1000, 2000, 1, 4, 2), rng)
-    b = rng.standard_normal(k.N)
-    K = sp.csc_matrix((nz, k.rowval, k.colptr), shape=(k.N, k.N)).toarray()
-    K = K + K.T - np.diag(np.diag(K))
-    xd = np.linalg.solve(K, b)
-    monkeypatch.setenv("PLANCHECK_VERBOSE", "1")
-    rc0, x0, _, st0 = ps.run(k.N, k.colptr, k.rowval, nz, ds, b, max_width=64, relax=1, policy=2 + 16 * 2)
-    capfd.readouterr()
-    monkeypatch.setenv("PLANCHECK_LA_SCHED", "1")
-    monkeypatch.setenv("PLANCHECK_LA_RATE", str(rate))
-    rc, x, _, st = ps.run(k.N, k.colptr, k.rowval, nz, ds, b, max_width=64, relax=1, policy=2 + 16 * 2)
-    err = capfd.readouterr().err
-    assert rc0 == 0 and rc == 0
-    assert np.linalg.norm(x - xd) <= 1e-9 * max(1.0, np.linalg.norm(xd))
-    assert np.linalg.norm(x - x0) <= 1e-10 * max(1.0, np.linalg.norm(x0))
-    moved = int(err.split(" update tasks rescheduled")[0].split()[-1])
-    assert st["ntasks"] == st0["ntasks"]                  # the same updates ...
-    if rate < 1.0:
-        assert moved > 0 and st["ngroups"] < st0["ngroups"]     # ... merged per target tile

@@ -106,7 +106,7 @@ int main(int argc, char **argv) {
         int ntk = 0;
         for (int g = P.upd_stage_ptr[l]; g < P.upd_stage_ptr[l + 1]; g++) ntk += P.upd_groups[g].task_end - P.upd_groups[g].task_begin;
         printf("%5d %7d %7d %7ld %9ld %12.3e %8d %8d   dense: %6d groups (far %5d) %10.3e flops; tasks %7d avgfill %.2f\n", l, P.lvl_ptr[l + 1] - P.lvl_ptr[l], maxw, (long)maxr, (long)srw, lf[l],
-               P.upd_stage_ptr[l + 1] - P.upd_stage_ptr[l], P.fac_lvl_ptr[l + 1] - P.fac_lvl_ptr[l], P.upd_stage_ndense[l], P.upd_stage_nfar[l], lfd[l], ntk, ntk ? fills[l] / ntk : 0.0);
+               P.upd_stage_ptr[l + 1] - P.upd_stage_ptr[l], P.fac_lvl_ptr[l + 1] - P.fac_lvl_ptr[l], P.upd_stage_ndense[l], 0, lfd[l], ntk, ntk ? fills[l] / ntk : 0.0);
     }
     if (argc > 6) {   // debug: who owns ubuf position argv[5], as seen from supernode argv[6]
         const int64_t upos = atoll(argv[5]);
