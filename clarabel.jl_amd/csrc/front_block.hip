@@ -74,6 +74,17 @@ __device__ __forceinline__ void fb_st16(double *p, double a, double b) {
 // write-through latency of every streamed record on the pivot chain.  Nothing in the loops that use it communicates through global
 // memory inside the workgroup.
 __device__ __forceinline__ void fb_bar() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// An exec-masked block (s_cbranch_execz) between a matrix-core instruction and the first read of its accumulators (v_accvgpr_read)
+// is a trap: the waves that skip the block arrive at the read with fewer wait states than the compiler's hazard recogniser counted
+// along the fall-through path, and read accumulators that are still being written (measured in round 4: deterministic 1e-4 errors
+// of the factorisation with a store block of two of the four waves behind the rank-8 update).  The loops below keep such blocks
+// away from that path (they sit behind a barrier, next to wave 0's eliminations); where one cannot be avoided, this pins 24 wait
+// states (enough for the 16-pass FP64 MFMA) between the matrix-core instructions before it and whatever follows.
+__device__ __forceinline__ void fb_mfma_settle() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
 // "not written yet" in a stream record: a NaN no arithmetic produces (both halves equal, so a 32-bit fill pattern would do too)
 constexpr unsigned kFbSentHalf = 0xFFFFDEADu;
 constexpr unsigned long long kFbSentinel = 0xFFFFDEADFFFFDEADull;
@@ -317,6 +328,8 @@ k_front_block(DevPlan P, FrontBatch B, int *sync_all, double *scratch_all, doubl
     double (*colC)[64] = (double (*)[64])(Sa + 64 * 9 + 512);        // [8][64]   raw a_ik = d_k l_ik
     double *dsave = Sa + 64 * 9 + 1024;                              // [64]
     double *dinvs = Sa + 64 * 9 + 1024 + 64;                         // [64]      1/d_k as used on the chain (fb_rcp)
+    double (*colC2)[64] = (double (*)[64])(Sa + 64 * 9 + 1024 + 128);   // [8][64] second buffer of colC for the pivot loop (STREAM)
+    double lrow[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};       // STREAM, wave 3: the block of L(i, i-1) whose store is pending
     if (STREAM && diag && i > 0) {
         // ---- streamed step: this workgroup's rows of panel i-1, block by block behind the workgroup that eliminates tile i-1
         v4f64 xacc[4];
@@ -330,6 +343,18 @@ k_front_block(DevPlan P, FrontBatch B, int *sync_all, double *scratch_all, doubl
         double *ltile = ltiles + (int64_t)(i * (i - 1) / 2 + i - 1) * 4096;       // L(i, i-1), row-major, for the workgroups below
         if (tid == 0) sres = 1;
         __syncthreads();                                   // Sa / Sb (operands of the last regular step) are free
+        // Waves 0 and 1 fetch the records (wave 3 has write-through stores in flight: it must not wait on the vector-memory counter).
+        // The record of block Bk + 1 is REQUESTED while block Bk is processed (plain agent-scope loads, the compiler places the wait at
+        // their first use): a consumer that has fallen behind finds it complete and pays no memory round trip per block; one that is
+        // level with the producer sees the sentinel and polls.
+        const int pc = wv < 2 ? 2 * tid : 0, pe = (tid >= 64 && tid < 72) ? 512 + 2 * (tid - 64) : 0;
+        double n0 = 0.0, n1 = 0.0, n2 = 0.0, n3 = 0.0, n4 = 0.0, n5 = 0.0;
+        auto request = [&](const double *rec) {
+            n0 = fb_ld(rec + pc); n1 = fb_ld(rec + pc + 1); n2 = fb_ld(rec + pc + 256); n3 = fb_ld(rec + pc + 257);
+            n4 = fb_ld(rec + pe); n5 = fb_ld(rec + pe + 1);
+        };
+        auto fresh = [&](double v) { return (unsigned long long)__double_as_longlong(v) != kFbSentinel; };
+        if (wv < 2) request(rec0);
 #pragma unroll
         for (int Bk = 0; Bk < 8; Bk++) {
             {
@@ -340,23 +365,23 @@ k_front_block(DevPlan P, FrontBatch B, int *sync_all, double *scratch_all, doubl
                 }
             }
             double *CR = Sb + (Bk & 1) * kFbRec;           // the record: [8][64] raw columns of tile i-1, 8 pivots, 8 reciprocals
-            if (wv < 2) {                                  // waves 0, 1 poll (wave 3 has write-through stores in flight: it must not wait)
+            if (wv < 2) {
                 const double *rec = rec0 + (int64_t)Bk * kFbRec;
-                double2 d0, d1;
-                const bool ok = fb_poll2(rec + 2 * tid, rec + 2 * (tid + 128), d0, d1, err, P.flags + FL_FACFAIL, P.spin_limit);
-                CR[2 * tid] = d0.x; CR[2 * tid + 1] = d0.y;
-                CR[2 * tid + 256] = d1.x; CR[2 * tid + 257] = d1.y;
-                bool ok2 = true;
-                if (tid >= 64 && tid < 72) {
-                    double2 e0, e1;
-                    ok2 = fb_poll2(rec + 512 + 2 * (tid - 64), rec + 512 + 2 * (tid - 64), e0, e1, err, P.flags + FL_FACFAIL, P.spin_limit);
-                    CR[512 + 2 * (tid - 64)] = e0.x; CR[513 + 2 * (tid - 64)] = e0.y;
+                bool ok = true;
+                if (!(fresh(n0) && fresh(n1) && fresh(n2) && fresh(n3) && fresh(n4) && fresh(n5))) {      // not there yet: poll
+                    double2 d0, d1, e0, e1;
+                    ok = fb_poll2(rec + pc, rec + pc + 256, d0, d1, err, P.flags + FL_FACFAIL, P.spin_limit) &&
+                         fb_poll2(rec + pe, rec + pe, e0, e1, err, P.flags + FL_FACFAIL, P.spin_limit);
+                    n0 = d0.x; n1 = d0.y; n2 = d1.x; n3 = d1.y; n4 = e0.x; n5 = e0.y;
                 }
-                if (!(ok && ok2)) sres = 0;
+                CR[pc] = n0; CR[pc + 1] = n1; CR[pc + 256] = n2; CR[pc + 257] = n3;
+                if (pe) { CR[pe] = n4; CR[pe + 1] = n5; }
+                if (!ok) sres = 0;
             }
             fb_bar();
             if (sres == 0) return;                         // (uniform: nobody writes sres after this point)
             if (Bk == 0) FB_T(12);
+            if (wv < 2 && Bk < 7) request(rec0 + (int64_t)(Bk + 1) * kFbRec);
             if (wv == 0) {
                 double p[8], cr[28], dv[8];
 #pragma unroll
@@ -373,11 +398,14 @@ k_front_block(DevPlan P, FrontBatch B, int *sync_all, double *scratch_all, doubl
 #pragma unroll
                     for (int jj = kk + 1; jj < 8; jj++, t++) p[jj] = fma(-li, cr[t], p[jj]);
                 }
+            } else if (wv == 3 && Bk > 0) {                // next to wave 0's elimination: L(i, i-1)[row = lane][8 (Bk-1) ..], 64 bytes per lane
+#pragma unroll
+                for (int q = 0; q < 4; q++) fb_st16(ltile + lane * 64 + 8 * (Bk - 1) + 2 * q, lrow[2 * q], lrow[2 * q + 1]);
             }
             fb_bar();
-            if (wv == 3) {                                 // L(i, i-1)[row][8 Bk .. 8 Bk + 7] = l, 64 contiguous bytes per lane
+            if (wv == 3) {                                 // this block's l values, stored during the next block's elimination
 #pragma unroll
-                for (int q = 0; q < 4; q++) fb_st16(ltile + lane * 64 + 8 * Bk + 2 * q, colL[2 * q][lane], colL[2 * q + 1][lane]);
+                for (int q = 0; q < 8; q++) lrow[q] = colL[q][lane];
             }
 #pragma unroll
             for (int ks = 0; ks < 2; ks++) {
@@ -390,23 +418,38 @@ k_front_block(DevPlan P, FrontBatch B, int *sync_all, double *scratch_all, doubl
                 for (int sub = 0; sub < 4; sub++)
                     tacc[sub] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, colC[4 * ks + lk][16 * sub + l15], tacc[sub], 0, 0, 0);
             }
-            // Pc is rewritten at once (only wave 0 read it, before the barrier above); colL / colC by wave 0 after the next
-            // iteration's first barrier; the record buffer alternates
+            // straight from the matrix-core instructions to the next iteration's accumulator reads (fb_mfma_settle's comment); Pc is
+            // rewritten at once (only wave 0 read it, before the barrier above); colL / colC by wave 0 after the next iteration's
+            // first barrier; the record buffer alternates
         }
+        fb_mfma_settle();                                  // the trace stamps / the ballot below are exec-masked blocks in front of the pivots' reads of tacc
         FB_T(13);
     }
     FB_T(6);
     if (!diag) return;
     // ---- Per block of 8 pivots: the waves hand the block's 8 columns to wave 0 through LDS, wave 0 eliminates them without leaving
     //      the wavefront (lane = row; the pivot rule and arithmetic of k_factor_panel, kernels.hip), and every wave applies the rank-8
-    //      update to its 16 rows on the matrix core.  L11 is collected in Sb for the inverse and the solves.  STREAM: waves 1 and 2
-    //      publish the block's record for the diagonal workgroup that follows in this launch; the loop's barriers are LDS-only.
+    //      update to its 16 rows on the matrix core.  L11 is collected in Sb for the inverse and the solves.
+    //      STREAM: the loop's barriers are LDS-only; the raw columns alternate between two buffers so that waves 1 and 2 can publish
+    //      the record of block Bk - 1 (write-through stores, no flag) WHILE wave 0 eliminates block Bk -- they idle there anyway, and
+    //      nothing is added between the two barriers that bracket the matrix-core update.
     FB_T(7);
     const unsigned long long spos = __ballot(sgn_l > 0);
     int nreg = 0;
+    const bool pub = STREAM && i + 1 < nb && (wv == 1 || wv == 2);
+    auto publish = [&](int Bp) {                          // record of block Bp for the next diagonal workgroup
+        const int c = tid - 64;
+        const double *flat = (Bp & 1) ? &colC2[0][0] : &colC[0][0];
+        double *rec = stream + ((int64_t)i * 8 + Bp) * kFbRec;
+        fb_st16(rec + 2 * c, flat[2 * c], flat[2 * c + 1]);
+        fb_st16(rec + 2 * c + 256, flat[2 * c + 256], flat[2 * c + 257]);
+        if (c >= 64 && c < 68) fb_st16(rec + 512 + 2 * (c - 64), dsave[8 * Bp + 2 * (c - 64)], dsave[8 * Bp + 2 * (c - 64) + 1]);
+        if (c >= 68 && c < 72) fb_st16(rec + 520 + 2 * (c - 68), dinvs[8 * Bp + 2 * (c - 68)], dinvs[8 * Bp + 2 * (c - 68) + 1]);
+    };
     if (STREAM) fb_bar(); else __syncthreads();           // Sa (X_j) and Sb (the last operand tile / record) are free
 #pragma unroll
     for (int Bk = 0; Bk < 8; Bk++) {
+        double (*cC)[64] = (STREAM && (Bk & 1)) ? colC2 : colC;
         {
             const int sub = Bk >> 1, c0 = 8 * (Bk & 1);
             if (l15 >= c0 && l15 < c0 + 8) {
@@ -415,10 +458,6 @@ k_front_block(DevPlan P, FrontBatch B, int *sync_all, double *scratch_all, doubl
             }
         }
         if (STREAM) {
-            if (Bk == 2 && i > 0 && wv == 3) {            // wave 3 wrote L(i, i-1) during the streamed step: long drained by now
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (lane == 0) __hip_atomic_store(fl_L + 8 * i + (i - 1), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
             fb_bar();
         } else {
             if (Bk == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the L tile stores issued before the pivots have drained ...
@@ -440,7 +479,7 @@ k_front_block(DevPlan P, FrontBatch B, int *sync_all, double *scratch_all, doubl
                 const double dinv = fb_rcp(d);
                 const double li = reg * dinv;
                 colL[kk][lane] = li;
-                colC[kk][lane] = reg;
+                cC[kk][lane] = reg;
                 Sb[lane * FLD + k] = li;
                 if (lane == k) { dsave[k] = d; if (STREAM) dinvs[k] = dinv; }
 #pragma unroll
@@ -449,19 +488,20 @@ k_front_block(DevPlan P, FrontBatch B, int *sync_all, double *scratch_all, doubl
                     pcol[jj] = fma(-li, cj, pcol[jj]);
                 }
             }
-        }
-        if (STREAM) fb_bar(); else __syncthreads();
-        if (STREAM && i + 1 < nb) {                       // the block's record for the next diagonal workgroup (write-through, no flag)
-            double *rec = stream + ((int64_t)i * 8 + Bk) * kFbRec;
-            const double *flat = &colC[0][0];
-            if (wv == 1 || wv == 2) {
-                const int c = tid - 64;
-                fb_st16(rec + 2 * c, flat[2 * c], flat[2 * c + 1]);
-                fb_st16(rec + 2 * c + 256, flat[2 * c + 256], flat[2 * c + 257]);
-                if (c >= 64 && c < 68) fb_st16(rec + 512 + 2 * (c - 64), dsave[8 * Bk + 2 * (c - 64)], dsave[8 * Bk + 2 * (c - 64) + 1]);
-                if (c >= 68 && c < 72) fb_st16(rec + 520 + 2 * (c - 68), dinvs[8 * Bk + 2 * (c - 68)], dinvs[8 * Bk + 2 * (c - 68) + 1]);
+        } else if (STREAM) {                              // next to wave 0's elimination
+            if (pub && Bk > 0) publish(Bk - 1);
+            if (wv == 3 && i > 0) {
+                if (Bk == 0) {                            // the last block of L(i, i-1) from the streamed step
+#pragma unroll
+                    for (int q = 0; q < 4; q++) fb_st16(ltiles + (int64_t)(i * (i - 1) / 2 + i - 1) * 4096 + lane * 64 + 56 + 2 * q, lrow[2 * q], lrow[2 * q + 1]);
+                }
+                if (Bk == 2) {                            // ... drained long ago: hand the tile to the workgroups below
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (lane == 0) __hip_atomic_store(fl_L + 8 * i + (i - 1), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
         }
+        if (STREAM) fb_bar(); else __syncthreads();
         if (Bk < 7) {
             // a_ij -= sum_k l_ik a_jk over the block's 8 pivots, for the 16-column strips that still hold live columns
 #pragma unroll
@@ -470,11 +510,12 @@ k_front_block(DevPlan P, FrontBatch B, int *sync_all, double *scratch_all, doubl
 #pragma unroll
                 for (int sub = 0; sub < 4; sub++)
                     if (sub >= ((8 * Bk + 8) >> 4))
-                        tacc[sub] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, colC[4 * ks + lk][16 * sub + l15], tacc[sub], 0, 0, 0);
+                        tacc[sub] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, cC[4 * ks + lk][16 * sub + l15], tacc[sub], 0, 0, 0);
             }
         }
-        // Pc / colL / colC are rewritten after the next iteration's first barrier / by wave 0 after it: every wave is past its reads
+        // Pc / colL are rewritten after the next iteration's first barrier / by wave 0 after it: every wave is past its reads
     }
+    if (pub) publish(7);
     __syncthreads();
     FB_T(8);
     // ---- L11^-1 (blocked: 16 x 16 diagonal blocks by substitution, the rest on the matrix core), then  Minv = L11^-T D^-1

@@ -19,11 +19,17 @@ for _ in range(3):
     assert hk.kktsolver_update(cones)
 print("factor ms", hk.h.timing())
 t = hk.h.debug_dump(9).view(np.int64).reshape(-1, 8, 16) * 0.01   # microseconds
-names = ["start", "loaded", "minv seen", "minv in LDS", "trsm", "stores+pub", "updates", "tile->regs", "pivoted", "Ldiag/D", "inverse", "published"]
+names = ["start", "loaded", "minv seen", "minv in LDS", "trsm", "stores+pub", "updates", "tile->regs", "pivoted", "inverse", "published", "end",
+         "first record", "streamed"]
 for bi in (1, 8, 15):
     if bi >= len(t): continue
     t0 = t[bi, 0, 0]
     print(f"batch {bi}: stamps relative to workgroup 0's start (us)")
     for i in range(7):
         row = t[bi, i]
-        print("  wg", i, " ".join(f"{nm}={row[k]-t0:7.2f}" for k, nm in enumerate(names) if row[k] > 0))
+        print("  wg", i, " ".join(f"{nm}={row[k]-t0:7.2f}" for k, nm in enumerate(names) if k < 14 and row[k] > 0))
+    # the chain: start of the pivots of consecutive diagonal workgroups ("tile->regs" = stamp 7), end of the last one's pivots
+    piv = [t[bi, i, 7] - t0 for i in range(5) if t[bi, i, 7] > 0]
+    if len(piv) > 1:
+        print(f"  chain: pivots start at {[round(v, 2) for v in piv]} -> {np.mean(np.diff(piv)):.2f} us per panel; pivots themselves "
+              f"{np.mean([t[bi, i, 8] - t[bi, i, 7] for i in range(len(piv))]):.2f} us")
