@@ -40,6 +40,14 @@ __device__ __forceinline__ double fb_readlane(double x, int l) {   // l wave-uni
     const unsigned lo = __builtin_amdgcn_readlane((unsigned)u, l), hi = __builtin_amdgcn_readlane((unsigned)(u >> 32), l);
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
+// 1 / d on the pivot chain: the hardware reciprocal r (2^-27 or better), then r (1 + e + e^2) with e = 1 - d r -- three dependent
+// operations instead of the four of two Newton steps, error ~ e^3 + one rounding
+__device__ __forceinline__ double fb_rcp3(double d) {
+    const double r = __builtin_amdgcn_rcp(d);
+    const double e = fma(-d, r, 1.0);
+    const double e2 = fma(e, e, e);
+    return fma(r, e2, r);
+}
 __device__ __forceinline__ double fb_rcp(double d) {   // kernels.hip pivot_rcp
     double r = __builtin_amdgcn_rcp(d);
     r = fma(fma(-d, r, 1.0), r, r);
@@ -193,7 +201,10 @@ __device__ __forceinline__ void fb_extra_tiles(const DevPlan &P, int begin, int 
     for (int q = 0; q < per_wave && idx < count; q++, idx++) dense_tile<4, 4, true>(P, P.dgroups + begin + idx, lane, 0, 0);
 }
 
-#define FB_T(slot) do { if (trace && tid == 0 && i < 8) trace[(B.sync_off / 128 * 8 + i) * 16 + (slot)] = (long long)wall_clock64(); } while (0)
+#define FB_T(slot) do { if (trace && tid == 0 && i < 5) trace[(B.sync_off / 128 * 8 + i) * 16 + (slot)] = (long long)wall_clock64(); } while (0)
+// shader-clock stamps of workgroup 0's pivot loop, 4 per block of 8 pivots (trace words 80 ..): after the first barrier, after wave 0's
+// eliminations, after the second barrier, after the rank-8 update
+#define FB_TB(ph) do { if (trace && tid == 0 && i == 0) trace[(B.sync_off / 128 * 8 + 5) * 16 + 4 * Bk + (ph)] = (long long)clock64(); } while (0)
 template <bool STREAM>
 __global__ void __launch_bounds__(256)
 k_front_block(DevPlan P, FrontBatch B, int *sync_all, double *scratch_all, double *stream_all, double dyn_eps, double dyn_delta,
@@ -435,6 +446,7 @@ k_front_block(DevPlan P, FrontBatch B, int *sync_all, double *scratch_all, doubl
     //      nothing is added between the two barriers that bracket the matrix-core update.
     FB_T(7);
     const unsigned long long spos = __ballot(sgn_l > 0);
+    const double dyn_delta_inv = 1.0 / dyn_delta;
     int nreg = 0;
     const bool pub = STREAM && i + 1 < nb && (wv == 1 || wv == 2);
     auto publish = [&](int Bp) {                          // record of block Bp for the next diagonal workgroup
@@ -465,28 +477,56 @@ k_front_block(DevPlan P, FrontBatch B, int *sync_all, double *scratch_all, doubl
             if (Bk == 0 && i > 0 && tid == 0)                                // ... for every thread: hand the tile over
                 __hip_atomic_store(fl_L + 8 * i + (i - 1), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        FB_TB(0);
         if (wv == 0) {
-            double pcol[8];
+            // Wave 0 is ISSUE-bound here (one FP64 instruction per 8 cycles, one 32-bit one per 4; measured with pieces compiled out:
+            // DESIGN.md), so the loop is written for few instructions AND a short pivot-to-pivot chain:
+            //   d_k = a_kk - c_{k,k-1}^2 / d_{k-1}  ->  1 / d_k   is one fma, the hardware reciprocal and three more fma (fb_rcp3);
+            //   a_kk and c_{k,k-1} are fetched from the lanes that hold them one pivot EARLIER (with the updates of the pivots before
+            //   k-1 applied; what pivot k-1 contributes is the fma on the chain);
+            //   the pivot rule is evaluated next to the reciprocal and applied by register selects -- written so that the compiler
+            //   can neither branch on it (vector compare -> scalar branch -> reciprocal) nor mask the exec register for it (that costs
+            //   ~85 cycles per pivot: the scalar unit waits for the vector compare);
+            //   the pivots / reciprocals are written by one lane ONCE per block.
+            double pcol[8], dk[8], dik[8];
 #pragma unroll
             for (int q = 0; q < 8; q++) pcol[q] = Pc[lane * 9 + q];
+            double akk = fb_readlane(pcol[0], 8 * Bk), csq = 0.0, dinv_prev = 0.0;
 #pragma unroll
             for (int kk = 0; kk < 8; kk++) {
                 const int k = 8 * Bk + kk;
+                double d = fma(-csq, dinv_prev, akk);
+                const int sm = ((spos >> k) & 1ull) ? 0 : (int)0x80000000;               // expected sign negative: test -d, substitute -delta
+                const bool bad = __hiloint2double(__double2hiint(d) ^ sm, __double2loint(d)) < dyn_eps;
+                double dinv = fb_rcp3(d);
+                double dsub = __hiloint2double(__double2hiint(dyn_delta) ^ sm, __double2loint(dyn_delta));
+                double isub = __hiloint2double(__double2hiint(dyn_delta_inv) ^ sm, __double2loint(dyn_delta_inv));
+                asm volatile("" : "+v"(dinv), "+v"(dsub), "+v"(isub));                   // all three in vector registers, unconditionally
+                d = bad ? dsub : d;
+                dinv = bad ? isub : dinv;
+                nreg += bad ? 1 : 0;
+                dk[kk] = d;
+                dik[kk] = dinv;
                 const double reg = pcol[kk];
-                double d = fb_readlane(reg, k);
-                const double sg = ((spos >> k) & 1ull) ? 1.0 : -1.0;
-                if (d * sg < dyn_eps) { d = dyn_delta * sg; nreg++; }
-                const double dinv = fb_rcp(d);
+                if (kk < 7) {
+                    akk = fb_readlane(pcol[kk + 1], k + 1);
+                    const double cn = fb_readlane(reg, k + 1);
+                    csq = cn * cn;
+                }
+                dinv_prev = dinv;
                 const double li = reg * dinv;
                 colL[kk][lane] = li;
                 cC[kk][lane] = reg;
                 Sb[lane * FLD + k] = li;
-                if (lane == k) { dsave[k] = d; if (STREAM) dinvs[k] = dinv; }
 #pragma unroll
                 for (int jj = kk + 1; jj < 8; jj++) {
                     const double cj = fb_readlane(reg, 8 * Bk + jj);
                     pcol[jj] = fma(-li, cj, pcol[jj]);
                 }
+            }
+            if (lane == 0) {
+#pragma unroll
+                for (int q = 0; q < 8; q++) { dsave[8 * Bk + q] = dk[q]; dinvs[8 * Bk + q] = dik[q]; }
             }
         } else if (STREAM) {                              // next to wave 0's elimination
             if (pub && Bk > 0) publish(Bk - 1);
@@ -501,7 +541,9 @@ k_front_block(DevPlan P, FrontBatch B, int *sync_all, double *scratch_all, doubl
                 }
             }
         }
+        if (wv == 0) FB_TB(1);
         if (STREAM) fb_bar(); else __syncthreads();
+        FB_TB(2);
         if (Bk < 7) {
             // a_ij -= sum_k l_ik a_jk over the block's 8 pivots, for the 16-column strips that still hold live columns
 #pragma unroll
@@ -513,6 +555,7 @@ k_front_block(DevPlan P, FrontBatch B, int *sync_all, double *scratch_all, doubl
                         tacc[sub] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, cC[4 * ks + lk][16 * sub + l15], tacc[sub], 0, 0, 0);
             }
         }
+        FB_TB(3);
         // Pc / colL are rewritten after the next iteration's first barrier / by wave 0 after it: every wave is past its reads
     }
     if (pub) publish(7);

@@ -28,6 +28,14 @@ for bi in (1, 8, 15):
     for i in range(7):
         row = t[bi, i]
         print("  wg", i, " ".join(f"{nm}={row[k]-t0:7.2f}" for k, nm in enumerate(names) if k < 14 and row[k] > 0))
+    tb = t[bi, 5].reshape(-1) / 0.01          # raw shader-clock stamps of workgroup 0's pivot loop
+    tb = hk.h.debug_dump(9).view(np.int64).reshape(-1, 8, 16)[bi, 5:8].reshape(-1)[:32].reshape(8, 4)
+    if tb[0, 0] > 0:
+        print("  wg 0 pivot loop, shader cycles per block [barrier A -> pivots done | -> barrier B | -> rank-8 done | -> next barrier A]:")
+        for Bk in range(8):
+            nxt = tb[Bk + 1, 0] - tb[Bk, 3] if Bk < 7 else 0
+            print(f"    block {Bk}: {tb[Bk,1]-tb[Bk,0]:6d} {tb[Bk,2]-tb[Bk,1]:6d} {tb[Bk,3]-tb[Bk,2]:6d} {nxt:6d}")
+        print(f"    total {tb[7,3]-tb[0,0]} cycles for 8 blocks; wall clock pivots {t[bi,0,8]-t[bi,0,7]:.2f} us")
     # the chain: start of the pivots of consecutive diagonal workgroups ("tile->regs" = stamp 7), end of the last one's pivots
     piv = [t[bi, i, 7] - t0 for i in range(5) if t[bi, i, 7] > 0]
     if len(piv) > 1:
