@@ -317,6 +317,7 @@ int32_t hipkkt_set_qb(hipkkt_handle h, const double *q, const double *b) {
     if (n) HK_CHECK(hipMemcpyAsync(S->d_qb, q, n * sizeof(double), hipMemcpyHostToDevice, S->stream));
     if (m) HK_CHECK(hipMemcpyAsync(S->d_qb + n, b, m * sizeof(double), hipMemcpyHostToDevice, S->stream));
     HK_CHECK(hipStreamSynchronize(S->stream));
+    S->red_have_const = false;   // the resident constant-rhs solution (x2, z2) solved the OLD [-q; b]: never combine it with the new terms
     return HIPKKT_OK;
     HK_LEAVE
 }

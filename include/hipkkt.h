@@ -239,7 +239,11 @@ int32_t hipkkt_solve_multi_dev(hipkkt_handle h, int64_t nrhs, const double *rhs_
  *     (xi - x2)'P(xi - x2), x2'P x2} (host, required);  ir_steps[2] = refinement steps of the (x1, z1) / (x2, z2) solve (may be NULL)
  * The _dev form takes in_dev = [rhs_x | workz | var_x] (2n + m doubles) and writes lhs_dev = [dx | dz] (n + m doubles, may be NULL:
  * the step then stays in the handle and only the scalars cross PCIe).  Returns 0, HIPKKT_NUMERICAL_FAILURE when a solve failed
- * (the reference returns is_success = false), < 0 on usage / device errors (hipkkt_set_qb not called: HIPKKT_ERR_ARGUMENT). */
+ * (the reference returns is_success = false), < 0 on usage / device errors (hipkkt_set_qb not called: HIPKKT_ERR_ARGUMENT).
+ * ON ANY NON-ZERO RETURN lhs_x / lhs_z / lhs_dev / scal_out ARE UNSPECIFIED: the reduction and the copies of the step are enqueued
+ * behind the solves before their outcome is known (that is what makes it one synchronisation), so they may hold a rejected or
+ * non-finite iterate.  This differs from hipkkt_solve, which like kktsolver_getlhs! writes lhs only on success; the reference's
+ * caller returns at once on is_success = false (kktsystem.jl:172) and never reads lhs. */
 int32_t hipkkt_kkt_solve_reduced(hipkkt_handle h, const double *rhs_x, const double *workz, const double *var_x, const double *scal_in4,
                                  int32_t const_pending, double *lhs_x, double *lhs_z, double *scal_out10, int32_t ir_enable,
                                  double reltol, double abstol, int64_t max_iter, double stop_ratio, int64_t *ir_steps2);

@@ -27,9 +27,13 @@ mutable struct HipDirectLDLSolver{T} <: AbstractDirectLDLSolver{T}
     end
 end
 
-ldlsolver_constructor(::Val{:hip}) = HipDirectLDLSolver
-ldlsolver_matrix_shape(::Val{:hip}) = :triu
-ldlsolver_is_available(::Val{:hip}) = hip_is_available()
+# registration by Val dispatch (directldl_defaults.jl:12-30, pattern: ext/directldl_pardiso.jl:142-148).  :hip_ldl always means this
+# seam; :hip means it on a core without the KKT-solver registry of julia/clarabel_l1_seam.patch (kktsolver_hip.jl otherwise)
+for tok in (:hip, :hip_ldl)
+    @eval ldlsolver_constructor(::Val{$(QuoteNode(tok))}) = HipDirectLDLSolver
+    @eval ldlsolver_matrix_shape(::Val{$(QuoteNode(tok))}) = :triu
+    @eval ldlsolver_is_available(::Val{$(QuoteNode(tok))}) = hip_is_available()
+end
 
 linear_solver_info(s::HipDirectLDLSolver{T}) where {T} = hip_linear_solver_info(s.handle)
 

@@ -29,7 +29,15 @@ end
 hip_last_error(handle::Ptr{Cvoid} = C_NULL) =
     unsafe_string(ccall((:hipkkt_last_error, libhipkkt), Cstring, (Ptr{Cvoid},), handle))
 
-hip_is_available() = ccall((:hipkkt_is_available, libhipkkt), Int32, ()) > 0
+# include/hipkkt.h HIPKKT_ABI_VERSION this file was written against: signatures may change between versions, never within one
+const HIPKKT_ABI_VERSION = Int32(4)
+function hip_check_abi()
+    v = ccall((:hipkkt_abi_version, libhipkkt), Int32, ())
+    v == HIPKKT_ABI_VERSION || error("libclarabel_hipkkt implements ABI version $v, this extension was written against $HIPKKT_ABI_VERSION")
+    return true
+end
+
+hip_is_available() = hip_check_abi() && ccall((:hipkkt_is_available, libhipkkt), Int32, ()) > 0
 
 # gives the library's cache of device memory blocks back to the driver (e.g. before another package needs the HBM)
 hip_trim_cache() = ccall((:hipkkt_trim_cache, libhipkkt), Int32, (Int32,), hip_device())

@@ -1,7 +1,9 @@
 # Seam L1 -- HipKKTSolver <: AbstractKKTSolver  (contract: src/kktsolvers/kktsolver_defaults.jl:2-47; method-for-method twin of
 # src/kktsolvers/kktsolver_directldl.jl; Python twin: clarabel.jl_amd/kktsolver.py).  Everything below the method boundary runs
 # on the GPU: KKT assembly, Hs / sparse-cone value updates, static regulariser, numeric LDL^T, solves AND iterative refinement.
-# The one edit to Clarabel.jl this seam needs is the constructor choice at src/kktsystem.jl:33 (kktsystem_hip.patch).
+# What this seam needs from Clarabel.jl is julia/clarabel_l1_seam.patch: a KKT-solver registry next to the LDL one
+# (kktsolver_constructor(::Val{S}), used at src/kktsystem.jl:33 instead of the hard-wired DirectLDLKKTSolver) and three optional
+# capabilities with defaults in kktsolver_defaults.jl -- all extended from THIS file; the core never refers to the extension.
 #
 # Beyond the six contract methods, the rows SURVEY.md section 8(f) widens:
 #   N1  kktsolver_update_scaled!      update_scaling! + get_Hs! of Zero / Nonnegative / SecondOrder / PSD cones formed from (s, z)
@@ -140,8 +142,9 @@ function kktsolver_solve_multi!(ks::HipKKTSolver{T}, rhsx::Matrix{T}, rhsz::Matr
     return rc == 0
 end
 
-# N2 / N4: q and b resident in the plugin (once after set-up, again after update_q! / update_b!, data_updating.jl:108-130)
-function kktsolver_set_qb!(ks::HipKKTSolver{T}, q::Vector{T}, b::Vector{T}) where {T}
+# N2 / N4: q and b resident in the plugin (once after set-up, again from update_q! / update_b!: the hooks of
+# julia/clarabel_l1_seam.patch in data_updating.jl:109-150)
+function hip_set_qb!(ks::HipKKTSolver{T}, q::AbstractVector{T}, b::AbstractVector{T}) where {T}
     rc = ccall((:hipkkt_set_qb, libhipkkt), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), ks.handle, q, b)
     ks.has_qb = rc == 0
     return ks.has_qb
@@ -150,8 +153,8 @@ end
 # N2, second half: kkt_solve! (kktsystem.jl:135-215) between the caller's cone algebra (the vector c of Hs dz + ds = -c) and mul_Hs!.
 # workx = rhs.x, workz = c - rhs.z, x = variables.x;  const_pending: the constant-rhs solve that kkt_update! left pending runs in the
 # same call.  Writes lhs.x, lhs.z and returns (is_success, dtau).  One PCIe round trip, one host synchronisation.
-function kktsolver_kkt_solve_reduced!(ks::HipKKTSolver{T}, workx::Vector{T}, workz::Vector{T}, x::Vector{T}, τ::T, κ::T, rhsτ::T, rhsκ::T,
-                                      const_pending::Bool, lhsx::Vector{T}, lhsz::Vector{T}) where {T}
+function hip_kkt_solve_reduced!(ks::HipKKTSolver{T}, workx::AbstractVector{T}, workz::AbstractVector{T}, x::AbstractVector{T}, τ::T, κ::T, rhsτ::T, rhsκ::T,
+                                const_pending::Bool, lhsx::AbstractVector{T}, lhsz::AbstractVector{T}) where {T}
     st = ks.settings
     scal_in = T[τ, κ, rhsτ, rhsκ]
     scal_out = zeros(T, 10)
@@ -164,7 +167,8 @@ function kktsolver_kkt_solve_reduced!(ks::HipKKTSolver{T}, workx::Vector{T}, wor
     return (rc == 0, scal_out[1])
 end
 
-# N4: residuals_update!(residuals, variables, data), residuals.jl:1-37, from the resident P, A, q, b
+# N4: residuals_update!(residuals, variables, data), residuals.jl:1-37, from the resident P, A, q, b.  NOT wired into the IPM loop on the
+# Julia side: residuals_update! is called from solver.jl:227, which stays untouched; a caller that owns its loop may use it directly.
 function kktsolver_residuals!(ks::HipKKTSolver{T}, residuals, variables) where {T}
     scal5 = zeros(T, 5)
     rc = ccall((:hipkkt_residuals, libhipkkt), Int32,
@@ -184,3 +188,17 @@ kktsolver_update_A!(ks::HipKKTSolver{T}, A::SparseMatrixCSC{T}) where {T} =
     ccall((:hipkkt_update_A, libhipkkt), Int32, (Ptr{Cvoid}, Ptr{Float64}, Int64), ks.handle, A.nzval, nnz(A))
 
 kktsolver_linear_solver_info(ks::HipKKTSolver{T}) where {T} = hip_linear_solver_info(ks.handle)
+
+
+# ---- registration (seam L1): only on a core that carries julia/clarabel_l1_seam.patch.  Same Val-dispatch pattern as
+#      ldlsolver_constructor (directldl_defaults.jl:12-30, ext/directldl_pardiso.jl:142-148), extended from the extension.
+if isdefined(Clarabel, :kktsolver_constructor)
+    Clarabel.kktsolver_constructor(::Val{:hip}) = HipKKTSolver
+    Clarabel.kktsolver_defers_constant_rhs(::HipKKTSolver{T}) where {T} = true
+    Clarabel.kktsolver_has_reduced_solve(::HipKKTSolver{T}) where {T} = true
+    Clarabel.kktsolver_set_qb!(ks::HipKKTSolver{T}, q::AbstractVector{T}, b::AbstractVector{T}) where {T} = (hip_set_qb!(ks, q, b); nothing)
+    Clarabel.kktsolver_kkt_solve_reduced!(ks::HipKKTSolver{T}, workx::AbstractVector{T}, workz::AbstractVector{T}, x::AbstractVector{T},
+                                          τ::T, κ::T, rhsτ::T, rhsκ::T, const_pending::Bool,
+                                          lhsx::AbstractVector{T}, lhsz::AbstractVector{T}) where {T} =
+        hip_kkt_solve_reduced!(ks, workx, workz, x, τ, κ, rhsτ, rhsκ, const_pending, lhsx, lhsz)
+end

@@ -10,7 +10,7 @@
 # (src/json.jl:61-85) and, to pin the wire format both ways, written back with save_to_file (src/json.jl:25-58) next to the results.
 # Not executed in this repository's build image (no julia there); tests/test_julia_glue.py checks its ccall-free use of the plugin.
 using Clarabel, JSON, SparseArrays, LinearAlgebra
-include(joinpath(@__DIR__, "ClarabelHipKKTExt", "ClarabelHipKKTExt.jl"))
+include(joinpath(@__DIR__, "ext", "ClarabelHipKKTExt.jl"))
 
 function solve_and_dump(file::String, method::Symbol, outdir::String)
     solver = Clarabel.load_from_file(file)

@@ -1,15 +1,21 @@
-"""The Julia side of the C ABI ships as files (julia/ClarabelHipKKTExt/*.jl, julia/parity_dump.jl); there is no `julia` in the build
+"""The Julia side of the C ABI ships as files (julia/ext/*.jl, julia/clarabel_l1_seam.patch, julia/parity_dump.jl); there is no `julia` in the build
 image, so what can be checked without executing them is checked here: every `ccall((:sym, libhipkkt), Ret, (ArgTypes...), ...)`
 names a function declared in include/hipkkt.h, with the declared number of parameters, a matching return type and matching parameter
 type classes (Ptr{Float64} <-> double*, Int64 <-> int64_t, Ptr{Cvoid} <-> hipkkt_handle, ...); the `HipKKTOpts` struct mirrors
-`hipkkt_opts` field for field; and INTEGRATION.md refers to the files instead of carrying copies of them."""
+`hipkkt_opts` field for field; INTEGRATION.md refers to the files instead of carrying copies of them; and the core patch of seam L1
+is a REAL patch: it applies to the reference checkout (`patch --dry-run`, when /root/reference is there), never mentions the extension
+module (the core must not import what imports it), and every kktsolver_* function it calls is defined by the patch itself (generic
+default) and extended by the extension."""
+import shutil
+import subprocess
 import os
 import re
 
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-JL_DIR = os.path.join(ROOT, "julia", "ClarabelHipKKTExt")
+JL_DIR = os.path.join(ROOT, "julia", "ext")
+PATCH = os.path.join(ROOT, "julia", "clarabel_l1_seam.patch")
 JL_FILES = [os.path.join(JL_DIR, f) for f in ("ClarabelHipKKTExt.jl", "hipkkt_lib.jl", "directldl_hip.jl", "kktsolver_hip.jl")]
 
 
@@ -19,6 +25,7 @@ def _strip_c_comments(s):
 
 def c_prototypes():
     src = _strip_c_comments(open(os.path.join(ROOT, "include", "hipkkt.h")).read())
+    src = re.sub(r"^\s*#[^\n]*$", "", src, flags=re.M)      # preprocessor lines
     protos = {}
     for m in re.finditer(r"([A-Za-z_][\w\s\*]*?)\b(hipkkt_\w+)\s*\(([^()]*)\)\s*;", src):
         ret, name, params = m.group(1).strip(), m.group(2), m.group(3).strip()
@@ -89,7 +96,7 @@ def jl_ccalls(path):
 
 
 def test_files_exist_and_the_module_includes_them():
-    for f in JL_FILES + [os.path.join(JL_DIR, "kktsystem_hip.patch"), os.path.join(ROOT, "julia", "parity_dump.jl"),
+    for f in JL_FILES + [PATCH, os.path.join(ROOT, "julia", "parity_dump.jl"),
                          os.path.join(ROOT, "julia", "make_config_json.py"), os.path.join(ROOT, "julia", "compare_parity.py")]:
         assert os.path.isfile(f), f
     mod = open(JL_FILES[0]).read()
@@ -117,7 +124,7 @@ def test_the_plugins_cover_the_contract_and_the_widened_rows():
     """the symbols each seam must reach (SURVEY section 8b + 8f)"""
     used = {c[0] for f in JL_FILES[1:] for c in jl_ccalls(f)}
     l0 = {"hipkkt_create", "hipkkt_update_values", "hipkkt_scale_values", "hipkkt_refactor", "hipkkt_ldl_solve", "hipkkt_info",
-          "hipkkt_is_available", "hipkkt_destroy", "hipkkt_default_opts", "hipkkt_last_error"}
+          "hipkkt_is_available", "hipkkt_abi_version", "hipkkt_destroy", "hipkkt_default_opts", "hipkkt_last_error"}
     l1 = {"hipkkt_create_from_parts", "hipkkt_set_hs", "hipkkt_set_soc_batch", "hipkkt_set_genpow", "hipkkt_setrhs", "hipkkt_solve",
           "hipkkt_update_P", "hipkkt_update_A", "hipkkt_get_dims"}
     widened = {"hipkkt_set_cone_types", "hipkkt_update_scaling", "hipkkt_set_hs_psd", "hipkkt_solve_multi", "hipkkt_set_qb",
@@ -146,7 +153,63 @@ def test_opts_struct_mirrors_the_header():
 
 def test_integration_md_points_at_the_files():
     text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
-    for f in ("julia/ClarabelHipKKTExt/directldl_hip.jl", "julia/ClarabelHipKKTExt/kktsolver_hip.jl", "julia/ClarabelHipKKTExt/kktsystem_hip.patch",
-              "julia/parity_dump.jl"):
+    for f in ("julia/ext/directldl_hip.jl", "julia/ext/kktsolver_hip.jl", "julia/clarabel_l1_seam.patch", "julia/parity_dump.jl"):
         assert f in text, f
     assert "mutable struct HipDirectLDLSolver" not in text and "mutable struct HipKKTSolver" not in text      # no inlined copies
+
+
+# ---- seam L1: the core patch ------------------------------------------------------------------
+
+def _patch_added_lines():
+    return [ln[1:] for ln in open(PATCH).read().splitlines() if ln.startswith("+") and not ln.startswith("+++")]
+
+
+def test_core_patch_never_names_the_extension():
+    """the patch hard-coded ClarabelHipKKTExt.HipKKTSolver inside module Clarabel -- the core would have to import the
+    extension that imports it.  Registration is by Val dispatch, extended FROM the extension."""
+    text = open(PATCH).read()
+    for tok in ("ClarabelHipKKTExt.", "HipKKTSolver", "hipkkt", ":hip"):
+        assert tok not in text, tok
+    ext = open(os.path.join(JL_DIR, "kktsolver_hip.jl")).read()
+    assert "Clarabel.kktsolver_constructor(::Val{:hip}) = HipKKTSolver" in ext
+    assert "isdefined(Clarabel, :kktsolver_constructor)" in ext            # an unpatched core still loads the extension (seam L0 only)
+    l0 = open(os.path.join(JL_DIR, "directldl_hip.jl")).read()
+    assert "ldlsolver_constructor(::Val{" in l0 and ":hip_ldl" in l0
+
+
+def test_core_patch_defines_what_it_calls_and_the_extension_extends_it():
+    added = "\n".join(_patch_added_lines())
+    called = set(re.findall(r"\b(kktsolver_\w+!?)\(", added))
+    hooks = {"kktsolver_constructor", "kktsolver_defers_constant_rhs", "kktsolver_has_reduced_solve", "kktsolver_kkt_solve_reduced!",
+             "kktsolver_set_qb!"}
+    assert hooks <= called, hooks - called
+    ext = open(os.path.join(JL_DIR, "kktsolver_hip.jl")).read()
+    for f in hooks:
+        # a generic definition in the patch (default) ...
+        assert re.search(r"^\+\s*(function\s+)?" + re.escape(f) + r"\(", open(PATCH).read(), flags=re.M), f
+        # ... and a method for HipKKTSolver in the extension
+        assert "Clarabel." + f + "(" in ext, f
+    # the new struct field is a real hunk: declared, initialised by new(...), set and cleared
+    assert "const_pending::Bool" in added and "work_conic,false)" in added
+    assert "kktsystem.const_pending = true" in added and "kktsystem.const_pending = false" in added
+    # update_q! / update_b! reach the solver (ADVICE round 3: the resident q, b went stale)
+    assert added.count("kktsolver_set_qb!(s.kktsystem.kktsolver,s.data.q,s.data.b)") == 2
+    # the extension package stanza
+    assert 'ClarabelHipKKTExt = "AMDGPU"' in added
+
+
+@pytest.mark.skipif(not (os.path.isdir("/root/reference/src") and shutil.which("patch")), reason="needs the reference checkout and patch(1)")
+def test_core_patch_applies_to_the_reference():
+    r = subprocess.run(["patch", "-p1", "--dry-run", "-d", "/root/reference", "-i", PATCH], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    for f in ("src/kktsolvers/kktsolver_defaults.jl", "src/kktsystem.jl", "src/data_updating.jl", "Project.toml"):
+        assert f in r.stdout, r.stdout
+
+
+def test_extension_checks_the_abi_version():
+    lib = open(os.path.join(JL_DIR, "hipkkt_lib.jl")).read()
+    hdr = open(os.path.join(ROOT, "include", "hipkkt.h")).read()
+    v = re.search(r"#define\s+HIPKKT_ABI_VERSION\s+(\d+)", hdr).group(1)
+    assert f"const HIPKKT_ABI_VERSION = Int32({v})" in lib and "hipkkt_abi_version" in lib
+    from clarabel_jl_amd import hipkkt
+    assert hipkkt.ABI_VERSION == int(v)
