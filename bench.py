@@ -79,8 +79,10 @@ def pmc_counters(cfg):
     return None, "measured on other kernel sources: " + ", ".join(seen[:3]) + "; re-run tools/final_round.sh"
 
 
-def _cpu_batch_worker(seed):
-    """all-cores CPU baseline of cfg 4: one problem per core, the oracle (reference :qdldl restatement) as KKT solver"""
+def _cpu_batch_worker(arg):
+    """all-cores CPU baseline of cfg 4: one problem per core, the oracle (reference :qdldl restatement) as KKT solver -- on the
+    elimination order the HIP path used for the same problem (arg = (seed, perm)), so that the two runs are comparable at 1e-10;
+    perm = None: the oracle's own order (SuperLU MMD on K)"""
     import time as _t
 
     import clarabel_jl_amd  # noqa: F401
@@ -88,10 +90,12 @@ def _cpu_batch_worker(seed):
     from clarabel_jl_amd import problems as pr_
     from oracle.kkt_oracle import OracleKKTSolver
 
+    seed, perm = arg
     t0 = _t.perf_counter()
     P, q, A, b, cones = pr_.batch_problem(seed)
-    sol = cl_.Solver(P, q, A, b, cones, cl_.Settings(), kktsolver_factory=lambda *a: OracleKKTSolver(*a, ordering="mmd")).solve()
-    return sol.iterations, sol.status, _t.perf_counter() - t0, float(sol.obj_val), seed
+    order = "mmd" if perm is None else perm
+    sol = cl_.Solver(P, q, A, b, cones, cl_.Settings(), kktsolver_factory=lambda *a: OracleKKTSolver(*a, ordering=order)).solve()
+    return sol.iterations, sol.status, _t.perf_counter() - t0, float(sol.obj_val), seed, float(sol.r_prim), float(sol.r_dual)
 
 
 def _alg_bytes(S_, iterations):
@@ -126,7 +130,8 @@ def _gpu_batch_chunk(arg):
         P, q, A, b, cones = pr_.batch_problem(seed)
         S_ = cl_.Solver(P, q, A, b, cones, cl_.Settings(device_id=device))
         sol = S_.solve()
-        return seed, sol.iterations, sol.status, float(sol.obj_val), _alg_bytes(S_, sol.iterations)
+        return (seed, sol.iterations, sol.status, float(sol.obj_val), _alg_bytes(S_, sol.iterations), S_.kktsystem.kktsolver.h.perm(),
+                float(sol.r_prim), float(sol.r_dual))
 
     return b_.run_concurrent(one, seeds, in_flight)
 
@@ -146,7 +151,8 @@ def bench_batch(args, cl, torch, dist, rank, world, local):
         P, q, A, b, cones = problems.batch_problem(100 + mine[k % len(mine)])
         S_ = cl.Solver(P, q, A, b, cones, cl.Settings(device_id=local))
         sol = S_.solve()
-        return 100 + mine[k % len(mine)], sol.iterations, sol.status, float(sol.obj_val), _alg_bytes(S_, sol.iterations)
+        return (100 + mine[k % len(mine)], sol.iterations, sol.status, float(sol.obj_val), _alg_bytes(S_, sol.iterations),
+                S_.kktsystem.kktsolver.h.perm(), float(sol.r_prim), float(sol.r_dual))
 
     res = []
     pool = None
@@ -195,41 +201,55 @@ def bench_batch(args, cl, torch, dist, rank, world, local):
         import multiprocessing as mp
 
         ncores = min(os.cpu_count() or 1, 64)
+        by_seed = {r[0]: r for r in res}
         seeds = [r[0] for r in res][: max(ncores, min(len(res), 2 * ncores))]
+        jobs = [(sd, by_seed[sd][5]) for sd in seeds]
         t0 = time.perf_counter()
         with mp.get_context("spawn").Pool(ncores) as pool:
             t_spawn = time.perf_counter() - t0
-            pool.map(_cpu_batch_worker, seeds[: min(len(seeds), ncores)])          # warm the workers (imports, oracle build)
+            pool.map(_cpu_batch_worker, jobs[: min(len(jobs), ncores)])          # warm the workers (imports, oracle build)
             t1 = time.perf_counter()
-            out = pool.map(_cpu_batch_worker, seeds)
+            out = pool.map(_cpu_batch_worker, jobs)
             t_cpu = time.perf_counter() - t1
         cpu_baseline = {"value": round(sum(o[0] for o in out) / t_cpu, 2), "unit": "IPM-iterations/s (whole solves incl. set-up)",
                         "cores": ncores, "kind": "port",
                         "sample": f"{len(seeds)} of the same problems, one per core on {ncores} worker processes, oracle/ C restatement "
-                                  "of the :qdldl path inside the same numpy caller", "problems": len(seeds),
+                                  "of the :qdldl path inside the same numpy caller, on the HIP path's elimination order", "problems": len(seeds),
                         "wall_s": round(t_cpu, 3), "sum_of_per_problem_s": round(sum(o[2] for o in out), 3),
                         "one_core_iterations_per_s": round(sum(o[0] for o in out) / sum(o[2] for o in out), 2),
                         "host_cores_available": os.cpu_count(), "pool_start_s": round(t_spawn, 2)}
-        # parity of the same run: the problems of the CPU sample, HIP path vs oracle (the oracle on ITS OWN ordering, SuperLU MMD):
-        # status, iteration counts (+-1), objective.  The IPM stops at 1e-8, and the two paths use different elimination orders, so
-        # the objective gate here is 1e-7 relative; the 1e-10 comparison on a common order is tests/test_gpu_fullsize.py
-        # (test_batch_config_matches_oracle, all 256 seeds).
-        by_seed = {r[0]: r for r in res}
-        st_eq = it_eq = it_pm1 = 0
-        max_dobj = 0.0
+        # parity of the same run: the problems of the CPU sample, HIP path vs the oracle ON THE SAME ELIMINATION ORDER, whole IPM solves:
+        # status equal, iterations equal, objective (relative) and residuals (absolute) to 1e-10 -- the gate of BASELINE.md and of
+        # tests/test_gpu_fullsize.py::test_batch_config_matches_oracle.  A problem outside it is not waved through by a wider gate:
+        # the oracle is run once more on ITS OWN order (SuperLU MMD) and what the reference's arithmetic itself moves by between the
+        # two orders (CPU vs CPU) is recorded as the cause; "explained" = within 1e-10 + 4 x that spread and iterations within 1.
+        st_eq = it_eq = 0
+        max_dobj = max_dres = 0.0
+        exceptions = []
         for o in out:
-            g_ = by_seed.get(o[4])
-            if g_ is None:
-                continue
+            g_ = by_seed[o[4]]
             st_eq += g_[2] == o[1]
             it_eq += g_[1] == o[0]
-            it_pm1 += abs(g_[1] - o[0]) <= 1
-            if g_[2] == o[1] == "SOLVED":
-                max_dobj = max(max_dobj, abs(g_[3] - o[3]) / max(1.0, abs(o[3])))
-        parity = {"problems_compared": len(out), "status_equal": st_eq, "iterations_equal": it_eq, "iterations_within_1": it_pm1,
-                  "max_rel_dobj": float(f"{max_dobj:.3e}"), "tolerance": 1e-7,
-                  "pass": bool(st_eq == len(out) and it_pm1 == len(out) and max_dobj <= 1e-7),
-                  "note": "HIP path vs the oracle on its own ordering, whole IPM solves of the same problems in the same run"}
+            dobj = abs(g_[3] - o[3]) / max(1.0, abs(o[3])) if g_[2] == o[1] and o[1] in ("SOLVED", "ALMOST_SOLVED") else (0.0 if g_[2] == o[1] else float("inf"))
+            dres = max(abs(g_[6] - o[5]), abs(g_[7] - o[6])) if np.isfinite(dobj) else float("inf")
+            if g_[1] == o[0] and dobj <= 1e-10 and dres <= 1e-10:
+                max_dobj, max_dres = max(max_dobj, dobj), max(max_dres, dres)
+                continue
+            o2 = _cpu_batch_worker((o[4], None))
+            sp_obj = abs(o2[3] - o[3]) / max(1.0, abs(o[3]))
+            sp_res = max(abs(o2[5] - o[5]), abs(o2[6] - o[6]))
+            ok_ = bool(g_[2] == o[1] and abs(g_[1] - o[0]) <= 1 and abs(o2[0] - o[0]) <= 1 and dobj <= 1e-10 + 4.0 * sp_obj and dres <= 1e-10 + 4.0 * sp_res)
+            exceptions.append({"seed": o[4], "iterations_hip_oracle_oracle_mmd": [g_[1], o[0], o2[0]], "rel_dobj": float(f"{dobj:.3e}"),
+                               "dres": float(f"{dres:.3e}"), "oracle_own_spread_obj": float(f"{sp_obj:.3e}"),
+                               "oracle_own_spread_res": float(f"{sp_res:.3e}"), "explained": ok_,
+                               "cause": ("inside the oracle's own spread between two elimination orders (CPU vs CPU)" if ok_ else
+                                         "NOT explained by the ordering spread (see tests/test_gpu_fullsize.py: refinement-branch shadow run)")})
+        parity = {"problems_compared": len(out), "status_equal": st_eq, "iterations_equal": it_eq,
+                  "within_1e-10": len(out) - len(exceptions), "max_rel_dobj_of_those": float(f"{max_dobj:.3e}"),
+                  "max_dres_of_those": float(f"{max_dres:.3e}"), "tolerance": 1e-10, "exceptions": exceptions,
+                  "pass": bool(st_eq == len(out) and all(e["explained"] for e in exceptions)),
+                  "note": "HIP path vs the oracle on the SAME elimination order, whole IPM solves of the same problems in the same run; "
+                          "every problem outside 1e-10 is listed with its measured cause"}
     if rank == 0:
         print(json.dumps({
             "metric": "IPM iterations/sec + KKT factor+solve ms, 10k-var sparse QP, 1/2/4/8 GPU",
@@ -340,22 +360,23 @@ def main():
     ks = solver.kktsystem.kktsolver
     h = ks.h
     rec_iters, rec_time = sol.iterations, solver.info.timers["IP iteration"]     # (this run also copies every Hs / rhs into the trace)
-    # End-to-end rate: the same problem solved again by the plain plugin, (a) through the reference's own call
-    # sequence (L1 contract only) and (b) with the N2 + N4 hooks of section 8(f) on: reduced-system algebra of kkt_solve! and the
-    # residuals computed by the plugin from resident data.  (b) is the headline: it is what the shipped
-    # Julia glue (julia/ClarabelHipKKTExt) runs; both results are checked against the recording run.
+    # End-to-end rate of the NUMPY STAND-IN of the Julia caller (julia_standin/ipm.py; no Julia has run): the
+    # same problem solved again by the plain plugin, (a) through the reference's own call sequence (L1 contract only), (b) with the
+    # N2 hook on (reduced-system algebra of kkt_solve! by the plugin: what julia/clarabel_l1_seam.patch wires), (c) with N2 + N4 on
+    # (residuals_update! by the plugin too: NOT wired on the Julia side -- solver.jl / residuals.jl stay untouched, INTEGRATION.md
+    # section 5).  The headline is (b); three runs each, the MEDIAN counts.
     e2e_runs = {}
-    for tag, kw in (("l1_contract_only", {}), ("n2_n4_hooks", {"device_reduced": True, "device_residuals": True})):
+    for tag, kw in (("l1_contract_only", {}), ("n2_hook", {"device_reduced": True}), ("n2_n4_hooks", {"device_reduced": True, "device_residuals": True})):
         rates = []
-        for _rep in range(2):     # (wall time of a 0.1-0.2 s host loop: two runs, both reported, the better one counts)
+        for _rep in range(3):     # (wall time of a 0.1-0.2 s host loop: three runs, all reported, the median counts)
             s_ = cl.Solver(P, q, A, b, cones, cl.Settings(device_id=local, **kw), kktsolver_factory=lambda *a: HipKKTSolver(*a, **optkw))
             sol_ = s_.solve()
             rates.append(round(sol_.iterations / s_.info.timers["IP iteration"], 4))
-            e2e_runs[tag] = {"status": sol_.status, "ipm_iterations": sol_.iterations, "iterations_per_s": max(rates), "iterations_per_s_runs": list(rates),
+            e2e_runs[tag] = {"status": sol_.status, "ipm_iterations": sol_.iterations, "iterations_per_s": float(np.median(rates)), "iterations_per_s_runs": list(rates),
                              "objective_rel_diff_vs_recording_run": float(abs(sol_.obj_val - sol.obj_val) / max(1.0, abs(sol.obj_val)))}
             del s_
-    e2e_iters = e2e_runs["n2_n4_hooks"]["ipm_iterations"]
-    e2e_rate = e2e_runs["n2_n4_hooks"]["iterations_per_s"]
+    e2e_iters = e2e_runs["n2_hook"]["ipm_iterations"]
+    e2e_rate = e2e_runs["n2_hook"]["iterations_per_s"]
     tm = h.timing()
     # keep iterations that carry the regular 3 solves (the initial factorisation has 2 or 3)
     units = [t for t in trace if len(t["rhs"]) == 3]
@@ -500,24 +521,57 @@ def main():
                        note="fabric-side bytes (L2 misses; Infinity-Cache hits are counted): FETCH_SIZE x2 (calibrated on this access shape, "
                             "profiles/r03_a_traffic_calibration.txt) + WRITE_SIZE per launch")
     cm_f = cm["flops_factor"]
-    roofline = dict(bound="mfma", achieved=round(achieved, 3), peak=F64_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
-                    frac=round(achieved / F64_MFMA_PEAK_TFLOPS, 4), traffic=traffic, traffic_unavailable=why,
-                    mfma_busy_pct=None if ctr is None else ctr.get("mfma_busy_pct"),
-                    whole_factorisation=dict(note="SURVEY section 8(d)'s figure: F_factor / t_factor with F_factor = sum_j (c_j^2 + 3 c_j)",
-                                             flops=cm_f, ms=round(factor_ms, 4), achieved=round(cm_f / (factor_ms * 1e-3) / 1e12, 3),
-                                             frac=round(cm_f / (factor_ms * 1e-3) / 1e12 / F64_MFMA_PEAK_TFLOPS, 4)),
-                    frac_note=("achieved = algorithmic flops of the k_update_dense<4,4> / k_update_dense_tail launches / their HIP-event time.  Since round 3 "
-                               "the far tiles that would form a stage's partial last rounds ride in the next k_front_block launch instead "
-                               "(critical_path_kernel.extra_update_*): the stage launches that remain are whole rounds plus the sparse-tree launch, so this "
-                               "fraction describes fewer, smaller launches than `all_tiles_in_own_launches` (the same refactorisation with that mechanism off)"),
-                    all_tiles_in_own_launches=(None if not (p4n["dense4_launches"] > 0 and p4n["dense4_ms"] > 0) else dict(
-                        achieved=round(p4n["dense4_flops"] / (p4n["dense4_ms"] * 1e-3) / 1e12, 3),
-                        frac=round(p4n["dense4_flops"] / (p4n["dense4_ms"] * 1e-3) / 1e12 / F64_MFMA_PEAK_TFLOPS, 4),
-                        launches_per_refactor=p4n["dense4_launches"], ms_per_refactor=round(p4n["dense4_ms"], 4),
-                        front_block_ms_per_refactor=round(p4n["front_block_ms"], 4))),
-                    kernel=kern, **per_launch,
-                    all_update_kernels=dict(achieved=round(agg, 3), ms_per_refactor=round(upd, 4),
-                                            flops_per_refactor=flops_upd_kernels),
+    whole = cm_f / (factor_ms * 1e-3) / 1e12
+    # per-kernel table underneath the headline: the dense-update family (throughput-bound), the front-batch kernel (latency-bound; its
+    # matrix-core flops -- in-batch updates + the far tiles riding in its launches -- from the counter file), all update kernels
+    fbk = None
+    if p4.get("front_block_launches", 0) > 0:
+        cfb = (ctr or {}).get("front_block") or {}
+        hwf = cfb.get("hw_flops_per_refactor")
+        fbk = dict(kernel="k_front_block", bound="dependency latency (pivot chain of the front's diagonal tiles)",
+                   ms_per_refactor=round(p4["front_block_ms"], 4), launches_per_refactor=p4["front_block_launches"],
+                   share_of_factor_time=round(p4["front_block_ms"] / factor_ms, 3) if factor_ms > 0 else None,
+                   hw_flops_per_refactor=hwf, achieved=None if not hwf else round(hwf / (p4["front_block_ms"] * 1e-3) / 1e12, 3),
+                   frac=None if not hwf else round(hwf / (p4["front_block_ms"] * 1e-3) / 1e12 / F64_MFMA_PEAK_TFLOPS, 4),
+                   mfma_busy_pct=cfb.get("mfma_busy_pct"),
+                   flops_note="SQ_INSTS_VALU_MFMA_MOPS_F64 x 512 per refactorisation (counter file; null when it is stale): executed matrix-core flops of the "
+                              "panel batches and of the dense update tiles that ride in these launches as extra workgroups")
+    dense_k = dict(kernel=kern, bound="mfma", achieved=round(achieved, 3), frac=round(achieved / F64_MFMA_PEAK_TFLOPS, 4),
+                   mfma_busy_pct=None if ctr is None else ctr.get("mfma_busy_pct"), traffic=traffic, traffic_unavailable=why,
+                   share_of_factor_time=round(p4["dense4_ms"] / factor_ms, 3) if factor_ms > 0 and p4["dense4_ms"] > 0 else None,
+                   note=("algorithmic flops of the k_update_dense<4,4> / k_update_dense_tail launches / their HIP-event time.  The far tiles that would form a "
+                         "stage's partial last rounds ride in the next k_front_block launch instead (critical_path_kernel.extra_update_*): the launches "
+                         "that remain are whole rounds plus the sparse-tree launch; `all_tiles_in_own_launches` = the same refactorisation with that off"),
+                   all_tiles_in_own_launches=(None if not (p4n["dense4_launches"] > 0 and p4n["dense4_ms"] > 0) else dict(
+                       achieved=round(p4n["dense4_flops"] / (p4n["dense4_ms"] * 1e-3) / 1e12, 3),
+                       frac=round(p4n["dense4_flops"] / (p4n["dense4_ms"] * 1e-3) / 1e12 / F64_MFMA_PEAK_TFLOPS, 4),
+                       launches_per_refactor=p4n["dense4_launches"], ms_per_refactor=round(p4n["dense4_ms"], 4),
+                       front_block_ms_per_refactor=round(p4n["front_block_ms"], 4))),
+                   **per_launch)
+    # the solves: HBM-bound by their algorithmic bytes (B_solve = 2 (8 + 4) nnz(L) + 40 N per LDL solve, + B_spmv per
+    # refinement SpMV), in fact bound by the hand-off chain of the sweeps -- the fraction says how far
+    n_ldl = tm["n_ldl_solves"]
+    solve_bytes = n_ldl * (cm["bytes_solve"] + cm["bytes_spmv"])       # every LDL solve of a refined solve is followed by one residual SpMV
+    solve_s = tm["acc_solve_ms"] * 1e-3
+    hbm_solve = dict(bound="hbm", kernel="LDL solves + refinement SpMVs (k_front_fwd_sb / k_front_bwd_sb, k_fwd_seg / k_bwd_seg, k_spmv_residual, ...)",
+                     achieved=round(solve_bytes / solve_s / 1e9, 1) if solve_s > 0 else None, peak=8000.0, unit="GB/s",
+                     frac=round(solve_bytes / solve_s / 1e9 / 8000.0, 4) if solve_s > 0 else None,
+                     frac_of_measured_peak_6300=round(solve_bytes / solve_s / 1e9 / 6300.0, 4) if solve_s > 0 else None,
+                     ldl_solves=n_ldl, bytes_per_ldl_solve=cm["bytes_solve"], bytes_per_spmv=cm["bytes_spmv"], device_ms=round(tm["acc_solve_ms"], 3),
+                     note="algorithmic bytes of the timed steps' solves / their HIP-event time (two concurrent solves of a pair are charged their common "
+                          "span); the sweeps are latency-bound: ~22 hand-offs per front sweep, DESIGN.md section 5")
+    roofline = dict(bound="mfma", achieved=round(whole, 3), peak=F64_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
+                    frac=round(whole / F64_MFMA_PEAK_TFLOPS, 4),
+                    kernel="numeric LDL^T factorisation, all kernels (k_front_block, k_update_dense<4,4>, k_update_dense<1,2>, k_update_gather, k_factor_panel, ...)",
+                    what="SURVEY section 8(d): F_factor / t_factor with F_factor = sum_j (c_j^2 + 3 c_j) from the symbolic factor in use and t_factor = the "
+                         "mean HIP-event time of hipkkt_refactor over the timed steps",
+                    flops=cm_f, ms=round(factor_ms, 4),
+                    traffic=None if traffic is None else traffic["bytes_per_launch"], traffic_of="kernels.dense_update (per launch of the dominant throughput kernel)",
+                    traffic_unavailable=why,
+                    kernels=dict(dense_update=dense_k, front_block=fbk,
+                                 all_update_kernels=dict(achieved=round(agg, 3), frac=round(agg / F64_MFMA_PEAK_TFLOPS, 4), ms_per_refactor=round(upd, 4),
+                                                         flops_per_refactor=flops_upd_kernels)),
+                    solves=hbm_solve,
                     peak_source="MI355X datasheet FP64 matrix; tools/ubench.hip measures 72-77 TFLOP/s on the box")
 
     result = {
@@ -533,14 +587,16 @@ def main():
         "ipm_iterations_per_s_end_to_end": e2e_rate,
         "value_is": "replayed KKT iteration units per second with every input resident in HBM (tier rule for `value`); "
                     "`ipm_iterations_per_s_end_to_end` is SURVEY section 8(d)'s rate: iterations / wall time of the whole IPM loop "
-                    "incl. the host cone algebra (numpy stand-in of the Julia caller) and the PCIe transfers, with the N2 + N4 hooks on (end_to_end.runs)",
+                    "incl. the host cone algebra and the PCIe transfers -- of the numpy stand-in of the Julia caller (no Julia has run), with the N2 hook "
+                    "of julia/clarabel_l1_seam.patch on; median of three runs (end_to_end.runs)",
         "kkt_factor_ms": round(factor_ms, 4), "kkt_solve_ms_per_call": round(solve_ms, 4),
         "kkt_solve_calls_per_step": round(tm["n_solve_calls"] / max(1, args.steps), 2),
         "kkt_factor_plus_solves_ms": round(factor_ms + solve_ms * tm["n_solve_calls"] / max(1, args.steps), 4),
         "ldl_solves_per_step": round(ldl_per_unit, 2),
-        "end_to_end": {"ipm_iterations": e2e_iters, "status": e2e_runs["n2_n4_hooks"]["status"], "iterations_per_s": e2e_rate,
-                       "note": "full IPM loop of the numpy stand-in of the Julia caller incl. its host cone algebra and PCIe; headline = with the "
-                               "N2 (reduced-system algebra) + N4 (residuals) hooks on, `runs` holds it next to the L1-contract-only run",
+        "end_to_end": {"ipm_iterations": e2e_iters, "status": e2e_runs["n2_hook"]["status"], "iterations_per_s": e2e_rate,
+                       "caller": "julia_standin/ipm.py (numpy stand-in of the untouched Julia IPM loop); no Julia has run",
+                       "note": "headline = median of three runs with the N2 hook (reduced-system algebra by the plugin: wired by julia/clarabel_l1_seam.patch); "
+                               "`runs` holds it next to the L1-contract-only run and the N2 + N4 run (N4 is NOT wired on the Julia side)",
                        "runs": e2e_runs,
                        "recording_run": {"ipm_iterations": rec_iters, "iterations_per_s": round(rec_iters / rec_time, 4), "status": sol.status,
                                          "note": "the run the replayed trace was recorded from (copies every Hs / rhs on the host)"},
@@ -605,7 +661,8 @@ def main():
                 h.set_soc_batch(t["eta2"], t["u"], t["v"])
             okg, eps_g, nreg_g = h.refactor(st.static_regularization_enable, st.static_regularization_constant,
                                             st.static_regularization_proportional)
-            par["nreg_equal"] = par["nreg_equal"] and (nreg_g == L.oracle_kkt_nreg(cpu.k.h) or h.counters()["in_twin"])
+            par["nreg_equal"] = par["nreg_equal"] and nreg_g == L.oracle_kkt_nreg(cpu.k.h)
+            par["units_in_twin"] = par.get("units_in_twin", 0) + int(h.counters()["in_twin"])
             par["eps_equal"] = par["eps_equal"] and abs(eps_g - eps.value) <= 1e-16 * max(1.0, eps.value)
             for r, rd, xc, sc in zip(t["rhs"], t["rhs_d"], xs_c, steps_c):
                 h.setrhs_dev(rd.data_ptr())

@@ -190,7 +190,8 @@ int32_t hipkkt_get_kkt(hipkkt_handle h, int64_t *colptr, int64_t *rowval, double
 
 int32_t hipkkt_get_perm(hipkkt_handle h, int64_t *perm) {
     if (!h || !perm) return HIPKKT_ERR_ARGUMENT;
-    for (int k = 0; k < h->N; k++) perm[k] = h->plan.perm[k] + h->opts.index_base;
+    const hipkkt_solver *T = (h->using_fallback && h->fallback) ? h->fallback : h;   // the order of the factorisation in use
+    for (int k = 0; k < h->N; k++) perm[k] = T->plan.perm[k] + h->opts.index_base;
     return HIPKKT_OK;
 }
 

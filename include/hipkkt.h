@@ -122,7 +122,9 @@ int32_t hipkkt_get_cost_model(hipkkt_handle h, double *out8);
 
 /* copies of host-side structures (tests, Julia-side bookkeeping).  Any pointer may be NULL. */
 int32_t hipkkt_get_kkt(hipkkt_handle h, int64_t *colptr, int64_t *rowval, double *nzval);
-int32_t hipkkt_get_perm(hipkkt_handle h, int64_t *perm);     /* perm[k] = index eliminated k-th */
+/* perm[k] = index eliminated k-th, of the factorisation IN USE: while the last factorisation lives in the robust-order twin
+ * (hipkkt_get_counters out[4]) that is the twin's minimum-degree order, otherwise the handle's own */
+int32_t hipkkt_get_perm(hipkkt_handle h, int64_t *perm);
 int32_t hipkkt_get_dsigns(hipkkt_handle h, int64_t *dsigns);
 /* which: 0 = map.P, 1 = map.A, 2 = map.Hsblocks, 3 = map.diagP, 4 = map.diag_full
  * (ref: LDLDataMap fields, directldl_datamaps.jl:170-181) */

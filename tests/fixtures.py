@@ -131,6 +131,30 @@ def scale_cones(cones, rng):
     return s, z
 
 
+def scale_cones_late(cones, rng, mu=1e-9, span=6.0):
+    """a late-IPM-like iterate: s and z nearly complementary (s o z ~ mu e) with eigenvalues / entries spread over 10^span --
+    the kind of scaling on which an elimination order that takes the cone blocks first can break down"""
+    m = cones.numel
+    s, z = np.zeros(m), np.zeros(m)
+    for c, r in zip(cones.cones, cones.rng_cones):
+        if isinstance(c, cl.cones.PSDTriangleCone):
+            Q, _ = np.linalg.qr(rng.standard_normal((c.n, c.n)))
+            ls = 10.0 ** rng.uniform(-span, 0.0, c.n)
+            s[r] = c.mat_to_svec((Q * ls) @ Q.T)
+            z[r] = c.mat_to_svec((Q * (mu / ls)) @ Q.T)
+        elif isinstance(c, cl.cones.SecondOrderCone):
+            for v in (s, z):
+                t = rng.standard_normal(c.dim)
+                t[0] = np.linalg.norm(t[1:]) * (1.0 + 10.0 ** rng.uniform(-span, -1.0))
+                v[r] = t
+        else:
+            ls = 10.0 ** rng.uniform(-span, 0.0, c.numel)
+            s[r] = ls
+            z[r] = mu / ls
+    assert cones.update_scaling(s, z, mu)
+    return s, z
+
+
 class ShadowKKT:
     """Test infrastructure: the ORACLE drives an IPM run while the HIP solver is handed the very same inputs at every KKT call
     (same elimination order); per solve the two solutions and refinement-step counts are recorded in `log` as

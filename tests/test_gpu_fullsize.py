@@ -14,7 +14,7 @@ import clarabel_jl_amd  # noqa: F401  (registers the dotted package directory)
 import julia_standin as cl
 from clarabel_jl_amd import problems
 from clarabel_jl_amd.kktsolver import HipKKTSolver
-from tests.fixtures import scale_cones
+from tests.fixtures import scale_cones, scale_cones_late
 
 pytestmark = pytest.mark.gpu
 
@@ -121,6 +121,55 @@ def test_full_size_matches_oracle(name, oracle_factory):
         assert np.max(np.abs(lx_g - lx_c)) <= 1e-10 * scale and np.max(np.abs(lz_g - lz_c)) <= 1e-10 * scale
 
 
+@pytest.mark.parametrize("trigger", ["forced", "late-iterate"])
+def test_twin_factorisation_matches_oracle_in_the_robust_order(trigger, oracle_factory, monkeypatch):
+    """hipkkt_refactor's fallback: a factorisation that breaks down in the cheap "cone rows first" order is
+    repeated on a twin handle in the minimum-degree order on K.  At cfg 5's size the oracle cannot follow into that order (5e12 scalar
+    flops), so the twin is compared HERE, on the same problem family reduced to 8 x PSD(24), n = 300: the cheap order is chosen
+    (3.2e8 against 3.8e9 flops) and the oracle factors the twin's permutation in seconds.  Same assertions as
+    test_full_size_matches_oracle: resident K bit for bit, regulariser and dynamic-regularisation count equal, unrefined solve 1e-9,
+    refined solve 1e-10.  "forced": HIPKKT_FORCE_TWIN=1 declares the cheap order broken down on a benign iterate; "late-iterate": a
+    nearly complementary scaling spread over 12 decades, the kind of iterate on which it really does (skipped if it survives)."""
+    if trigger == "forced":
+        monkeypatch.setenv("HIPKKT_FORCE_TWIN", "1")
+    monkeypatch.setenv("HIPKKT_PLAN_CACHE", "0")
+    rng = np.random.default_rng(31)
+    Pt, A, cones = _prep(problems.sdp_blocks(n=300, ncones=8, dim=24, seed=5))
+    m, n = A.shape
+    st = cl.Settings()
+    hk = HipKKTSolver(Pt, A, cones, m, n, st)
+    assert hk.h.counters()["ordering"] == 1, "the cheap order was not chosen: the twin path is not exercised"
+    perm_cheap = hk.h.perm()
+    if trigger == "forced":
+        scale_cones(cones, rng)
+    else:
+        scale_cones_late(cones, rng, mu=1e-10, span=6.0)
+    ok = hk.kktsolver_update(cones)
+    c = hk.h.counters()
+    if trigger != "forced" and not c["in_twin"]:
+        pytest.skip(f"this iterate did not break the cheap order down (factorisation ok = {ok})")
+    assert ok and c["in_twin"] and c["twin_exists"] and c["twin_refactors"] >= 1
+    perm_twin = hk.h.perm()                       # the order of the factorisation in use: the twin's
+    assert sorted(perm_twin) == list(range(len(perm_twin))) and not np.array_equal(perm_twin, perm_cheap)
+    ok_ = oracle_factory(Pt, A, cones, m, n, st, ordering=perm_twin)
+    assert ok_.kktsolver_update(cones)
+    o = ok_.k
+    assert np.array_equal(hk.h.kkt()[2], o.nzval)
+    assert abs(hk.diagonal_regularizer - ok_.diagonal_regularizer) <= 1e-16 * max(1.0, ok_.diagonal_regularizer)
+    assert hk.last_nreg == o.L.oracle_kkt_nreg(o.h)
+    b = rng.standard_normal(o.N)
+    xg, xc = hk.h.ldl_solve(b), o.ldl_solve(b)
+    assert np.max(np.abs(xg - xc)) <= 1e-9 * max(1.0, np.max(np.abs(xc)))
+    for rep in range(2):
+        rx, rz = rng.standard_normal(n), rng.standard_normal(m)
+        lx_g, lz_g, lx_c, lz_c = np.zeros(n), np.zeros(m), np.zeros(n), np.zeros(m)
+        hk.kktsolver_setrhs(rx, rz)
+        ok_.kktsolver_setrhs(rx, rz)
+        assert hk.kktsolver_solve(lx_g, lz_g) and ok_.kktsolver_solve(lx_c, lz_c)
+        scale = max(1.0, np.max(np.abs(lx_c)), np.max(np.abs(lz_c)))
+        assert np.max(np.abs(lx_g - lx_c)) <= 1e-10 * scale and np.max(np.abs(lz_g - lz_c)) <= 1e-10 * scale
+
+
 @pytest.mark.parametrize("name", ["cfg2a", "cfg3", "cfg5"])
 def test_full_size_ipm_end_to_end(name):
     P, q, A, b, cones = FULL[name]()
@@ -128,6 +177,66 @@ def test_full_size_ipm_end_to_end(name):
     assert sol.status == "SOLVED"
     assert abs(sol.obj_val - sol.obj_val_dual) <= 1e-6 * max(1.0, abs(sol.obj_val))
     assert sol.r_prim < 1e-8 and sol.r_dual < 1e-8
+
+
+def _traces_agree(tg, tc, upto, tol=1e-10):
+    """per-iteration records of two IPM runs (julia_standin/ipm.py Solver.trace) up to iteration `upto`: objective relative,
+    residuals absolute (info.jl:50-51), step length and centring parameter"""
+    worst = {}
+    for it in range(upto + 1):
+        a, b = _trace_at(tg, it), _trace_at(tc, it)
+        assert a is not None and b is not None, it
+        for key, rel in (("cost_primal", True), ("cost_dual", True), ("res_primal", False), ("res_dual", False)):
+            d = abs(a[key] - b[key]) / (max(1.0, abs(b[key])) if rel else 1.0)
+            worst[key] = max(worst.get(key, 0.0), d)
+            assert d <= tol, (it, key, a[key], b[key])
+    return worst
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("name,max_iter", [("cfg3", None), ("cfg2a", 5), ("cfg5", None)])
+def test_full_size_ipm_matches_oracle(name, max_iter, oracle_factory, capsys):
+    """The whole IPM at FULL size against the oracle on the same elimination order, iterate by iterate: objective (relative) and
+    residuals (absolute, info.jl:50-51) to 1e-10 at EVERY iteration, status and iteration count equal.  Oracle cost on one host core:
+    cfg 3 ~5.4 s per iteration (~80 s), cfg 2a ~25 s per iteration (the first 5 iterations: max_iter = 5 on both sides), cfg 5
+    ~18 s per iteration.  cfg 5's last iteration breaks down in the cheap order ON BOTH PATHS: the HIP path repeats it on its
+    robust-order twin and ends SOLVED; the oracle, held to the cheap order (it cannot follow into the twin's at this size: that is
+    test_twin_factorisation_matches_oracle_in_the_robust_order's job on the reduced config), must report the factorisation failure
+    at exactly that iteration, and every iteration before it agrees to 1e-10."""
+    P, q, A, b, cones = FULL[name]()
+    stg = cl.Settings() if max_iter is None else cl.Settings(max_iter=max_iter)
+    sg = cl.Solver(P, q, A, b, cones, stg)
+    sg.trace = []
+    solg = sg.solve()
+    hg = sg.kktsystem.kktsolver.h
+    twin_its = hg.counters()["twin_refactors"]
+    # the cheap order's permutation (the handle reports the twin's while the last factorisation lives there)
+    perm = hg.perm() if not hg.counters()["in_twin"] else None
+    if perm is None:
+        import os
+        os.environ["HIPKKT_PLAN_CACHE"] = "0"
+        Pt, At, cn = _prep((P, q, A, b, cones))
+        perm = HipKKTSolver(Pt, At, cn, At.shape[0], At.shape[1], cl.Settings()).h.perm()
+    stc = cl.Settings() if max_iter is None else cl.Settings(max_iter=max_iter)
+    sc = cl.Solver(P, q, A, b, cones, stc, kktsolver_factory=lambda *a: oracle_factory(*a, ordering=perm))
+    sc.trace = []
+    solc = sc.solve()
+    with capsys.disabled():
+        print(f"\n[full-size-ipm {name}] hip {solg.status} in {solg.iterations} iterations (factorisations repeated on the twin: {twin_its}); "
+              f"oracle {solc.status} in {solc.iterations}")
+    if twin_its == 0:
+        assert solg.status == solc.status and solg.iterations == solc.iterations
+        worst = _traces_agree(sg.trace, sc.trace, solc.iterations if max_iter is None else min(max_iter, solc.iterations))
+        assert abs(solg.obj_val - solc.obj_val) <= 1e-10 * max(1.0, abs(solc.obj_val))
+        assert abs(solg.r_prim - solc.r_prim) <= 1e-10 and abs(solg.r_dual - solc.r_dual) <= 1e-10
+    else:
+        # the oracle stops where the cheap order breaks down; the HIP path went on from there on its twin
+        assert solg.status == "SOLVED" and solc.status == "NUMERICAL_ERROR"
+        last_common = len(sc.trace) - 1
+        assert last_common >= 5 and solg.iterations >= last_common
+        worst = _traces_agree(sg.trace, sc.trace, last_common)
+    with capsys.disabled():
+        print(f"[full-size-ipm {name}] worst differences over the compared iterations: " + ", ".join(f"{k} {v:.2e}" for k, v in worst.items()))
 
 
 BATCH_SAMPLE = (100, 113, 126, 137, 150, 168, 187, 201, 222, 240, 255, 271, 300, 318, 339, 355)   # 126 ends ALMOST_SOLVED on both paths

@@ -28,10 +28,10 @@ def per_dispatch(path):
     return out
 
 
-def family(d, counter):
+def family(d, counter, fam=FAMILY):
     rows = []
     for kn, v in d.get(counter, {}).items():
-        if any(f in kn for f in FAMILY):
+        if any(f in kn for f in fam):
             rows += v
     return rows
 
@@ -53,6 +53,19 @@ def main(cfg, out, fetch_db, write_db, sq_db, grbm_db):
              hw_flops_per_launch=round(mops * 512.0 / max(1, nS)) if mops else None,
              hw_flops_note="SQ_INSTS_VALU_MFMA_MOPS_F64 x 512: what the matrix cores executed, padding of ragged tiles and K remainders included",
              sources=[os.path.basename(os.path.dirname(p)) for p in (fetch_db, write_db, sq_db, grbm_db)])
+    # the other big block of a refactorisation: the front-batch kernel (its own in-batch updates AND the far tiles riding in it as
+    # extra workgroups) -- matrix-core flops per refactorisation from the counters (one k_init_panels dispatch per refactorisation)
+    FB = ("k_front_block",)
+    nref = max(1, len(family(S, "SQ_INSTS_VALU_MFMA_MOPS_F64", ("k_init_panels",))))
+    fb_mops = sum(r[0] for r in family(S, "SQ_INSTS_VALU_MFMA_MOPS_F64", FB))
+    fb_busy = sum(r[0] for r in family(S, "SQ_VALU_MFMA_BUSY_CYCLES", FB))
+    fb_active = sum(r[1] for r in family(G, "GRBM_GUI_ACTIVE", FB))
+    nfS, nfG = len(family(S, "SQ_VALU_MFMA_BUSY_CYCLES", FB)), len(family(G, "GRBM_GUI_ACTIVE", FB))
+    d["front_block"] = dict(launches_in_trace=nfS, refactorisations_in_trace=nref,
+                            hw_flops_per_refactor=round(fb_mops * 512.0 / nref) if fb_mops else None,
+                            mfma_busy_pct=round(100.0 * (fb_busy / max(1, nfS)) / ((fb_active / max(1, nfG)) * 1024.0), 2) if fb_active else None)
+    all_mops = sum(r[0] for kn, v in S.get("SQ_INSTS_VALU_MFMA_MOPS_F64", {}).items() for r in v)
+    d["hw_flops_per_refactor_all_kernels"] = round(all_mops * 512.0 / nref) if all_mops else None
     with open(out, "w") as f:
         json.dump(d, f, indent=1)
     print(json.dumps(d))
