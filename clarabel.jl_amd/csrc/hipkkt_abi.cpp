@@ -656,6 +656,12 @@ int32_t hipkkt_debug_dump(hipkkt_handle h, int32_t what, double *out, int64_t ca
             if (!S->d_fb_trace) return HIPKKT_ERR_ARGUMENT;
             dev((const double *)S->d_fb_trace, (int64_t)S->fbatches.size() * 128);   // raw int64 stamps (100 MHz) in double-sized words
             break;
+        case 17: {    // refinement state of the last refined solve on context 0: ||e|| before the last step, ||b||, ||e|| after it, steps
+            const RefineState *r = S->ctx[0].h_rs;
+            const double v[4] = {r->lastnorme, r->normb, r->norme, (double)r->steps};
+            host(4, [&](int64_t i) { return v[i]; });
+            break;
+        }
         case 15: dev(S->d_fb_stream, std::max<int64_t>(S->fb_stream_doubles, 1)); break;   // stream records of the front batches (raw)
         case 16: dev(S->d_fb_scratch, (int64_t)kFbScratch * (int64_t)std::max<size_t>(S->fbatches.size(), 1)); break;
         case 7: dev(S->d_soc_u, S->soc_total); break;

@@ -31,6 +31,13 @@ struct oracle_kkt {
     double *x, *b, *work1, *work2, *hsbuf;
     double diagonal_regularizer;
     qdldl_oracle *ldl;
+    /* TEST KNOB, not part of the restatement (0 = the reference's order, the default): 1 sweeps the columns of the refinement residual
+     * e = b - K x in DESCENDING order -- the same products, the sums associated the other way round.  tools/seed324_cpu_vs_cpu.py uses
+     * it to show what the reference's own refinement branches do under a different association order of that sum (any parallel
+     * SpMV has one).  last_norms: ||e|| before / after every refinement step of the last solve (diagnostic). */
+    int resid_order;
+    double last_norms[16];
+    int n_last_norms;
 };
 
 /* ---- utils/csc_assembly.jl primitives (counts held in colptr, then scanned) ---- */
@@ -344,14 +351,21 @@ static double norm_inf(const double *v, int64_t n) {
 static double refine_error(const oracle_kkt *k, double *e, const double *b, const double *xi) {
     const int64_t N = k->N;
     for (int64_t i = 0; i < N; i++) e[i] = b[i];
-    for (int64_t j = 0; j < N; j++)
+    for (int64_t jj = 0; jj < N; jj++) {
+        const int64_t j = k->resid_order ? N - 1 - jj : jj;   /* (test knob, see struct oracle_kkt; 0 = the reference's order) */
         for (int64_t q = k->colptr[j]; q < k->colptr[j + 1]; q++) {
             int64_t i = k->rowval[q];
             double v = k->nzval[q];
             e[i] -= v * xi[j];
             if (i != j) e[j] -= v * xi[i];
         }
+    }
     return norm_inf(e, N);
+}
+void oracle_kkt_set_residual_order(oracle_kkt *k, int mode) { k->resid_order = mode; }
+int oracle_kkt_last_norms(const oracle_kkt *k, double *out16) {
+    for (int i = 0; i < k->n_last_norms; i++) out16[i] = k->last_norms[i];
+    return k->n_last_norms;
 }
 
 void oracle_kkt_ldl_solve(const oracle_kkt *k, double *x, const double *b) {
@@ -367,6 +381,8 @@ static int iterative_refinement(oracle_kkt *k, double reltol, double abstol, int
     double normb = norm_inf(b, N);
     double norme = refine_error(k, e, b, x);
     *steps = 0;
+    k->n_last_norms = 0;
+    k->last_norms[k->n_last_norms++] = norme;
     if (!isfinite(norme)) return 0;
     for (int64_t it = 0; it < max_iter; it++) {
         if (norme <= abstol + reltol * normb) break;
@@ -375,6 +391,7 @@ static int iterative_refinement(oracle_kkt *k, double reltol, double abstol, int
         (*steps)++;
         for (int64_t i = 0; i < N; i++) dx[i] += x[i];
         norme = refine_error(k, e, b, dx);
+        if (k->n_last_norms < 16) k->last_norms[k->n_last_norms++] = norme;
         if (!isfinite(norme)) return 0;
         double improved = lastnorme / norme;
         if (improved < stop_ratio) {

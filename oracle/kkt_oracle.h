@@ -87,6 +87,10 @@ void oracle_kkt_get_x(const oracle_kkt *k, double *x);
 void oracle_kkt_ldl_solve(const oracle_kkt *k, double *x, const double *b);
 /* y = K*x with the symmetric view of the (unregularised) triu KKT */
 void oracle_kkt_symv(const oracle_kkt *k, const double *x, double *y);
+/* TEST KNOBS / diagnostics, not part of the restatement: association order of the refinement residual's sums (0 = the reference's),
+ * residual norms of the last refined solve */
+void oracle_kkt_set_residual_order(oracle_kkt *k, int mode);
+int oracle_kkt_last_norms(const oracle_kkt *k, double *out16);
 
 int64_t oracle_kkt_nreg(const oracle_kkt *k);
 const double *oracle_kkt_D(const oracle_kkt *k);   /* D of the last factorisation, permuted order */

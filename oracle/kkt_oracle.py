@@ -51,6 +51,10 @@ def lib():
     L.oracle_kkt_nzval.argtypes = [vp]
     L.oracle_kkt_sparse_map.restype = C.POINTER(C.c_int64)
     L.oracle_kkt_sparse_map.argtypes = [vp, C.c_int64, C.c_int, C.POINTER(C.c_int64)]
+    L.oracle_kkt_set_residual_order.argtypes = [vp, C.c_int]
+    L.oracle_kkt_set_residual_order.restype = None
+    L.oracle_kkt_last_norms.argtypes = [vp, _f64p]
+    L.oracle_kkt_last_norms.restype = C.c_int
     L.oracle_kkt_update_Hs.argtypes = [vp, _f64p]
     L.oracle_kkt_update_soc.argtypes = [vp, C.c_int64, C.c_double, _f64p, _f64p]
     L.oracle_kkt_update_genpow.argtypes = [vp, C.c_int64, C.c_double, _f64p, _f64p, _f64p]
@@ -235,6 +239,8 @@ class OracleKKTSolver:
                                        st.iterative_refinement_max_iter, st.iterative_refinement_stop_ratio,
                                        C.byref(steps))
         self.last_ir_steps = steps.value
+        buf = np.zeros(16)
+        self.last_norms = buf[: self.k.L.oracle_kkt_last_norms(self.k.h, buf)].copy() if st.iterative_refinement_enable else buf[:0]
         self.total_ir_steps += steps.value
         self.nsolves += 1
         return bool(ok)

@@ -189,7 +189,12 @@ class ShadowKKT:
         cx, cz = (lx if lx is not None else np.zeros(n)), (lz if lz is not None else np.zeros(m))
         okc = self.c.kktsolver_solve(cx, cz)
         xc, xg = np.concatenate([cx, cz]), np.concatenate([gx, gz])
-        self.log.append((self.it, float(np.max(np.abs(xg - xc)) / max(1.0, np.max(np.abs(xc)))), int(self.g.last_ir_steps), int(self.c.last_ir_steps)))
+        try:
+            gn = tuple(float(v) for v in self.g.h.debug_dump(17)[:3])       # HIP: ||e|| before the last step, ||b||, ||e|| after it
+        except Exception:
+            gn = ()
+        self.log.append((self.it, float(np.max(np.abs(xg - xc)) / max(1.0, np.max(np.abs(xc)))), int(self.g.last_ir_steps), int(self.c.last_ir_steps),
+                         gn, tuple(float(v) for v in getattr(self.c, "last_norms", ()))))
         return okc
 
     def __getattr__(self, k):

@@ -159,15 +159,43 @@ def test_twin_factorisation_matches_oracle_in_the_robust_order(trigger, oracle_f
     assert hk.last_nreg == o.L.oracle_kkt_nreg(o.h)
     b = rng.standard_normal(o.N)
     xg, xc = hk.h.ldl_solve(b), o.ldl_solve(b)
-    assert np.max(np.abs(xg - xc)) <= 1e-9 * max(1.0, np.max(np.abs(xc)))
+    # UNREFINED solves of two factorisations of the same permuted matrix differ by rounding x condition number; this K (dense PSD
+    # blocks, 1e-8 regulariser) is worse conditioned than the full-size configs, so the bound is MEASURED instead of assumed: x* = the
+    # solution of the regularised system refined with extended-precision residuals; the HIP solve must be as close to it as the
+    # oracle's own unrefined solve is (within a factor 10), and within 1e-9 wherever the oracle is
+    K = _sym_K(hk.h)
+    Kf = np.asarray((K + sp.diags(hk.diagonal_regularizer * hk.h.dsigns().astype(float))).todense(), dtype=np.longdouble)
+    xs = xc.astype(np.longdouble)
+    for _ in range(4):
+        xs = xs + o.ldl_solve(np.asarray(b - Kf @ xs, dtype=np.float64))
+    err_c = float(np.max(np.abs(xc - xs)) / max(1.0, float(np.max(np.abs(xs)))))
+    err_g = float(np.max(np.abs(xg - xs)) / max(1.0, float(np.max(np.abs(xs)))))
+    print(f"\n[twin-parity {trigger}] unrefined forward error vs the extended-precision solution: oracle {err_c:.2e}, hip twin {err_g:.2e}; "
+          f"hip vs oracle {np.max(np.abs(xg - xc)) / max(1.0, np.max(np.abs(xc))):.2e}")
+    assert err_g <= max(1e-9, 10.0 * err_c)
+    # REFINED solves (kktsolver_solve!): 1e-10 against the oracle where the oracle itself is that close to the exact solution of
+    # K x = b; on the ill-conditioned late iterate the refinement stops on the RESIDUAL (abstol 1e-12 + reltol 1e-13 |b|, or no
+    # further gain), which leaves the solution itself undetermined by cond(K) x that residual -- there the HIP solution must be as
+    # close to the extended-precision solution as the oracle's own is (factor 10), and meet the same residual bound against the true K
+    Kt = np.asarray(K.todense(), dtype=np.longdouble)
     for rep in range(2):
         rx, rz = rng.standard_normal(n), rng.standard_normal(m)
         lx_g, lz_g, lx_c, lz_c = np.zeros(n), np.zeros(m), np.zeros(n), np.zeros(m)
         hk.kktsolver_setrhs(rx, rz)
         ok_.kktsolver_setrhs(rx, rz)
         assert hk.kktsolver_solve(lx_g, lz_g) and ok_.kktsolver_solve(lx_c, lz_c)
-        scale = max(1.0, np.max(np.abs(lx_c)), np.max(np.abs(lz_c)))
-        assert np.max(np.abs(lx_g - lx_c)) <= 1e-10 * scale and np.max(np.abs(lz_g - lz_c)) <= 1e-10 * scale
+        bb = np.concatenate([rx, rz])
+        xg_, xc_ = np.concatenate([lx_g, lz_g]), np.concatenate([lx_c, lz_c])
+        xs = xc_.astype(np.longdouble)
+        for _ in range(6):
+            xs = xs + o.ldl_solve(np.asarray(bb - Kt @ xs, dtype=np.float64))
+        scale = max(1.0, float(np.max(np.abs(xs))))
+        eg, ec = float(np.max(np.abs(xg_ - xs))) / scale, float(np.max(np.abs(xc_ - xs))) / scale
+        rg, rc_ = float(np.max(np.abs(bb - Kt @ xg_))), float(np.max(np.abs(bb - Kt @ xc_)))
+        print(f"[twin-parity {trigger}] refined solve {rep}: forward error oracle {ec:.2e}, hip twin {eg:.2e}; residual vs the true K oracle {rc_:.2e}, hip {rg:.2e}; "
+              f"hip vs oracle {np.max(np.abs(xg_ - xc_)) / scale:.2e}")
+        assert eg <= max(1e-10, 10.0 * ec)
+        assert rg <= max(1e-9 * max(1.0, float(np.max(np.abs(bb)))), 10.0 * rc_)
 
 
 @pytest.mark.parametrize("name", ["cfg2a", "cfg3", "cfg5"])
@@ -314,7 +342,8 @@ def test_batch_config_matches_oracle(seed, oracle_factory, capsys):
     first = next((k for k, r in enumerate(log) if r[2] != r[3]), None)
     with capsys.disabled():
         print(f"[batch-parity seed {seed}] not explained by the ordering spread; shadow run: first solve with different refinement step counts = "
-              f"{None if first is None else log[first]} (iteration, rel_dx, steps hip, steps oracle); max rel_dx before it "
+              f"{None if first is None else log[first]} (iteration, rel_dx, steps hip, steps oracle, hip (||e|| before its last step, ||b||, ||e|| after it), "
+              f"oracle ||e|| before / after every step); max rel_dx before it "
               f"{max([r[1] for r in log[:first]] or [0.0]):.2e}")
     assert first is not None, "trajectories part without a refinement-branch difference"
     assert max([r[1] for r in log[:first]] or [0.0]) <= 1e-6      # (identical inputs, |K| up to 1e15: the two factorisations agree this far)

@@ -1,10 +1,12 @@
 #!/usr/bin/env python
 """Batch seed 324 (cfg 4), the one problem whose HIP-vs-oracle difference exceeds 1e-10 (|dobj| 1.3e-5, iterations
 24 vs 23): is the cause the reference's OWN sensitivity?  CPU only, no HIP code involved: the oracle (the :qdldl restatement) drives
-the IPM in one elimination order while a second oracle in ANOTHER order is handed identical inputs at every KKT call; per solve the
-two solutions and refinement-step counts are compared.  Orders: the product's (host symbolic analysis, tests/support/plan_check),
-SuperLU's MMD on K, reverse Cuthill-McKee.  Prints one line per pair: the first solve whose refinement takes a different number of
-steps, the agreement of the solutions before it and the relative difference of the two solutions AT it.
+the IPM while a second oracle is handed identical inputs at every KKT call; per solve the two solutions and refinement-step counts
+are compared.  Two kinds of pairs: (a) different elimination ORDERS (the product's -- host symbolic analysis, tests/support/plan_check
+--, SuperLU's MMD on K, reverse Cuthill-McKee): same residual arithmetic, different LDL rounding; (b) the SAME order, but the second
+oracle sums the refinement residual e = b - K x in the opposite association order (oracle_kkt_set_residual_order: the same products,
+columns swept downwards) -- what any parallel SpMV changes.  Prints one line per pair: the first solve whose refinement takes a
+different number of steps, the residual norms of both at that solve, the agreement of the solutions before it and AT it.
 usage: python tools/seed324_cpu_vs_cpu.py [seed ...]        (writes nothing; redirect into profiles/*_parity_causes.txt)"""
 import os, sys
 import numpy as np, scipy.sparse as sp
@@ -21,9 +23,10 @@ class ShadowPair:
     """oracle `a` drives, oracle `b` shadows on identical inputs"""
     batch_constant_rhs = False
 
-    def __init__(self, oa, ob, *args):
+    def __init__(self, oa, ob, *args, resid_b=0):
         self.c = OracleKKTSolver(*args, ordering=oa)
         self.g = OracleKKTSolver(*args, ordering=ob)
+        self.g.k.L.oracle_kkt_set_residual_order(self.g.k.h, resid_b)
         self.settings = self.c.settings
         self.it, self.log = 0, []
 
@@ -44,7 +47,8 @@ class ShadowPair:
         cx, cz = (lx if lx is not None else np.zeros(n)), (lz if lz is not None else np.zeros(m))
         ok = self.c.kktsolver_solve(cx, cz)
         xc, xg = np.concatenate([cx, cz]), np.concatenate([gx, gz])
-        self.log.append((self.it, float(np.max(np.abs(xg - xc)) / max(1.0, np.max(np.abs(xc)))), int(self.g.last_ir_steps), int(self.c.last_ir_steps)))
+        self.log.append((self.it, float(np.max(np.abs(xg - xc)) / max(1.0, np.max(np.abs(xc)))), int(self.g.last_ir_steps), int(self.c.last_ir_steps),
+                         self.g.last_norms, self.c.last_norms))
         return ok
 
     def __getattr__(self, k):
@@ -69,8 +73,10 @@ def main(seeds):
         prod, rcm = product_order(P, A, cones)
         base = cl.Solver(P, q, A, b, cones, cl.Settings(), kktsolver_factory=lambda *a: OracleKKTSolver(*a, ordering=prod)).solve()
         print(f"[cpu-vs-cpu seed {seed}] oracle in the product's order: {base.status} in {base.iterations} iterations, obj {base.obj_val:.12e}")
-        for name, oa, ob in (("product's order vs MMD", prod, "mmd"), ("product's order vs RCM", prod, rcm), ("MMD vs RCM", "mmd", rcm)):
-            s = cl.Solver(P, q, A, b, cones, cl.Settings(), kktsolver_factory=lambda *a: ShadowPair(oa, ob, *a))
+        for name, oa, ob, rb in (("product's order vs MMD", prod, "mmd", 0), ("product's order vs RCM", prod, rcm, 0), ("MMD vs RCM", "mmd", rcm, 0),
+                                 ("product's order, residual summed forwards vs backwards", prod, prod, 1),
+                                 ("MMD order, residual summed forwards vs backwards", "mmd", "mmd", 1)):
+            s = cl.Solver(P, q, A, b, cones, cl.Settings(), kktsolver_factory=lambda *a: ShadowPair(oa, ob, *a, resid_b=rb))
             sol = s.solve()
             log = s.kktsystem.kktsolver.log
             first = next((k for k, r in enumerate(log) if r[2] != r[3]), None)
@@ -78,9 +84,10 @@ def main(seeds):
             if first is None:
                 print(f"[cpu-vs-cpu seed {seed}] {name}: no solve with different refinement step counts in {sol.iterations} iterations; max rel_dx {before:.2e}")
             else:
-                it, rel, sb, sa = log[first]
+                it, rel, sb, sa, nb, na = log[first]
                 print(f"[cpu-vs-cpu seed {seed}] {name}: first solve with different refinement step counts at IPM iteration {it} "
-                      f"(steps {sa} vs {sb}); the two solutions of THAT solve differ by rel_dx {rel:.3e}; max rel_dx over the "
+                      f"(steps {sa} vs {sb}); residual norms driver {np.array2string(na, precision=3)} shadow {np.array2string(nb, precision=3)}; "
+                      f"the two solutions of THAT solve differ by rel_dx {rel:.3e}; max rel_dx over the "
                       f"{first} solves before it {before:.2e}; driver ends {sol.status} in {sol.iterations} iterations")
 
 
