@@ -20,6 +20,13 @@ void enqueue_factor_level(hipkkt_solver *S, int l) {
         launch_factor_panel(S->stream, S->dp, P.fac_lvl_ptr[l], n, S->opts.dynamic_reg_eps, S->opts.dynamic_reg_delta);
 }
 
+// split-K part of a stage's dense updates (hipkkt_setup.cpp plan_split_k): the chunk tiles, then their fixed-order reduction
+void enqueue_split_k(hipkkt_solver *S, int l) {
+    if (S->split_group_count[l] <= 0) return;
+    launch_update_dense(S->stream, S->dp, S->split_group_begin[l], S->split_group_count[l], false);
+    launch_split_reduce(S->stream, S->dp, S->d_split_recs + S->split_rec_ptr[l], S->split_rec_ptr[l + 1] - S->split_rec_ptr[l]);
+}
+
 // Schur-complement updates applied after level l is factored: dense register tiles (matrix cores),
 // per-entry gather lists (tiny scattered contributions), relative-index scatter (whatever is left).
 // The three kinds own disjoint target tiles, so their order inside a stage is immaterial.
@@ -29,6 +36,7 @@ void enqueue_updates(hipkkt_solver *S, int l, int dense_skip_tail = 0) {
     hipStream_t st = S->stream;
     const int g0 = P.upd_stage_ptr[l], nd = P.upd_stage_ndense[l], ng = P.upd_stage_ngather[l];
     launch_update_dense(st, S->dp, g0, nd - dense_skip_tail, nd > 0 && P.upd_stage_flops_dense[l] >= 1.5e6 * nd);
+    enqueue_split_k(S, l);
     launch_update_gather(st, S->dp, P.gath_stage_ptr[l], P.gath_stage_ptr[l + 1] - P.gath_stage_ptr[l], S->gath_heavy_ptr[l],
                          S->gath_heavy_ptr[l + 1] - S->gath_heavy_ptr[l]);
     launch_update_stage(st, S->dp, g0 + nd + ng, P.upd_stage_ptr[l + 1] - g0 - nd - ng);
@@ -278,6 +286,7 @@ static int32_t refactor_once(hipkkt_handle h, int32_t static_reg_enable, double 
                 const double xf = skip > 0 ? dense_flops(g0 + nd - skip, skip) : 0.0;
                 S->prof_extra_tiles += skip; S->prof_extra_flops += xf;
                 launch_update_dense(st, S->dp, g0, nd - skip, nd > 0 && P.upd_stage_flops_dense[l] >= 1.5e6 * nd);
+                enqueue_split_k(S, l);
                 if (nd - skip > 384) {   // the one-wavefront-per-tile variant (see launch_update_dense)
                     HK_CHECK(hipEventCreate(&c2));
                     HK_CHECK(hipEventRecord(c2, st));

@@ -159,6 +159,10 @@ struct hipkkt_solver {
     int wmax_all = 1;
     int inv_nsmall = 0, inv_wsmall = 1, inv_nwide = 0;   // split of the diagonal-block inversions (kernels.hip)
     std::vector<int64_t> p_off;
+    // split-K of stages with few target tiles and long contribution lists (hipkkt_setup.cpp plan_split_k): per level, the range of the
+    // sub-groups appended to the dense-group records and of the reduce records
+    std::vector<int> split_group_begin, split_group_count, split_rec_ptr;
+    SplitRec *d_split_recs = nullptr;
     std::vector<int64_t> gath_heavy_ptr;   // [nlevels+1] into the list of heavy gather entries (kernels.hip k_update_gather_heavy)
 
     // device index arrays for value updates

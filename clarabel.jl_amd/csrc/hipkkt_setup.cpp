@@ -89,6 +89,7 @@ void init_runtime(hipkkt_solver *S) {
 // (re)builds every device-resident structure from S->plan and S->img (values included)
 static void build_front_batches(hipkkt_solver *S);
 static void order_far_stages(hipkkt_solver *S);
+static int64_t plan_split_k(hipkkt_solver *S, std::vector<DenseGroup> &dg);
 void setup_device(hipkkt_solver *S) {
     HK_CHECK(hipSetDevice(S->device));
     for (GraphSlot *g : {&S->g_factor, &S->ctx[0].g_ldl, &S->ctx[0].g_first, &S->ctx[0].g_step, &S->ctx[1].g_ldl, &S->ctx[1].g_first,
@@ -332,8 +333,8 @@ void setup_device(hipkkt_solver *S) {
     D.rel = S->upload(P.rel);
     D.upd_tasks = S->upload(P.upd_tasks);
     D.upd_groups = S->upload(P.upd_groups);
+    std::vector<DenseGroup> dg(P.upd_groups.size());       // uploaded after the front batches are known (plan_split_k appends to it)
     {
-        std::vector<DenseGroup> dg(P.upd_groups.size());
         const bool no_full_tiles = [] { const char *e = getenv("HIPKKT_FULL_TILES"); return e && e[0] == '0'; }();   // bit-identity test of the full-tile core
         for (size_t q = 0; q < dg.size(); q++) {
             const UpdGroup &G = P.upd_groups[q];
@@ -349,7 +350,6 @@ void setup_device(hipkkt_solver *S) {
             dg[q] = {P.sn_panel[t] + G.row_base, rt, std::min(kUpdRows, rt - G.row_base), P.sn_first[t + 1] - P.sn_first[t],
                      G.task_begin, G.task_end, full ? 1 : 0};
         }
-        D.dgroups = S->upload(dg);
     }
     D.upd_tmap = S->upload(P.upd_tmap);
     {
@@ -422,8 +422,11 @@ void setup_device(hipkkt_solver *S) {
     D.front_sync = S->dalloc<int>(std::max(P.front_sync_ints, 16));
     fill_async(S->stream, D.front_sync, 0, (size_t)std::max(P.front_sync_ints, 16) * sizeof(int));
     build_front_batches(S);
+    const int64_t split_scratch = plan_split_k(S, dg);
+    D.dgroups = S->upload(dg);
     D.kval = S->upload(S->img.nzval);
-    D.Lx = S->dalloc<double>(P.panel_doubles);
+    D.Lx = S->dalloc<double>(P.panel_doubles + split_scratch);
+    if (split_scratch) fill_async(S->stream, D.Lx + P.panel_doubles, 0, (size_t)split_scratch * sizeof(double));
     D.Ldiag = S->dalloc<double>(P.diag_doubles);
     D.Linv = S->dalloc<double>(P.diag_doubles);
     D.LinvT = S->dalloc<double>(P.diag_doubles);
@@ -556,6 +559,62 @@ static void order_far_stages(hipkkt_solver *S) {
         A.has_next = next;
         A.next_blk = next ? (P.front_panels[P.fronts[(size_t)hb[b + 1].front].fp_off + hb[b + 1].p0].r + 63) / 64 : 0;
     }
+}
+
+// Split-K (kernels.hip k_split_reduce).  A dense launch lasts as long as its longest tile, and a tile's time is its number of
+// contributions: in cfg 5 the 136 tiles of the variables' block receive 20 cones x 4 panels = 80+ contributions per update batch next
+// to thousands of tiles with 4-10 (measured: a 1788-tile launch took 809 us, of which the other tiles need ~100).  Tiles with at
+// least twice the stage's typical number of contributions are cut into chunks of about that size, one wavefront per chunk; the
+// original group record is switched off (wt = 0: dense_tile returns at once), the chunk records are appended to `dg`, partial
+// tiles live behind the panels in Lx.  Stages inside the front batches are left alone (their tile order is significant).  Returns the
+// scratch doubles needed.
+static int64_t plan_split_k(hipkkt_solver *S, std::vector<DenseGroup> &dg) {
+    const HostPlan &P = S->plan;
+    S->split_group_begin.assign(std::max(P.nlevels, 1), 0);
+    S->split_group_count.assign(std::max(P.nlevels, 1), 0);
+    S->split_rec_ptr.assign(P.nlevels + 1, 0);
+    std::vector<SplitRec> recs;
+    int64_t scratch_max = 0;
+    {
+        const char *e = getenv("HIPKKT_SPLIT_K");         // 0: never (A/B timing, comparison test)
+        if (e && e[0] == '0') { S->d_split_recs = S->upload(recs); return 0; }
+    }
+    for (int l = 0; l < P.nlevels; l++) {
+        S->split_rec_ptr[l + 1] = S->split_rec_ptr[l];
+        const int g0 = P.upd_stage_ptr[l], nd = P.upd_stage_ndense[l];
+        if (nd == 0 || S->lvl_fb[l] != -1) continue;
+        int64_t ntasks = 0;
+        for (int g = g0; g < g0 + nd; g++) ntasks += dg[g].task_end - dg[g].task_begin;
+        // chunk size = the stage's typical tile (average contributions per tile, at least 4).  Only launches of the one-wavefront-
+        // per-tile kernel qualify (<= 384 tiles go to the strip kernel, 8 wavefronts per tile already), and only when the longest
+        // tile outlasts two typical ones by >= 6 contributions (~40 us at 64 columns each): the chunk launch and the reduction
+        // cost ~30 us of their own (measured on cfg 1 / 2a / 2b / 3, where a looser rule split a few tiles and lost 0.03-0.05 ms)
+        const int chunk = std::max(4, (int)((ntasks + nd - 1) / nd));
+        int max_nt = 0;
+        for (int g = g0; g < g0 + nd; g++) max_nt = std::max(max_nt, dg[g].task_end - dg[g].task_begin);
+        if (nd <= 384 || max_nt < 2 * chunk + 6) continue;
+        int64_t scratch = 0;
+        S->split_group_begin[l] = (int)dg.size();
+        for (int g = g0; g < g0 + nd; g++) {
+            const int nt = dg[g].task_end - dg[g].task_begin;
+            const int parts = std::min(16, nt / chunk);
+            if (nt < 2 * chunk || parts < 2) continue;
+            recs.push_back({dg[g].tile_off, P.panel_doubles + scratch, dg[g].rt, dg[g].nrt, dg[g].wt, parts});
+            for (int q = 0; q < parts; q++) {
+                const int tb = dg[g].task_begin + (int)((int64_t)nt * q / parts), te = dg[g].task_begin + (int)((int64_t)nt * (q + 1) / parts);
+                dg.push_back({P.panel_doubles + scratch, 64, dg[g].nrt, dg[g].wt, tb, te, dg[g].pad});
+                scratch += 4096;
+            }
+            dg[g].wt = 0;                                   // switched off
+        }
+        S->split_group_count[l] = (int)dg.size() - S->split_group_begin[l];
+        S->split_rec_ptr[l + 1] = (int)recs.size();
+        scratch_max = std::max(scratch_max, scratch);
+    }
+    S->d_split_recs = S->upload(recs);
+    if (getenv("HIPKKT_VERBOSE") && !recs.empty())
+        fprintf(stderr, "hipkkt: split-K: %zu target tiles cut into %zu chunks, %.1f MB of partial tiles\n", recs.size(), dg.size() - P.upd_groups.size(), scratch_max * 8e-6);
+    return scratch_max;
 }
 
 // One launch of k_front_block per qualifying update batch of a front (symbolic.cpp front_batches).  HIPKKT_FRONT_BLOCK=0: never.

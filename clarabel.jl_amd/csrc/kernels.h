@@ -16,6 +16,8 @@ void launch_factor_panel(hipStream_t st, const DevPlan &P, int item_begin, int n
 void launch_update_stage(hipStream_t st, const DevPlan &P, int group_begin, int ngroups);
 // full_k: the tiles of this launch carry whole panels of sources (>= 1.5 MFLOP per tile): a partial last round is cut into pieces
 void launch_update_dense(hipStream_t st, const DevPlan &P, int group_begin, int ngroups, bool full_k = false);
+// split-K: adds the partial tiles of `n` split target tiles to their targets (fixed order) and clears them (kernels.hip k_split_reduce)
+void launch_split_reduce(hipStream_t st, const DevPlan &P, const SplitRec *recs, int n);
 void launch_fwd_narrow(hipStream_t st, const DevPlan &P, int sn_begin, int n, int wmax, double *y, double *z);
 void launch_bwd_narrow(hipStream_t st, const DevPlan &P, int sn_begin, int n, int wmax, const double *z, double *x, double *xout);
 void launch_psd_hs(hipStream_t st, double *kval, const int64_t *map_hs, int64_t hs_off, const double *W, int n);

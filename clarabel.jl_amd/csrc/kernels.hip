@@ -2023,6 +2023,28 @@ void launch_update_dense(hipStream_t st, const DevPlan &P, int group_begin, int 
         hipLaunchKernelGGL((k_update_dense<1, 2>), dim3(ngroups * 2), dim3(256), 0, st, P, group_begin, ngroups);
     }
 }
+// Split-K (hipkkt_setup.cpp plan_split_k): a stage with FEW target tiles and MANY contributions per tile (cfg 5: the 1000 x 1000 block
+// of the variables = 136 tiles, each fed by 20 cones x 5 panels per update batch, K = 6400) kept 136 of the 1024 SIMDs busy for 0.7 ms
+// per batch.  The contributions of such a tile are cut into up to 16 chunks, each accumulated by a wavefront of its own into a partial
+// tile that starts from zero (the unchanged tile code of dense_tile.h on a scratch tile); this kernel adds the partial tiles to the
+// target in a FIXED order (deterministic) and clears them for the next stage.
+__global__ void __launch_bounds__(256)
+k_split_reduce(DevPlan P, const SplitRec *recs) {
+    const SplitRec R = recs[blockIdx.x];
+    double *tp = P.Lx + R.tile_off, *sc = P.Lx + R.scratch_off;
+    for (int idx = threadIdx.x; idx < 4096; idx += 256) {
+        const int row = idx & 63, col = idx >> 6;
+        double s = 0.0;
+        for (int q = 0; q < R.nparts; q++) {
+            s += sc[(int64_t)q * 4096 + idx];
+            sc[(int64_t)q * 4096 + idx] = 0.0;
+        }
+        if (row < R.nrt && col < R.wt) tp[row + (int64_t)col * R.rt] += s;
+    }
+}
+void launch_split_reduce(hipStream_t st, const DevPlan &P, const SplitRec *recs, int n) {
+    if (n > 0) hipLaunchKernelGGL(k_split_reduce, dim3(n), dim3(256), 0, st, P, recs);
+}
 void launch_fwd_narrow(hipStream_t st, const DevPlan &P, int sn_begin, int n, int wmax, double *y, double *z) {
     if (n <= 0) return;
     if (wmax <= 4) hipLaunchKernelGGL(k_fwd_narrow<4>, dim3(nblk(n)), dim3(256), 0, st, P, sn_begin, n, y, z);

@@ -64,6 +64,13 @@ struct DenseGroup {
     int32_t task_begin, task_end, pad;
 };
 
+// Split-K of a dense target tile (hipkkt_setup.cpp plan_split_k): the tile's contributions are accumulated by `nparts` wavefronts into
+// partial tiles (64 x 64, column-major, at Lx + scratch_off + q * 4096) and added to the target in a fixed order by k_split_reduce
+struct SplitRec {
+    int64_t tile_off, scratch_off;
+    int32_t rt, nrt, wt, nparts;
+};
+
 // Device-side record of a factor item for k_factor_panel: everything the kernel needs in one load.
 struct FacRec {
     int64_t panel_off, diag_off, lt_off;   // offsets into Lx / Ldiag / LT

@@ -397,6 +397,34 @@ def test_streamed_pivot_chain_equals_whole_tile_handoff(name, monkeypatch):
     assert np.array_equal(hk1.h.debug_dump(5), d1)
 
 
+def test_split_k_of_long_tiles_equals_unsplit_updates(monkeypatch):
+    """hipkkt_setup.cpp plan_split_k / kernels.hip k_split_reduce (round 4): in cfg 5 the tiles of the variables' block receive 80+
+    contributions per update batch next to thousands of tiles with 4-10; they are cut into chunks accumulated by separate wavefronts
+    and added in a fixed order.  Same contributions, another association order: D, the dynamic-regularisation count and the unrefined
+    solve agree with the unsplit factorisation (HIPKKT_SPLIT_K=0) to rounding, and the split run is deterministic."""
+    rng = np.random.default_rng(23)
+    Pt, A, cones = _prep(FULL["cfg5"]())
+    m, n = A.shape
+    scale_cones(cones, rng)
+    monkeypatch.setenv("HIPKKT_PLAN_CACHE", "0")
+    monkeypatch.setenv("HIPKKT_SPLIT_K", "0")
+    hk0 = HipKKTSolver(Pt, A, cones, m, n, cl.Settings())
+    assert hk0.kktsolver_update(cones)
+    monkeypatch.setenv("HIPKKT_SPLIT_K", "1")
+    hk1 = HipKKTSolver(Pt, A, cones, m, n, cl.Settings())
+    assert hk1.kktsolver_update(cones)
+    assert not hk0.h.counters()["in_twin"] and not hk1.h.counters()["in_twin"]
+    assert hk0.last_nreg == hk1.last_nreg
+    d0, d1 = hk0.h.debug_dump(5), hk1.h.debug_dump(5)
+    assert np.all(np.sign(d0) == np.sign(d1)) and not np.array_equal(d0, d1)      # (the split is really on: another association order)
+    assert np.max(np.abs(d1 - d0) / np.abs(d0)) <= 1e-8
+    b = rng.standard_normal(hk0.h.N)
+    x0, x1 = hk0.h.ldl_solve(b), hk1.h.ldl_solve(b)
+    assert np.max(np.abs(x1 - x0)) <= 1e-9 * max(1.0, np.max(np.abs(x0)))
+    assert hk1.kktsolver_update(cones)
+    assert np.array_equal(hk1.h.ldl_solve(b), x1) and np.array_equal(hk1.h.debug_dump(5), d1)
+
+
 @pytest.mark.parametrize("name", ["cfg1", "cfg2a"])
 def test_super_block_sweeps_equal_panel_sweeps(name, monkeypatch):
     """front_sweep.hip (two hand-offs per super-block of 8 panels, explicit inverse of the super-block's diagonal block) against the
