@@ -161,7 +161,7 @@ int32_t hipkkt_refactor(hipkkt_handle h, int32_t static_reg_enable, double eps_c
     if (h) h->using_fallback = false;
     int32_t rc = refactor_once(h, static_reg_enable, eps_const, eps_prop, eps_used, n_dynamic_reg);
     // tests: HIPKKT_FORCE_TWIN=1 treats every successful factorisation in the cheap order as broken down, so that the robust-order
-    // twin can be compared with the oracle in ITS permutation on problems the oracle finishes in seconds
+    // twin can be checked in ITS permutation on problems a scalar CPU factorisation finishes in seconds
     static const bool force_twin = [] { const char *e = getenv("HIPKKT_FORCE_TWIN"); return e && e[0] == '1'; }();
     if (force_twin && rc == HIPKKT_OK && h && h->plan.ordering_used == 1) rc = HIPKKT_NUMERICAL_FAILURE;
     if (rc != HIPKKT_NUMERICAL_FAILURE || !h || h->plan.ordering_used != 1) return rc;
