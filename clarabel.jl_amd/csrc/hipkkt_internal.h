@@ -133,6 +133,7 @@ struct hipkkt_solver {
     // streamed pivot chain of k_front_block (front_block.hip): per (batch, panel, 8-pivot block) one record of 528 doubles that the
     // diagonal workgroup publishes as it eliminates and the next diagonal workgroup polls (sentinel-filled before every factorisation)
     double *d_fb_stream = nullptr;
+    hipStream_t idle_stream = nullptr;   // never carries work: see init_runtime (hipkkt_setup.cpp)
     int64_t fb_stream_doubles = 0;
     bool fb_streamed = true;             // HIPKKT_FB_STREAM=0: the round-3 chain (hand-off of the explicit inverse after all 64 pivots)
     // per front batch: what the next batch of the same front needs from this batch's far stage ([columns of the next batch | rest]
@@ -288,6 +289,7 @@ struct hipkkt_solver {
         rp.pinned_free(device, h_flags);
         for (hipEvent_t e : {ev0, ev1, ev2, ev3}) rp.event_put(device, e);
         rp.stream_put(device, 0, stream);
+        rp.stream_put(device, 1, idle_stream);
     }
 };
 

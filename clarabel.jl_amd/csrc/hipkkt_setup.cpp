@@ -56,6 +56,12 @@ void init_runtime(hipkkt_solver *S) {
     RuntimePool &rp = RuntimePool::get();
     auto need = [&](void *p) { if (!p) throw DeviceError{"creating a stream / event / pinned buffer failed"}; return p; };
     S->stream = (hipStream_t)need(rp.stream_get(S->device, 0));
+    // A third stream per handle that never carries work.  Measured (cfg 4, 6 worker processes on one GPU, round 4): with only the main
+    // stream (high priority) and the second solve context's stream a process keeps 2 hardware queues and the batch runs at 560 IPM
+    // iterations/s; with this idle low-priority stream next to them 1070-1130; with two idle ones 930; a normal-priority main stream
+    // 820-880.  One problem alone (cfg 2a) does not notice.  How the runtime spreads streams over hardware queues is not documented:
+    // the stream count is kept where the measurement put it (it was the "side" stream of rounds 1-3, dropped once and missed).
+    S->idle_stream = (hipStream_t)need(rp.stream_get(S->device, 1));
     {
         const char *fx = getenv("HIPKKT_FB_EXTRA");   // 0: every far stage applies all of its tiles in its own launch (A/B timing, bit-identity test)
         S->fb_extra = !(fx && fx[0] == '0');
