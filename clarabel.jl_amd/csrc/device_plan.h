@@ -36,6 +36,11 @@ struct GathPair {
     int32_t K;                    // its width
     int32_t dfirst;               // first pivot of the source in D
 };
+// 64 rows of a dense triangle of K (k_spmv_dense_tri, kernels.hip)
+struct DenseTriStrip {
+    int c0, d, i0, pad;   // the triangle's first row / column, its dimension; first row of the strip inside it
+    int64_t col0;         // the triangle's first entry in DevPlan::dtri_col
+};
 // One update batch of a front factored by ONE launch of k_front_block (front_block.hip): nb consecutive 64-column panels
 constexpr int kFbMax = 5;         // panels per launch (= the longest update batch)
 struct FrontBatch {
@@ -94,6 +99,10 @@ struct DevPlan {
     const int64_t *sym_q;
     const int *long_rows;        // rows of that view with more than long_row_threshold() entries (one workgroup each in the SpMV)
     int n_long_rows;
+    const DenseTriStrip *dtri_strips;   // dense triangles of K that left the view (symbolic.h HostPlan::dtri), 64 rows each
+    const int64_t *dtri_col;
+    int n_dtri_strips;
+    double *dense_acc;           // [N] their part of K x, written by k_spmv_dense_tri and added by the view's kernels (per solve context)
     const FrontPanel *front_panels;
     const int64_t *front_gptr;
     const int *front_gidx;

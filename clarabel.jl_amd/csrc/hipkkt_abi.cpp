@@ -662,6 +662,8 @@ int32_t hipkkt_debug_dump(hipkkt_handle h, int32_t what, double *out, int64_t ca
             host(4, [&](int64_t i) { return v[i]; });
             break;
         }
+        case 18: dev(S->ctx[0].d_e, S->N); break;       // residual b - K x of the last SpMV on context 0 (original ordering)
+        case 19: host(1, [&](int64_t) { return (double)P.dtri.size(); }); break;   // dense triangles of K outside the symmetric view
         case 15: dev(S->d_fb_stream, std::max<int64_t>(S->fb_stream_doubles, 1)); break;   // stream records of the front batches (raw)
         case 16: dev(S->d_fb_scratch, (int64_t)kFbScratch * (int64_t)std::max<size_t>(S->fbatches.size(), 1)); break;
         case 7: dev(S->d_soc_u, S->soc_total); break;

@@ -401,6 +401,16 @@ void setup_device(hipkkt_solver *S) {
         D.long_rows = S->upload(lr);
         D.n_long_rows = (int)lr.size();
     }
+    {
+        // dense triangles of K (symbolic.h HostPlan::dtri): one workgroup of k_spmv_dense_tri per 64 rows of a triangle
+        std::vector<DenseTriStrip> strips;
+        for (const DenseTri &T : P.dtri)
+            for (int i0 = 0; i0 < T.d; i0 += 64) strips.push_back(DenseTriStrip{T.c0, T.d, i0, 0, T.col0});
+        D.dtri_strips = S->upload(strips);
+        D.n_dtri_strips = (int)strips.size();
+        D.dtri_col = S->upload(P.dtri_col);
+        D.dense_acc = nullptr;                 // per solve context (below)
+    }
     D.front_panels = S->upload(P.front_panels);
     D.front_gptr = S->upload(P.front_gptr);
     D.front_gidx = S->upload(P.front_gidx);
@@ -503,6 +513,10 @@ void setup_device(hipkkt_solver *S) {
         C.d_rs = (RefineState *)S->dalloc<double>(sizeof(RefineState) / sizeof(double) + 1);
         fill_async(S->stream, C.d_rs, 0, sizeof(RefineState));
         C.dp = D;
+        if (D.n_dtri_strips > 0) {
+            C.dp.dense_acc = S->dalloc<double>(N);     // rows outside the triangles stay 0 for ever, the others are rewritten by every SpMV
+            fill_async(S->stream, C.dp.dense_acc, 0, (size_t)std::max(N, 1) * sizeof(double));
+        }
         if (c > 0) {   // private copies of everything a solve writes besides its vectors
             const size_t nx = (size_t)std::max(N, 1), np_ = (size_t)std::max<int64_t>(S->p_off[P.nsuper], 1);
             const size_t nsync = seg_sync_ints(S->nseg, P.nsuper), nfs = (size_t)std::max(P.front_sync_ints, 16);
@@ -670,6 +684,10 @@ int32_t finish_create(hipkkt_solver *S, const hipkkt_opts *opts, hipkkt_handle *
     po.front_min_panels = opts->front_min_panels == 0 ? 4 : std::max(0, opts->front_min_panels);
     po.n_hold = S->l1 ? (int)S->img.n : 0;
     {
+        const char *dt = getenv("HIPKKT_DENSE_TRI");   // 0: dense Hs triangles stay in the symmetric view (A/B timing, parity test of k_spmv_dense_tri)
+        po.dense_tri_first_col = (S->l1 && !(dt && dt[0] == '0')) ? (int)S->img.n : -1;
+    }
+    {
         const char *mr = getenv("HIPKKT_FRONT_BLOCK_MIN_ROWS");   // tests: 0, so that small fronts take the front-batch kernel too
         if (mr) po.front_block_min_width = atoi(mr);
         const char *sh = getenv("HIPKKT_SUPERHOP");    // 0: one hop per panel in the front sweeps; N: fronts of >= N panels go super-block by super-block
@@ -725,9 +743,9 @@ int32_t finish_create(hipkkt_solver *S, const hipkkt_opts *opts, hipkkt_handle *
     std::shared_ptr<const HostPlan> cached;
     if (PlanCache::enabled()) {
         char buf[256];
-        snprintf(buf, sizeof buf, "%d|%d|%d|%d|%.17g|%.17g|%d|%d|%d|%d|%d|%d|%d", po.max_width, (int)po.relax, po.update_policy, po.update_batch,
+        snprintf(buf, sizeof buf, "%d|%d|%d|%d|%.17g|%.17g|%d|%d|%d|%d|%d|%d|%d|%d|%d", po.max_width, (int)po.relax, po.update_policy, po.update_batch,
                  po.amd_dense_scale, po.dense_min_cover, po.n_hold, po.front_block_min_width, po.front_min_panels, po.superhop, po.nd_mode,
-                 po.nd_leaf, uperm ? 1 : 0);
+                 po.nd_leaf, uperm ? 1 : 0, po.dense_tri_first_col, po.dense_tri_min_dim);
         optkey = buf;
         ckey = PlanCache::fnv(1469598103934665603ull, S->img.colptr.data(), S->img.colptr.size() * sizeof(int64_t));
         ckey = PlanCache::fnv(ckey, S->img.rowval.data(), S->img.rowval.size() * sizeof(int64_t));

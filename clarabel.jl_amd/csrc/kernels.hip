@@ -1617,7 +1617,7 @@ constexpr int kLongRow = 192;
 __device__ __forceinline__ void spmv_short_rows(const int64_t *__restrict__ rowptr, const int *__restrict__ col,
                                                 const int64_t *__restrict__ qidx, const double *__restrict__ kval,
                                                 const double *__restrict__ b, const double *__restrict__ xi, double *__restrict__ e,
-                                                int n, unsigned long long *__restrict__ norm_slot) {
+                                                int n, unsigned long long *__restrict__ norm_slot, const double *__restrict__ dacc) {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     const int row = gid >> 2, sub = gid & 3;
     double acc = 0.0;
@@ -1632,6 +1632,7 @@ __device__ __forceinline__ void spmv_short_rows(const int64_t *__restrict__ rowp
     acc += __shfl_xor(acc, 2, 64);
     double a = 0.0;
     if (mine && sub == 0) {
+        if (dacc) acc += dacc[row];         // the row's part inside a dense triangle (k_spmv_dense_tri; 0 for every other row)
         const double ev = b[row] - acc;
         e[row] = ev;
         a = fabs(ev);
@@ -1642,7 +1643,7 @@ __device__ __forceinline__ void spmv_short_rows(const int64_t *__restrict__ rowp
 __device__ __forceinline__ void spmv_long_row(int row, const int64_t *__restrict__ rowptr, const int *__restrict__ col,
                                               const int64_t *__restrict__ qidx, const double *__restrict__ kval,
                                               const double *__restrict__ b, const double *__restrict__ xi, double *__restrict__ e,
-                                              unsigned long long *__restrict__ norm_slot) {
+                                              unsigned long long *__restrict__ norm_slot, const double *__restrict__ dacc) {
     __shared__ double red[4];
     const int64_t p0 = rowptr[row], p1 = rowptr[row + 1];
     double acc = 0.0;
@@ -1651,7 +1652,7 @@ __device__ __forceinline__ void spmv_long_row(int row, const int64_t *__restrict
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
     if (threadIdx.x == 0) {
-        const double ev = b[row] - (((red[0] + red[1]) + red[2]) + red[3]);
+        const double ev = b[row] - ((((red[0] + red[1]) + red[2]) + red[3]) + (dacc ? dacc[row] : 0.0));
         e[row] = ev;
         atomic_max_abs(norm_slot, ev);
     }
@@ -1659,14 +1660,63 @@ __device__ __forceinline__ void spmv_long_row(int row, const int64_t *__restrict
 __global__ void __launch_bounds__(256)
 k_spmv_residual(const int64_t *__restrict__ rowptr, const int *__restrict__ col, const int64_t *__restrict__ qidx,
                 const double *__restrict__ kval, const double *__restrict__ b, const double *__restrict__ xi,
-                double *__restrict__ e, int n, unsigned long long *__restrict__ norm_slot) {
-    spmv_short_rows(rowptr, col, qidx, kval, b, xi, e, n, norm_slot);
+                double *__restrict__ e, int n, unsigned long long *__restrict__ norm_slot, const double *__restrict__ dacc) {
+    spmv_short_rows(rowptr, col, qidx, kval, b, xi, e, n, norm_slot, dacc);
 }
 __global__ void __launch_bounds__(256)
 k_spmv_long(const int *__restrict__ long_rows, const int64_t *__restrict__ rowptr, const int *__restrict__ col,
             const int64_t *__restrict__ qidx, const double *__restrict__ kval, const double *__restrict__ b,
-            const double *__restrict__ xi, double *__restrict__ e, unsigned long long *__restrict__ norm_slot) {
-    spmv_long_row(long_rows[blockIdx.x], rowptr, col, qidx, kval, b, xi, e, norm_slot);
+            const double *__restrict__ xi, double *__restrict__ e, unsigned long long *__restrict__ norm_slot,
+            const double *__restrict__ dacc) {
+    spmv_long_row(long_rows[blockIdx.x], rowptr, col, qidx, kval, b, xi, e, norm_slot, dacc);
+}
+
+// The dense triangles of K that left the symmetric view (symbolic.h HostPlan::dtri: the packed upper triangles of PSD-cone Hs blocks,
+// column c0 + j = rows c0 .. c0 + j, contiguous in kval from col_off[j]): acc_out[c0 + i] = sum_j H(i, j) x[c0 + j] of the symmetric H.
+// One workgroup (8 wavefronts) per 64 rows i0 .. i0 + 63 of a triangle; every stored entry is read twice, both times coalesced:
+//   row part     sum_{j >= i} H(i, j) x_j: lane = row, the wavefronts take the columns j = i0 + w, i0 + w + 8, ...  (entry (i, j) sits at
+//                col_off[j] + i: 64 consecutive doubles per column and wavefront)
+//   column part  sum_{r < i} H(r, i) x_r: column i's rows 0 .. i - 1 are contiguous; every wavefront takes 8 of the strip's columns,
+//                lanes stride over the rows, fixed reduction tree
+// against 2 x (8 + 4 + 8) bytes per entry through the view (one of the two gathers strided: one value per cache line).  Fixed
+// partition and summation order: deterministic.  cfg 5 (20 triangles of 1275): 345 -> see DESIGN.md us per SpMV.
+__global__ void __launch_bounds__(512)
+k_spmv_dense_tri(const DenseTriStrip *__restrict__ strips, const int64_t *__restrict__ col_off, const double *__restrict__ kval,
+                 const RefineState *st, const double *__restrict__ x0, const double *__restrict__ x1, double *__restrict__ acc_out) {
+    if (st && !st->active) return;
+    const double *__restrict__ x = st ? (st->cur ? x0 : x1) : x0;       // st: the candidate iterate of a refinement step (k_spmv_residual_cand)
+    __shared__ double part[8][64];
+    __shared__ double csum[64];
+    const DenseTriStrip T = strips[blockIdx.x];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int i = T.i0 + lane;
+    const int64_t *__restrict__ co = col_off + T.col0;
+    const double *__restrict__ xb = x + T.c0;
+    double a = 0.0;
+#pragma unroll 4
+    for (int j = T.i0 + w; j < T.d; j += 8) {
+        const double v = kval[co[j] + (i <= j ? i : j)];      // (lanes right of the diagonal re-read the diagonal entry: never out of the column)
+        a = fma(i <= j ? v : 0.0, xb[j], a);
+    }
+    part[w][lane] = a;
+    for (int c = 0; c < 8; c++) {
+        const int ci = T.i0 + 8 * w + c;                      // wave-uniform
+        double s = 0.0;
+        if (ci < T.d) {
+            const double *__restrict__ colv = kval + co[ci];
+#pragma unroll 4
+            for (int r = lane; r < ci; r += 64) s = fma(colv[r], xb[r], s);
+        }
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+        if (lane == 0) csum[8 * w + c] = s;
+    }
+    __syncthreads();
+    if (w == 0 && i < T.d) {
+        double t = csum[lane];
+#pragma unroll
+        for (int q = 0; q < 8; q++) t += part[q][lane];
+        acc_out[T.c0 + i] = t;
+    }
 }
 
 // the three sparse products of residuals_update! (residuals.jl:12-25) from the RESIDENT KKT
@@ -1941,17 +1991,17 @@ __global__ void __launch_bounds__(256)
 k_spmv_residual_cand(const int64_t *__restrict__ rowptr, const int *__restrict__ col, const int64_t *__restrict__ qidx,
                      const double *__restrict__ kval, const double *__restrict__ b, const RefineState *st,
                      const double *__restrict__ x0, const double *__restrict__ x1, double *__restrict__ e, int n,
-                     unsigned long long *__restrict__ norm_slot) {
+                     unsigned long long *__restrict__ norm_slot, const double *__restrict__ dacc) {
     if (!st->active) return;           // the norm slot keeps its previous value; k_refine_decide ignores it when inactive
-    spmv_short_rows(rowptr, col, qidx, kval, b, st->cur ? x0 : x1, e, n, norm_slot);
+    spmv_short_rows(rowptr, col, qidx, kval, b, st->cur ? x0 : x1, e, n, norm_slot, dacc);
 }
 __global__ void __launch_bounds__(256)
 k_spmv_long_cand(const int *__restrict__ long_rows, const int64_t *__restrict__ rowptr, const int *__restrict__ col,
                  const int64_t *__restrict__ qidx, const double *__restrict__ kval, const double *__restrict__ b,
                  const RefineState *st, const double *__restrict__ x0, const double *__restrict__ x1, double *__restrict__ e,
-                 unsigned long long *__restrict__ norm_slot) {
+                 unsigned long long *__restrict__ norm_slot, const double *__restrict__ dacc) {
     if (!st->active) return;
-    spmv_long_row(long_rows[blockIdx.x], rowptr, col, qidx, kval, b, st->cur ? x0 : x1, e, norm_slot);
+    spmv_long_row(long_rows[blockIdx.x], rowptr, col, qidx, kval, b, st->cur ? x0 : x1, e, norm_slot, dacc);
 }
 
 __global__ void k_add(double *__restrict__ dst, const double *__restrict__ a, int n) {
@@ -2152,12 +2202,16 @@ void launch_front_bwd(hipStream_t st, const DevPlan &P, const FrontDesc &F, cons
 }
 void launch_spmv_residual(hipStream_t st, const DevPlan &P, const double *b, const double *xi, double *e, int n,
                           unsigned long long *slot) {
+    const double *dacc = P.n_dtri_strips > 0 ? P.dense_acc : nullptr;
+    if (dacc)
+        hipLaunchKernelGGL(k_spmv_dense_tri, dim3(P.n_dtri_strips), dim3(512), 0, st, P.dtri_strips, P.dtri_col, P.kval, (const RefineState *)nullptr,
+                           xi, xi, P.dense_acc);
     if (n > 0)
         hipLaunchKernelGGL(k_spmv_residual, dim3(nblk((int64_t)n * 4)), dim3(256), 0, st, P.sym_rowptr, P.sym_col, P.sym_q,
-                           P.kval, b, xi, e, n, slot);
+                           P.kval, b, xi, e, n, slot, dacc);
     if (P.n_long_rows > 0)
         hipLaunchKernelGGL(k_spmv_long, dim3(P.n_long_rows), dim3(256), 0, st, P.long_rows, P.sym_rowptr, P.sym_col, P.sym_q, P.kval, b,
-                           xi, e, slot);
+                           xi, e, slot, dacc);
 }
 void launch_block_products(hipStream_t st, const DevPlan &P, const double *x, const double *z, double *Px, double *ATz,
                            double *Ax, int n, int m) {
@@ -2178,12 +2232,15 @@ void launch_refine_copy_out(hipStream_t st, const RefineState *rs, const double 
 }
 void launch_spmv_residual_cand(hipStream_t st, const DevPlan &P, const double *b, const RefineState *rs, const double *x0,
                                const double *x1, double *e, int n, unsigned long long *slot) {
+    const double *dacc = P.n_dtri_strips > 0 ? P.dense_acc : nullptr;
+    if (dacc)
+        hipLaunchKernelGGL(k_spmv_dense_tri, dim3(P.n_dtri_strips), dim3(512), 0, st, P.dtri_strips, P.dtri_col, P.kval, rs, x0, x1, P.dense_acc);
     if (n > 0)
         hipLaunchKernelGGL(k_spmv_residual_cand, dim3(nblk((int64_t)n * 4)), dim3(256), 0, st, P.sym_rowptr, P.sym_col, P.sym_q,
-                           P.kval, b, rs, x0, x1, e, n, slot);
+                           P.kval, b, rs, x0, x1, e, n, slot, dacc);
     if (P.n_long_rows > 0)
         hipLaunchKernelGGL(k_spmv_long_cand, dim3(P.n_long_rows), dim3(256), 0, st, P.long_rows, P.sym_rowptr, P.sym_col, P.sym_q, P.kval,
-                           b, rs, x0, x1, e, slot);
+                           b, rs, x0, x1, e, slot, dacc);
 }
 int long_row_threshold() { return kLongRow; }
 int residual_blocks(int n, int m) { return (int)nblk((int64_t)(n + m) * 4); }

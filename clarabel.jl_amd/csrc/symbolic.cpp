@@ -812,10 +812,38 @@ std::string build_plan(int N, const int64_t *Ap, const int64_t *Ai, const int64_
 
     if (cancelled) return "cancelled";
     // ---- 16. symmetric CSR view of K in the ORIGINAL ordering (iterative-refinement SpMV)
+    //      minus the dense triangles (symbolic.h HostPlan::dtri): greedy from the left, a triangle starts at c0 and grows while column
+    //      c0 + j holds >= j + 1 entries, ends on its diagonal and has row c0 exactly j entries before it (rows sorted and distinct: the
+    //      j + 1 last entries are then c0 .. c0 + j)
+    P.dtri.clear();
+    P.dtri_col.clear();
+    std::vector<int> tri_c0(N, -1);       // per column: first row of its triangle, -1 outside
+    if (opt.dense_tri_first_col >= 0) {
+        auto grows = [&](int c0, int j) {
+            const int c = c0 + j;
+            return c < N && Ap[c + 1] - Ap[c] >= j + 1 && Ai[Ap[c + 1] - 1] == c && Ai[Ap[c + 1] - 1 - j] == c0;
+        };
+        for (int c = std::max(0, opt.dense_tri_first_col); c < N;) {
+            int d = 0;
+            while (grows(c, d)) d++;
+            if (d >= std::max(2, opt.dense_tri_min_dim)) {
+                P.dtri.push_back(DenseTri{c, d, (int64_t)P.dtri_col.size()});
+                for (int j = 0; j < d; j++) {
+                    tri_c0[c + j] = c;
+                    P.dtri_col.push_back(Ap[c + j + 1] - 1 - j);
+                }
+                c += d;
+            } else {
+                c++;
+            }
+        }
+    }
+    auto in_tri = [&](int i, int j) { return tri_c0[j] >= 0 && i >= tri_c0[j]; };   // (i <= j: column j's rows from c0 on are the triangle's)
     P.sym_rowptr.assign(N + 1, 0);
     for (int j = 0; j < N; j++)
         for (int64_t q = Ap[j]; q < Ap[j + 1]; q++) {
             int i = (int)Ai[q];
+            if (in_tri(i, j)) continue;
             P.sym_rowptr[i + 1]++;
             if (i != j) P.sym_rowptr[j + 1]++;
         }
@@ -827,6 +855,7 @@ std::string build_plan(int N, const int64_t *Ap, const int64_t *Ai, const int64_
         for (int j = 0; j < N; j++)
             for (int64_t q = Ap[j]; q < Ap[j + 1]; q++) {
                 int i = (int)Ai[q];
+                if (in_tri(i, j)) continue;
                 P.sym_col[nxt[i]] = j; P.sym_q[nxt[i]++] = q;
                 if (i != j) { P.sym_col[nxt[j]] = i; P.sym_q[nxt[j]++] = q; }
             }

@@ -106,6 +106,11 @@ constexpr int kSbG = 8;           // panels per super-block of the front sweeps
 constexpr int kSbMinPanels = 10;  // fronts with fewer panels always keep one hop per panel (a second super-block must exist)
 constexpr int kSbMaxPanels = 1024; // ... and so do fronts with more (the sweeps keep a panel table in LDS)
 
+struct DenseTri {
+    int c0, d;        // first row / column (original ordering), dimension
+    int64_t col0;     // first entry of its columns' offsets in HostPlan::dtri_col
+};
+
 struct PlanOptions {
     int max_width = kMaxSnWidth;
     bool relax = true;
@@ -126,6 +131,10 @@ struct PlanOptions {
     int nd_mode = 1;           // nested dissection candidate: 0 never, 1 when the latency + throughput model predicts a
                                // >= 20 % cheaper KKT iteration than minimum degree, 2 always
     int nd_leaf = 256;         // subgraphs of at most this many nodes are ordered by minimum degree
+    int dense_tri_first_col = -1;   // >= 0: dense triangles of K at or right of this column leave the symmetric view (HostPlan::dtri); the
+                               // L1 seam passes n: the kernels that walk the view for P and A (residuals, reduced system) never need Hs.
+                               // Needs sorted row indices inside the columns of K (the assembled image has them)
+    int dense_tri_min_dim = 128;
     // called (synchronously, from build_plan) with the minimum-degree order on K just BEFORE the "cone rows first" candidate is
     // evaluated against it: the caller may start preparing the robust fallback (a twin analysed in that order) speculatively
     // while this analysis goes on; HostPlan::ordering_used tells afterwards whether it will ever be needed
@@ -188,9 +197,15 @@ struct HostPlan {
     int front_sync_ints = 0;
     int64_t sbinv_doubles = 0;        // storage of the super-block inverse tiles of all fronts (FrontDesc::sbinv_off)
 
-    std::vector<int64_t> sym_rowptr;  // full symmetric CSR view of K (original ordering)
+    std::vector<int64_t> sym_rowptr;  // symmetric CSR view of K (original ordering) WITHOUT the entries of the dense triangles below
     std::vector<int> sym_col;
     std::vector<int64_t> sym_q;       // index into Kval
+    // Dense triangles of K (PlanOptions::dense_tri_first_col): runs of >= dense_tri_min_dim consecutive columns c0 .. c0 + d - 1 whose
+    // column c0 + j ends with the rows c0 .. c0 + j -- the packed upper triangle a PSD cone's Hs block is stored as
+    // (directldl_kkt_assembly.jl:49-57, _csc_colcount_dense_triangle).  The residual SpMV of the refinement takes them from the values
+    // alone (k_spmv_dense_tri: no index traffic, coalesced) instead of through 2 x 12 bytes of indices per entry of the view.
+    std::vector<DenseTri> dtri;
+    std::vector<int64_t> dtri_col;    // per triangle column (DenseTri::col0 + j): index into Kval of its entry in row c0
 
     // statistics / cost model
     int64_t nnzL = 0;            // strictly-lower structural nonzeros of L (column counts)

@@ -19,8 +19,20 @@ def lib():
         L.plan_check_run.restype = C.c_int
         L.plan_check_run.argtypes = [C.c_int64, _i64p, _i64p, _f64p, _i64p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                      C.c_double, C.c_double, _f64p, _f64p, _i64p, _f64p, C.c_int]
+        L.plan_check_symmetric_product.restype = C.c_int
+        L.plan_check_symmetric_product.argtypes = [C.c_int64, _i64p, _i64p, _f64p, C.c_int, C.c_int, _f64p, _f64p, _f64p]
         _lib = L
     return _lib
+
+
+def symmetric_product(N, colptr, rowval, nzval, x, first_col=-1, min_dim=128):
+    """K x through the plan's symmetric view + dense triangles (host restatement of the refinement's SpMV kernels)"""
+    y = np.zeros(N)
+    st = np.zeros(3)
+    rc = lib().plan_check_symmetric_product(N, np.ascontiguousarray(colptr, dtype=np.int64), np.ascontiguousarray(rowval, dtype=np.int64),
+                                            np.ascontiguousarray(nzval, dtype=np.float64), first_col, min_dim,
+                                            np.ascontiguousarray(x, dtype=np.float64), y, st)
+    return rc, y, dict(triangles=int(st[0]), view_entries=int(st[1]), triangle_dims=int(st[2]))
 
 
 STAT_NAMES = ["nsuper", "nlevels", "nnzL", "panel_doubles", "ntasks", "ngroups", "etree_height",

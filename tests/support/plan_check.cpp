@@ -172,6 +172,37 @@ struct SbEmu {
 
 extern "C" {
 
+// y = K x of the symmetric K the way the refinement's SpMV kernels take it: the symmetric view (without the dense triangles) row by row
+// plus, per dense triangle, the row part and the column part of k_spmv_dense_tri (kernels.hip) from the packed columns alone.
+// stats: [0] triangles found [1] entries left in the view [2] sum of the triangles' dimensions
+int plan_check_symmetric_product(int64_t N, const int64_t *Ap, const int64_t *Ai, const double *Ax, int first_col, int min_dim,
+                                 const double *x, double *y, double *stats) {
+    HostPlan P;
+    PlanOptions opt;
+    opt.dense_tri_first_col = first_col;
+    opt.dense_tri_min_dim = min_dim;
+    std::string err = build_plan((int)N, Ap, Ai, nullptr, opt, P);
+    if (!err.empty()) { fprintf(stderr, "build_plan: %s\n", err.c_str()); return -1; }
+    for (int i = 0; i < N; i++) {
+        double a = 0;
+        for (int64_t p = P.sym_rowptr[i]; p < P.sym_rowptr[i + 1]; p++) a += Ax[P.sym_q[p]] * x[P.sym_col[p]];
+        y[i] = a;
+    }
+    int64_t dims = 0;
+    for (const DenseTri &T : P.dtri) {
+        const int64_t *co = P.dtri_col.data() + T.col0;
+        dims += T.d;
+        for (int i = 0; i < T.d; i++) {
+            double a = 0;
+            for (int j = i; j < T.d; j++) a += Ax[co[j] + i] * x[T.c0 + j];     // row part
+            for (int r = 0; r < i; r++) a += Ax[co[i] + r] * x[T.c0 + r];       // column part
+            y[T.c0 + i] += a;
+        }
+    }
+    stats[0] = (double)P.dtri.size(); stats[1] = (double)P.sym_rowptr[N]; stats[2] = (double)dims;
+    return 0;
+}
+
 // stats: [0] nsuper [1] nlevels [2] nnzL [3] panel_doubles [4] ntasks [5] ngroups [6] etree_height
 //        [7] flops_colcount [8] flops_update [9] flops_exec [10] nreg [11] max group tasks
 int plan_check_run(int64_t N, const int64_t *Ap, const int64_t *Ai, const double *Ax, const int64_t *dsigns,

@@ -229,8 +229,8 @@ def test_full_size_ipm_matches_oracle(name, max_iter, oracle_factory, capsys):
     cfg 3 ~5.4 s per iteration (~80 s), cfg 2a ~25 s per iteration (the first 5 iterations: max_iter = 5 on both sides), cfg 5
     ~18 s per iteration.  cfg 5's last iteration breaks down in the cheap order ON BOTH PATHS: the HIP path repeats it on its
     robust-order twin and ends SOLVED; the oracle, held to the cheap order (it cannot follow into the twin's at this size: that is
-    test_twin_factorisation_matches_oracle_in_the_robust_order's job on the reduced config), must report the factorisation failure
-    at exactly that iteration, and every iteration before it agrees to 1e-10."""
+    test_twin_factorisation_matches_oracle_in_the_robust_order's job on the reduced config), must stop on the factorisation failure
+    at exactly that iteration (NUMERICAL_ERROR, or ALMOST_SOLVED when its last good iterate meets the reduced tolerances), and every iteration before it agrees to 1e-10."""
     P, q, A, b, cones = FULL[name]()
     stg = cl.Settings() if max_iter is None else cl.Settings(max_iter=max_iter)
     sg = cl.Solver(P, q, A, b, cones, stg)
@@ -259,7 +259,9 @@ def test_full_size_ipm_matches_oracle(name, max_iter, oracle_factory, capsys):
         assert abs(solg.r_prim - solc.r_prim) <= 1e-10 and abs(solg.r_dual - solc.r_dual) <= 1e-10
     else:
         # the oracle stops where the cheap order breaks down; the HIP path went on from there on its twin
-        assert solg.status == "SOLVED" and solc.status == "NUMERICAL_ERROR"
+        # (a failed factorisation ends the reference's loop with NUMERICAL_ERROR, which info_post_process! turns into ALMOST_SOLVED when
+        # the last good iterate meets the reduced tolerances: solver.jl:368, info.jl:198-212 -- cfg 5's does)
+        assert solg.status == "SOLVED" and solc.status in ("NUMERICAL_ERROR", "ALMOST_SOLVED")
         last_common = len(sc.trace) - 1
         assert last_common >= 5 and solg.iterations >= last_common
         worst = _traces_agree(sg.trace, sc.trace, last_common)
@@ -423,6 +425,47 @@ def test_split_k_of_long_tiles_equals_unsplit_updates(monkeypatch):
     assert np.max(np.abs(x1 - x0)) <= 1e-9 * max(1.0, np.max(np.abs(x0)))
     assert hk1.kktsolver_update(cones)
     assert np.array_equal(hk1.h.ldl_solve(b), x1) and np.array_equal(hk1.h.debug_dump(5), d1)
+
+
+def test_dense_triangle_spmv_matches_host_product(monkeypatch):
+    """kernels.hip k_spmv_dense_tri (round 4): the packed upper triangles of PSD-cone Hs blocks leave the symmetric CSR view of the
+    refinement's SpMV and are multiplied from their values alone.  The residual e = b - K x the device computes (debug_dump 18, right
+    after an unrefined solve: max_iter = 0) against the host product with the K the handle holds, entry by entry at the rounding level
+    of the row's terms -- with the triangles in their own kernel and (HIPKKT_DENSE_TRI=0) inside the view; the refined solves of the
+    two modes agree and take the same number of steps."""
+    rng = np.random.default_rng(29)
+    Pt, A, cones = _prep(problems.sdp_blocks(n=300, ncones=8, dim=24, seed=7))     # 8 triangles of dimension 300
+    m, n = A.shape
+    scale_cones(cones, rng)
+    monkeypatch.setenv("HIPKKT_PLAN_CACHE", "0")
+    rx, rz = rng.standard_normal(n), rng.standard_normal(m)
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("HIPKKT_DENSE_TRI", mode)
+        hk = HipKKTSolver(Pt, A, cones, m, n, cl.Settings())
+        assert hk.kktsolver_update(cones)
+        assert int(hk.h.debug_dump(19)[0]) == (8 if mode == "1" else 0)
+        hk.h.setrhs(rx, rz)
+        x, z = np.zeros(n), np.zeros(m)
+        ok, steps = hk.h.solve(x, z, True, max_iter=0)
+        assert ok and steps == 0
+        e = hk.h.debug_dump(18)
+        colptr, rowval, nz = hk.h.kkt()
+        N = hk.h.N
+        K = sp.csc_matrix((nz, rowval, colptr), shape=(N, N))
+        K = K + sp.triu(K, 1).T
+        xs = np.concatenate([x, z, np.zeros(N - n - m)])
+        bs = np.concatenate([rx, rz, np.zeros(N - n - m)])
+        scale = abs(K) @ np.abs(xs) + np.abs(bs)
+        assert np.all(np.abs(e - (bs - K @ xs)) <= 1e-13 * scale), mode
+        x2, z2 = np.zeros(n), np.zeros(m)
+        ok, steps2 = hk.h.solve(x2, z2, True)
+        assert ok
+        out[mode] = (x, z, x2, z2, steps2)
+    assert np.array_equal(out["1"][0], out["0"][0]) and np.array_equal(out["1"][1], out["0"][1])      # (the unrefined solve never sees the SpMV)
+    assert out["1"][4] == out["0"][4]
+    for a_, b_ in ((out["1"][2], out["0"][2]), (out["1"][3], out["0"][3])):
+        assert np.max(np.abs(a_ - b_)) <= 1e-12 * max(1.0, np.max(np.abs(b_)))
 
 
 @pytest.mark.parametrize("name", ["cfg1", "cfg2a"])

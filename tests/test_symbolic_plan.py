@@ -128,3 +128,32 @@ def test_super_block_front_sweeps_reproduce_dense_solve(maxw, monkeypatch, capfd
     assert np.linalg.norm(x - x0) <= 1e-10 * max(1.0, np.linalg.norm(x0))
 
 
+
+
+def test_dense_triangles_leave_the_symmetric_view_and_the_product_is_unchanged():
+    """PSD-cone Hs blocks (packed upper triangles, directldl_kkt_assembly.jl:49-57) are found from the pattern alone, taken out of the
+    symmetric view and multiplied from their packed columns (the host restatement of k_spmv_dense_tri): K x must equal the plain
+    product; with the search off (first_col = -1) or the blocks below the minimum dimension nothing leaves the view."""
+    rng = np.random.default_rng(11)
+    prob = problems.sdp_blocks(n=40, ncones=3, dim=16, seed=3)       # 3 x PSD(16): triangles of dimension 136
+    k, nz, ds = _kkt(prob, rng)
+    n = prob[0].shape[0]
+    K = sp.csc_matrix((nz, k.rowval, k.colptr), shape=(k.N, k.N)).toarray()
+    K = K + K.T - np.diag(np.diag(K))
+    x = rng.standard_normal(k.N)
+    full = int(2 * len(nz) - k.N)
+    rc, y, st = ps.symmetric_product(k.N, k.colptr, k.rowval, nz, x, first_col=n, min_dim=128)
+    assert rc == 0 and st["triangles"] == 3 and st["triangle_dims"] == 3 * 136
+    assert st["view_entries"] == full - 3 * 136 * 136
+    assert np.linalg.norm(y - K @ x) <= 1e-12 * np.linalg.norm(K @ x)
+    for kw in (dict(first_col=-1, min_dim=128), dict(first_col=n, min_dim=137)):
+        rc, y, st = ps.symmetric_product(k.N, k.colptr, k.rowval, nz, x, **kw)
+        assert rc == 0 and st["triangles"] == 0 and st["view_entries"] == full
+        assert np.linalg.norm(y - K @ x) <= 1e-12 * np.linalg.norm(K @ x)
+    # a problem without PSD cones: nothing to find
+    k2, nz2, _ = _kkt(problems.portfolio_socp(n=40, nsoc=3, socdim=9, seed=1), rng)
+    rc, y2, st2 = ps.symmetric_product(k2.N, k2.colptr, k2.rowval, nz2, np.ones(k2.N), first_col=40, min_dim=4)
+    assert rc == 0
+    K2 = sp.csc_matrix((nz2, k2.rowval, k2.colptr), shape=(k2.N, k2.N)).toarray()
+    K2 = K2 + K2.T - np.diag(np.diag(K2))
+    assert np.linalg.norm(y2 - K2 @ np.ones(k2.N)) <= 1e-12 * np.linalg.norm(K2 @ np.ones(k2.N))
