@@ -576,7 +576,7 @@ std::string build_plan(int N, const int64_t *Ap, const int64_t *Ai, const int64_
         for (auto &G : P.upd_groups) {
             const int t = G.tgt, ft = P.sn_first[t];
             bool all_contig = true;
-            double covered = 0, flops = 0;
+            double covered = 0;
             for (int q = G.task_begin; q < G.task_end; q++) {
                 UpdTask &T = P.upd_tasks[q];
                 const int *srows = &P.sn_rows[P.sn_rowptr[T.src]];
@@ -587,15 +587,35 @@ std::string build_plan(int N, const int64_t *Ap, const int64_t *Ai, const int64_
                 T.geom = ((r0 - G.row_base) & 255) | ((c0 & 255) << 8) | (contig ? 1 << 16 : 0);
                 all_contig = all_contig && contig;
                 covered += (double)T.nrows * T.ncols;
-                flops += 2.0 * T.nrows * T.ncols * (P.sn_first[T.src + 1] - P.sn_first[T.src]);
             }
             const double ntasks = G.task_end - G.task_begin;
             const double fill = covered / (ntasks * kUpdRows * kMaxSnWidth);
             // dense enough per contribution -> matrix-core path; otherwise the contributions are single
             // entries of tiny leaf supernodes -> per-entry gather
             G.dense = ((all_contig && fill >= 0.4) || fill >= 0.3 || covered >= opt.dense_min_cover * ntasks) ? 1 : 2;
-            if (G.dense != 1) { gather_pairs_bound += (int64_t)covered; continue; }
-            P.flops_update_dense += flops;
+            if (G.dense != 1) gather_pairs_bound += (int64_t)covered;
+        }
+        // A stage with a dense launch of its own (>= 128 tiles) absorbs its thin tiles of few contributions (<= 8) as a few more tiles of
+        // that launch; as per-entry gather lists they are a launch of their own AFTER it whose duration is one long dependent dot
+        // product (cfg 5: 158 such tiles behind 6288 dense ones, 70 us per stage, 0.49 ms of a 5.1 ms factorisation -> 4.63 ms).
+        // Not in stages without such a launch: with the rule applied everywhere cfg 2a / cfg 1 / cfg 3 lose 1.5 / 5 / 1 % (tiles with
+        // tile maps as small launches of the sparse tree cost more than their gather lists); with it they are unchanged (measured).
+        for (int l = 0; l < P.nlevels; l++) {
+            int nd0 = 0;
+            for (int g = P.upd_stage_ptr[l]; g < P.upd_stage_ptr[l + 1]; g++) nd0 += P.upd_groups[g].dense == 1;
+            if (nd0 < 128) continue;
+            for (int g = P.upd_stage_ptr[l]; g < P.upd_stage_ptr[l + 1]; g++) {
+                UpdGroup &G = P.upd_groups[g];
+                if (G.dense == 2 && G.task_end - G.task_begin <= 8) G.dense = 1;
+            }
+        }
+        for (auto &G : P.upd_groups) {
+            if (G.dense != 1) continue;
+            const int ft = P.sn_first[G.tgt];
+            for (int q = G.task_begin; q < G.task_end; q++) {
+                const UpdTask &T = P.upd_tasks[q];
+                P.flops_update_dense += 2.0 * T.nrows * T.ncols * (P.sn_first[T.src + 1] - P.sn_first[T.src]);
+            }
             // contributions that do not land contiguously get explicit tile maps (tile row / column ->
             // source row offset or -1): k_update_dense then gathers its operands through them
             for (int q = G.task_begin; q < G.task_end; q++) {
