@@ -1,18 +1,23 @@
 #!/bin/bash
 # Final evidence of a round: GPU test suite, bench lines for every config, rocprofv3 kernel stats and the hardware-counter passes of
 # cfg 2a / 3 / 5 (FETCH_SIZE, WRITE_SIZE, SQ matrix-core counters, GRBM_GUI_ACTIVE -- each in its OWN pass, with --kernel-trace only,
-# as /opt/skills/guides/MI355X_MICROARCH.md prescribes).   usage (via gpurun): bash tools/final_round.sh <tag> [quick|full] [nocounters]
+# as /opt/skills/guides/MI355X_MICROARCH.md prescribes).   usage (via gpurun): bash tools/final_round.sh <tag> [quick|full|notests|testsonly] [nocounters]
 tag=${1:-final}; mode=${2:-full}; ctrs=${3:-counters}
 mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+if [ "$mode" != "notests" ]; then
 sel="gpu"; [ "$mode" = "quick" ] && sel="gpu and not slow"
-(timeout 2400 python -m pytest tests -m "$sel" -q -s > gpurun_out/pytest_gpu_$tag.log 2>&1; echo "pytest rc=$?" >> gpurun_out/pytest_gpu_$tag.log); tail -3 gpurun_out/pytest_gpu_$tag.log
+# (6 worker processes: the slow part of the suite is the oracle's scalar CPU factorisations, the GPU box has 256 cores)
+(timeout 2400 python -m pytest tests -m "$sel" -q -s -n 6 > gpurun_out/pytest_gpu_$tag.log 2>&1; echo "pytest rc=$?" >> gpurun_out/pytest_gpu_$tag.log); tail -3 gpurun_out/pytest_gpu_$tag.log
 grep -h "batch-parity\|order-parity\|full-size-ipm\|twin-parity" gpurun_out/pytest_gpu_$tag.log > gpurun_out/parity_causes_$tag.txt
+fi
+[ "$mode" = "testsonly" ] && exit 0
 # ---- counter passes first: bench.py then finds counter files stamped with the current kernel sources
 if [ "$ctrs" = "counters" ]; then
 for c in 2a 3 5; do
-  extra=""; [ $c = 5 ] && extra="--steps 2 --warmup 1"; [ $c != 5 ] && extra="--steps 2 --warmup 1"
-  pass() { rm -rf gpurun_out/$1_${c}_$tag; timeout 600 rocprofv3 --pmc $2 --kernel-trace -d gpurun_out/$1_${c}_$tag -o p -- python tools/ab_variant.py $c pmc 4 > gpurun_out/$1_${c}_$tag.log 2>&1; }
+  # cfg 2a: the bench command itself; cfg 3 / 5: refactor + refined-solve loops without the end-to-end runs (tools/ab_variant.py)
+  cmd="python tools/ab_variant.py $c pmc 3"; [ $c = 2a ] && cmd="python bench.py --steps 2 --warmup 1 --no-cpu-baseline"
+  pass() { rm -rf gpurun_out/$1_${c}_$tag; timeout 600 rocprofv3 --pmc $2 --kernel-trace -d gpurun_out/$1_${c}_$tag -o p -- $cmd > gpurun_out/$1_${c}_$tag.log 2>&1; }
   pass pmcf FETCH_SIZE
   pass pmcw WRITE_SIZE
   pass pmcm "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_BUSY_CU_CYCLES"
@@ -34,7 +39,8 @@ timeout 900 python bench.py --config 4 --warmup 4 > gpurun_out/bench_4_$tag.log 
 #      be dominated by the one factorisation on the robust-order twin)
 for c in 2a 2b 3 5; do
   rm -rf gpurun_out/prof_${c}_$tag
-  timeout 500 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_${c}_$tag -o p -- python tools/ab_variant.py $c prof 10 > gpurun_out/prof_${c}_$tag.log 2>&1
+  cmd="python bench.py --config $c --steps 5 --warmup 2 --no-cpu-baseline"; [ $c = 5 ] && cmd="python tools/ab_variant.py 5 prof 8"
+  timeout 500 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_${c}_$tag -o p -- $cmd > gpurun_out/prof_${c}_$tag.log 2>&1
   python tools/prof_summary.py $(ls gpurun_out/prof_${c}_$tag/*results.db | head -1) > gpurun_out/prof_summary_${c}_$tag.txt 2>&1
   grep "^AB" gpurun_out/prof_${c}_$tag.log >> gpurun_out/prof_summary_${c}_$tag.txt
 done
