@@ -63,8 +63,7 @@ static double dense_stage_cost_us(int m) {
 }
 int fb_extra_tiles_of_stage(int nd, int ncrit, int next_blk, int *per_wave_out) {
     constexpr int cus = 254, rmin = 64, pw_max = 2;
-    static const double pen[3] = {0.0, [] { const char *e = getenv("HIPKKT_FB_EXTRA_PEN1"); return e ? atof(e) : 10.0; }(),
-                                  [] { const char *e = getenv("HIPKKT_FB_EXTRA_PEN2"); return e ? atof(e) : 28.0; }()};   // what the panel launch gains in duration (us)
+    constexpr double pen[3] = {0.0, 10.0, 28.0};     // what the panel launch gains in duration (us) with one / two tiles per wavefront
     double best = dense_stage_cost_us(nd);
     int best_r = 0, best_pw = 1;
     for (int pw = 1; pw <= pw_max; pw++) {
@@ -162,7 +161,7 @@ int32_t hipkkt_refactor(hipkkt_handle h, int32_t static_reg_enable, double eps_c
     int32_t rc = refactor_once(h, static_reg_enable, eps_const, eps_prop, eps_used, n_dynamic_reg);
     // tests: HIPKKT_FORCE_TWIN=1 treats every successful factorisation in the cheap order as broken down, so that the robust-order
     // twin can be checked in ITS permutation on problems a scalar CPU factorisation finishes in seconds
-    static const bool force_twin = [] { const char *e = getenv("HIPKKT_FORCE_TWIN"); return e && e[0] == '1'; }();
+    const bool force_twin = [] { const char *e = getenv("HIPKKT_FORCE_TWIN"); return e && e[0] == '1'; }();   // (read per call: a test process sets it for one test)
     if (force_twin && rc == HIPKKT_OK && h && h->plan.ordering_used == 1) rc = HIPKKT_NUMERICAL_FAILURE;
     if (rc != HIPKKT_NUMERICAL_FAILURE || !h || h->plan.ordering_used != 1) return rc;
     hipkkt_solver *S = h;

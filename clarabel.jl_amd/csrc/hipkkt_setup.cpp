@@ -23,7 +23,7 @@ struct PlanCache {
     static constexpr size_t kMaxEntries = 8;
     static constexpr int64_t kMaxNnzL = 40000000;      // bigger plans (hundreds of MB of work lists) are not kept
     static PlanCache &get() { static PlanCache c; return c; }
-    static bool enabled() { static const bool on = [] { const char *e = getenv("HIPKKT_PLAN_CACHE"); return !(e && e[0] == '0'); }(); return on; }
+    static bool enabled() { const char *e = getenv("HIPKKT_PLAN_CACHE"); return !(e && e[0] == '0'); }   // (read per call: tests switch it)
     static uint64_t fnv(uint64_t h, const void *p, size_t n) {
         const unsigned char *b = (const unsigned char *)p;
         for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 1099511628211ull; }

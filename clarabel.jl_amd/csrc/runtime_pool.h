@@ -3,8 +3,7 @@
 // hipFree calls of ONE handle cost 18-40 ms (HIPKKT_VERBOSE: "runtime objects", "destroy") against 20-50 ms for its whole solve, so a
 // destroyed handle parks its objects here and the next one on the same device takes them.  Everything handed back is idle (the owner
 // synchronises its streams first); recycled memory is NOT zero -- like fresh hipMalloc memory, nothing may rely on its contents
-// (HIPKKT_POISON=1 fills every buffer with NaNs to prove it).  The cache is never torn down: at process exit the HIP runtime may
-// already be gone.  HIPKKT_NO_POOL=1 bypasses it (A/B measurements).
+// The cache is never torn down: at process exit the HIP runtime may already be gone.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -153,10 +152,6 @@ private:
         std::vector<hipStream_t> streams[3];
         std::vector<hipEvent_t> events;
     };
-    RuntimePool() {
-        const char *e = getenv("HIPKKT_NO_POOL");
-        on_ = !(e && e[0] == '1');
-    }
     bool on_ = true;
     std::mutex mu_;
     std::map<int, Dev> dev_;
