@@ -46,4 +46,4 @@ for c in 2a 2b 3 5; do
 done
 timeout 300 python tools/fb_trace.py > gpurun_out/fbtrace_$tag.txt 2>&1
 head -8 gpurun_out/pmc_summary_2a_$tag.txt
-find gpurun_out -name "*.db" -size +30M -delete
+find gpurun_out -name "*.db" -delete      # (only the summaries travel back: gpurun merges at most 64 MiB)
