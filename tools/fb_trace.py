@@ -25,7 +25,7 @@ for bi in (1, 8, 15):
     if bi >= len(t): continue
     t0 = t[bi, 0, 0]
     print(f"batch {bi}: stamps relative to workgroup 0's start (us)")
-    for i in range(7):
+    for i in range(5):
         row = t[bi, i]
         print("  wg", i, " ".join(f"{nm}={row[k]-t0:7.2f}" for k, nm in enumerate(names) if k < 14 and row[k] > 0))
     tb = t[bi, 5].reshape(-1) / 0.01          # raw shader-clock stamps of workgroup 0's pivot loop
