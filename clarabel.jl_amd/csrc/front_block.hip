@@ -260,6 +260,16 @@ k_front_block(DevPlan P, FrontBatch B, int *sync_all, double *scratch_all, doubl
         }
     }
     FB_T(1);
+    // A diagonal workgroup's own tile lives in accumulators of its own from the start: its update by panel j needs nothing from another
+    // workgroup, so it is applied FIRST in every step and the waits for the tiles L(k, j) of the workgroups above overlap with it
+    // (round 4: the next diagonal workgroup's streamed step starts 2 us earlier; same updates in the same order: bit-identical).
+    v4f64 tacc[4];
+#pragma unroll
+    for (int sub = 0; sub < 4; sub++) {
+        tacc[sub] = (v4f64){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < kFbMax; k++) if (k == i) tacc[sub] = acc[k][sub];
+    }
     // ---- the columns left of this block's own tile
 #pragma unroll
     for (int j = 0; j < kFbMax; j++) {
@@ -303,37 +313,37 @@ k_front_block(DevPlan P, FrontBatch B, int *sync_all, double *scratch_all, doubl
                 if (diag) fb_publish(fl_L + 8 * i + j);
             }   // (last: the panel copy is made from the scratch tile after this workgroup's own pivots)
             if (j == nsteps - 1) FB_T(5);
-            // A_k -= (X_j D_j) L(k,j)^T
+            // A_k -= (X_j D_j) L(k,j)^T: the diagonal tile first (L(i,j) is this workgroup's own X_j) ...
+            if (diag) {
+#pragma unroll
+                for (int kk = 0; kk < 16; kk++) {
+                    const double a = -(Sa[(16 * wv + l15) * FLD + 4 * kk + lk] * Sd[4 * kk + lk]);
+#pragma unroll
+                    for (int sub = 0; sub < 4; sub++)
+                        tacc[sub] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Sa[(16 * sub + l15) * FLD + 4 * kk + lk], tacc[sub], 0, 0, 0);
+                }
+            }
+            // ... then the tiles that need the L(k,j) of the diagonal workgroups above
 #pragma unroll
             for (int k = j + 1; k < kFbMax; k++) {
-                if (k < ncb) {
-                    const bool own = diag && k == i;       // the diagonal tile: L(i,j) is this workgroup's X_j
-                    if (!own) {
-                        if (!fb_wait(fl_L + 8 * k + j, err, P.flags + FL_FACFAIL, P.spin_limit, &sres)) return;
-                        fb_tile_load(ltiles + (int64_t)(k * (k - 1) / 2 + j) * 4096, Sb, tid);
-                        __syncthreads();
-                    }
-                    const double *Bs = own ? Sa : Sb;
+                if (k < ncb && !(diag && k == i)) {
+                    if (!fb_wait(fl_L + 8 * k + j, err, P.flags + FL_FACFAIL, P.spin_limit, &sres)) return;
+                    fb_tile_load(ltiles + (int64_t)(k * (k - 1) / 2 + j) * 4096, Sb, tid);
+                    __syncthreads();
 #pragma unroll
                     for (int kk = 0; kk < 16; kk++) {
                         const double a = -(Sa[(16 * wv + l15) * FLD + 4 * kk + lk] * Sd[4 * kk + lk]);
 #pragma unroll
                         for (int sub = 0; sub < 4; sub++)
-                            acc[k][sub] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Bs[(16 * sub + l15) * FLD + 4 * kk + lk], acc[k][sub], 0, 0, 0);
+                            acc[k][sub] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Sb[(16 * sub + l15) * FLD + 4 * kk + lk], acc[k][sub], 0, 0, 0);
                     }
                     __syncthreads();                      // Sb is overwritten by the next tile / the next step
                 }
             }
+            if (diag) __syncthreads();                    // Sa (X_j, read by the diagonal tile's update) is rewritten by the next step
         }
     }
-    // ---- the diagonal tile stays in the accumulators (rows 16 wv + lk + 4 reg, columns 16 sub + l15).
-    v4f64 tacc[4];
-#pragma unroll
-    for (int sub = 0; sub < 4; sub++) {
-        tacc[sub] = (v4f64){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int k = 0; k < kFbMax; k++) if (k == i) tacc[sub] = acc[k][sub];
-    }
+    // ---- the diagonal tile stays in its accumulators tacc (rows 16 wv + lk + 4 reg, columns 16 sub + l15).
     double *Pc = Sa;                                                 // [64][9]   the block's columns, by row
     double (*colL)[64] = (double (*)[64])(Sa + 64 * 9);              // [8][64]   l_ik
     double (*colC)[64] = (double (*)[64])(Sa + 64 * 9 + 512);        // [8][64]   raw a_ik = d_k l_ik
@@ -535,7 +545,7 @@ k_front_block(DevPlan P, FrontBatch B, int *sync_all, double *scratch_all, doubl
 #pragma unroll
                     for (int q = 0; q < 4; q++) fb_st16(ltiles + (int64_t)(i * (i - 1) / 2 + i - 1) * 4096 + lane * 64 + 56 + 2 * q, lrow[2 * q], lrow[2 * q + 1]);
                 }
-                if (Bk == 2) {                            // ... drained long ago: hand the tile to the workgroups below
+                if (Bk == 1) {                            // ... drained by now (issued one block = 1.4 us ago): hand the tile to the workgroups below
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     if (lane == 0) __hip_atomic_store(fl_L + 8 * i + (i - 1), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }

@@ -1679,7 +1679,7 @@ k_spmv_long(const int *__restrict__ long_rows, const int64_t *__restrict__ rowpt
 //   column part  sum_{r < i} H(r, i) x_r: column i's rows 0 .. i - 1 are contiguous; every wavefront takes 8 of the strip's columns,
 //                lanes stride over the rows, fixed reduction tree
 // against 2 x (8 + 4 + 8) bytes per entry through the view (one of the two gathers strided: one value per cache line).  Fixed
-// partition and summation order: deterministic.  cfg 5 (20 triangles of 1275): 345 -> see DESIGN.md us per SpMV.
+// partition and summation order: deterministic.  cfg 5 (20 triangles of 1275): 345 -> 86 us per SpMV (2 x 130 MB at 3.4 TB/s, fabric side).
 __global__ void __launch_bounds__(512)
 k_spmv_dense_tri(const DenseTriStrip *__restrict__ strips, const int64_t *__restrict__ col_off, const double *__restrict__ kval,
                  const RefineState *st, const double *__restrict__ x0, const double *__restrict__ x1, double *__restrict__ acc_out) {
