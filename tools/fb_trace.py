@@ -41,3 +41,12 @@ for bi in (1, 8, 15):
     if len(piv) > 1:
         print(f"  chain: pivots start at {[round(v, 2) for v in piv]} -> {np.mean(np.diff(piv)):.2f} us per panel; pivots themselves "
               f"{np.mean([t[bi, i, 8] - t[bi, i, 7] for i in range(len(piv))]):.2f} us")
+        # streamed chain: what one panel of the chain is made of: lead = the consumer's first record after the
+        # producer's pivot start (it needs the tile L(i, i-1) first), then 8 records; tail = streamed -> its own pivot start
+        for i in range(2, len(piv)):
+            if t[bi, i, 12] > 0 and t[bi, i, 13] > 0:
+                lead = t[bi, i, 12] - t[bi, i - 1, 7]
+                per_rec = (t[bi, i, 13] - t[bi, i, 12]) / 8.0
+                behind = t[bi, i, 13] - t[bi, i - 1, 8]
+                print(f"    wg {i}: first record {lead:5.2f} us after wg {i-1}'s pivot start, {per_rec:4.2f} us per record, last record done "
+                      f"{behind:5.2f} us after wg {i-1}'s last pivot (producer: {(t[bi, i-1, 8] - t[bi, i-1, 7]) / 8.0:4.2f} us per block)")
