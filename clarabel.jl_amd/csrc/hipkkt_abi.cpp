@@ -596,6 +596,16 @@ int32_t hipkkt_get_timing(hipkkt_handle h, double *o) {
 
 int32_t hipkkt_abi_version(void) { return HIPKKT_ABI_VERSION; }
 
+int32_t hipkkt_box_probe(int32_t device_id, double *out, int64_t cap) {
+    if (!out || cap < 0) return HIPKKT_ERR_ARGUMENT;
+    double o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    try {
+        if (hipkkt::box_probe(device_id, o) != 0) return HIPKKT_ERR_DEVICE;
+    } catch (...) { return HIPKKT_ERR_DEVICE; }
+    for (int64_t i = 0; i < cap && i < 8; i++) out[i] = o[i];
+    return HIPKKT_OK;
+}
+
 int32_t hipkkt_get_profile(hipkkt_handle h, double *out, int64_t cap) {
     if (!h || !out || cap < 0) return HIPKKT_ERR_ARGUMENT;
     const double o[10] = {h->t_last_update, h->prof_dense4_ms, h->prof_dense4_flops, (double)h->prof_dense4_launches, h->prof_fb_ms,

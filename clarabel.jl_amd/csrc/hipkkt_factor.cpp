@@ -161,8 +161,8 @@ int32_t hipkkt_refactor(hipkkt_handle h, int32_t static_reg_enable, double eps_c
     int32_t rc = refactor_once(h, static_reg_enable, eps_const, eps_prop, eps_used, n_dynamic_reg);
     // tests: HIPKKT_FORCE_TWIN=1 treats every successful factorisation in the cheap order as broken down, so that the robust-order
     // twin can be checked in ITS permutation on problems a scalar CPU factorisation finishes in seconds
-    const bool force_twin = [] { const char *e = getenv("HIPKKT_FORCE_TWIN"); return e && e[0] == '1'; }();   // (read per call: a test process sets it for one test)
-    if (force_twin && rc == HIPKKT_OK && h && h->plan.ordering_used == 1) rc = HIPKKT_NUMERICAL_FAILURE;
+    // (read once per handle in init_runtime: no getenv on the refactor path)
+    if (h && h->force_twin && rc == HIPKKT_OK && h && h->plan.ordering_used == 1) rc = HIPKKT_NUMERICAL_FAILURE;
     if (rc != HIPKKT_NUMERICAL_FAILURE || !h || h->plan.ordering_used != 1) return rc;
     hipkkt_solver *S = h;
     try {

@@ -29,6 +29,7 @@
 #include "runtime_pool.h"
 #include "symbolic.h"
 
+namespace hipkkt { int box_probe(int device, double *out); }   // probe.hip
 namespace hipkkt_host {
 using namespace hipkkt;
 
@@ -144,6 +145,7 @@ struct hipkkt_solver {
         int ncrit = 0;                                  // far stage: the first ncrit dense groups are the next batch's columns
     };
     std::vector<NextBatch> next_batch;
+    bool force_twin = false;             // HIPKKT_FORCE_TWIN=1 at create (tests): see hipkkt_refactor
     bool fb_extra = true;                // the partial last round of a batch's far updates rides in the next k_front_block launch (HIPKKT_FB_EXTRA=0: off)
     long long *d_fb_trace = nullptr;     // HIPKKT_FB_TRACE=1: wall-clock stamps of the first 8 workgroups of every batch (debug_dump 9)
     bool persist_allowed = true;         // false: HIPKKT_NO_PERSIST (never tried)

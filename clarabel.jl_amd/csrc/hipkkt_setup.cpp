@@ -23,7 +23,7 @@ struct PlanCache {
     static constexpr size_t kMaxEntries = 8;
     static constexpr int64_t kMaxNnzL = 40000000;      // bigger plans (hundreds of MB of work lists) are not kept
     static PlanCache &get() { static PlanCache c; return c; }
-    static bool enabled() { const char *e = getenv("HIPKKT_PLAN_CACHE"); return !(e && e[0] == '0'); }   // (read per call: tests switch it)
+    static bool enabled() { const char *e = getenv("HIPKKT_PLAN_CACHE"); return !(e && e[0] == '0'); }   // (read ONCE per create call below)
     static uint64_t fnv(uint64_t h, const void *p, size_t n) {
         const unsigned char *b = (const unsigned char *)p;
         for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 1099511628211ull; }
@@ -67,6 +67,8 @@ void init_runtime(hipkkt_solver *S) {
         S->fb_extra = !(fx && fx[0] == '0');
         const char *fs = getenv("HIPKKT_FB_STREAM");  // 0: the pivot chain of k_front_block hands over L11^-T D^-1 after all 64 pivots (round-3 form)
         S->fb_streamed = !(fs && fs[0] == '0');
+        const char *ft = getenv("HIPKKT_FORCE_TWIN"); // 1 (tests): every successful factorisation in the cheap order counts as broken down (hipkkt_refactor)
+        S->force_twin = ft && ft[0] == '1';
     }
     static_assert(SC_COUNT * sizeof(double) <= RuntimePool::kPinned && sizeof(RefineState) <= RuntimePool::kPinned, "pinned chunk too small");
     for (hipEvent_t *e : {&S->ev0, &S->ev1, &S->ev2, &S->ev3}) *e = (hipEvent_t)need(rp.event_get(S->device));
@@ -741,7 +743,8 @@ int32_t finish_create(hipkkt_solver *S, const hipkkt_opts *opts, hipkkt_handle *
     uint64_t ckey = 0;
     std::string optkey;
     std::shared_ptr<const HostPlan> cached;
-    if (PlanCache::enabled()) {
+    const bool plan_cache_on = PlanCache::enabled();
+    if (plan_cache_on) {
         char buf[256];
         snprintf(buf, sizeof buf, "%d|%d|%d|%d|%.17g|%.17g|%d|%d|%d|%d|%d|%d|%d|%d|%d", po.max_width, (int)po.relax, po.update_policy, po.update_batch,
                  po.amd_dense_scale, po.dense_min_cover, po.n_hold, po.front_block_min_width, po.front_min_panels, po.superhop, po.nd_mode,
@@ -758,7 +761,7 @@ int32_t finish_create(hipkkt_solver *S, const hipkkt_opts *opts, hipkkt_handle *
         S->plan.timing_note = "plan cache hit";
     } else {
         err = build_plan((int)S->img.N, S->img.colptr.data(), S->img.rowval.data(), uperm, po, S->plan);
-        if (err.empty() && PlanCache::enabled()) PlanCache::get().put(ckey, optkey, S->img, S->plan);
+        if (err.empty() && plan_cache_on) PlanCache::get().put(ckey, optkey, S->img, S->plan);
     }
     po.on_alternative_order = nullptr;
     if (!err.empty()) { g_create_error = err; delete S; return HIPKKT_ERR_ARGUMENT; }

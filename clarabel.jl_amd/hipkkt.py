@@ -27,7 +27,7 @@ SYMBOLS = [
     "hipkkt_update_P", "hipkkt_update_A", "hipkkt_refactor", "hipkkt_setrhs", "hipkkt_setrhs_dev", "hipkkt_solve",
     "hipkkt_solve_dev", "hipkkt_solve_multi", "hipkkt_solve_multi_dev", "hipkkt_kkt_solve_reduced", "hipkkt_kkt_solve_reduced_dev", "hipkkt_ldl_solve", "hipkkt_get_timing", "hipkkt_reset_timing", "hipkkt_get_profile", "hipkkt_get_profile_launches", "hipkkt_set_profiling",
     "hipkkt_get_counters", "hipkkt_debug_dump", "hipkkt_debug_extra_tiles", "hipkkt_set_qb", "hipkkt_residuals", "hipkkt_residuals_dev",
-    "hipkkt_selftest_mfma", "hipkkt_last_error",
+    "hipkkt_selftest_mfma", "hipkkt_box_probe", "hipkkt_last_error",
 ]
 
 
@@ -115,6 +115,7 @@ def lib():
     L.hipkkt_debug_extra_tiles.argtypes = [i32, i32, i32, C.POINTER(i32)]
     L.hipkkt_debug_extra_tiles.restype = i32
     L.hipkkt_selftest_mfma.argtypes = [i32, C.POINTER(f64)]
+    L.hipkkt_box_probe.argtypes = [i32, vp, i64]
     L.hipkkt_last_error.argtypes = [vp]
     L.hipkkt_last_error.restype = C.c_char_p
     for nm in SYMBOLS:
@@ -462,3 +463,15 @@ class Handle:
         x = np.zeros(self.N)
         self._chk(self.L.hipkkt_ldl_solve(self.h, x, np.ascontiguousarray(b, dtype=np.float64)), "ldl_solve")
         return x
+
+
+def box_probe(device=0):
+    """hipkkt_box_probe: the shader clock one busy wavefront gets and the flag round trip between workgroups on the same / on
+    different XCDs -- what the latency-bound kernels depend on (include/hipkkt.h)."""
+    out = np.zeros(8)
+    rc = lib().hipkkt_box_probe(device, out.ctypes.data, 8)
+    if rc != 0:
+        raise HipKKTError(f"hipkkt_box_probe failed ({rc})")
+    return {"shader_ghz_one_busy_wave": round(float(out[0]), 4), "flag_round_trip_ns_same_xcd": float(out[1]),
+            "flag_round_trip_ns_other_xcd": float(out[2]), "xcds_seen": int(out[3]), "core_clock_mhz": float(out[4]),
+            "memory_clock_mhz": float(out[5]), "compute_units": int(out[6])}

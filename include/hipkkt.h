@@ -321,6 +321,14 @@ int32_t hipkkt_debug_extra_tiles(int32_t nd, int32_t ncrit, int32_t next_blk, in
  * against a host product with an asymmetric B (returns 0 when they agree to 1e-12) */
 int32_t hipkkt_selftest_mfma(int32_t device_id, double *max_err);
 
+/* diagnostic, no handle needed: what the latency-bound kernels of the factorisation (k_front_block, k_factor_panel, the sweeps) depend
+ * on and the matrix-core- / memory-bound ones do not.  out[0] = the shader clock (GHz) one busy wavefront really gets (shader cycles
+ * against the 100 MHz constant clock), out[1] / out[2] = round trip (ns) of a flag between two workgroups on the SAME / on DIFFERENT
+ * XCDs with relaxed agent-scope atomics (the hand-offs of the front kernels; -1 = no such pair), out[3] = XCDs seen, out[4] / out[5] =
+ * the runtime's core / memory clock (MHz), out[6] = compute units, out[7] = reserved.  Writes min(cap, 8) values.  bench.py prints it
+ * in its JSON line so that a slow line names its cause. */
+int32_t hipkkt_box_probe(int32_t device_id, double *out, int64_t cap);
+
 /* last error text for this handle (or for a failed create when h == NULL); never NULL */
 const char *hipkkt_last_error(hipkkt_handle h);
 

@@ -22,3 +22,15 @@ def oracle_factory():
         return OracleKKTSolver(P, A, cones, m, n, settings, ordering=ordering)
 
     return fac
+
+
+@pytest.fixture(autouse=True)
+def _hipkkt_env_is_restored():
+    """Every HIPKKT_* switch a test sets (or leaks) is gone again for the next test: the suite must give the same result as one
+    process in file order (the driver's `pytest -x -q -m gpu`) and spread over xdist workers."""
+    before = {k: v for k, v in os.environ.items() if k.startswith("HIPKKT_")}
+    yield
+    for k in [k for k in os.environ if k.startswith("HIPKKT_")]:
+        if k not in before:
+            del os.environ[k]
+    os.environ.update(before)

@@ -223,7 +223,7 @@ def _traces_agree(tg, tc, upto, tol=1e-10):
 
 @pytest.mark.slow
 @pytest.mark.parametrize("name,max_iter", [("cfg3", None), ("cfg2a", 5), ("cfg5", None)])
-def test_full_size_ipm_matches_oracle(name, max_iter, oracle_factory, capsys):
+def test_full_size_ipm_matches_oracle(name, max_iter, oracle_factory, capsys, monkeypatch):
     """The whole IPM at FULL size against the oracle on the same elimination order, iterate by iterate: objective (relative) and
     residuals (absolute, info.jl:50-51) to 1e-10 at EVERY iteration, status and iteration count equal.  Oracle cost on one host core:
     cfg 3 ~5.4 s per iteration (~80 s), cfg 2a ~25 s per iteration (the first 5 iterations: max_iter = 5 on both sides), cfg 5
@@ -241,8 +241,7 @@ def test_full_size_ipm_matches_oracle(name, max_iter, oracle_factory, capsys):
     # the cheap order's permutation (the handle reports the twin's while the last factorisation lives there)
     perm = hg.perm() if not hg.counters()["in_twin"] else None
     if perm is None:
-        import os
-        os.environ["HIPKKT_PLAN_CACHE"] = "0"
+        monkeypatch.setenv("HIPKKT_PLAN_CACHE", "0")
         Pt, At, cn = _prep((P, q, A, b, cones))
         perm = HipKKTSolver(Pt, At, cn, At.shape[0], At.shape[1], cl.Settings()).h.perm()
     stc = cl.Settings() if max_iter is None else cl.Settings(max_iter=max_iter)

@@ -61,8 +61,11 @@ __global__ void k_lat(double *out, long long *st, double seed) {
 }
 
 template <int VAR>
-__global__ void __launch_bounds__(64) k_piv(const double *A, double *Lout, double *Dout, long long *st, double eps, double delta) {
+__global__ void __launch_bounds__(64) k_piv(const double *A, double *Lout, double *Dout, long long *st, double eps, double delta, int cold) {
     const int lane = threadIdx.x;
+    // cold: drop the instruction cache first -- the real kernel runs its fully unrolled pivot code ONCE per workgroup, i.e. every
+    // instruction of it comes from L2 (round 5: is that what 290 cycles per pivot in the kernel against 101 here are made of?)
+    if (cold) asm volatile("s_icache_inv\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
     double a[64];
 #pragma unroll
     for (int c = 0; c < 64; c++) a[c] = A[lane + 64 * c];
@@ -131,6 +134,60 @@ __global__ void __launch_bounds__(64) k_piv(const double *A, double *Lout, doubl
     if (lane == 0) { st[0] = tp; st[1] = nreg; }
 }
 
+// the same chain ("fast" arithmetic) as a ROLLED loop over the 8 blocks with the tile in LDS (lane = row, stride 65): 1/8 of the code,
+// seven of eight iterations run from a warm instruction cache whatever the state at entry
+__global__ void __launch_bounds__(64) k_piv_rolled(const double *A, double *Lout, double *Dout, long long *st, double eps, double delta, int cold) {
+    __shared__ double T[64 * 65];
+    const int lane = threadIdx.x;
+    for (int c = 0; c < 64; c++) T[lane * 65 + c] = A[lane + 64 * c];
+    __syncthreads();
+    if (cold) asm volatile("s_icache_inv\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
+    int nreg = 0;
+    long long tp = 0;
+#pragma unroll 1
+    for (int Bk = 0; Bk < 8; Bk++) {
+        const long long t0 = clock64();
+        double pcol[8], lcol[8], dk[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) pcol[q] = T[lane * 65 + 8 * Bk + q];
+        double akk = rl(pcol[0], 8 * Bk), csq = 0.0, dinv_prev = 0.0;
+#pragma unroll
+        for (int kk = 0; kk < 8; kk++) {
+            const int k = 8 * Bk + kk;
+            double d = fma(-csq, dinv_prev, akk);
+            const bool bad = d < eps;
+            double dinv = rcp3(d);
+            if (bad) { d = delta; dinv = 1.0 / delta; nreg++; }
+            dk[kk] = d;
+            if (kk < 7) {
+                akk = rl(pcol[kk + 1], k + 1);
+                const double cn = rl(pcol[kk], k + 1);
+                csq = cn * cn;
+            }
+            dinv_prev = dinv;
+            const double reg = pcol[kk];
+            const double li = reg * dinv;
+            lcol[kk] = li;
+#pragma unroll
+            for (int jj = kk + 1; jj < 8; jj++) pcol[jj] = fma(-li, rl(reg, 8 * Bk + jj), pcol[jj]);
+        }
+        tp += clock64() - t0;
+#pragma unroll
+        for (int kk = 0; kk < 8; kk++) {
+            T[lane * 65 + 8 * Bk + kk] = lcol[kk];
+            if (lane == 8 * Bk + kk) Dout[8 * Bk + kk] = dk[kk];
+        }
+        for (int c = 8 * Bk + 8; c < 64; c++) {
+            double a = T[lane * 65 + c];
+#pragma unroll
+            for (int kk = 0; kk < 8; kk++) a = fma(-lcol[kk], rl(lcol[kk], c) * dk[kk], a);
+            T[lane * 65 + c] = a;
+        }
+    }
+    for (int c = 0; c < 64; c++) Lout[lane + 64 * c] = T[lane * 65 + c];
+    if (lane == 0) { st[0] = tp; st[1] = nreg; }
+}
+
 int main() {
     std::vector<double> h(64 * 64);
     for (int i = 0; i < 64; i++) for (int j = 0; j < 64; j++) h[i + j * 64] = (i == j ? 70.0 : 0.0) + 0.01 * (((i + 1) * 31 + (j + 1) * 17 + (i ^ j)) % 13);
@@ -147,13 +204,33 @@ int main() {
     std::vector<double> L0(64 * 64), L1(64 * 64), D0(64), D1(64);
     for (int rep = 0; rep < 2; rep++)
         for (int var = 0; var < 2; var++) {
-            if (var == 0) hipLaunchKernelGGL(k_piv<0>, dim3(1), dim3(64), 0, 0, dA, dL, dD, ds, 1e-13, 2e-7);
-            else hipLaunchKernelGGL(k_piv<1>, dim3(1), dim3(64), 0, 0, dA, dL, dD, ds, 1e-13, 2e-7);
+            if (var == 0) hipLaunchKernelGGL(k_piv<0>, dim3(1), dim3(64), 0, 0, dA, dL, dD, ds, 1e-13, 2e-7, 0);
+            else hipLaunchKernelGGL(k_piv<1>, dim3(1), dim3(64), 0, 0, dA, dL, dD, ds, 1e-13, 2e-7, 0);
             hipMemcpy(hs, ds, 64, hipMemcpyDeviceToHost);
             hipMemcpy(var ? L1.data() : L0.data(), dL, 64 * 64 * 8, hipMemcpyDeviceToHost);
             hipMemcpy(var ? D1.data() : D0.data(), dD, 64 * 8, hipMemcpyDeviceToHost);
             if (rep) printf("%s: %lld cycles for 64 pivots (8 blocks, without the rank-8 updates) = %.0f per pivot, nreg %lld\n", var ? "fast" : "cur ", hs[0], hs[0] / 64.0, hs[1]);
         }
+    // instruction cache dropped at entry (s_icache_inv): unrolled against rolled
+    for (int rep = 0; rep < 3; rep++) {
+        hipLaunchKernelGGL(k_piv<1>, dim3(1), dim3(64), 0, 0, dA, dL, dD, ds, 1e-13, 2e-7, 1);
+        hipMemcpy(hs, ds, 64, hipMemcpyDeviceToHost);
+        printf("fast, unrolled, instruction cache dropped at entry: %lld cycles = %.0f per pivot\n", hs[0], hs[0] / 64.0);
+    }
+    for (int cold = 0; cold < 2; cold++)
+        for (int rep = 0; rep < 2; rep++) {
+            hipLaunchKernelGGL(k_piv_rolled, dim3(1), dim3(64), 0, 0, dA, dL, dD, ds, 1e-13, 2e-7, cold);
+            hipMemcpy(hs, ds, 64, hipMemcpyDeviceToHost);
+            printf("fast, ROLLED over the blocks (tile in LDS), %s: %lld cycles = %.0f per pivot\n", cold ? "cache dropped at entry" : "warm", hs[0], hs[0] / 64.0);
+        }
+    {
+        std::vector<double> L2(64 * 64), D2(64);
+        hipMemcpy(L2.data(), dL, 64 * 64 * 8, hipMemcpyDeviceToHost);
+        hipMemcpy(D2.data(), dD, 64 * 8, hipMemcpyDeviceToHost);
+        double e = 0;
+        for (int i = 0; i < 64; i++) e = std::fmax(e, std::fabs(D2[i] - D0[i]) / std::fabs(D0[i]));
+        printf("rolled vs cur: max rel diff D %.2e\n", e);
+    }
     double eL = 0, eD = 0;
     for (int i = 0; i < 64; i++) for (int j = 0; j < i; j++) eL = std::fmax(eL, std::fabs(L1[i + 64 * j] - L0[i + 64 * j]) / std::fmax(1e-300, std::fabs(L0[i + 64 * j])));
     for (int i = 0; i < 64; i++) eD = std::fmax(eD, std::fabs(D1[i] - D0[i]) / std::fabs(D0[i]));
