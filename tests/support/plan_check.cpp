@@ -348,6 +348,48 @@ int plan_check_run(int64_t N, const int64_t *Ap, const int64_t *Ai, const double
     std::vector<double> y(N), ub(P.ubuf_len, 0.0);
     for (int k = 0; k < N; k++) y[k] = b[P.perm[k]];
     SbEmu sbe(P, Lx, Ld);
+    // PLANCHECK_EXPLICIT_INV: 1 = diagonal-block solves as products with the explicit inverses, like the kernels; 2 = the same with one
+    // step of refinement against the factored block itself, y += Linv (b - L y), on the blocks whose inverse has an entry above
+    // PLANCHECK_INV_TAU in magnitude (default 0: every block) -- the kernels' polished form (round 5)
+    const int xmode = getenv("PLANCHECK_EXPLICIT_INV") ? atoi(getenv("PLANCHECK_EXPLICIT_INV")) : 0;
+    const bool xinv = xmode >= 1;
+    const double xtau = getenv("PLANCHECK_INV_TAU") ? atof(getenv("PLANCHECK_INV_TAU")) : 0.0;
+    int64_t nflag = 0;
+    auto flagged = [&](int s_, int w_) {
+        if (xmode < 2) return false;
+        double mx = 0;
+        const double *li = &sbe.Linv[P.sn_diag[s_]];
+        for (int q = 0; q < w_ * w_; q++) mx = std::max(mx, std::fabs(li[q]));
+        return mx > xtau;
+    };
+    // v <- L^-1 v (trans = false) or L^-T v (trans = true) of a w x w unit-lower block through its explicit inverse
+    auto inv_apply = [&](int s_, int w_, double *v, bool trans) {
+        const double *li = &sbe.Linv[P.sn_diag[s_]];
+        const double *ld_ = &Ld[P.sn_diag[s_]];
+        std::vector<double> b0(v, v + w_), t(w_), rr(w_);
+        auto mul_inv = [&](const std::vector<double> &in, std::vector<double> &out) {
+            for (int i = 0; i < w_; i++) {
+                double a = 0;
+                if (!trans) for (int k = 0; k <= i; k++) a += li[i + (size_t)k * w_] * in[k];
+                else for (int k = i; k < w_; k++) a += li[k + (size_t)i * w_] * in[k];
+                out[i] = a;
+            }
+        };
+        mul_inv(b0, t);
+        if (flagged(s_, w_)) {
+            nflag++;
+            for (int i = 0; i < w_; i++) {          // r = b - L t  (or L^T t)
+                double a = b0[i] - t[i];
+                if (!trans) for (int k = 0; k < i; k++) a -= ld_[i + (size_t)k * w_] * t[k];
+                else for (int k = i + 1; k < w_; k++) a -= ld_[k + (size_t)i * w_] * t[k];
+                rr[i] = a;
+            }
+            std::vector<double> c(w_);
+            mul_inv(rr, c);
+            for (int i = 0; i < w_; i++) t[i] += c[i];
+        }
+        for (int i = 0; i < w_; i++) v[i] = t[i];
+    };
     for (int lvl = 0; lvl < P.nlevels; lvl++) {
         for (int q = P.lvl_ptr[lvl]; q < P.lvl_ptr[lvl + 1]; q++) {
             int s = P.lvl_sn[q], w = W(s), r = R(s), f = P.sn_first[s];
@@ -360,6 +402,8 @@ int plan_check_run(int64_t N, const int64_t *Ap, const int64_t *Ai, const double
                 for (int64_t g = P.g_ptr[slot0 + k]; g < P.g_ptr[slot0 + k + 1]; g++) v += ub[P.g_idx[g]];
                 y[f + k] -= v;
             }
+            if (xinv) inv_apply(s, w, &y[f], false);        // the kernels' form (k_fwd_level): y_J = Linv * rhs, a lower-triangular GEMV
+            else
             for (int k = 0; k < w; k++)
                 for (int i = k + 1; i < w; i++) y[f + i] -= ld[i + (size_t)k * w] * y[f + k];
             for (int i = w; i < r; i++) {
@@ -383,6 +427,8 @@ int plan_check_run(int64_t N, const int64_t *Ap, const int64_t *Ai, const double
                 const double *ld = &Ld[P.sn_diag[me.sn]];
                 const double *pan = &Lx[me.panel_off];
                 for (int k = 0; k < me.w; k++) y[me.f + k] -= acc[F.cw * p + k];
+                if (xinv) inv_apply(me.sn, me.w, &y[me.f], false);
+                else
                 for (int k = 0; k < me.w; k++)
                     for (int i = k + 1; i < me.w; i++) y[me.f + i] -= ld[i + (size_t)k * me.w] * y[me.f + k];
                 for (int j = me.w; j < me.r; j++) {      // local row j = front row cw*p + j
@@ -409,11 +455,14 @@ int plan_check_run(int64_t N, const int64_t *Ap, const int64_t *Ai, const double
                 for (int i = w; i < r; i++) a += pan[i + (size_t)k * r] * y[rows[i]];
                 y[f + k] -= a;
             }
+            if (xinv) inv_apply(s, w, &y[f], true);        // k_bwd_final: x_J = Linv^T t
+            else
             for (int k = w - 1; k >= 0; k--)
                 for (int i = k + 1; i < w; i++) y[f + k] -= ld[i + (size_t)k * w] * y[f + i];
         }
     }
     for (int k = 0; k < N; k++) x[P.perm[k]] = y[k];
+    if (xmode >= 2) stats[11] = (double)nflag;   // (diagnostic: block solves that took the refinement step)
     return 0;
 }
 }
