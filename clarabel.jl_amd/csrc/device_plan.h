@@ -58,7 +58,8 @@ struct FrontBatch {
     int32_t x_begin, x_count;
 };
 constexpr int64_t kFbScratch = (int64_t)kFbMax * 4160 + (int64_t)(kFbMax * (kFbMax - 1) / 2) * 4096;   // doubles per batch
-constexpr int kFbRec = 528;       // one streamed block of 8 pivots: [8][64] raw columns a_rk = d_k l_rk, 8 pivots d_k, 8 reciprocals
+constexpr int kFbRec = 768;       // one streamed block of 8 pivots.  front_block2.hip: 12 chunks of 64 lanes (8 of raw columns a_rk = d_k l_rk in
+                                  // operand order, 2 of T = L_bb^-T D_b^-1, 2 of the pivots); front_block.hip uses the first 528: [8][64] raw columns, d, 1/d
 constexpr int64_t kFbStream = (int64_t)kFbMax * 8 * kFbRec;   // doubles per batch
 constexpr int kGathHeavy = 24;    // target entries with more pairs than this get a wavefront of their own
 

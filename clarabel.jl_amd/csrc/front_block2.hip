@@ -1,0 +1,563 @@
+// K4 over a FRONT, one launch per update batch -- second form of the kernel (round 5; the first form is front_block.hip, kept behind
+// HIPKKT_FB_V2=0 for comparison).  Same contract, same work split (workgroup b owns the b-th 64-row block of the batch's first panel,
+// the first nb workgroups are the "diagonal" workgroups whose tiles form the critical chain), same hand-off protocol (write-through
+// payload, flag / NaN sentinel, bounded spins that abort through FL_FACFAIL) -- but every tile lives TRANSPOSED in the FP64
+// matrix-core accumulators: lane (l15, lk) of wavefront w holds the entries (row 16 w + l15, column 16 sub + lk + 4 reg) of a tile.
+// With D[m][n] += A[m][k] B[k][n], lane (l15, lk): A[l15][lk], B[lk][l15], D[lk + 4 reg][l15], a product  C^T = S^T R^T  takes its
+// B operand -- the workgroup's own rows R -- STRAIGHT FROM THE ACCUMULATOR REGISTERS (k-step kk <-> sub = kk / 4, reg = kk % 4) and
+// its A operand -- data shared by all rows: the inverse of a diagonal block, the rows of a diagonal workgroup above, a streamed block
+// of pivots -- from global memory in "operand order" (one coalesced 512-byte load per k-step and 16-row strip).  Consequences:
+//   * no LDS staging and no workgroup barrier anywhere in the steps left of the diagonal: the four wavefronts of a workgroup run
+//     independently; tiles are loaded from / stored to the panels directly from the accumulator layout;
+//   * the consumer of the streamed pivot chain is 2 + <= 8 + 8 matrix-core instructions per block of 8 pivots, all operands in
+//     registers or prefetched: l = p T with T = L_bb^-T D_b^-1 of the block's 8 x 8 diagonal part (formed by an idle wavefront of the
+//     producer), then the rank-8 updates.  It keeps up with the producer however late it starts, so the chain advances by
+//     8 pivot blocks + one hand-off per panel (round 4: + a lead of 8 us and a consumer no faster than the producer);
+//   * the loops over the pivot blocks / stream records are ROLLED (two blocks per iteration, the live 16-column strips rotate through
+//     fixed registers): 1/4 of the code on the critical path.
+// LDS carries only what crosses wavefronts: the diagonal tile's update (X D of all 64 rows), the pivot loop (block columns -> wave 0,
+// its l / raw columns -> everybody) and the blocked inverse of L11.
+//
+// Scratch layouts of a batch (private to this kernel; same sizes as the first form):
+//   operand order of a 64 x 64 tile M, value M(mu, kappa):  offset (16 (mu / 16) + kappa / 4) * 64 + 16 (kappa % 4) + mu % 16
+//   scratch + j * 4160            Minv_j^T in operand order, i.e. value (c, k) = (L_jj^-T D_j^-1)[k][c]; then the 64 pivots d
+//   ltiles + tri(k, j) * 4096     L(k,j) D_j in operand order (mu = row of block k, kappa = column of panel j)
+//   stream + (8 j + Bk) * kFbRec  record of pivot block Bk of tile j, 12 chunks of 64 lanes: chunks 2 q + e (q < 4, e < 2): raw column
+//                                 a[c = 16 q + l15][k' = 4 e + lk] = d_k' l_ck' of the tile's rows; 8 + e: T[4 e + lk][l15] (0 for
+//                                 l15 >= 8); 10 + e: d[4 e + lk]
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels.h"
+#include "dense_tile.h"
+
+namespace hipkkt {
+namespace {
+
+constexpr int LDT = 65;   // LDS row stride of the 64 x 64 tiles of the inverse
+constexpr int CS = 68;    // row stride of the pivot loop's column buffers (the four k-rows a lane quad reads sit in different banks)
+
+__device__ __forceinline__ int f2_ldi(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double f2_ld(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void f2_st(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double f2_readlane(double x, int l) {   // l wave-uniform
+    const unsigned long long u = (unsigned long long)__double_as_longlong(x);
+    const unsigned lo = __builtin_amdgcn_readlane((unsigned)u, l), hi = __builtin_amdgcn_readlane((unsigned)(u >> 32), l);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ __forceinline__ double f2_rcp3(double d) {   // front_block.hip fb_rcp3
+    const double r = __builtin_amdgcn_rcp(d);
+    const double e = fma(-d, r, 1.0);
+    const double e2 = fma(e, e, e);
+    return fma(r, e2, r);
+}
+// LDS-only workgroup barrier (front_block.hip fb_bar: __syncthreads() would also wait for the write-through stores in flight)
+__device__ __forceinline__ void f2_bar() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// front_block.hip fb_mfma_settle: wait states between matrix-core instructions and an exec-masked block / a loop back-edge
+__device__ __forceinline__ void f2_settle() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+constexpr unsigned long long kSent = 0xFFFFDEADFFFFDEADull;   // "not written yet" in a stream record (k_fb_reset, front_block.hip)
+__device__ __forceinline__ bool f2_fresh(double v) { return (unsigned long long)__double_as_longlong(v) != kSent; }
+
+// Wave-level wait for a counter of another workgroup: every lane polls the same word and the value is made wave-uniform, so the
+// loop is a scalar branch (no exec-masked block next to matrix-core code).  false = timed out / somebody else failed.
+__device__ __forceinline__ bool f2_wait(const int *flag, int want, int *err, int *failflag, unsigned lim) {
+    for (unsigned spins = 0;; spins++) {
+        if (__builtin_amdgcn_readfirstlane(f2_ldi(flag)) >= want) return true;
+        if ((spins & 63u) == 63u || lim < 64u) {
+            if (spins > lim) {
+                __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((threadIdx.x & 63) == 0) atomicOr(failflag, 1);
+                return false;
+            }
+            if (__builtin_amdgcn_readfirstlane(f2_ldi(err)) != 0) return false;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+// this wavefront's write-through stores have drained: count it in (consumers wait for all four wavefronts)
+__device__ __forceinline__ void f2_wave_done(int *flag) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ void f2_extra_tiles(const DevPlan &P, int begin, int count, int xb, int per_wave) {   // front_block.hip fb_extra_tiles
+    const int lane = threadIdx.x & 63;
+    int idx = rfl((xb * 4 + (int)(threadIdx.x >> 6)) * per_wave);
+    for (int q = 0; q < per_wave && idx < count; q++, idx++) dense_tile<4, 4, true>(P, P.dgroups + begin + idx, lane, 0, 0);
+}
+
+#define F2_T(slot) do { if (TRACE) { if (trace && tid == 0 && i < 5) trace[(B.sync_off / 128 * 8 + i) * 16 + (slot)] = (long long)wall_clock64(); } } while (0)
+#define F2_TB(ph) do { if (TRACE) { if (trace && tid == 0 && i == 0) trace[(B.sync_off / 128 * 8 + 5) * 16 + 4 * Bk + (ph)] = (long long)clock64(); } } while (0)
+
+template <bool TRACE>
+__global__ void __launch_bounds__(256)
+k_front_block2(DevPlan P, FrontBatch B, int *sync_all, double *scratch_all, double *stream_all, double dyn_eps, double dyn_delta,
+               long long *trace) {
+    // S0: regular steps: two buffers [4 waves][16 k-steps][64 lanes] of X D (diagonal workgroups); streamed step: the l d exchange at
+    //     S0 + 4096; pivot loop: Pc, colL, cC (two buffers), dsave, dinvs at S0; inverse: X at S0, products at S0 + 4160
+    __shared__ double S0[8320];
+    __shared__ double S1[64 * LDT];     // L11 of the diagonal tile (unit lower, row-major stride LDT)
+    __shared__ double Sd[64];
+    __shared__ int sblk;
+    int *sync = sync_all + B.sync_off;
+    int *err = sync + 1, *fl_minv = sync + 32, *fl_L = sync + 64;
+    double *scratch = scratch_all + B.scratch_off;
+    double *ltiles = scratch + (int64_t)kFbMax * 4160;
+    double *stream = stream_all + B.stream_off;
+    const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lk = lane >> 4;
+    const int wv = rfl(tid >> 6);
+    if ((int)blockIdx.x >= B.i_end - B.i_base) {          // extra workgroup: tiles of the previous update stage (no hand-off, no LDS)
+        f2_extra_tiles(P, B.x_begin, B.x_count, (int)blockIdx.x - (B.i_end - B.i_base), B.pad > 0 ? B.pad : 1);
+        return;
+    }
+    if (tid == 0) sblk = atomicAdd(sync + B.tick, 1);
+    __syncthreads();
+    const int i = rfl(B.i_base + sblk);                   // row block of this workgroup
+    if (i >= B.i_end) return;
+    F2_T(0);
+    const FrontPanel *fp = P.front_panels + B.fp_off;
+    const int nb = B.nb;
+    const bool diag = i < nb;
+    const int ncb = diag ? i + 1 : nb;                    // column blocks held here
+    const int nsteps = diag ? i - 1 : nb;                 // regular steps; a diagonal workgroup's last panel (i - 1) is streamed
+    const int nr = min(64, B.r0 - 64 * i);
+    const int n = 16 * wv + l15;                          // this lane's row of the block
+    const bool rowok = n < nr;
+    const int f = diag ? fp[i].f : 0;
+    const signed char sgn_l = diag ? P.sgn_perm[f + lane] : (signed char)0;
+    int *failflag = P.flags + FL_FACFAIL;
+    const unsigned lim = P.spin_limit;
+
+    // ---- the row block, straight into the accumulator layout (16 loads per tile and lane, 128-byte segments)
+    v4f64 acc[kFbMax][4];
+#pragma unroll
+    for (int k = 0; k < kFbMax; k++) {
+        if (k < ncb) {
+            const FrontPanel pk = fp[k];
+            const double *src = P.Lx + pk.panel_off + 64 * (i - k) + n;
+#pragma unroll
+            for (int sub = 0; sub < 4; sub++)
+#pragma unroll
+                for (int reg = 0; reg < 4; reg++) acc[k][sub][reg] = rowok ? src[(int64_t)(16 * sub + lk + 4 * reg) * pk.r] : 0.0;
+        } else {
+#pragma unroll
+            for (int sub = 0; sub < 4; sub++) acc[k][sub] = (v4f64){0.0, 0.0, 0.0, 0.0};
+        }
+    }
+    // a diagonal workgroup's own tile lives in registers of its own from the start (it is updated in every step)
+    v4f64 tr[4];
+#pragma unroll
+    for (int sub = 0; sub < 4; sub++) {
+        tr[sub] = (v4f64){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < kFbMax; k++)
+            if (k == i) tr[sub] = acc[k][sub];
+    }
+    F2_T(1);
+
+    // ---- the panels left of this block: X_j^T = Minv_j^T A_j^T, then A_k^T -= (L(k,j) D_j) X_j^T for the tiles right of it
+#pragma unroll
+    for (int j = 0; j < kFbMax; j++) {
+        if (j < nsteps) {                                 // workgroup-uniform
+            if (!f2_wait(fl_minv + j, 1, err, failflag, lim)) return;
+            const FrontPanel pj = fp[j];
+            const double *mv = scratch + (int64_t)j * 4160;
+            double dj[4][4];                              // pivots of this lane's columns m = 16 sub + lk + 4 reg
+#pragma unroll
+            for (int sub = 0; sub < 4; sub++)
+#pragma unroll
+                for (int reg = 0; reg < 4; reg++) dj[sub][reg] = f2_ld(mv + 4096 + 16 * sub + lk + 4 * reg);
+            v4f64 x[4];
+#pragma unroll
+            for (int so = 0; so < 4; so++) {
+                x[so] = (v4f64){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int kk = 0; kk < 4 * so + 4; kk++)   // Minv is upper triangular: k <= c
+                    x[so] = __builtin_amdgcn_mfma_f64_16x16x4f64(f2_ld(mv + (so * 16 + kk) * 64 + lane), acc[j][kk >> 2][kk & 3], x[so], 0, 0, 0);
+            }
+            if (diag) {
+                // L(i,j) D_j for the workgroups below (operand order: this lane's entry is exactly its own slot), the same through
+                // LDS for the other wavefronts of this workgroup, then the diagonal tile  T_ii -= (X D) X^T
+                double *lt = ltiles + (int64_t)(i * (i - 1) / 2 + j) * 4096;
+                double *xd = S0 + (j & 1) * 4096;
+#pragma unroll
+                for (int sub = 0; sub < 4; sub++)
+#pragma unroll
+                    for (int reg = 0; reg < 4; reg++) {
+                        const double v = x[sub][reg] * dj[sub][reg];
+                        f2_st(lt + (wv * 16 + 4 * sub + reg) * 64 + lane, v);
+                        xd[(wv * 16 + 4 * sub + reg) * 64 + lane] = v;
+                    }
+                f2_bar();
+#pragma unroll
+                for (int so = 0; so < 4; so++)
+#pragma unroll
+                    for (int kk = 0; kk < 16; kk++)
+                        tr[so] = __builtin_amdgcn_mfma_f64_16x16x4f64(-xd[(so * 16 + kk) * 64 + lane], x[kk >> 2][kk & 3], tr[so], 0, 0, 0);
+                f2_settle();
+                f2_wave_done(fl_L + 8 * i + j);
+            }
+            // the panel (column-major) and its row-major copy for the backward solves
+            f2_settle();
+            if (rowok) {
+                double *dst = P.Lx + pj.panel_off + 64 * (i - j) + n;
+                double *lt2 = P.LT + pj.lt_off + (int64_t)(64 * (i - j) - 64 + n) * 64;
+#pragma unroll
+                for (int sub = 0; sub < 4; sub++)
+#pragma unroll
+                    for (int reg = 0; reg < 4; reg++) {
+                        dst[(int64_t)(16 * sub + lk + 4 * reg) * pj.r] = x[sub][reg];
+                        lt2[16 * sub + lk + 4 * reg] = x[sub][reg];
+                    }
+            }
+            // the tiles that need the rows of the diagonal workgroups above
+#pragma unroll
+            for (int k = j + 1; k < kFbMax; k++) {
+                if (k < ncb && !(diag && k == i)) {
+                    if (!f2_wait(fl_L + 8 * k + j, 4, err, failflag, lim)) return;
+                    const double *lt = ltiles + (int64_t)(k * (k - 1) / 2 + j) * 4096;
+#pragma unroll
+                    for (int so = 0; so < 4; so++)
+#pragma unroll
+                        for (int kk = 0; kk < 16; kk++)
+                            acc[k][so] = __builtin_amdgcn_mfma_f64_16x16x4f64(-f2_ld(lt + (so * 16 + kk) * 64 + lane), x[kk >> 2][kk & 3], acc[k][so], 0, 0, 0);
+                }
+            }
+        }
+    }
+    F2_T(2);
+    if (!diag) return;
+
+    // ---- streamed step: this workgroup's rows of panel i - 1, record by record behind the workgroup that eliminates tile i - 1.
+    //      Rolled over pairs of records; xr[0] is always the 16-column strip the current records belong to.
+    if (i > 0) {
+        v4f64 xr[4];                                      // the tile of panel i - 1
+#pragma unroll
+        for (int sub = 0; sub < 4; sub++) {
+            xr[sub] = (v4f64){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int k = 0; k < kFbMax; k++)
+                if (k == i - 1) xr[sub] = acc[k][sub];
+        }
+        const double *rec0 = stream + (int64_t)(i - 1) * 8 * kFbRec;
+        const FrontPanel pl = fp[i - 1];
+        double *lt_out = ltiles + (int64_t)(i * (i - 1) / 2 + i - 1) * 4096;
+        double *ldx = S0 + 4096;                          // [2 buffers][4 waves][2][64 lanes]
+        f2_bar();                                         // the X D buffers of the regular steps are free
+        double nc[4][2], nt[2], nd[2];
+        auto request = [&](const double *rec, int sbn) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int qq = min(sbn + q, 3);
+                nc[q][0] = f2_ld(rec + (qq * 2) * 64 + lane);
+                nc[q][1] = f2_ld(rec + (qq * 2 + 1) * 64 + lane);
+            }
+            nt[0] = f2_ld(rec + 8 * 64 + lane); nt[1] = f2_ld(rec + 9 * 64 + lane);
+            nd[0] = f2_ld(rec + 10 * 64 + lane); nd[1] = f2_ld(rec + 11 * 64 + lane);
+        };
+        auto all_fresh = [&]() {
+            bool ok = f2_fresh(nt[0]) && f2_fresh(nt[1]) && f2_fresh(nd[0]) && f2_fresh(nd[1]);
+#pragma unroll
+            for (int q = 0; q < 4; q++) ok = ok && f2_fresh(nc[q][0]) && f2_fresh(nc[q][1]);
+            return __builtin_amdgcn_readfirstlane((int)(__ballot(ok) == ~0ull)) != 0;
+        };
+        request(rec0, 0);
+#pragma unroll 1
+        for (int sb = 0; sb < 4; sb++) {
+#pragma unroll
+            for (int par = 0; par < 2; par++) {
+                const int Bk = 2 * sb + par;
+                const double *rec = rec0 + (int64_t)Bk * kFbRec;
+                for (unsigned spins = 0; !all_fresh(); spins++) {      // level with the producer: poll (bounded)
+                    if ((spins & 63u) == 63u || lim < 64u) {
+                        if (spins > lim) {
+                            __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (lane == 0) atomicOr(failflag, 1);
+                            return;
+                        }
+                        if (__builtin_amdgcn_readfirstlane(f2_ldi(err)) != 0) return;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                    request(rec, sb);
+                }
+                if (Bk == 0) F2_T(3);
+                double cr[4][2], tv[2], dv[2];
+#pragma unroll
+                for (int q = 0; q < 4; q++) { cr[q][0] = nc[q][0]; cr[q][1] = nc[q][1]; }
+                tv[0] = nt[0]; tv[1] = nt[1]; dv[0] = nd[0]; dv[1] = nd[1];
+                if (Bk < 7) request(rec + kFbRec, par ? sb + 1 : sb);   // the next record is requested while this one is processed
+                // l^T = T^T p^T: the block's 8 columns of the strip are the B operand as they stand
+                v4f64 lT = {0.0, 0.0, 0.0, 0.0};
+                lT = __builtin_amdgcn_mfma_f64_16x16x4f64(tv[0], xr[0][2 * par], lT, 0, 0, 0);
+                lT = __builtin_amdgcn_mfma_f64_16x16x4f64(tv[1], xr[0][2 * par + 1], lT, 0, 0, 0);
+                // l d for the other wavefronts (diagonal tile) and for the workgroups below
+                const double ld0 = lT[0] * dv[0], ld1 = lT[1] * dv[1];
+                double *lx = ldx + par * 512;
+                lx[(wv * 2) * 64 + lane] = ld0;
+                lx[(wv * 2 + 1) * 64 + lane] = ld1;
+                f2_st(lt_out + (wv * 16 + 2 * Bk) * 64 + lane, ld0);
+                f2_st(lt_out + (wv * 16 + 2 * Bk + 1) * 64 + lane, ld1);
+                // rank-8 update of the columns right of the block
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    if (q < 4 - sb && !(par == 1 && q == 0)) {
+                        xr[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(-cr[q][0], lT[0], xr[q], 0, 0, 0);
+                        xr[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(-cr[q][1], lT[1], xr[q], 0, 0, 0);
+                    }
+                }
+                f2_bar();
+#pragma unroll
+                for (int so = 0; so < 4; so++) {
+                    tr[so] = __builtin_amdgcn_mfma_f64_16x16x4f64(-lx[(so * 2) * 64 + lane], lT[0], tr[so], 0, 0, 0);
+                    tr[so] = __builtin_amdgcn_mfma_f64_16x16x4f64(-lx[(so * 2 + 1) * 64 + lane], lT[1], tr[so], 0, 0, 0);
+                }
+                // the panel and its row-major copy: columns m = 8 Bk + 4 e + lk of row n
+                f2_settle();
+                if (rowok) {
+                    double *dst = P.Lx + pl.panel_off + 64 + n;
+                    double *lt2 = P.LT + pl.lt_off + (int64_t)n * 64;
+                    const int m0 = 8 * Bk + lk;
+                    dst[(int64_t)m0 * pl.r] = lT[0];
+                    dst[(int64_t)(m0 + 4) * pl.r] = lT[1];
+                    lt2[m0] = lT[0];
+                    lt2[m0 + 4] = lT[1];
+                }
+            }
+            xr[0] = xr[1]; xr[1] = xr[2]; xr[2] = xr[3];
+            f2_settle();
+        }
+        F2_T(4);
+    }
+
+    // ---- the diagonal tile.  Per block of 8 pivots: every wave hands the block's 8 columns of its rows to wave 0 through LDS, wave 0
+    //      eliminates them without leaving the wavefront (lane = row; the pivot rule and arithmetic of k_factor_panel / front_block.hip),
+    //      every wave applies the rank-8 update to its 16 rows on the matrix core.  Waves 1 - 3 publish the record of block Bk - 1
+    //      WHILE wave 0 eliminates block Bk (wave 1 forms T of that block first).  tr[0] is always the strip the block belongs to.
+    double *Pc = S0;                                      // [64][9]   the block's columns, by row
+    double *colL = S0 + 576;                              // [8][CS]   l_ik
+    double *cCa = colL + 8 * CS, *cCb = cCa + 8 * CS;     // [8][CS]   raw a_ik = d_k l_ik, two buffers
+    double *dsave = cCb + 8 * CS, *dinvs = dsave + 64;    // [64] d_k, [64] 1 / d_k as used on the chain
+    double *L11 = S1;
+    const unsigned long long spos = __ballot(sgn_l > 0);
+    const double dyn_delta_inv = 1.0 / dyn_delta;
+    int nreg = 0;
+    const bool pub = i + 1 < nb;
+    auto publish = [&](int Bp) {                          // waves 1 - 3: record of block Bp for the next diagonal workgroup
+        const double *cP = (Bp & 1) ? cCb : cCa;
+        double *rec = stream + ((int64_t)i * 8 + Bp) * kFbRec;
+        if (wv == 1) {
+            // row kq of X = L_bb^-1 by back substitution (x_j = -sum_{m > j} x_m L_mj for j < kq), every lane the full recurrence
+            // with uniform LDS reads; T[k][k'] = X[k'][k] / d_k'
+            const int kq = l15 & 7, o = 8 * Bp;
+            double xs[8];
+#pragma unroll
+            for (int m = 0; m < 8; m++) xs[m] = m == kq ? 1.0 : 0.0;
+#pragma unroll
+            for (int j = 6; j >= 0; j--) {
+                double v = 0.0;
+#pragma unroll
+                for (int m = j + 1; m < 8; m++) v = fma(-xs[m], L11[(o + m) * LDT + o + j], v);
+                xs[j] = j < kq ? v : xs[j];
+            }
+            const double di = dinvs[o + kq];
+            const double s0 = lk == 0 ? xs[0] : (lk == 1 ? xs[1] : (lk == 2 ? xs[2] : xs[3]));
+            const double s1 = lk == 0 ? xs[4] : (lk == 1 ? xs[5] : (lk == 2 ? xs[6] : xs[7]));
+            f2_st(rec + 8 * 64 + lane, l15 < 8 ? s0 * di : 0.0);
+            f2_st(rec + 9 * 64 + lane, l15 < 8 ? s1 * di : 0.0);
+            f2_st(rec + 10 * 64 + lane, dsave[o + lk]);
+            f2_st(rec + 11 * 64 + lane, dsave[o + 4 + lk]);
+        } else if (wv >= 2) {
+            const int q0 = 2 * (wv - 2);
+#pragma unroll
+            for (int q = 0; q < 2; q++)
+#pragma unroll
+                for (int e = 0; e < 2; e++) f2_st(rec + ((q0 + q) * 2 + e) * 64 + lane, cP[(4 * e + lk) * CS + 16 * (q0 + q) + l15]);
+        }
+    };
+    f2_bar();                                             // the l d buffers of the streamed step are free
+    F2_T(5);
+#pragma unroll 1
+    for (int sb = 0; sb < 4; sb++) {
+#pragma unroll
+        for (int par = 0; par < 2; par++) {
+            const int Bk = 2 * sb + par;
+            double *cC = par ? cCb : cCa;
+            Pc[n * 9 + lk] = tr[0][2 * par];
+            Pc[n * 9 + 4 + lk] = tr[0][2 * par + 1];
+            f2_bar();
+            F2_TB(0);
+            if (wv == 0) {
+                // front_block.hip's lean chain: d_k = a_kk - c_{k,k-1}^2 / d_{k-1} -> 1 / d_k is one fma, the hardware reciprocal
+                // and three more fma; a_kk and c_{k,k-1} are fetched one pivot earlier; the pivot rule is evaluated next to the
+                // reciprocal and applied by register selects (no branch, no exec mask)
+                double pcol[8], dk[8], dik[8];
+#pragma unroll
+                for (int q = 0; q < 8; q++) pcol[q] = Pc[lane * 9 + q];
+                double akk = f2_readlane(pcol[0], 8 * Bk), csq = 0.0, dinv_prev = 0.0;
+#pragma unroll
+                for (int kk = 0; kk < 8; kk++) {
+                    const int k = 8 * Bk + kk;
+                    double d = fma(-csq, dinv_prev, akk);
+                    const int sm = ((spos >> k) & 1ull) ? 0 : (int)0x80000000;               // expected sign negative: test -d, substitute -delta
+                    const bool bad = __hiloint2double(__double2hiint(d) ^ sm, __double2loint(d)) < dyn_eps;
+                    double dinv = f2_rcp3(d);
+                    double dsub = __hiloint2double(__double2hiint(dyn_delta) ^ sm, __double2loint(dyn_delta));
+                    double isub = __hiloint2double(__double2hiint(dyn_delta_inv) ^ sm, __double2loint(dyn_delta_inv));
+                    asm volatile("" : "+v"(dinv), "+v"(dsub), "+v"(isub));                   // all three in vector registers, unconditionally
+                    d = bad ? dsub : d;
+                    dinv = bad ? isub : dinv;
+                    nreg += bad ? 1 : 0;
+                    dk[kk] = d;
+                    dik[kk] = dinv;
+                    const double reg = pcol[kk];
+                    if (kk < 7) {
+                        akk = f2_readlane(pcol[kk + 1], k + 1);
+                        const double cn = f2_readlane(reg, k + 1);
+                        csq = cn * cn;
+                    }
+                    dinv_prev = dinv;
+                    const double li = reg * dinv;
+                    colL[kk * CS + lane] = li;
+                    cC[kk * CS + lane] = reg;
+                    L11[lane * LDT + k] = li;
+#pragma unroll
+                    for (int jj = kk + 1; jj < 8; jj++) {
+                        const double cj = f2_readlane(reg, 8 * Bk + jj);
+                        pcol[jj] = fma(-li, cj, pcol[jj]);
+                    }
+                }
+                if (lane == 0) {
+#pragma unroll
+                    for (int q = 0; q < 8; q++) { dsave[8 * Bk + q] = dk[q]; dinvs[8 * Bk + q] = dik[q]; }
+                }
+            } else {                                      // next to wave 0's elimination
+                if (Bk == 1 && i > 0) f2_wave_done(fl_L + 8 * i + (i - 1));   // this wave's stores of L(i, i-1) D (streamed step) have drained long ago
+                if (pub && Bk > 0) publish(Bk - 1);
+            }
+            F2_TB(1);
+            f2_bar();
+            F2_TB(2);
+            if (wv == 0 && Bk == 1 && i > 0) f2_wave_done(fl_L + 8 * i + (i - 1));
+            if (Bk < 7) {
+                // a_ij -= sum_k l_ik a_jk over the block's 8 pivots, for the strips that still hold live columns
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    if (q < 4 - sb && !(par == 1 && q == 0)) {
+#pragma unroll
+                        for (int e = 0; e < 2; e++)
+                            tr[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(-cC[(4 * e + lk) * CS + 16 * (sb + q) + l15], colL[(4 * e + lk) * CS + n], tr[q], 0, 0, 0);
+                    }
+                }
+            }
+            f2_settle();
+            F2_TB(3);
+        }
+        tr[0] = tr[1]; tr[1] = tr[2]; tr[2] = tr[3];
+        f2_settle();
+    }
+    if (pub && wv > 0) publish(7);
+    __syncthreads();
+    F2_T(6);
+    // ---- L11^-1 (blocked: 16 x 16 diagonal blocks by substitution, the rest on the matrix core), then  Minv = L11^-T D^-1
+    double *Sa = S0, *St = S0 + 4160;
+    const double *Sb = S1;
+    auto mm16 = [&](const double *A, int ar, int ac, const double *Bm, int br, int bc, int nk) {
+        v4f64 c = {0.0, 0.0, 0.0, 0.0};
+        for (int kk = 0; kk < nk; kk++)
+            c = __builtin_amdgcn_mfma_f64_16x16x4f64(A[(ar + l15) * LDT + ac + 4 * kk + lk], Bm[(br + 4 * kk + lk) * LDT + bc + l15], c, 0, 0, 0);
+        return c;
+    };
+    double dkeep = 0.0;
+    if (tid < 64) { dkeep = dsave[tid]; Sd[tid] = 1.0 / dkeep; }
+    __syncthreads();
+    for (int idx = tid; idx < 64 * LDT; idx += 256) Sa[idx] = 0.0;
+    __syncthreads();
+    if (tid < 64) {   // thread = column j of diagonal block bq
+        const int bq = tid >> 4, jc = tid & 15, o = 16 * bq;
+        double xx[16];
+#pragma unroll
+        for (int c = 0; c < 16; c++) xx[c] = c == jc ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+#pragma unroll
+            for (int r_ = k + 1; r_ < 16; r_++) xx[r_] = fma(-Sb[(o + r_) * LDT + o + k], xx[k], xx[r_]);
+#pragma unroll
+        for (int c = 0; c < 16; c++) Sa[(o + c) * LDT + o + jc] = xx[c];
+    }
+    __syncthreads();
+    if (wv < 2) {     // block size 16, pairs (0,1) and (2,3):  T = L21 X11
+        const int o = 32 * wv;
+        const v4f64 c = mm16(Sb, o + 16, o, Sa, o, o, 4);
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) St[(o + 16 + lk + 4 * reg) * LDT + o + l15] = c[reg];
+    }
+    __syncthreads();
+    if (wv < 2) {     // X21 = -X22 T
+        const int o = 32 * wv;
+        const v4f64 c = mm16(Sa, o + 16, o + 16, St, o + 16, o, 4);
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) Sa[(o + 16 + lk + 4 * reg) * LDT + o + l15] = -c[reg];
+    }
+    __syncthreads();
+    {                 // block size 32:  T = L21 X11, one 16 x 16 piece per wave
+        const int ti = wv >> 1, tj = wv & 1;
+        const v4f64 c = mm16(Sb, 32 + 16 * ti, 0, Sa, 0, 16 * tj, 8);
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) St[(32 + 16 * ti + lk + 4 * reg) * LDT + 16 * tj + l15] = c[reg];
+    }
+    __syncthreads();
+    {                 // X21 = -X22 T
+        const int ti = wv >> 1, tj = wv & 1;
+        const v4f64 c = mm16(Sa, 32 + 16 * ti, 32, St, 32, 16 * tj, 8);
+        __syncthreads();                                  // every wave has read the X22 rows it needs before X21 is written
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) Sa[(32 + 16 * ti + lk + 4 * reg) * LDT + 16 * tj + l15] = -c[reg];
+    }
+    __syncthreads();
+    {
+        // Minv^T in operand order: value (c, k) = Minv[k][c] = W[c][k] / d_c for c >= k (W = L11^-1), then the pivots
+        double *mv = scratch + (int64_t)i * 4160;
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const int g = wv + 4 * q;                     // group = 16 (c / 16) + k / 4; this wave's lanes are the group's 64 slots
+            const int c = 16 * (g >> 4) + l15, k = 4 * (g & 15) + lk;
+            f2_st(mv + g * 64 + lane, c >= k ? Sa[c * LDT + k] * Sd[c] : 0.0);
+        }
+        if (tid < 64) f2_st(mv + 4096 + tid, dkeep);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(fl_minv + i, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    F2_T(7);
+    // ---- off the critical path: the factored block for the solves' explicit inverses, D and 1/D (exact division)
+    {
+        double *ld = P.Ldiag + fp[i].diag_off;
+        for (int idx = tid; idx < 4096; idx += 256) {
+            const int r_ = idx & 63, k = idx >> 6;
+            ld[idx] = r_ > k ? Sb[r_ * LDT + k] : (r_ == k ? 1.0 : 0.0);
+        }
+        if (tid < 64) {
+            P.D[f + tid] = dkeep;
+            P.Dinv[f + tid] = Sd[tid];
+            if (!isfinite(Sd[tid])) atomicOr(P.flags + FL_NONFINITE, 1);
+        }
+        if (lane == 0 && nreg) atomicAdd(P.flags + FL_NREG, nreg);
+    }
+    F2_T(8);
+}
+
+}  // namespace
+
+void launch_front_block2(hipStream_t st, const DevPlan &P, const FrontBatch &B, int *sync_all, double *scratch_all, double *stream_all,
+                         double dyn_eps, double dyn_delta, long long *trace) {
+    if (B.i_end <= B.i_base) return;
+    const dim3 grid(B.i_end - B.i_base + (B.x_count + 4 * std::max(B.pad, 1) - 1) / (4 * std::max(B.pad, 1)));
+    if (trace) hipLaunchKernelGGL(k_front_block2<true>, grid, dim3(256), 0, st, P, B, sync_all, scratch_all, stream_all, dyn_eps, dyn_delta, trace);
+    else hipLaunchKernelGGL(k_front_block2<false>, grid, dim3(256), 0, st, P, B, sync_all, scratch_all, stream_all, dyn_eps, dyn_delta, trace);
+}
+
+}  // namespace hipkkt

@@ -107,8 +107,10 @@ void enqueue_factor(hipkkt_solver *S, int static_enable, double eps_const, doubl
                 FrontBatch B = S->fbatches[(size_t)cur_bi];
                 B.x_begin = extra_begin; B.x_count = extra_count; B.pad = extra_pw;     // far tiles of the stage before (fb_extra_tiles_of_stage)
                 extra_begin = extra_count = 0;
-                launch_front_block(st, S->dp, B, S->d_fb_sync, S->d_fb_scratch, S->d_fb_stream, S->opts.dynamic_reg_eps,
-                                   S->opts.dynamic_reg_delta, S->fb_streamed, S->d_fb_trace);
+                if (S->fb_v2) launch_front_block2(st, S->dp, B, S->d_fb_sync, S->d_fb_scratch, S->d_fb_stream, S->opts.dynamic_reg_eps,
+                                                  S->opts.dynamic_reg_delta, S->d_fb_trace);
+                else launch_front_block(st, S->dp, B, S->d_fb_sync, S->d_fb_scratch, S->d_fb_stream, S->opts.dynamic_reg_eps,
+                                        S->opts.dynamic_reg_delta, S->fb_streamed, S->d_fb_trace);
             }
             const bool last = l + 1 >= P.nlevels || S->lvl_fb[l + 1] != -2;
             if (!last) continue;                          // the stages inside the batch are applied by the kernel itself
@@ -259,8 +261,10 @@ static int32_t refactor_once(hipkkt_handle h, int32_t static_reg_enable, double 
                     FrontBatch B = S->fbatches[(size_t)cur_bi];
                     B.x_begin = extra_begin; B.x_count = extra_count; B.pad = extra_pw;
                     extra_begin = extra_count = 0;
-                    launch_front_block(st, S->dp, B, S->d_fb_sync, S->d_fb_scratch, S->d_fb_stream, S->opts.dynamic_reg_eps,
-                                       S->opts.dynamic_reg_delta, S->fb_streamed, S->d_fb_trace);
+                    if (S->fb_v2) launch_front_block2(st, S->dp, B, S->d_fb_sync, S->d_fb_scratch, S->d_fb_stream, S->opts.dynamic_reg_eps,
+                                                      S->opts.dynamic_reg_delta, S->d_fb_trace);
+                    else launch_front_block(st, S->dp, B, S->d_fb_sync, S->d_fb_scratch, S->d_fb_stream, S->opts.dynamic_reg_eps,
+                                            S->opts.dynamic_reg_delta, S->fb_streamed, S->d_fb_trace);
                     HK_CHECK(hipEventRecord(b, st));
                     evf.push_back(a);
                     evf.push_back(b);

@@ -67,6 +67,8 @@ void init_runtime(hipkkt_solver *S) {
         S->fb_extra = !(fx && fx[0] == '0');
         const char *fs = getenv("HIPKKT_FB_STREAM");  // 0: the pivot chain of k_front_block hands over L11^-T D^-1 after all 64 pivots (round-3 form)
         S->fb_streamed = !(fs && fs[0] == '0');
+        const char *f2 = getenv("HIPKKT_FB_V2");     // 0: the first form of the front-batch kernel (front_block.hip; A/B timing, comparison test)
+        S->fb_v2 = !(f2 && f2[0] == '0') && S->fb_streamed;   // (HIPKKT_FB_STREAM=0 asks for the round-3 chain, which only the first form has)
         const char *ft = getenv("HIPKKT_FORCE_TWIN"); // 1 (tests): every successful factorisation in the cheap order counts as broken down (hipkkt_refactor)
         S->force_twin = ft && ft[0] == '1';
     }
@@ -668,7 +670,7 @@ static void build_front_batches(hipkkt_solver *S) {
     S->d_fb_sync = S->dalloc<int>(128 * nb_);
     S->d_fb_scratch = S->dalloc<double>((size_t)kFbScratch * nb_);
     fill_async(S->stream, S->d_fb_sync, 0, 128 * nb_ * sizeof(int));
-    S->fb_stream_doubles = S->fb_streamed ? (int64_t)kFbStream * (int64_t)nb_ : 0;
+    S->fb_stream_doubles = (S->fb_streamed || S->fb_v2) ? (int64_t)kFbStream * (int64_t)nb_ : 0;
     S->d_fb_stream = S->dalloc<double>((size_t)std::max<int64_t>(S->fb_stream_doubles, 1));
     if (getenv("HIPKKT_FB_TRACE")) {
         S->d_fb_trace = (long long *)S->dalloc<double>(nb_ * 128);

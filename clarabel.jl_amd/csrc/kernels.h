@@ -24,6 +24,9 @@ void launch_psd_hs(hipStream_t st, double *kval, const int64_t *map_hs, int64_t 
 // front_block.hip
 void launch_front_block(hipStream_t st, const DevPlan &P, const FrontBatch &B, int *sync_all, double *scratch_all, double *stream_all,
                         double dyn_eps, double dyn_delta, bool streamed, long long *trace = nullptr);
+// front_block2.hip: the same batch with every tile transposed in the accumulators (round 5; the default)
+void launch_front_block2(hipStream_t st, const DevPlan &P, const FrontBatch &B, int *sync_all, double *scratch_all, double *stream_all,
+                         double dyn_eps, double dyn_delta, long long *trace = nullptr);
 // zeroes the sync words of all front batches and fills the stream records of the streamed pivot chain with the "not yet written" sentinel
 void launch_fb_reset(hipStream_t st, int *sync_all, int nsync, double *stream_all, int64_t nstream);
 // front_sweep.hip: super-block sweeps over a front (FrontDesc::sb_g > 0) and the super-block inverses they need

@@ -398,6 +398,47 @@ def test_streamed_pivot_chain_equals_whole_tile_handoff(name, monkeypatch):
     assert np.array_equal(hk1.h.debug_dump(5), d1)
 
 
+@pytest.mark.parametrize("name", ["cfg2a", "cfg3"])
+def test_front_block_second_form_equals_first_form(name, monkeypatch):
+    """front_block2.hip (round 5: every tile transposed in the matrix-core accumulators, operands of the steps left of the diagonal
+    straight from registers / global memory, the streamed block of 8 pivots consumed as l = p T with T = L_bb^-T D_b^-1) against
+    front_block.hip (HIPKKT_FB_V2=0, round 4's streamed chain by substitution).  Same factorisation, another rounding of L(i, i-1):
+    D, the dynamic-regularisation count and the unrefined LDL solve agree to rounding, the refined solves agree, and the second form
+    is deterministic (bit-identical when repeated)."""
+    rng = np.random.default_rng(22)
+    Pt, A, cones = _prep(FULL[name]())
+    m, n = A.shape
+    scale_cones(cones, rng)
+    monkeypatch.setenv("HIPKKT_PLAN_CACHE", "0")
+    monkeypatch.setenv("HIPKKT_FB_V2", "0")
+    hk0 = HipKKTSolver(Pt, A, cones, m, n, cl.Settings())
+    assert hk0.kktsolver_update(cones)
+    monkeypatch.setenv("HIPKKT_FB_V2", "1")
+    hk1 = HipKKTSolver(Pt, A, cones, m, n, cl.Settings())
+    assert hk1.kktsolver_update(cones)
+    c = hk1.h.counters()
+    assert c["front_batches"] > 0 and c["front_block"] and c["sweep_timeouts"] == 0
+    assert hk0.h.counters()["front_block"]
+    assert hk0.last_nreg == hk1.last_nreg
+    d0, d1 = hk0.h.debug_dump(5), hk1.h.debug_dump(5)
+    assert np.all(np.sign(d0) == np.sign(d1))
+    assert np.max(np.abs(d1 - d0) / np.maximum(np.abs(d0), 1e-300)) <= 1e-6      # pivots of an ill-conditioned K: rounding, amplified
+    b = rng.standard_normal(hk0.h.N)
+    x0, x1 = hk0.h.ldl_solve(b), hk1.h.ldl_solve(b)
+    assert np.max(np.abs(x1 - x0)) <= 1e-9 * max(1.0, np.max(np.abs(x0)))
+    rx, rz = rng.standard_normal(n), rng.standard_normal(m)
+    sols = []
+    for hk in (hk0, hk1):
+        lx, lz = np.zeros(n), np.zeros(m)
+        hk.kktsolver_setrhs(rx, rz)
+        assert hk.kktsolver_solve(lx, lz)
+        sols.append(np.concatenate([lx, lz]))
+    assert np.max(np.abs(sols[1] - sols[0])) <= 1e-9 * max(1.0, np.max(np.abs(sols[0])))
+    assert hk1.kktsolver_update(cones)
+    assert np.array_equal(hk1.h.ldl_solve(b), x1)
+    assert np.array_equal(hk1.h.debug_dump(5), d1)
+
+
 def test_split_k_of_long_tiles_equals_unsplit_updates(monkeypatch):
     """hipkkt_setup.cpp plan_split_k / kernels.hip k_split_reduce (round 4): in cfg 5 the tiles of the variables' block receive 80+
     contributions per update batch next to thousands of tiles with 4-10; they are cut into chunks accumulated by separate wavefronts

@@ -147,6 +147,7 @@ def test_plan_variants_agree(policy, maxw, oracle_factory):
     {"HIPKKT_NO_PERSIST": "1"},
     {"HIPKKT_NO_FRONT": "1"},
     {"HIPKKT_FB_STREAM": "0", "HIPKKT_FRONT_BLOCK_MIN_ROWS": "0"},
+    {"HIPKKT_FB_V2": "0", "HIPKKT_FRONT_BLOCK_MIN_ROWS": "0"},
     {"HIPKKT_FRONT_BLOCK_MIN_ROWS": "0"},
     {"HIPKKT_ORDERING": "amd"},
     {"HIPKKT_FRONT_BLOCK": "0"},
