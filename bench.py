@@ -129,9 +129,12 @@ def _gpu_batch_chunk(arg):
     def one(seed):
         P, q, A, b, cones = pr_.batch_problem(seed)
         S_ = cl_.Solver(P, q, A, b, cones, cl_.Settings(device_id=device))
+        # the elimination order the oracle is held to in the parity leg: taken BEFORE the solve (afterwards the handle reports its
+        # robust-order twin's permutation while the last factorisation lives there)
+        perm = S_.kktsystem.kktsolver.h.perm()
         sol = S_.solve()
-        return (seed, sol.iterations, sol.status, float(sol.obj_val), _alg_bytes(S_, sol.iterations), S_.kktsystem.kktsolver.h.perm(),
-                float(sol.r_prim), float(sol.r_dual))
+        return (seed, sol.iterations, sol.status, float(sol.obj_val), _alg_bytes(S_, sol.iterations), perm,
+                float(sol.r_prim), float(sol.r_dual), int(S_.kktsystem.kktsolver.h.counters()["twin_refactors"]))
 
     return b_.run_concurrent(one, seeds, in_flight)
 

@@ -13,8 +13,6 @@
 //     registers or prefetched: l = p T with T = L_bb^-T D_b^-1 of the block's 8 x 8 diagonal part (formed by an idle wavefront of the
 //     producer), then the rank-8 updates.  It keeps up with the producer however late it starts, so the chain advances by
 //     8 pivot blocks + one hand-off per panel (round 4: + a lead of 8 us and a consumer no faster than the producer);
-//   * the loops over the pivot blocks / stream records are ROLLED (two blocks per iteration, the live 16-column strips rotate through
-//     fixed registers): 1/4 of the code on the critical path.
 // LDS carries only what crosses wavefronts: the diagonal tile's update (X D of all 64 rows), the pivot loop (block columns -> wave 0,
 // its l / raw columns -> everybody) and the blocked inverse of L11.
 //
@@ -171,13 +169,20 @@ k_front_block2(DevPlan P, FrontBatch B, int *sync_all, double *scratch_all, doub
             for (int sub = 0; sub < 4; sub++)
 #pragma unroll
                 for (int reg = 0; reg < 4; reg++) dj[sub][reg] = f2_ld(mv + 4096 + 16 * sub + lk + 4 * reg);
+            // operands first, all in flight at once (a relaxed atomic load next to its use would make every k-step a memory round
+            // trip: measured 30 us per step), then the products.  Minv is upper triangular: k <= c, 4 so + 4 k-steps per strip
+            double am[40];
+#pragma unroll
+            for (int so = 0, t = 0; so < 4; so++)
+#pragma unroll
+                for (int kk = 0; kk < 4 * so + 4; kk++, t++) am[t] = f2_ld(mv + (so * 16 + kk) * 64 + lane);
             v4f64 x[4];
 #pragma unroll
-            for (int so = 0; so < 4; so++) {
+            for (int so = 0, t = 0; so < 4; so++) {
                 x[so] = (v4f64){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                for (int kk = 0; kk < 4 * so + 4; kk++)   // Minv is upper triangular: k <= c
-                    x[so] = __builtin_amdgcn_mfma_f64_16x16x4f64(f2_ld(mv + (so * 16 + kk) * 64 + lane), acc[j][kk >> 2][kk & 3], x[so], 0, 0, 0);
+                for (int kk = 0; kk < 4 * so + 4; kk++, t++)
+                    x[so] = __builtin_amdgcn_mfma_f64_16x16x4f64(am[t], acc[j][kk >> 2][kk & 3], x[so], 0, 0, 0);
             }
             if (diag) {
                 // L(i,j) D_j for the workgroups below (operand order: this lane's entry is exactly its own slot), the same through
@@ -221,10 +226,16 @@ k_front_block2(DevPlan P, FrontBatch B, int *sync_all, double *scratch_all, doub
                     if (!f2_wait(fl_L + 8 * k + j, 4, err, failflag, lim)) return;
                     const double *lt = ltiles + (int64_t)(k * (k - 1) / 2 + j) * 4096;
 #pragma unroll
-                    for (int so = 0; so < 4; so++)
+                    for (int h = 0; h < 2; h++) {         // two strips at a time: 32 operands in flight
+                        double al[32];
 #pragma unroll
-                        for (int kk = 0; kk < 16; kk++)
-                            acc[k][so] = __builtin_amdgcn_mfma_f64_16x16x4f64(-f2_ld(lt + (so * 16 + kk) * 64 + lane), x[kk >> 2][kk & 3], acc[k][so], 0, 0, 0);
+                        for (int t = 0; t < 32; t++) al[t] = f2_ld(lt + (h * 32 + t) * 64 + lane);
+#pragma unroll
+                        for (int t = 0; t < 32; t++) {
+                            const int so = 2 * h + (t >> 4), kk = t & 15;
+                            acc[k][so] = __builtin_amdgcn_mfma_f64_16x16x4f64(-al[t], x[kk >> 2][kk & 3], acc[k][so], 0, 0, 0);
+                        }
+                    }
                 }
             }
         }
@@ -233,7 +244,6 @@ k_front_block2(DevPlan P, FrontBatch B, int *sync_all, double *scratch_all, doub
     if (!diag) return;
 
     // ---- streamed step: this workgroup's rows of panel i - 1, record by record behind the workgroup that eliminates tile i - 1.
-    //      Rolled over pairs of records; xr[0] is always the 16-column strip the current records belong to.
     if (i > 0) {
         v4f64 xr[4];                                      // the tile of panel i - 1
 #pragma unroll
@@ -248,95 +258,90 @@ k_front_block2(DevPlan P, FrontBatch B, int *sync_all, double *scratch_all, doub
         double *lt_out = ltiles + (int64_t)(i * (i - 1) / 2 + i - 1) * 4096;
         double *ldx = S0 + 4096;                          // [2 buffers][4 waves][2][64 lanes]
         f2_bar();                                         // the X D buffers of the regular steps are free
-        double nc[4][2], nt[2], nd[2];
-        auto request = [&](const double *rec, int sbn) {
+        // Ring of three records in registers: while record Bk is processed, records Bk + 1 and Bk + 2 are in flight (a consumer that
+        // has fallen behind finds them complete and pays no memory round trip per record; one that is level with the producer sees
+        // the sentinel and polls).  Fully unrolled: the strip / register of a block's columns is static.
+        double rc[3][4][2], rt[3][2], rd[3][2];
+#define F2_REQUEST(slot, Bq) do { \
+            const double *rq_ = rec0 + (int64_t)(Bq) * kFbRec; \
+            _Pragma("unroll") for (int q = (Bq) >> 1; q < 4; q++) { \
+                rc[slot][q][0] = f2_ld(rq_ + (q * 2) * 64 + lane); rc[slot][q][1] = f2_ld(rq_ + (q * 2 + 1) * 64 + lane); } \
+            rt[slot][0] = f2_ld(rq_ + 8 * 64 + lane); rt[slot][1] = f2_ld(rq_ + 9 * 64 + lane); \
+            rd[slot][0] = f2_ld(rq_ + 10 * 64 + lane); rd[slot][1] = f2_ld(rq_ + 11 * 64 + lane); } while (0)
+        F2_REQUEST(0, 0); F2_REQUEST(1, 1); F2_REQUEST(2, 2);
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const int qq = min(sbn + q, 3);
-                nc[q][0] = f2_ld(rec + (qq * 2) * 64 + lane);
-                nc[q][1] = f2_ld(rec + (qq * 2 + 1) * 64 + lane);
+        for (int Bk = 0; Bk < 8; Bk++) {
+            const int sb = Bk >> 1, par = Bk & 1, sl = Bk % 3;
+            for (unsigned spins = 0;; spins++) {               // level with the producer: poll (bounded)
+                bool ok = f2_fresh(rt[sl][0]) && f2_fresh(rt[sl][1]) && f2_fresh(rd[sl][0]) && f2_fresh(rd[sl][1]);
+#pragma unroll
+                for (int q = sb; q < 4; q++) ok = ok && f2_fresh(rc[sl][q][0]) && f2_fresh(rc[sl][q][1]);
+                if (__builtin_amdgcn_readfirstlane((int)(__ballot(ok) == ~0ull)) != 0) break;
+                if ((spins & 63u) == 63u || lim < 64u) {
+                    if (spins > lim) {
+                        __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (lane == 0) atomicOr(failflag, 1);
+                        return;
+                    }
+                    if (__builtin_amdgcn_readfirstlane(f2_ldi(err)) != 0) return;
+                }
+                __builtin_amdgcn_s_sleep(1);
+                F2_REQUEST(sl, Bk);
             }
-            nt[0] = f2_ld(rec + 8 * 64 + lane); nt[1] = f2_ld(rec + 9 * 64 + lane);
-            nd[0] = f2_ld(rec + 10 * 64 + lane); nd[1] = f2_ld(rec + 11 * 64 + lane);
-        };
-        auto all_fresh = [&]() {
-            bool ok = f2_fresh(nt[0]) && f2_fresh(nt[1]) && f2_fresh(nd[0]) && f2_fresh(nd[1]);
+            if (Bk == 0) F2_T(3);
+            double cr[4][2], tv[2], dv[2];
 #pragma unroll
-            for (int q = 0; q < 4; q++) ok = ok && f2_fresh(nc[q][0]) && f2_fresh(nc[q][1]);
-            return __builtin_amdgcn_readfirstlane((int)(__ballot(ok) == ~0ull)) != 0;
-        };
-        request(rec0, 0);
-#pragma unroll 1
-        for (int sb = 0; sb < 4; sb++) {
+            for (int q = sb; q < 4; q++) { cr[q][0] = rc[sl][q][0]; cr[q][1] = rc[sl][q][1]; }
+            tv[0] = rt[sl][0]; tv[1] = rt[sl][1]; dv[0] = rd[sl][0]; dv[1] = rd[sl][1];
+            if (Bk + 3 < 8) F2_REQUEST(sl, Bk + 3);
+            // l^T = T^T p^T: the block's 8 columns of the strip are the B operand as they stand
+            v4f64 lT = {0.0, 0.0, 0.0, 0.0};
+            lT = __builtin_amdgcn_mfma_f64_16x16x4f64(tv[0], xr[sb][2 * par], lT, 0, 0, 0);
+            lT = __builtin_amdgcn_mfma_f64_16x16x4f64(tv[1], xr[sb][2 * par + 1], lT, 0, 0, 0);
+            // l d for the other wavefronts (diagonal tile) and for the workgroups below
+            const double ld0 = lT[0] * dv[0], ld1 = lT[1] * dv[1];
+            double *lx = ldx + par * 512;
+            lx[(wv * 2) * 64 + lane] = ld0;
+            lx[(wv * 2 + 1) * 64 + lane] = ld1;
+            f2_st(lt_out + (wv * 16 + 2 * Bk) * 64 + lane, ld0);
+            f2_st(lt_out + (wv * 16 + 2 * Bk + 1) * 64 + lane, ld1);
+            // rank-8 update of the columns right of the block (the block's own strip: only when its second half is still to come)
 #pragma unroll
-            for (int par = 0; par < 2; par++) {
-                const int Bk = 2 * sb + par;
-                const double *rec = rec0 + (int64_t)Bk * kFbRec;
-                for (unsigned spins = 0; !all_fresh(); spins++) {      // level with the producer: poll (bounded)
-                    if ((spins & 63u) == 63u || lim < 64u) {
-                        if (spins > lim) {
-                            __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            if (lane == 0) atomicOr(failflag, 1);
-                            return;
-                        }
-                        if (__builtin_amdgcn_readfirstlane(f2_ldi(err)) != 0) return;
-                    }
-                    __builtin_amdgcn_s_sleep(1);
-                    request(rec, sb);
-                }
-                if (Bk == 0) F2_T(3);
-                double cr[4][2], tv[2], dv[2];
+            for (int q = sb + par; q < 4; q++) {
+                xr[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(-cr[q][0], lT[0], xr[q], 0, 0, 0);
+                xr[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(-cr[q][1], lT[1], xr[q], 0, 0, 0);
+            }
+            f2_bar();
+            {
+                double la[4][2];
 #pragma unroll
-                for (int q = 0; q < 4; q++) { cr[q][0] = nc[q][0]; cr[q][1] = nc[q][1]; }
-                tv[0] = nt[0]; tv[1] = nt[1]; dv[0] = nd[0]; dv[1] = nd[1];
-                if (Bk < 7) request(rec + kFbRec, par ? sb + 1 : sb);   // the next record is requested while this one is processed
-                // l^T = T^T p^T: the block's 8 columns of the strip are the B operand as they stand
-                v4f64 lT = {0.0, 0.0, 0.0, 0.0};
-                lT = __builtin_amdgcn_mfma_f64_16x16x4f64(tv[0], xr[0][2 * par], lT, 0, 0, 0);
-                lT = __builtin_amdgcn_mfma_f64_16x16x4f64(tv[1], xr[0][2 * par + 1], lT, 0, 0, 0);
-                // l d for the other wavefronts (diagonal tile) and for the workgroups below
-                const double ld0 = lT[0] * dv[0], ld1 = lT[1] * dv[1];
-                double *lx = ldx + par * 512;
-                lx[(wv * 2) * 64 + lane] = ld0;
-                lx[(wv * 2 + 1) * 64 + lane] = ld1;
-                f2_st(lt_out + (wv * 16 + 2 * Bk) * 64 + lane, ld0);
-                f2_st(lt_out + (wv * 16 + 2 * Bk + 1) * 64 + lane, ld1);
-                // rank-8 update of the columns right of the block
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    if (q < 4 - sb && !(par == 1 && q == 0)) {
-                        xr[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(-cr[q][0], lT[0], xr[q], 0, 0, 0);
-                        xr[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(-cr[q][1], lT[1], xr[q], 0, 0, 0);
-                    }
-                }
-                f2_bar();
+                for (int so = 0; so < 4; so++) { la[so][0] = lx[(so * 2) * 64 + lane]; la[so][1] = lx[(so * 2 + 1) * 64 + lane]; }
 #pragma unroll
                 for (int so = 0; so < 4; so++) {
-                    tr[so] = __builtin_amdgcn_mfma_f64_16x16x4f64(-lx[(so * 2) * 64 + lane], lT[0], tr[so], 0, 0, 0);
-                    tr[so] = __builtin_amdgcn_mfma_f64_16x16x4f64(-lx[(so * 2 + 1) * 64 + lane], lT[1], tr[so], 0, 0, 0);
-                }
-                // the panel and its row-major copy: columns m = 8 Bk + 4 e + lk of row n
-                f2_settle();
-                if (rowok) {
-                    double *dst = P.Lx + pl.panel_off + 64 + n;
-                    double *lt2 = P.LT + pl.lt_off + (int64_t)n * 64;
-                    const int m0 = 8 * Bk + lk;
-                    dst[(int64_t)m0 * pl.r] = lT[0];
-                    dst[(int64_t)(m0 + 4) * pl.r] = lT[1];
-                    lt2[m0] = lT[0];
-                    lt2[m0 + 4] = lT[1];
+                    tr[so] = __builtin_amdgcn_mfma_f64_16x16x4f64(-la[so][0], lT[0], tr[so], 0, 0, 0);
+                    tr[so] = __builtin_amdgcn_mfma_f64_16x16x4f64(-la[so][1], lT[1], tr[so], 0, 0, 0);
                 }
             }
-            xr[0] = xr[1]; xr[1] = xr[2]; xr[2] = xr[3];
+            // the panel and its row-major copy: columns m = 8 Bk + 4 e + lk of row n
             f2_settle();
+            if (rowok) {
+                double *dst = P.Lx + pl.panel_off + 64 + n;
+                double *lt2 = P.LT + pl.lt_off + (int64_t)n * 64;
+                const int m0 = 8 * Bk + lk;
+                dst[(int64_t)m0 * pl.r] = lT[0];
+                dst[(int64_t)(m0 + 4) * pl.r] = lT[1];
+                lt2[m0] = lT[0];
+                lt2[m0 + 4] = lT[1];
+            }
         }
+#undef F2_REQUEST
         F2_T(4);
     }
 
     // ---- the diagonal tile.  Per block of 8 pivots: every wave hands the block's 8 columns of its rows to wave 0 through LDS, wave 0
     //      eliminates them without leaving the wavefront (lane = row; the pivot rule and arithmetic of k_factor_panel / front_block.hip),
     //      every wave applies the rank-8 update to its 16 rows on the matrix core.  Waves 1 - 3 publish the record of block Bk - 1
-    //      WHILE wave 0 eliminates block Bk (wave 1 forms T of that block first).  tr[0] is always the strip the block belongs to.
+    //      WHILE wave 0 eliminates block Bk (wave 1 forms T of that block first).
     double *Pc = S0;                                      // [64][9]   the block's columns, by row
     double *colL = S0 + 576;                              // [8][CS]   l_ik
     double *cCa = colL + 8 * CS, *cCb = cCa + 8 * CS;     // [8][CS]   raw a_ik = d_k l_ik, two buffers
@@ -380,14 +385,13 @@ k_front_block2(DevPlan P, FrontBatch B, int *sync_all, double *scratch_all, doub
     };
     f2_bar();                                             // the l d buffers of the streamed step are free
     F2_T(5);
-#pragma unroll 1
-    for (int sb = 0; sb < 4; sb++) {
 #pragma unroll
-        for (int par = 0; par < 2; par++) {
-            const int Bk = 2 * sb + par;
+    for (int Bk = 0; Bk < 8; Bk++) {
+        {
+            const int sb = Bk >> 1, par = Bk & 1;
             double *cC = par ? cCb : cCa;
-            Pc[n * 9 + lk] = tr[0][2 * par];
-            Pc[n * 9 + 4 + lk] = tr[0][2 * par + 1];
+            Pc[n * 9 + lk] = tr[sb][2 * par];
+            Pc[n * 9 + 4 + lk] = tr[sb][2 * par + 1];
             f2_bar();
             F2_TB(0);
             if (wv == 0) {
@@ -444,20 +448,21 @@ k_front_block2(DevPlan P, FrontBatch B, int *sync_all, double *scratch_all, doub
             if (wv == 0 && Bk == 1 && i > 0) f2_wave_done(fl_L + 8 * i + (i - 1));
             if (Bk < 7) {
                 // a_ij -= sum_k l_ik a_jk over the block's 8 pivots, for the strips that still hold live columns
+                double bl[2], av[4][2];
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    if (q < 4 - sb && !(par == 1 && q == 0)) {
+                for (int e = 0; e < 2; e++) bl[e] = colL[(4 * e + lk) * CS + n];
 #pragma unroll
-                        for (int e = 0; e < 2; e++)
-                            tr[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(-cC[(4 * e + lk) * CS + 16 * (sb + q) + l15], colL[(4 * e + lk) * CS + n], tr[q], 0, 0, 0);
-                    }
-                }
+                for (int q = sb + par; q < 4; q++)
+#pragma unroll
+                    for (int e = 0; e < 2; e++) av[q][e] = cC[(4 * e + lk) * CS + 16 * q + l15];
+#pragma unroll
+                for (int q = sb + par; q < 4; q++)
+#pragma unroll
+                    for (int e = 0; e < 2; e++) tr[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[q][e], bl[e], tr[q], 0, 0, 0);
             }
             f2_settle();
             F2_TB(3);
         }
-        tr[0] = tr[1]; tr[1] = tr[2]; tr[2] = tr[3];
-        f2_settle();
     }
     if (pub && wv > 0) publish(7);
     __syncthreads();

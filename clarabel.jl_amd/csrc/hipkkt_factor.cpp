@@ -93,7 +93,7 @@ void enqueue_factor(hipkkt_solver *S, int static_enable, double eps_const, doubl
     launch_zero_words(st, S->dp.scal, 2);                 // SC_MAXDIAG  (kernels.hip: why not hipMemsetAsync)
     launch_zero_words(st, S->dp.flags, FL_COUNT);
     launch_maxabs_gather(st, S->dp.kval, S->d_diag_full, S->N, (unsigned long long *)S->dp.scal + SC_MAXDIAG);
-    HK_CHECK(hipMemsetAsync(S->dp.Lx, 0, (size_t)P.panel_doubles * sizeof(double), st));
+    HK_CHECK(hipMemsetAsync(S->dp.Lx, 0, (size_t)(P.panel_doubles + S->split_scratch_doubles) * sizeof(double), st));   // (incl. the split-K partial tiles: a factorisation that aborted between a chunk launch and its reduce must not leave sums behind)
     launch_init_panels(st, S->dp, S->nnzK, static_enable, eps_const, eps_prop);
     const bool fb = S->use_front_block && !S->fbatches.empty();
     if (fb) launch_fb_reset(st, S->d_fb_sync, 128 * (int)S->fbatches.size(), S->d_fb_stream, S->fb_stream_doubles);
@@ -228,7 +228,7 @@ static int32_t refactor_once(hipkkt_handle h, int32_t static_reg_enable, double 
         launch_zero_words(st, S->dp.scal, 2);
         launch_zero_words(st, S->dp.flags, FL_COUNT);
         launch_maxabs_gather(st, S->dp.kval, S->d_diag_full, S->N, (unsigned long long *)S->dp.scal + SC_MAXDIAG);
-        HK_CHECK(hipMemsetAsync(S->dp.Lx, 0, (size_t)P.panel_doubles * sizeof(double), st));
+        HK_CHECK(hipMemsetAsync(S->dp.Lx, 0, (size_t)(P.panel_doubles + S->split_scratch_doubles) * sizeof(double), st));   // (incl. the split-K partial tiles: a factorisation that aborted between a chunk launch and its reduce must not leave sums behind)
         launch_init_panels(st, S->dp, S->nnzK, static_reg_enable, eps_const, eps_prop);
         std::vector<hipEvent_t> evs, evd;   // evs: all update kernels of a stage; evd: its k_update_dense<4,4> launch alone
         std::vector<int> evd_level;

@@ -145,6 +145,7 @@ struct hipkkt_solver {
         int ncrit = 0;                                  // far stage: the first ncrit dense groups are the next batch's columns
     };
     std::vector<NextBatch> next_batch;
+    int64_t split_scratch_doubles = 0;   // split-K partial tiles behind the panels in Lx (cleared with them before every factorisation)
     bool fb_v2 = true;                   // front batches by front_block2.hip (tiles transposed in the accumulators, round 5); HIPKKT_FB_V2=0: front_block.hip
     bool force_twin = false;             // HIPKKT_FORCE_TWIN=1 at create (tests): see hipkkt_refactor
     bool fb_extra = true;                // the partial last round of a batch's far updates rides in the next k_front_block launch (HIPKKT_FB_EXTRA=0: off)

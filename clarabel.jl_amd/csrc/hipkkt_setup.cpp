@@ -443,6 +443,7 @@ void setup_device(hipkkt_solver *S) {
     fill_async(S->stream, D.front_sync, 0, (size_t)std::max(P.front_sync_ints, 16) * sizeof(int));
     build_front_batches(S);
     const int64_t split_scratch = plan_split_k(S, dg);
+    S->split_scratch_doubles = split_scratch;
     D.dgroups = S->upload(dg);
     D.kval = S->upload(S->img.nzval);
     D.Lx = S->dalloc<double>(P.panel_doubles + split_scratch);
