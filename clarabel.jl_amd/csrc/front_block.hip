@@ -94,8 +94,8 @@ __device__ __forceinline__ void fb_mfma_settle() {
     __builtin_amdgcn_sched_barrier(0);
 }
 // "not written yet" in a stream record: a NaN no arithmetic produces (both halves equal, so a 32-bit fill pattern would do too)
-constexpr unsigned kFbSentHalf = 0xFFFFDEADu;
-constexpr unsigned long long kFbSentinel = 0xFFFFDEADFFFFDEADull;
+constexpr unsigned kFbSentHalf = 0xFFFFFFFFu;               // (all ones: front_block2.hip tests a whole record with unsigned maxima of the high words)
+constexpr unsigned long long kFbSentinel = 0xFFFFFFFFFFFFFFFFull;
 __device__ __forceinline__ bool fb_fresh(v4u r) {
     return !(r[0] == kFbSentHalf && r[1] == kFbSentHalf) && !(r[2] == kFbSentHalf && r[3] == kFbSentHalf);
 }

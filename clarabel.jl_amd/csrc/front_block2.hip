@@ -25,6 +25,7 @@
 //                                 l15 >= 8); 10 + e: d[4 e + lk]
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "kernels.h"
 #include "dense_tile.h"
@@ -57,8 +58,17 @@ __device__ __forceinline__ void f2_settle() {
     asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
 }
-constexpr unsigned long long kSent = 0xFFFFDEADFFFFDEADull;   // "not written yet" in a stream record (k_fb_reset, front_block.hip)
-__device__ __forceinline__ bool f2_fresh(double v) { return (unsigned long long)__double_as_longlong(v) != kSent; }
+// "not written yet" in a stream record = all ones (k_fb_reset, front_block.hip): a NaN no arithmetic produces.  A record is complete
+// when the unsigned maximum of the high words of its values is below 0xFFFFFFFF (two v_max3_u32 per six values).
+__device__ __forceinline__ unsigned f2_hi(double v) { return (unsigned)__double2hiint(v); }
+__device__ __forceinline__ unsigned f2_max3(unsigned a, unsigned b, unsigned c) { return max(max(a, b), c); }
+// uniform base + 32-bit lane offset (+ immediate): one instruction per access, no 64-bit address arithmetic on the vector side
+__device__ __forceinline__ double f2_ldo(const double *base, unsigned byte_off) {
+    return __hip_atomic_load((const HK_GLOBAL double *)((const HK_GLOBAL char *)base + byte_off), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void f2_sto(double *base, unsigned byte_off, double v) {
+    __hip_atomic_store((HK_GLOBAL double *)((HK_GLOBAL char *)base + byte_off), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 // Wave-level wait for a counter of another workgroup: every lane polls the same word and the value is made wave-uniform, so the
 // loop is a scalar branch (no exec-masked block next to matrix-core code).  false = timed out / somebody else failed.
@@ -128,6 +138,7 @@ k_front_block2(DevPlan P, FrontBatch B, int *sync_all, double *scratch_all, doub
     const int f = diag ? fp[i].f : 0;
     const signed char sgn_l = diag ? P.sgn_perm[f + lane] : (signed char)0;
     int *failflag = P.flags + FL_FACFAIL;
+    const unsigned lane8 = 8u * (unsigned)lane;
     const unsigned lim = P.spin_limit;
 
     // ---- the row block, straight into the accumulator layout (16 loads per tile and lane, 128-byte segments)
@@ -136,15 +147,20 @@ k_front_block2(DevPlan P, FrontBatch B, int *sync_all, double *scratch_all, doub
     for (int k = 0; k < kFbMax; k++) {
         if (k < ncb) {
             const FrontPanel pk = fp[k];
-            const double *src = P.Lx + pk.panel_off + 64 * (i - k) + n;
+            // (rows past the front's last one: the load goes to the last valid row and is zeroed afterwards -- a conditional load
+            // would put every one of the 16 loads into an exec-masked block of its own with a wait in front of it)
+            const double *src = P.Lx + pk.panel_off + 64 * (i - k) + min(n, nr - 1);
 #pragma unroll
             for (int sub = 0; sub < 4; sub++)
 #pragma unroll
-                for (int reg = 0; reg < 4; reg++) acc[k][sub][reg] = rowok ? src[(int64_t)(16 * sub + lk + 4 * reg) * pk.r] : 0.0;
-        } else {
+                for (int reg = 0; reg < 4; reg++) acc[k][sub][reg] = src[(int64_t)(16 * sub + lk + 4 * reg) * pk.r];
+            if (nr < 64) {
 #pragma unroll
-            for (int sub = 0; sub < 4; sub++) acc[k][sub] = (v4f64){0.0, 0.0, 0.0, 0.0};
-        }
+                for (int sub = 0; sub < 4; sub++)
+#pragma unroll
+                    for (int reg = 0; reg < 4; reg++) acc[k][sub][reg] = rowok ? acc[k][sub][reg] : 0.0;
+            }
+        }                                                 // (tiles k >= ncb are never touched: every use below is guarded the same way)
     }
     // a diagonal workgroup's own tile lives in registers of its own from the start (it is updated in every step)
     v4f64 tr[4];
@@ -158,55 +174,82 @@ k_front_block2(DevPlan P, FrontBatch B, int *sync_all, double *scratch_all, doub
     F2_T(1);
 
     // ---- the panels left of this block: X_j^T = Minv_j^T A_j^T, then A_k^T -= (L(k,j) D_j) X_j^T for the tiles right of it
+    double *STG = S1;                                     // staging tile of the shared operand (S1 holds L11 only from the pivots on)
+    const unsigned tid8 = 8u * (unsigned)tid;
+    auto stage_tile = [&](const double *tile) {           // 64 x 64 tile in operand order, global -> LDS, all four waves
+        double v[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) v[q] = f2_ldo(tile + (q >> 1) * 512, tid8 + (q & 1) * 2048);
+        f2_bar();                                         // everybody is done with the tile before
+#pragma unroll
+        for (int q = 0; q < 16; q++) STG[tid + 256 * q] = v[q];
+        f2_bar();
+    };
 #pragma unroll
     for (int j = 0; j < kFbMax; j++) {
         if (j < nsteps) {                                 // workgroup-uniform
             if (!f2_wait(fl_minv + j, 1, err, failflag, lim)) return;
+            if (j == nsteps - 1) F2_T(9);
             const FrontPanel pj = fp[j];
             const double *mv = scratch + (int64_t)j * 4160;
-            double dj[4][4];                              // pivots of this lane's columns m = 16 sub + lk + 4 reg
-#pragma unroll
-            for (int sub = 0; sub < 4; sub++)
-#pragma unroll
-                for (int reg = 0; reg < 4; reg++) dj[sub][reg] = f2_ld(mv + 4096 + 16 * sub + lk + 4 * reg);
-            // operands first, all in flight at once (a relaxed atomic load next to its use would make every k-step a memory round
-            // trip: measured 30 us per step), then the products.  Minv is upper triangular: k <= c, 4 so + 4 k-steps per strip
-            double am[40];
-#pragma unroll
-            for (int so = 0, t = 0; so < 4; so++)
-#pragma unroll
-                for (int kk = 0; kk < 4 * so + 4; kk++, t++) am[t] = f2_ld(mv + (so * 16 + kk) * 64 + lane);
+            // The A operand -- the same for all four waves -- comes through LDS: every thread fetches 16 values of the tile (all in
+            // flight at once, one memory round trip), the tile is laid down in operand order, each wave reads its k-steps back
+            // (lane-contiguous: no bank conflicts).  [Direct loads per wave, first version of this kernel: four times the traffic, and
+            // a relaxed atomic load next to its use makes every k-step a round trip -- 30 us per step.]
+            stage_tile(mv);
             v4f64 x[4];
 #pragma unroll
-            for (int so = 0, t = 0; so < 4; so++) {
+            for (int so = 0; so < 4; so++) {              // Minv is upper triangular: k <= c, 4 so + 4 k-steps per strip
+                double am[16];
+#pragma unroll
+                for (int kk = 0; kk < 4 * so + 4; kk++) am[kk] = STG[(so * 16 + kk) * 64 + lane];
                 x[so] = (v4f64){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                for (int kk = 0; kk < 4 * so + 4; kk++, t++)
-                    x[so] = __builtin_amdgcn_mfma_f64_16x16x4f64(am[t], acc[j][kk >> 2][kk & 3], x[so], 0, 0, 0);
+                for (int kk = 0; kk < 4 * so + 4; kk++)
+                    x[so] = __builtin_amdgcn_mfma_f64_16x16x4f64(am[kk], acc[j][kk >> 2][kk & 3], x[so], 0, 0, 0);
             }
+            if (j == nsteps - 1) F2_T(10);
             if (diag) {
-                // L(i,j) D_j for the workgroups below (operand order: this lane's entry is exactly its own slot), the same through
-                // LDS for the other wavefronts of this workgroup, then the diagonal tile  T_ii -= (X D) X^T
-                double *lt = ltiles + (int64_t)(i * (i - 1) / 2 + j) * 4096;
+                // L(i,j) D_j for the workgroups below (operand order: this lane's entry is exactly its own slot) and, through LDS, for
+                // the other wavefronts of this workgroup
+                double *lt = ltiles + (int64_t)(i * (i - 1) / 2 + j) * 4096 + (wv * 16) * 64;
                 double *xd = S0 + (j & 1) * 4096;
+                double dj[4][4];                          // pivots of this lane's columns m = 16 sub + lk + 4 reg (all loads in flight
+#pragma unroll                                            // before the first use: they are ordered with the stores below)
+                for (int sub = 0; sub < 4; sub++)
+#pragma unroll
+                    for (int reg = 0; reg < 4; reg++) dj[sub][reg] = f2_ld(mv + 4096 + 16 * sub + lk + 4 * reg);
 #pragma unroll
                 for (int sub = 0; sub < 4; sub++)
 #pragma unroll
                     for (int reg = 0; reg < 4; reg++) {
                         const double v = x[sub][reg] * dj[sub][reg];
-                        f2_st(lt + (wv * 16 + 4 * sub + reg) * 64 + lane, v);
+                        f2_sto(lt + (4 * sub + (reg & 2)) * 64, lane8 + (reg & 1) * 512, v);
                         xd[(wv * 16 + 4 * sub + reg) * 64 + lane] = v;
                     }
+            }
+#pragma unroll
+            for (int so = 0; so < 4; so++) x[so] = -x[so];    // from here on X is only the B operand of updates:  A -= (L D) X^T
+            if (diag) {
+                // the diagonal tile  T_ii -= (X D) X^T
+                const double *xd = S0 + (j & 1) * 4096;
                 f2_bar();
 #pragma unroll
-                for (int so = 0; so < 4; so++)
+                for (int so = 0; so < 4; so++) {
+                    double xa[16];
+#pragma unroll
+                    for (int kk = 0; kk < 16; kk++) xa[kk] = xd[(so * 16 + kk) * 64 + lane];
 #pragma unroll
                     for (int kk = 0; kk < 16; kk++)
-                        tr[so] = __builtin_amdgcn_mfma_f64_16x16x4f64(-xd[(so * 16 + kk) * 64 + lane], x[kk >> 2][kk & 3], tr[so], 0, 0, 0);
+                        tr[so] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[kk], x[kk >> 2][kk & 3], tr[so], 0, 0, 0);
+                }
                 f2_settle();
+                if (j == nsteps - 1) F2_T(11);
                 f2_wave_done(fl_L + 8 * i + j);
+                if (j == nsteps - 1) F2_T(12);
             }
-            // the panel (column-major) and its row-major copy for the backward solves
+            // the panel (column-major) and its row-major copy for the backward solves -- after the hand-off: the flag waits for this
+            // wave's outstanding stores, and these 32 strided ones are slow to drain (x holds -X by now)
             f2_settle();
             if (rowok) {
                 double *dst = P.Lx + pj.panel_off + 64 * (i - j) + n;
@@ -215,8 +258,8 @@ k_front_block2(DevPlan P, FrontBatch B, int *sync_all, double *scratch_all, doub
                 for (int sub = 0; sub < 4; sub++)
 #pragma unroll
                     for (int reg = 0; reg < 4; reg++) {
-                        dst[(int64_t)(16 * sub + lk + 4 * reg) * pj.r] = x[sub][reg];
-                        lt2[16 * sub + lk + 4 * reg] = x[sub][reg];
+                        dst[(int64_t)(16 * sub + lk + 4 * reg) * pj.r] = -x[sub][reg];
+                        lt2[16 * sub + lk + 4 * reg] = -x[sub][reg];
                     }
             }
             // the tiles that need the rows of the diagonal workgroups above
@@ -224,17 +267,17 @@ k_front_block2(DevPlan P, FrontBatch B, int *sync_all, double *scratch_all, doub
             for (int k = j + 1; k < kFbMax; k++) {
                 if (k < ncb && !(diag && k == i)) {
                     if (!f2_wait(fl_L + 8 * k + j, 4, err, failflag, lim)) return;
+                    if (j == nsteps - 1 && k == i - 1) F2_T(13);
                     const double *lt = ltiles + (int64_t)(k * (k - 1) / 2 + j) * 4096;
+                    stage_tile(lt);
 #pragma unroll
-                    for (int h = 0; h < 2; h++) {         // two strips at a time: 32 operands in flight
-                        double al[32];
+                    for (int so = 0; so < 4; so++) {
+                        double al[16];
 #pragma unroll
-                        for (int t = 0; t < 32; t++) al[t] = f2_ld(lt + (h * 32 + t) * 64 + lane);
+                        for (int kk = 0; kk < 16; kk++) al[kk] = STG[(so * 16 + kk) * 64 + lane];
 #pragma unroll
-                        for (int t = 0; t < 32; t++) {
-                            const int so = 2 * h + (t >> 4), kk = t & 15;
-                            acc[k][so] = __builtin_amdgcn_mfma_f64_16x16x4f64(-al[t], x[kk >> 2][kk & 3], acc[k][so], 0, 0, 0);
-                        }
+                        for (int kk = 0; kk < 16; kk++)
+                            acc[k][so] = __builtin_amdgcn_mfma_f64_16x16x4f64(al[kk], x[kk >> 2][kk & 3], acc[k][so], 0, 0, 0);
                     }
                 }
             }
@@ -244,15 +287,15 @@ k_front_block2(DevPlan P, FrontBatch B, int *sync_all, double *scratch_all, doub
     if (!diag) return;
 
     // ---- streamed step: this workgroup's rows of panel i - 1, record by record behind the workgroup that eliminates tile i - 1.
+    v4f64 xr[4];                                          // the tile of panel i - 1, L(i, i-1) after the streamed step
+#pragma unroll
+    for (int sub = 0; sub < 4; sub++) {
+        xr[sub] = (v4f64){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < kFbMax; k++)
+            if (k == i - 1) xr[sub] = acc[k][sub];
+    }
     if (i > 0) {
-        v4f64 xr[4];                                      // the tile of panel i - 1
-#pragma unroll
-        for (int sub = 0; sub < 4; sub++) {
-            xr[sub] = (v4f64){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int k = 0; k < kFbMax; k++)
-                if (k == i - 1) xr[sub] = acc[k][sub];
-        }
         const double *rec0 = stream + (int64_t)(i - 1) * 8 * kFbRec;
         const FrontPanel pl = fp[i - 1];
         double *lt_out = ltiles + (int64_t)(i * (i - 1) / 2 + i - 1) * 4096;
@@ -260,23 +303,27 @@ k_front_block2(DevPlan P, FrontBatch B, int *sync_all, double *scratch_all, doub
         f2_bar();                                         // the X D buffers of the regular steps are free
         // Ring of three records in registers: while record Bk is processed, records Bk + 1 and Bk + 2 are in flight (a consumer that
         // has fallen behind finds them complete and pays no memory round trip per record; one that is level with the producer sees
-        // the sentinel and polls).  Fully unrolled: the strip / register of a block's columns is static.
+        // the sentinel and polls).  Fully unrolled: the strip / register of a block's columns is static.  The loop is instruction-
+        // issue bound (one wavefront issues every ~5 cycles): uniform base + lane offset addressing, one negation per record (the B
+        // operand), the freshness test by unsigned maxima, the panel stores after the pivots.
         double rc[3][4][2], rt[3][2], rd[3][2];
 #define F2_REQUEST(slot, Bq) do { \
             const double *rq_ = rec0 + (int64_t)(Bq) * kFbRec; \
             _Pragma("unroll") for (int q = (Bq) >> 1; q < 4; q++) { \
-                rc[slot][q][0] = f2_ld(rq_ + (q * 2) * 64 + lane); rc[slot][q][1] = f2_ld(rq_ + (q * 2 + 1) * 64 + lane); } \
-            rt[slot][0] = f2_ld(rq_ + 8 * 64 + lane); rt[slot][1] = f2_ld(rq_ + 9 * 64 + lane); \
-            rd[slot][0] = f2_ld(rq_ + 10 * 64 + lane); rd[slot][1] = f2_ld(rq_ + 11 * 64 + lane); } while (0)
+                rc[slot][q][0] = f2_ldo(rq_, lane8 + (q * 2) * 512); rc[slot][q][1] = f2_ldo(rq_, lane8 + (q * 2 + 1) * 512); } \
+            rt[slot][0] = f2_ldo(rq_ + 512, lane8); rt[slot][1] = f2_ldo(rq_ + 512, lane8 + 512); \
+            rd[slot][0] = f2_ldo(rq_ + 512, lane8 + 1024); rd[slot][1] = f2_ldo(rq_ + 512, lane8 + 1536); } while (0)
         F2_REQUEST(0, 0); F2_REQUEST(1, 1); F2_REQUEST(2, 2);
+        double *lt_w = lt_out + (wv * 16) * 64;            // this wave's 16 rows of L(i, i-1) D in operand order
 #pragma unroll
         for (int Bk = 0; Bk < 8; Bk++) {
             const int sb = Bk >> 1, par = Bk & 1, sl = Bk % 3;
             for (unsigned spins = 0;; spins++) {               // level with the producer: poll (bounded)
-                bool ok = f2_fresh(rt[sl][0]) && f2_fresh(rt[sl][1]) && f2_fresh(rd[sl][0]) && f2_fresh(rd[sl][1]);
+                unsigned m = f2_max3(f2_hi(rt[sl][0]), f2_hi(rt[sl][1]), f2_hi(rd[sl][0]));
+                m = max(m, f2_hi(rd[sl][1]));
 #pragma unroll
-                for (int q = sb; q < 4; q++) ok = ok && f2_fresh(rc[sl][q][0]) && f2_fresh(rc[sl][q][1]);
-                if (__builtin_amdgcn_readfirstlane((int)(__ballot(ok) == ~0ull)) != 0) break;
+                for (int q = sb; q < 4; q++) m = f2_max3(m, f2_hi(rc[sl][q][0]), f2_hi(rc[sl][q][1]));
+                if (__builtin_amdgcn_readfirstlane((int)(__ballot(m != 0xFFFFFFFFu) == ~0ull)) != 0) break;
                 if ((spins & 63u) == 63u || lim < 64u) {
                     if (spins > lim) {
                         __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -298,53 +345,53 @@ k_front_block2(DevPlan P, FrontBatch B, int *sync_all, double *scratch_all, doub
             v4f64 lT = {0.0, 0.0, 0.0, 0.0};
             lT = __builtin_amdgcn_mfma_f64_16x16x4f64(tv[0], xr[sb][2 * par], lT, 0, 0, 0);
             lT = __builtin_amdgcn_mfma_f64_16x16x4f64(tv[1], xr[sb][2 * par + 1], lT, 0, 0, 0);
+            const double l0 = lT[0], l1 = lT[1], nl0 = -l0, nl1 = -l1;
             // l d for the other wavefronts (diagonal tile) and for the workgroups below
-            const double ld0 = lT[0] * dv[0], ld1 = lT[1] * dv[1];
+            const double ld0 = l0 * dv[0], ld1 = l1 * dv[1];
             double *lx = ldx + par * 512;
             lx[(wv * 2) * 64 + lane] = ld0;
             lx[(wv * 2 + 1) * 64 + lane] = ld1;
-            f2_st(lt_out + (wv * 16 + 2 * Bk) * 64 + lane, ld0);
-            f2_st(lt_out + (wv * 16 + 2 * Bk + 1) * 64 + lane, ld1);
+            f2_sto(lt_w + (Bk >> 2) * 512, lane8 + (2 * (Bk & 3)) * 512, ld0);
+            f2_sto(lt_w + (Bk >> 2) * 512, lane8 + (2 * (Bk & 3) + 1) * 512, ld1);
+            // the finished columns stay in the tile's registers (stored to the panel after the pivots); the record's raw columns
+            // are zero on the rows of its own block, so the update of the block's own strip leaves them alone
+            xr[sb][2 * par] = l0;
+            xr[sb][2 * par + 1] = l1;
             // rank-8 update of the columns right of the block (the block's own strip: only when its second half is still to come)
 #pragma unroll
             for (int q = sb + par; q < 4; q++) {
-                xr[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(-cr[q][0], lT[0], xr[q], 0, 0, 0);
-                xr[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(-cr[q][1], lT[1], xr[q], 0, 0, 0);
+                xr[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(cr[q][0], nl0, xr[q], 0, 0, 0);
+                xr[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(cr[q][1], nl1, xr[q], 0, 0, 0);
             }
             f2_bar();
             {
+                // (the strips right of a wave's own rows are the upper triangle, but the slowest wave -- the last, all four strips --
+                // sets the pace at the barrier: no per-wave branches here)
                 double la[4][2];
 #pragma unroll
                 for (int so = 0; so < 4; so++) { la[so][0] = lx[(so * 2) * 64 + lane]; la[so][1] = lx[(so * 2 + 1) * 64 + lane]; }
 #pragma unroll
                 for (int so = 0; so < 4; so++) {
-                    tr[so] = __builtin_amdgcn_mfma_f64_16x16x4f64(-la[so][0], lT[0], tr[so], 0, 0, 0);
-                    tr[so] = __builtin_amdgcn_mfma_f64_16x16x4f64(-la[so][1], lT[1], tr[so], 0, 0, 0);
+                    tr[so] = __builtin_amdgcn_mfma_f64_16x16x4f64(la[so][0], nl0, tr[so], 0, 0, 0);
+                    tr[so] = __builtin_amdgcn_mfma_f64_16x16x4f64(la[so][1], nl1, tr[so], 0, 0, 0);
                 }
             }
-            // the panel and its row-major copy: columns m = 8 Bk + 4 e + lk of row n
-            f2_settle();
-            if (rowok) {
-                double *dst = P.Lx + pl.panel_off + 64 + n;
-                double *lt2 = P.LT + pl.lt_off + (int64_t)n * 64;
-                const int m0 = 8 * Bk + lk;
-                dst[(int64_t)m0 * pl.r] = lT[0];
-                dst[(int64_t)(m0 + 4) * pl.r] = lT[1];
-                lt2[m0] = lT[0];
-                lt2[m0 + 4] = lT[1];
-            }
         }
+        f2_settle();
 #undef F2_REQUEST
         F2_T(4);
     }
 
     // ---- the diagonal tile.  Per block of 8 pivots: every wave hands the block's 8 columns of its rows to wave 0 through LDS, wave 0
     //      eliminates them without leaving the wavefront (lane = row; the pivot rule and arithmetic of k_factor_panel / front_block.hip),
-    //      every wave applies the rank-8 update to its 16 rows on the matrix core.  Waves 1 - 3 publish the record of block Bk - 1
-    //      WHILE wave 0 eliminates block Bk (wave 1 forms T of that block first).
+    //      and the rank-8 update goes to the matrix core -- split in two: behind the elimination only the strip that holds the NEXT
+    //      block's columns is updated (2 instructions per wave, then the columns go back to wave 0); the other live strips are
+    //      updated by waves 1 - 3 WHILE wave 0 eliminates the next block (they would idle there), followed by the record of the
+    //      finished block for the next diagonal workgroup (wave 1 forms T of that block first).  A wave's rows need the strips up to
+    //      its own only (the rest is the upper triangle), so wave 0 takes part in the update of block 0 alone.
     double *Pc = S0;                                      // [64][9]   the block's columns, by row
-    double *colL = S0 + 576;                              // [8][CS]   l_ik
-    double *cCa = colL + 8 * CS, *cCb = cCa + 8 * CS;     // [8][CS]   raw a_ik = d_k l_ik, two buffers
+    double *colLa = S0 + 576, *colLb = colLa + 8 * CS;    // [8][CS]   l_ik, two buffers
+    double *cCa = colLb + 8 * CS, *cCb = cCa + 8 * CS;    // [8][CS]   raw a_ik = d_k l_ik, two buffers
     double *dsave = cCb + 8 * CS, *dinvs = dsave + 64;    // [64] d_k, [64] 1 / d_k as used on the chain
     double *L11 = S1;
     const unsigned long long spos = __ballot(sgn_l > 0);
@@ -371,98 +418,125 @@ k_front_block2(DevPlan P, FrontBatch B, int *sync_all, double *scratch_all, doub
             const double di = dinvs[o + kq];
             const double s0 = lk == 0 ? xs[0] : (lk == 1 ? xs[1] : (lk == 2 ? xs[2] : xs[3]));
             const double s1 = lk == 0 ? xs[4] : (lk == 1 ? xs[5] : (lk == 2 ? xs[6] : xs[7]));
-            f2_st(rec + 8 * 64 + lane, l15 < 8 ? s0 * di : 0.0);
-            f2_st(rec + 9 * 64 + lane, l15 < 8 ? s1 * di : 0.0);
-            f2_st(rec + 10 * 64 + lane, dsave[o + lk]);
-            f2_st(rec + 11 * 64 + lane, dsave[o + 4 + lk]);
+            f2_sto(rec + 512, lane8, l15 < 8 ? s0 * di : 0.0);
+            f2_sto(rec + 512, lane8 + 512, l15 < 8 ? s1 * di : 0.0);
+            f2_sto(rec + 512, lane8 + 1024, dsave[o + lk]);
+            f2_sto(rec + 512, lane8 + 1536, dsave[o + 4 + lk]);
         } else if (wv >= 2) {
+            // the raw columns, zero on the rows up to the block's own (the consumer keeps its finished columns in the same registers)
             const int q0 = 2 * (wv - 2);
 #pragma unroll
             for (int q = 0; q < 2; q++)
 #pragma unroll
-                for (int e = 0; e < 2; e++) f2_st(rec + ((q0 + q) * 2 + e) * 64 + lane, cP[(4 * e + lk) * CS + 16 * (q0 + q) + l15]);
+                for (int e = 0; e < 2; e++) {
+                    const int c = 16 * (q0 + q) + l15;
+                    f2_sto(rec, lane8 + ((q0 + q) * 2 + e) * 512, c > 8 * Bp + 7 ? cP[(4 * e + lk) * CS + c] : 0.0);
+                }
         }
+    };
+    // wave 0's elimination of one block.  RULE = false: the dynamic-regularisation rule (D_k s_k < eps => D_k = delta s_k) is only
+    // TESTED, at the end of the block from the eight pivots (wave 0 is instruction-issue bound: selects, sign masks and the count
+    // cost a quarter of its instructions); a block that needs it is repeated with RULE = true from the same input.  Same arithmetic
+    // in both forms, so a factorisation without substituted pivots is bit-identical to one computed by the RULE form alone.
+    auto eliminate = [&](auto rule_tag, int Bk, double *cL, double *cC) -> bool {
+        constexpr bool RULE = decltype(rule_tag)::value;
+        double pcol[8], dk[8], dik[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) pcol[q] = Pc[lane * 9 + q];
+        double akk = f2_readlane(pcol[0], 8 * Bk), csq = 0.0, dinv_prev = 0.0;
+        int nr_ = 0;
+#pragma unroll
+        for (int kk = 0; kk < 8; kk++) {
+            const int k = 8 * Bk + kk;
+            double d = fma(-csq, dinv_prev, akk);
+            double dinv = f2_rcp3(d);
+            if (RULE) {
+                const int sm = ((spos >> k) & 1ull) ? 0 : (int)0x80000000;               // expected sign negative: test -d, substitute -delta
+                const bool bad = __hiloint2double(__double2hiint(d) ^ sm, __double2loint(d)) < dyn_eps;
+                double dsub = __hiloint2double(__double2hiint(dyn_delta) ^ sm, __double2loint(dyn_delta));
+                double isub = __hiloint2double(__double2hiint(dyn_delta_inv) ^ sm, __double2loint(dyn_delta_inv));
+                asm volatile("" : "+v"(dinv), "+v"(dsub), "+v"(isub));                   // all three in vector registers, unconditionally
+                d = bad ? dsub : d;
+                dinv = bad ? isub : dinv;
+                nr_ += bad ? 1 : 0;
+            }
+            dk[kk] = d;
+            dik[kk] = dinv;
+            const double reg = pcol[kk];
+            if (kk < 7) {
+                akk = f2_readlane(pcol[kk + 1], k + 1);
+                const double cn = f2_readlane(reg, k + 1);
+                csq = cn * cn;
+            }
+            dinv_prev = dinv;
+            const double li = reg * dinv;
+            cL[kk * CS + lane] = li;
+            cC[kk * CS + lane] = reg;
+            L11[lane * LDT + k] = li;
+#pragma unroll
+            for (int jj = kk + 1; jj < 8; jj++) {
+                const double cj = f2_readlane(reg, 8 * Bk + jj);
+                pcol[jj] = fma(-li, cj, pcol[jj]);
+            }
+        }
+        if (!RULE) {
+            bool anybad = false;
+#pragma unroll
+            for (int kk = 0; kk < 8; kk++) {
+                const int sm = ((spos >> (8 * Bk + kk)) & 1ull) ? 0 : (int)0x80000000;
+                anybad = anybad || __hiloint2double(__double2hiint(dk[kk]) ^ sm, __double2loint(dk[kk])) < dyn_eps;
+            }
+            if (__builtin_amdgcn_readfirstlane((int)anybad)) return false;
+        }
+        nreg += nr_;
+        if (lane == 0) {
+#pragma unroll
+            for (int q = 0; q < 8; q++) { dsave[8 * Bk + q] = dk[q]; dinvs[8 * Bk + q] = dik[q]; }
+        }
+        return true;
+    };
+    // rank-8 update of strip q of this wave's rows with block Bq (buffers of its parity)
+    auto update_strip = [&](int Bq, int q) {
+        const double *cL = (Bq & 1) ? colLb : colLa, *cC = (Bq & 1) ? cCb : cCa;
+        const double b0 = -cL[lk * CS + n], b1 = -cL[(4 + lk) * CS + n];
+        tr[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(cC[lk * CS + 16 * q + l15], b0, tr[q], 0, 0, 0);
+        tr[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(cC[(4 + lk) * CS + 16 * q + l15], b1, tr[q], 0, 0, 0);
     };
     f2_bar();                                             // the l d buffers of the streamed step are free
     F2_T(5);
 #pragma unroll
     for (int Bk = 0; Bk < 8; Bk++) {
-        {
-            const int sb = Bk >> 1, par = Bk & 1;
-            double *cC = par ? cCb : cCa;
+        const int sb = Bk >> 1, par = Bk & 1;
+        if (wv >= sb) {                                   // (the rows of the waves before are dead)
             Pc[n * 9 + lk] = tr[sb][2 * par];
             Pc[n * 9 + 4 + lk] = tr[sb][2 * par + 1];
-            f2_bar();
-            F2_TB(0);
-            if (wv == 0) {
-                // front_block.hip's lean chain: d_k = a_kk - c_{k,k-1}^2 / d_{k-1} -> 1 / d_k is one fma, the hardware reciprocal
-                // and three more fma; a_kk and c_{k,k-1} are fetched one pivot earlier; the pivot rule is evaluated next to the
-                // reciprocal and applied by register selects (no branch, no exec mask)
-                double pcol[8], dk[8], dik[8];
-#pragma unroll
-                for (int q = 0; q < 8; q++) pcol[q] = Pc[lane * 9 + q];
-                double akk = f2_readlane(pcol[0], 8 * Bk), csq = 0.0, dinv_prev = 0.0;
-#pragma unroll
-                for (int kk = 0; kk < 8; kk++) {
-                    const int k = 8 * Bk + kk;
-                    double d = fma(-csq, dinv_prev, akk);
-                    const int sm = ((spos >> k) & 1ull) ? 0 : (int)0x80000000;               // expected sign negative: test -d, substitute -delta
-                    const bool bad = __hiloint2double(__double2hiint(d) ^ sm, __double2loint(d)) < dyn_eps;
-                    double dinv = f2_rcp3(d);
-                    double dsub = __hiloint2double(__double2hiint(dyn_delta) ^ sm, __double2loint(dyn_delta));
-                    double isub = __hiloint2double(__double2hiint(dyn_delta_inv) ^ sm, __double2loint(dyn_delta_inv));
-                    asm volatile("" : "+v"(dinv), "+v"(dsub), "+v"(isub));                   // all three in vector registers, unconditionally
-                    d = bad ? dsub : d;
-                    dinv = bad ? isub : dinv;
-                    nreg += bad ? 1 : 0;
-                    dk[kk] = d;
-                    dik[kk] = dinv;
-                    const double reg = pcol[kk];
-                    if (kk < 7) {
-                        akk = f2_readlane(pcol[kk + 1], k + 1);
-                        const double cn = f2_readlane(reg, k + 1);
-                        csq = cn * cn;
-                    }
-                    dinv_prev = dinv;
-                    const double li = reg * dinv;
-                    colL[kk * CS + lane] = li;
-                    cC[kk * CS + lane] = reg;
-                    L11[lane * LDT + k] = li;
-#pragma unroll
-                    for (int jj = kk + 1; jj < 8; jj++) {
-                        const double cj = f2_readlane(reg, 8 * Bk + jj);
-                        pcol[jj] = fma(-li, cj, pcol[jj]);
-                    }
-                }
-                if (lane == 0) {
-#pragma unroll
-                    for (int q = 0; q < 8; q++) { dsave[8 * Bk + q] = dk[q]; dinvs[8 * Bk + q] = dik[q]; }
-                }
-            } else {                                      // next to wave 0's elimination
-                if (Bk == 1 && i > 0) f2_wave_done(fl_L + 8 * i + (i - 1));   // this wave's stores of L(i, i-1) D (streamed step) have drained long ago
-                if (pub && Bk > 0) publish(Bk - 1);
-            }
-            F2_TB(1);
-            f2_bar();
-            F2_TB(2);
-            if (wv == 0 && Bk == 1 && i > 0) f2_wave_done(fl_L + 8 * i + (i - 1));
-            if (Bk < 7) {
-                // a_ij -= sum_k l_ik a_jk over the block's 8 pivots, for the strips that still hold live columns
-                double bl[2], av[4][2];
-#pragma unroll
-                for (int e = 0; e < 2; e++) bl[e] = colL[(4 * e + lk) * CS + n];
-#pragma unroll
-                for (int q = sb + par; q < 4; q++)
-#pragma unroll
-                    for (int e = 0; e < 2; e++) av[q][e] = cC[(4 * e + lk) * CS + 16 * q + l15];
-#pragma unroll
-                for (int q = sb + par; q < 4; q++)
-#pragma unroll
-                    for (int e = 0; e < 2; e++) tr[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[q][e], bl[e], tr[q], 0, 0, 0);
-            }
-            f2_settle();
-            F2_TB(3);
         }
+        f2_bar();
+        F2_TB(0);
+        if (wv == 0) {
+            double *cL = par ? colLb : colLa, *cC = par ? cCb : cCa;
+            if (!eliminate(std::false_type{}, Bk, cL, cC)) eliminate(std::true_type{}, Bk, cL, cC);
+        } else {                                          // next to wave 0's elimination
+            if (Bk == 0 && i > 0) f2_wave_done(fl_L + 8 * i + (i - 1));   // L(i, i-1) D of the streamed step: these waves idle here anyway while their last stores drain
+            if (Bk > 0) {
+                // the rest of block Bk - 1's update: strips right of the one that was updated at once, up to this wave's own
+#pragma unroll
+                for (int q = sb + 1; q < 4; q++)
+                    if (q <= wv) update_strip(Bk - 1, q);
+                if (pub) publish(Bk - 1);
+            }
+        }
+        F2_TB(1);
+        f2_bar();
+        F2_TB(2);
+        if (wv == 0 && Bk == 0 && i > 0) f2_wave_done(fl_L + 8 * i + (i - 1));   // (wave 0: after its first elimination -- its stores are a block time old)
+        if (Bk < 7) {
+            // the strip of the next block's columns, at once
+            const int u = (Bk + 1) >> 1;
+            if (u <= wv) update_strip(Bk, u);
+        }
+        f2_settle();
+        F2_TB(3);
     }
     if (pub && wv > 0) publish(7);
     __syncthreads();
@@ -551,6 +625,19 @@ k_front_block2(DevPlan P, FrontBatch B, int *sync_all, double *scratch_all, doub
             if (!isfinite(Sd[tid])) atomicOr(P.flags + FL_NONFINITE, 1);
         }
         if (lane == 0 && nreg) atomicAdd(P.flags + FL_NREG, nreg);
+    }
+    if (i > 0 && rowok) {
+        // L(i, i-1) from the streamed step (kept in the tile's registers): the panel and its row-major copy for the backward solves
+        const FrontPanel pl = fp[i - 1];
+        double *dst = P.Lx + pl.panel_off + 64 + n;
+        double *lt2 = P.LT + pl.lt_off + (int64_t)n * 64;
+#pragma unroll
+        for (int sub = 0; sub < 4; sub++)
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) {
+                dst[(int64_t)(16 * sub + lk + 4 * reg) * pl.r] = xr[sub][reg];
+                lt2[16 * sub + lk + 4 * reg] = xr[sub][reg];
+            }
     }
     F2_T(8);
 }

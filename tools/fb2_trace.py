@@ -20,7 +20,8 @@ for _ in range(3):
 print("factor ms", {k: round(float(v), 4) for k, v in hk.h.timing().items()})
 raw = hk.h.debug_dump(9).view(np.int64).reshape(-1, 8, 16)
 t = raw * 0.01   # microseconds
-names = ["start", "loaded", "steps done", "first record", "streamed", "pivots start", "pivots end", "minv published", "end"]
+names = ["start", "loaded", "steps done", "first record", "streamed", "pivots start", "pivots end", "minv published", "end",
+         "last step: minv seen", "X done", "diag tile done", "L flag raised", "L(i-1, j) seen"]
 periods = []
 for bi in range(len(t)):
     t0 = t[bi, 0, 0]
