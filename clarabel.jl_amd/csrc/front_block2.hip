@@ -129,9 +129,13 @@ k_front_block2(DevPlan P, FrontBatch B, int *sync_all, double *scratch_all, doub
     F2_T(0);
     const FrontPanel *fp = P.front_panels + B.fp_off;
     const int nb = B.nb;
-    const bool diag = i < nb;
+    // the two kinds of workgroup are compiled separately (diagonal: at most kFbMax - 3 regular steps, then the streamed steps and the
+    // pivots; below the diagonal: kFbMax regular steps and nothing else) -- one body with run-time flags spills registers
+    auto body = [&](auto diag_tag) {
+    constexpr bool diag = decltype(diag_tag)::value;
     const int ncb = diag ? i + 1 : nb;                    // column blocks held here
-    const int nsteps = diag ? i - 1 : nb;                 // regular steps; a diagonal workgroup's last panel (i - 1) is streamed
+    const int nsteps = diag ? 0 : nb;                     // regular steps (with the published inverses): the workgroups below the diagonal;
+                                                          // a diagonal workgroup takes every panel left of its tile from the stream
     const int nr = min(64, B.r0 - 64 * i);
     const int n = 16 * wv + l15;                          // this lane's row of the block
     const bool rowok = n < nr;
@@ -173,6 +177,117 @@ k_front_block2(DevPlan P, FrontBatch B, int *sync_all, double *scratch_all, doub
     }
     F2_T(1);
 
+    // ---- consumer of the streamed pivot chain: the eight records of tile jt turn this workgroup's tile t of panel jt into its rows of
+    //      L (l = p T per block of 8 columns, then the rank-8 update of the columns right of it), wave by wave, everything in
+    //      registers.  WITH_TR (the panel next to the own tile, jt = i - 1): every record also updates the diagonal tile (l d of all
+    //      64 rows through LDS, one barrier per record) and goes out as L(i, jt) D for the workgroups below.  Without (jt = i - 2):
+    //      no LDS, no barrier; the pivots of the lane's columns are returned in dcol for the step that follows.
+    //      Ring of three records in registers: while record Bk is processed, records Bk + 1 and Bk + 2 are in flight (a fourth
+    //      slot changed nothing: the loop is bound by its 18 FP64 matrix-core instructions of 64 cycles each per record) (a consumer that
+    //      has fallen behind finds them complete and pays no memory round trip per record; one that is level with the producer sees
+    //      the sentinel and polls).  Fully unrolled: the strip / register of a block's columns is static.  The loop is instruction-
+    //      issue bound (one wavefront issues every ~5 cycles): uniform base + lane offset addressing, one negation per record (the B
+    //      operand), the freshness test by unsigned maxima, the panel stores elsewhere.
+    auto consume = [&](auto with_tr_tag, int jt, v4f64 (&t)[4], double (&dcol)[4][4]) -> bool {
+        constexpr bool WITH_TR = decltype(with_tr_tag)::value;
+        const double *rec0 = stream + (int64_t)jt * 8 * kFbRec;
+        double *ldx = S0 + 4096;                          // [2 buffers][4 waves][2][64 lanes]
+        double rc[3][4][2], rt[3][2], rd[3][2];
+        double pn0 = 0.0, pn1 = 0.0;                      // -l of the record before (WITH_TR: its diagonal-tile update trails by one record)
+#define F2_REQUEST(slot, Bq) do { \
+            const double *rq_ = rec0 + (int64_t)(Bq) * kFbRec; \
+            _Pragma("unroll") for (int q = (Bq) >> 1; q < 4; q++) { \
+                rc[slot][q][0] = f2_ldo(rq_, lane8 + (q * 2) * 512); rc[slot][q][1] = f2_ldo(rq_, lane8 + (q * 2 + 1) * 512); } \
+            rt[slot][0] = f2_ldo(rq_ + 512, lane8); rt[slot][1] = f2_ldo(rq_ + 512, lane8 + 512); \
+            rd[slot][0] = f2_ldo(rq_ + 512, lane8 + 1024); rd[slot][1] = f2_ldo(rq_ + 512, lane8 + 1536); } while (0)
+        F2_REQUEST(0, 0); F2_REQUEST(1, 1); F2_REQUEST(2, 2);
+#pragma unroll
+        for (int Bk = 0; Bk < 8; Bk++) {
+            const int sb = Bk >> 1, par = Bk & 1, sl = Bk % 3;
+            for (unsigned spins = 0;; spins++) {               // level with the producer: poll (bounded)
+                unsigned m = f2_max3(f2_hi(rt[sl][0]), f2_hi(rt[sl][1]), f2_hi(rd[sl][0]));
+                m = max(m, f2_hi(rd[sl][1]));
+#pragma unroll
+                for (int q = sb; q < 4; q++) m = f2_max3(m, f2_hi(rc[sl][q][0]), f2_hi(rc[sl][q][1]));
+                if (__builtin_amdgcn_readfirstlane((int)(__ballot(m != 0xFFFFFFFFu) == ~0ull)) != 0) break;
+                if ((spins & 63u) == 63u || lim < 64u) {
+                    if (spins > lim) {
+                        __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (lane == 0) atomicOr(failflag, 1);
+                        return false;
+                    }
+                    if (__builtin_amdgcn_readfirstlane(f2_ldi(err)) != 0) return false;
+                }
+                __builtin_amdgcn_s_sleep(1);
+                F2_REQUEST(sl, Bk);
+            }
+            if (WITH_TR && Bk == 0) F2_T(3);
+            double cr[4][2], tv[2], dv[2];
+#pragma unroll
+            for (int q = sb; q < 4; q++) { cr[q][0] = rc[sl][q][0]; cr[q][1] = rc[sl][q][1]; }
+            tv[0] = rt[sl][0]; tv[1] = rt[sl][1]; dv[0] = rd[sl][0]; dv[1] = rd[sl][1];
+            if (Bk + 3 < 8) F2_REQUEST(sl, Bk + 3);
+            // l^T = T^T p^T: the block's 8 columns of the strip are the B operand as they stand
+            v4f64 lT = {0.0, 0.0, 0.0, 0.0};
+            lT = __builtin_amdgcn_mfma_f64_16x16x4f64(tv[0], t[sb][2 * par], lT, 0, 0, 0);
+            lT = __builtin_amdgcn_mfma_f64_16x16x4f64(tv[1], t[sb][2 * par + 1], lT, 0, 0, 0);
+            if (WITH_TR && Bk > 0) {
+                // while l of this record is on its way through the matrix core: the diagonal tile's update by the record BEFORE
+                // (its l d of all 64 rows went to LDS in the previous iteration; the barrier closes that exchange).  The strips right
+                // of a wave's own rows are the upper triangle, but the slowest wave -- the last, all four strips -- sets the pace at
+                // the barrier: no per-wave branches here.
+                f2_bar();
+                const double *lp = ldx + ((Bk - 1) & 1) * 512;
+                double la[4][2];
+#pragma unroll
+                for (int so = 0; so < 4; so++) { la[so][0] = lp[(so * 2) * 64 + lane]; la[so][1] = lp[(so * 2 + 1) * 64 + lane]; }
+#pragma unroll
+                for (int so = 0; so < 4; so++) {
+                    tr[so] = __builtin_amdgcn_mfma_f64_16x16x4f64(la[so][0], pn0, tr[so], 0, 0, 0);
+                    tr[so] = __builtin_amdgcn_mfma_f64_16x16x4f64(la[so][1], pn1, tr[so], 0, 0, 0);
+                }
+            }
+            const double l0 = lT[0], l1 = lT[1], nl0 = -l0, nl1 = -l1;
+            if (WITH_TR) {
+                // l d for the other wavefronts (diagonal tile, next iteration) and for the workgroups below
+                const double ld0 = l0 * dv[0], ld1 = l1 * dv[1];
+                double *lx = ldx + par * 512;
+                lx[(wv * 2) * 64 + lane] = ld0;
+                lx[(wv * 2 + 1) * 64 + lane] = ld1;
+                pn0 = nl0; pn1 = nl1;
+            }
+            // (no global store in this loop: on gfx9 loads and stores share one in-order counter, and a write-through store takes
+            // a microsecond to be acknowledged -- a wave that stores here waits for its stores whenever it waits for a record)
+            dcol[sb][2 * par] = dv[0];
+            dcol[sb][2 * par + 1] = dv[1];
+            // the finished columns stay in the tile's registers; the record's raw columns are zero on the rows of its own block, so
+            // the update of the block's own strip leaves them alone
+            t[sb][2 * par] = l0;
+            t[sb][2 * par + 1] = l1;
+            // rank-8 update of the columns right of the block, the strip of the NEXT block's columns first (the block's own strip:
+            // only when its second half is still to come)
+#pragma unroll
+            for (int q = sb + par; q < 4; q++) {
+                t[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(cr[q][0], nl0, t[q], 0, 0, 0);
+                t[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(cr[q][1], nl1, t[q], 0, 0, 0);
+            }
+        }
+        if (WITH_TR) {                                    // the diagonal tile's update by the last record
+            f2_bar();
+            const double *lp = ldx + 512;
+            double la[4][2];
+#pragma unroll
+            for (int so = 0; so < 4; so++) { la[so][0] = lp[(so * 2) * 64 + lane]; la[so][1] = lp[(so * 2 + 1) * 64 + lane]; }
+#pragma unroll
+            for (int so = 0; so < 4; so++) {
+                tr[so] = __builtin_amdgcn_mfma_f64_16x16x4f64(la[so][0], pn0, tr[so], 0, 0, 0);
+                tr[so] = __builtin_amdgcn_mfma_f64_16x16x4f64(la[so][1], pn1, tr[so], 0, 0, 0);
+            }
+        }
+#undef F2_REQUEST
+        return true;
+    };
+
     // ---- the panels left of this block: X_j^T = Minv_j^T A_j^T, then A_k^T -= (L(k,j) D_j) X_j^T for the tiles right of it
     double *STG = S1;                                     // staging tile of the shared operand (S1 holds L11 only from the pivots on)
     const unsigned tid8 = 8u * (unsigned)tid;
@@ -186,18 +301,24 @@ k_front_block2(DevPlan P, FrontBatch B, int *sync_all, double *scratch_all, doub
         f2_bar();
     };
 #pragma unroll
-    for (int j = 0; j < kFbMax; j++) {
-        if (j < nsteps) {                                 // workgroup-uniform
-            if (!f2_wait(fl_minv + j, 1, err, failflag, lim)) return;
-            if (j == nsteps - 1) F2_T(9);
+    for (int j = 0; j < (diag ? 0 : kFbMax); j++) {
+        if (j < nsteps) {                                 // workgroup-uniform (diagonal workgroups: j < i - 2, the last two panels are streamed)
             const FrontPanel pj = fp[j];
             const double *mv = scratch + (int64_t)j * 4160;
+            v4f64 x[4];
+            double dj[4][4];                              // pivots of this lane's columns m = 16 sub + lk + 4 reg (diagonal workgroups)
+            if (!f2_wait(fl_minv + j, 1, err, failflag, lim)) return;
+            if (diag) {
+#pragma unroll
+                for (int sub = 0; sub < 4; sub++)
+#pragma unroll
+                    for (int reg = 0; reg < 4; reg++) dj[sub][reg] = f2_ld(mv + 4096 + 16 * sub + lk + 4 * reg);
+            }
             // The A operand -- the same for all four waves -- comes through LDS: every thread fetches 16 values of the tile (all in
             // flight at once, one memory round trip), the tile is laid down in operand order, each wave reads its k-steps back
             // (lane-contiguous: no bank conflicts).  [Direct loads per wave, first version of this kernel: four times the traffic, and
             // a relaxed atomic load next to its use makes every k-step a round trip -- 30 us per step.]
             stage_tile(mv);
-            v4f64 x[4];
 #pragma unroll
             for (int so = 0; so < 4; so++) {              // Minv is upper triangular: k <= c, 4 so + 4 k-steps per strip
                 double am[16];
@@ -208,17 +329,11 @@ k_front_block2(DevPlan P, FrontBatch B, int *sync_all, double *scratch_all, doub
                 for (int kk = 0; kk < 4 * so + 4; kk++)
                     x[so] = __builtin_amdgcn_mfma_f64_16x16x4f64(am[kk], acc[j][kk >> 2][kk & 3], x[so], 0, 0, 0);
             }
-            if (j == nsteps - 1) F2_T(10);
             if (diag) {
                 // L(i,j) D_j for the workgroups below (operand order: this lane's entry is exactly its own slot) and, through LDS, for
                 // the other wavefronts of this workgroup
                 double *lt = ltiles + (int64_t)(i * (i - 1) / 2 + j) * 4096 + (wv * 16) * 64;
                 double *xd = S0 + (j & 1) * 4096;
-                double dj[4][4];                          // pivots of this lane's columns m = 16 sub + lk + 4 reg (all loads in flight
-#pragma unroll                                            // before the first use: they are ordered with the stores below)
-                for (int sub = 0; sub < 4; sub++)
-#pragma unroll
-                    for (int reg = 0; reg < 4; reg++) dj[sub][reg] = f2_ld(mv + 4096 + 16 * sub + lk + 4 * reg);
 #pragma unroll
                 for (int sub = 0; sub < 4; sub++)
 #pragma unroll
@@ -244,9 +359,7 @@ k_front_block2(DevPlan P, FrontBatch B, int *sync_all, double *scratch_all, doub
                         tr[so] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[kk], x[kk >> 2][kk & 3], tr[so], 0, 0, 0);
                 }
                 f2_settle();
-                if (j == nsteps - 1) F2_T(11);
                 f2_wave_done(fl_L + 8 * i + j);
-                if (j == nsteps - 1) F2_T(12);
             }
             // the panel (column-major) and its row-major copy for the backward solves -- after the hand-off: the flag waits for this
             // wave's outstanding stores, and these 32 strided ones are slow to drain (x holds -X by now)
@@ -267,7 +380,6 @@ k_front_block2(DevPlan P, FrontBatch B, int *sync_all, double *scratch_all, doub
             for (int k = j + 1; k < kFbMax; k++) {
                 if (k < ncb && !(diag && k == i)) {
                     if (!f2_wait(fl_L + 8 * k + j, 4, err, failflag, lim)) return;
-                    if (j == nsteps - 1 && k == i - 1) F2_T(13);
                     const double *lt = ltiles + (int64_t)(k * (k - 1) / 2 + j) * 4096;
                     stage_tile(lt);
 #pragma unroll
@@ -284,9 +396,89 @@ k_front_block2(DevPlan P, FrontBatch B, int *sync_all, double *scratch_all, doub
         }
     }
     F2_T(2);
-    if (!diag) return;
+    if constexpr (!diag) return;
+    else {
 
-    // ---- streamed step: this workgroup's rows of panel i - 1, record by record behind the workgroup that eliminates tile i - 1.
+    // ---- a diagonal workgroup's panels j2 < i - 1 from the stream (a later reader of tile j2's records, behind the workgroups i' < i):
+    //      no step waits for the inverse of a tile, which is published 4 - 5 us after its pivots.  Then the step's hand-off and
+    //      updates as in the regular steps.  One copy of the code, rolled over j2; the tiles are selected by run-time index.
+#pragma unroll 1
+    for (int j2 = 0; j2 < i - 1; j2++) {
+        v4f64 x[4];
+#pragma unroll
+        for (int sub = 0; sub < 4; sub++) {
+            x[sub] = (v4f64){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int k = 0; k < kFbMax; k++)
+                if (k == j2) x[sub] = acc[k][sub];
+        }
+        double dj[4][4];
+        if (!consume(std::false_type{}, j2, x, dj)) return;
+        if (j2 == i - 2) F2_T(9);
+        {
+            double *lt = ltiles + (int64_t)(i * (i - 1) / 2 + j2) * 4096 + (wv * 16) * 64;
+            double *xd = S0 + (j2 & 1) * 4096;
+#pragma unroll
+            for (int sub = 0; sub < 4; sub++)
+#pragma unroll
+                for (int reg = 0; reg < 4; reg++) {
+                    const double v = x[sub][reg] * dj[sub][reg];
+                    f2_sto(lt + (4 * sub + (reg & 2)) * 64, lane8 + (reg & 1) * 512, v);
+                    xd[(wv * 16 + 4 * sub + reg) * 64 + lane] = v;
+                }
+#pragma unroll
+            for (int so = 0; so < 4; so++) x[so] = -x[so];
+            f2_bar();
+#pragma unroll
+            for (int so = 0; so < 4; so++) {
+                double xa[16];
+#pragma unroll
+                for (int kk = 0; kk < 16; kk++) xa[kk] = xd[(so * 16 + kk) * 64 + lane];
+#pragma unroll
+                for (int kk = 0; kk < 16; kk++)
+                    tr[so] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[kk], x[kk >> 2][kk & 3], tr[so], 0, 0, 0);
+            }
+            f2_settle();
+            if (j2 == i - 2) F2_T(11);
+            f2_wave_done(fl_L + 8 * i + j2);
+        }
+        // the tiles between panel j2 and the own one need L(k, j2) D of the diagonal workgroups above (raised after THEIR step j2)
+#pragma unroll 1
+        for (int k = j2 + 1; k < i; k++) {
+            if (!f2_wait(fl_L + 8 * k + j2, 4, err, failflag, lim)) return;
+            if (j2 == i - 2) F2_T(13);
+            stage_tile(ltiles + (int64_t)(k * (k - 1) / 2 + j2) * 4096);
+            v4f64 t[4];
+#pragma unroll
+            for (int sub = 0; sub < 4; sub++) {
+                t[sub] = (v4f64){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int kk = 0; kk < kFbMax; kk++)
+                    if (kk == k) t[sub] = acc[kk][sub];
+            }
+#pragma unroll
+            for (int so = 0; so < 4; so++) {
+                double al[16];
+#pragma unroll
+                for (int kk = 0; kk < 16; kk++) al[kk] = STG[(so * 16 + kk) * 64 + lane];
+#pragma unroll
+                for (int kk = 0; kk < 16; kk++)
+                    t[so] = __builtin_amdgcn_mfma_f64_16x16x4f64(al[kk], x[kk >> 2][kk & 3], t[so], 0, 0, 0);
+            }
+#pragma unroll
+            for (int sub = 0; sub < 4; sub++)
+#pragma unroll
+                for (int kk = 0; kk < kFbMax; kk++)
+                    if (kk == k) acc[kk][sub] = t[sub];
+        }
+        // the finished rows stay in the tile's registers (x holds -X); they go to the panel at the very end -- a store here would
+        // sit in front of the next step's record loads on the memory counter
+#pragma unroll
+        for (int sub = 0; sub < 4; sub++)
+#pragma unroll
+            for (int kk = 0; kk < kFbMax; kk++)
+                if (kk == j2) acc[kk][sub] = -x[sub];
+    }
     v4f64 xr[4];                                          // the tile of panel i - 1, L(i, i-1) after the streamed step
 #pragma unroll
     for (int sub = 0; sub < 4; sub++) {
@@ -295,90 +487,18 @@ k_front_block2(DevPlan P, FrontBatch B, int *sync_all, double *scratch_all, doub
         for (int k = 0; k < kFbMax; k++)
             if (k == i - 1) xr[sub] = acc[k][sub];
     }
+    // ---- streamed step: this workgroup's rows of panel i - 1, record by record behind the workgroup that eliminates tile i - 1.
     if (i > 0) {
-        const double *rec0 = stream + (int64_t)(i - 1) * 8 * kFbRec;
-        const FrontPanel pl = fp[i - 1];
-        double *lt_out = ltiles + (int64_t)(i * (i - 1) / 2 + i - 1) * 4096;
-        double *ldx = S0 + 4096;                          // [2 buffers][4 waves][2][64 lanes]
-        f2_bar();                                         // the X D buffers of the regular steps are free
-        // Ring of three records in registers: while record Bk is processed, records Bk + 1 and Bk + 2 are in flight (a consumer that
-        // has fallen behind finds them complete and pays no memory round trip per record; one that is level with the producer sees
-        // the sentinel and polls).  Fully unrolled: the strip / register of a block's columns is static.  The loop is instruction-
-        // issue bound (one wavefront issues every ~5 cycles): uniform base + lane offset addressing, one negation per record (the B
-        // operand), the freshness test by unsigned maxima, the panel stores after the pivots.
-        double rc[3][4][2], rt[3][2], rd[3][2];
-#define F2_REQUEST(slot, Bq) do { \
-            const double *rq_ = rec0 + (int64_t)(Bq) * kFbRec; \
-            _Pragma("unroll") for (int q = (Bq) >> 1; q < 4; q++) { \
-                rc[slot][q][0] = f2_ldo(rq_, lane8 + (q * 2) * 512); rc[slot][q][1] = f2_ldo(rq_, lane8 + (q * 2 + 1) * 512); } \
-            rt[slot][0] = f2_ldo(rq_ + 512, lane8); rt[slot][1] = f2_ldo(rq_ + 512, lane8 + 512); \
-            rd[slot][0] = f2_ldo(rq_ + 512, lane8 + 1024); rd[slot][1] = f2_ldo(rq_ + 512, lane8 + 1536); } while (0)
-        F2_REQUEST(0, 0); F2_REQUEST(1, 1); F2_REQUEST(2, 2);
-        double *lt_w = lt_out + (wv * 16) * 64;            // this wave's 16 rows of L(i, i-1) D in operand order
+        double dl[4][4];
+        f2_bar();                                         // the X D buffers of the steps before are free
+        if (!consume(std::true_type{}, i - 1, xr, dl)) return;
+        // L(i, i-1) D for the workgroups below (operand order); the flag follows during the first pivot block
+        double *lt = ltiles + (int64_t)(i * (i - 1) / 2 + i - 1) * 4096 + (wv * 16) * 64;
 #pragma unroll
-        for (int Bk = 0; Bk < 8; Bk++) {
-            const int sb = Bk >> 1, par = Bk & 1, sl = Bk % 3;
-            for (unsigned spins = 0;; spins++) {               // level with the producer: poll (bounded)
-                unsigned m = f2_max3(f2_hi(rt[sl][0]), f2_hi(rt[sl][1]), f2_hi(rd[sl][0]));
-                m = max(m, f2_hi(rd[sl][1]));
+        for (int sub = 0; sub < 4; sub++)
 #pragma unroll
-                for (int q = sb; q < 4; q++) m = f2_max3(m, f2_hi(rc[sl][q][0]), f2_hi(rc[sl][q][1]));
-                if (__builtin_amdgcn_readfirstlane((int)(__ballot(m != 0xFFFFFFFFu) == ~0ull)) != 0) break;
-                if ((spins & 63u) == 63u || lim < 64u) {
-                    if (spins > lim) {
-                        __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (lane == 0) atomicOr(failflag, 1);
-                        return;
-                    }
-                    if (__builtin_amdgcn_readfirstlane(f2_ldi(err)) != 0) return;
-                }
-                __builtin_amdgcn_s_sleep(1);
-                F2_REQUEST(sl, Bk);
-            }
-            if (Bk == 0) F2_T(3);
-            double cr[4][2], tv[2], dv[2];
-#pragma unroll
-            for (int q = sb; q < 4; q++) { cr[q][0] = rc[sl][q][0]; cr[q][1] = rc[sl][q][1]; }
-            tv[0] = rt[sl][0]; tv[1] = rt[sl][1]; dv[0] = rd[sl][0]; dv[1] = rd[sl][1];
-            if (Bk + 3 < 8) F2_REQUEST(sl, Bk + 3);
-            // l^T = T^T p^T: the block's 8 columns of the strip are the B operand as they stand
-            v4f64 lT = {0.0, 0.0, 0.0, 0.0};
-            lT = __builtin_amdgcn_mfma_f64_16x16x4f64(tv[0], xr[sb][2 * par], lT, 0, 0, 0);
-            lT = __builtin_amdgcn_mfma_f64_16x16x4f64(tv[1], xr[sb][2 * par + 1], lT, 0, 0, 0);
-            const double l0 = lT[0], l1 = lT[1], nl0 = -l0, nl1 = -l1;
-            // l d for the other wavefronts (diagonal tile) and for the workgroups below
-            const double ld0 = l0 * dv[0], ld1 = l1 * dv[1];
-            double *lx = ldx + par * 512;
-            lx[(wv * 2) * 64 + lane] = ld0;
-            lx[(wv * 2 + 1) * 64 + lane] = ld1;
-            f2_sto(lt_w + (Bk >> 2) * 512, lane8 + (2 * (Bk & 3)) * 512, ld0);
-            f2_sto(lt_w + (Bk >> 2) * 512, lane8 + (2 * (Bk & 3) + 1) * 512, ld1);
-            // the finished columns stay in the tile's registers (stored to the panel after the pivots); the record's raw columns
-            // are zero on the rows of its own block, so the update of the block's own strip leaves them alone
-            xr[sb][2 * par] = l0;
-            xr[sb][2 * par + 1] = l1;
-            // rank-8 update of the columns right of the block (the block's own strip: only when its second half is still to come)
-#pragma unroll
-            for (int q = sb + par; q < 4; q++) {
-                xr[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(cr[q][0], nl0, xr[q], 0, 0, 0);
-                xr[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(cr[q][1], nl1, xr[q], 0, 0, 0);
-            }
-            f2_bar();
-            {
-                // (the strips right of a wave's own rows are the upper triangle, but the slowest wave -- the last, all four strips --
-                // sets the pace at the barrier: no per-wave branches here)
-                double la[4][2];
-#pragma unroll
-                for (int so = 0; so < 4; so++) { la[so][0] = lx[(so * 2) * 64 + lane]; la[so][1] = lx[(so * 2 + 1) * 64 + lane]; }
-#pragma unroll
-                for (int so = 0; so < 4; so++) {
-                    tr[so] = __builtin_amdgcn_mfma_f64_16x16x4f64(la[so][0], nl0, tr[so], 0, 0, 0);
-                    tr[so] = __builtin_amdgcn_mfma_f64_16x16x4f64(la[so][1], nl1, tr[so], 0, 0, 0);
-                }
-            }
-        }
+            for (int reg = 0; reg < 4; reg++) f2_sto(lt + (4 * sub + (reg & 2)) * 64, lane8 + (reg & 1) * 512, xr[sub][reg] * dl[sub][reg]);
         f2_settle();
-#undef F2_REQUEST
         F2_T(4);
     }
 
@@ -626,20 +746,31 @@ k_front_block2(DevPlan P, FrontBatch B, int *sync_all, double *scratch_all, doub
         }
         if (lane == 0 && nreg) atomicAdd(P.flags + FL_NREG, nreg);
     }
-    if (i > 0 && rowok) {
-        // L(i, i-1) from the streamed step (kept in the tile's registers): the panel and its row-major copy for the backward solves
-        const FrontPanel pl = fp[i - 1];
-        double *dst = P.Lx + pl.panel_off + 64 + n;
-        double *lt2 = P.LT + pl.lt_off + (int64_t)n * 64;
+    if (rowok) {
+        // this workgroup's rows of the panels left of its tile (kept in the tiles' registers since their steps): the panels
+        // (column-major) and their row-major copies for the backward solves
 #pragma unroll
-        for (int sub = 0; sub < 4; sub++)
+        for (int k = 0; k < kFbMax - 1; k++) {
+            if (k < i) {
+                const FrontPanel pk = fp[k];
+                double *dst = P.Lx + pk.panel_off + 64 * (i - k) + n;
+                double *lt2 = P.LT + pk.lt_off + (int64_t)(64 * (i - k) - 64 + n) * 64;
 #pragma unroll
-            for (int reg = 0; reg < 4; reg++) {
-                dst[(int64_t)(16 * sub + lk + 4 * reg) * pl.r] = xr[sub][reg];
-                lt2[16 * sub + lk + 4 * reg] = xr[sub][reg];
+                for (int sub = 0; sub < 4; sub++)
+#pragma unroll
+                    for (int reg = 0; reg < 4; reg++) {
+                        const double v = k == i - 1 ? xr[sub][reg] : acc[k][sub][reg];
+                        dst[(int64_t)(16 * sub + lk + 4 * reg) * pk.r] = v;
+                        lt2[16 * sub + lk + 4 * reg] = v;
+                    }
             }
+        }
     }
     F2_T(8);
+    }
+    };   // body
+    if (i < nb) body(std::true_type{});
+    else body(std::false_type{});
 }
 
 }  // namespace

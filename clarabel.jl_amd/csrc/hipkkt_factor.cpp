@@ -62,8 +62,13 @@ static double dense_stage_cost_us(int m) {
     return k == 0 ? 77.0 : 65.0 * (k + 1);
 }
 int fb_extra_tiles_of_stage(int nd, int ncrit, int next_blk, int *per_wave_out) {
-    constexpr int cus = 254, rmin = 64, pw_max = 2;
-    constexpr double pen[3] = {0.0, 10.0, 28.0};     // what the panel launch gains in duration (us) with one / two tiles per wavefront
+    constexpr int cus = 254, rmin = 64;
+    // what the panel launch gains in duration (us) with one / two tiles per wavefront; experiments: HIPKKT_FB_EXTRA_PW=<max tiles per
+    // wavefront>,<penalty 1>,<penalty 2>
+    static const struct Tun { int pw_max; double pen[3]; Tun() : pw_max(1), pen{0.0, 10.0, 28.0} {   // (round 5: one tile per wavefront since the panel chain got shorter than two tile times)
+        if (const char *e = getenv("HIPKKT_FB_EXTRA_PW")) { double a = pen[1], b = pen[2]; int m = pw_max; if (sscanf(e, "%d,%lf,%lf", &m, &a, &b) >= 1) { pw_max = std::max(1, std::min(m, 2)); pen[1] = a; pen[2] = b; } } } } tun;
+    const int pw_max = tun.pw_max;
+    const double *pen = tun.pen;
     double best = dense_stage_cost_us(nd);
     int best_r = 0, best_pw = 1;
     for (int pw = 1; pw <= pw_max; pw++) {

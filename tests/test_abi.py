@@ -69,5 +69,5 @@ def test_extra_tile_choice_is_consistent():
                     m = nd - r
                     assert r >= 64
                     assert m <= 384 or m == ncrit or m == 768 or m % 1024 in (0, 256, 512), (nd, ncrit, next_blk, r)
-    assert seen_two
+    assert not seen_two      # round 5: one tile per wavefront (the panel chain of front_block2.hip is shorter than two tile times)
     assert L.hipkkt_debug_extra_tiles(3403, 435, 82, None) > 0 and L.hipkkt_debug_extra_tiles(50, 10, 10, None) == 0

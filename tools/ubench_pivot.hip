@@ -188,6 +188,29 @@ __global__ void __launch_bounds__(64) k_piv_rolled(const double *A, double *Lout
     if (lane == 0) { st[0] = tp; st[1] = nreg; }
 }
 
+// accuracy of the reciprocal refinements against the correctly rounded quotient 1.0 / d: the raw v_rcp_f64, one Newton step
+// r (1 + e), the three-term form r (1 + e + e^2) used on the pivot chain, two Newton steps
+__global__ void k_rcpacc(double *out, unsigned long long seed) {
+    unsigned long long x = seed + 0x9E3779B97F4A7C15ull * (blockIdx.x * blockDim.x + threadIdx.x + 1);
+    double m0 = 0, m1 = 0, m3 = 0, m2 = 0;
+    for (int it = 0; it < 4096; it++) {
+        x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+        const double mant = 1.0 + (double)(x >> 12) * (1.0 / 4503599627370496.0);
+        const int ex = (int)((x >> 3) & 127) - 64;
+        const double d = ldexp(mant, ex) * ((x & 1) ? -1.0 : 1.0);
+        const double q = 1.0 / d;
+        const double r = __builtin_amdgcn_rcp(d);
+        const double e = fma(-d, r, 1.0);
+        const double r1 = fma(r, e, r);
+        const double r3 = fma(r, fma(e, e, e), r);
+        double r2 = fma(fma(-d, r, 1.0), r, r); r2 = fma(fma(-d, r2, 1.0), r2, r2);
+        const double u = fabs(q) * 1.1102230246251565e-16;   // half an ulp-ish unit: 2^-53 |q|
+        m0 = fmax(m0, fabs(r - q) / u); m1 = fmax(m1, fabs(r1 - q) / u); m3 = fmax(m3, fabs(r3 - q) / u); m2 = fmax(m2, fabs(r2 - q) / u);
+    }
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    out[4 * t] = m0; out[4 * t + 1] = m1; out[4 * t + 2] = m3; out[4 * t + 3] = m2;
+}
+
 int main() {
     std::vector<double> h(64 * 64);
     for (int i = 0; i < 64; i++) for (int j = 0; j < 64; j++) h[i + j * 64] = (i == j ? 70.0 : 0.0) + 0.01 * (((i + 1) * 31 + (j + 1) * 17 + (i ^ j)) % 13);
@@ -230,6 +253,16 @@ int main() {
         double e = 0;
         for (int i = 0; i < 64; i++) e = std::fmax(e, std::fabs(D2[i] - D0[i]) / std::fabs(D0[i]));
         printf("rolled vs cur: max rel diff D %.2e\n", e);
+    }
+    {
+        double *da; const int nt = 64 * 256;
+        hipMalloc(&da, nt * 4 * 8);
+        hipLaunchKernelGGL(k_rcpacc, dim3(64), dim3(256), 0, 0, da, 12345ull);
+        std::vector<double> ha(nt * 4);
+        hipMemcpy(ha.data(), da, nt * 4 * 8, hipMemcpyDeviceToHost);
+        double m[4] = {0, 0, 0, 0};
+        for (int t = 0; t < nt; t++) for (int q = 0; q < 4; q++) m[q] = std::fmax(m[q], ha[4 * t + q]);
+        printf("reciprocal error in units of 2^-53 |1/d| over 6.7e7 values: raw v_rcp_f64 %.3g, one Newton step %.3g, r(1+e+e^2) %.3g, two Newton steps %.3g\n", m[0], m[1], m[2], m[3]);
     }
     double eL = 0, eD = 0;
     for (int i = 0; i < 64; i++) for (int j = 0; j < i; j++) eL = std::fmax(eL, std::fabs(L1[i + 64 * j] - L0[i + 64 * j]) / std::fmax(1e-300, std::fabs(L0[i + 64 * j])));
