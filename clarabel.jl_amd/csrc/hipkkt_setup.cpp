@@ -432,7 +432,8 @@ void setup_device(hipkkt_solver *S) {
         D.seg_ticket = 3;                                  // bit 0: forward sweep, bit 1: backward sweep take their items by atomic ticket
         const char *sl = getenv("HIPKKT_SPIN_LIMIT");      // tests force a sweep time-out with a tiny bound
         D.spin_limit = sl ? (unsigned)strtoul(sl, nullptr, 10) : (1u << 20);
-        D.dbg = 0;
+        const char *df = getenv("HIPKKT_DEBUG_FLAGS");    // timing experiments only: results are WRONG when set (device_plan.h DevPlan::dbg)
+        D.dbg = df ? atoi(df) : 0;
     }
     {
         const size_t nsync = seg_sync_ints(S->nseg, P.nsuper);
