@@ -7,7 +7,7 @@
 namespace hipkkt {
 
 enum { SC_MAXDIAG = 0, SC_NORMB = 1, SC_NORME = 2, SC_COUNT = 8 };  // 64-bit scalar slots
-enum { FL_NONFINITE = 0, FL_NREG = 1, FL_FRONTFAIL = 2, FL_FACFAIL = 3, FL_COUNT = 4 };   // int flags (FL_FACFAIL: k_front_block gave up)
+enum { FL_NONFINITE = 0, FL_NREG = 1, FL_FRONTFAIL = 2, FL_FACFAIL = 3, FL_NPOLISH = 4, FL_COUNT = 8 };   // int flags (FL_FACFAIL: k_front_block gave up)
 
 // hand-off slot of the persistent sweeps: a value and its self-validating tag (kernels.hip front_slot_* / seg_slot_*)
 struct __attribute__((aligned(16))) FrontSlot {
@@ -116,6 +116,8 @@ struct DevPlan {
     int *seg_sync;               // [0,nseg) forward tickets, [nseg,2nseg) backward tickets, then per-supernode counters:
     int seg_ticket;              // bit 0 / bit 1: forward / backward segment-sweep items are atomic tickets (default 3); 0: blockIdx
     unsigned spin_limit;         // bound of every spin loop of the persistent sweeps (default 2^20; HIPKKT_SPIN_LIMIT)
+    int *sn_polish;              // [nsuper] 1: the block solves with this supernode take one refinement step (written by k_invert_diag_wide per factorisation)
+    double polish_tau;           // threshold on the largest |entry| of a wide block's explicit inverse (64; HIPKKT_ACCURATE)
     int dbg;                     // timing experiments only (HIPKKT_DEBUG_FLAGS; results are WRONG when set): bit 0 = the super-block sweeps skip
                                  // their L tile loads (what remains is the hand-off chain)
     int nseg;                    //   fdone[nsuper], bdone[nsuper], pdone[nsuper]; error word last   // per front: {ticket, error, flags[np]} (zeroed before every front kernel)

@@ -608,9 +608,10 @@ int32_t hipkkt_box_probe(int32_t device_id, double *out, int64_t cap) {
 
 int32_t hipkkt_get_profile(hipkkt_handle h, double *out, int64_t cap) {
     if (!h || !out || cap < 0) return HIPKKT_ERR_ARGUMENT;
-    const double o[10] = {h->t_last_update, h->prof_dense4_ms, h->prof_dense4_flops, (double)h->prof_dense4_launches, h->prof_fb_ms,
-                          (double)h->prof_fb_launches, (double)h->prof_fb_panels, h->prof_fb_flops, h->prof_extra_tiles, h->prof_extra_flops};
-    for (int64_t i = 0; i < cap && i < 10; i++) out[i] = o[i];   // never more than the caller's buffer holds
+    const double o[12] = {h->t_last_update, h->prof_dense4_ms, h->prof_dense4_flops, (double)h->prof_dense4_launches, h->prof_fb_ms,
+                          (double)h->prof_fb_launches, (double)h->prof_fb_panels, h->prof_fb_flops, h->prof_extra_tiles, h->prof_extra_flops,
+                          (double)h->last_npolish, (double)h->n_accurate_factorisations};
+    for (int64_t i = 0; i < cap && i < 12; i++) out[i] = o[i];   // never more than the caller's buffer holds
     return HIPKKT_OK;
 }
 
@@ -634,7 +635,7 @@ int32_t hipkkt_get_counters(hipkkt_handle h, int64_t *out, int64_t cap) {
     o[8] = (int64_t)h->fbatches.size(); o[9] = h->use_front_block ? 1 : 0;
     plan_cache_counts(&o[10], &o[11]);   // process-wide: symbolic plans taken from / not found in the plan cache
     o[12] = h->fb_streamed ? 1 : 0;
-    o[13] = 0;
+    o[13] = h->n_accurate_factorisations;
     for (int64_t i = 0; i < cap && i < 14; i++) out[i] = o[i];
     return HIPKKT_OK;
 }

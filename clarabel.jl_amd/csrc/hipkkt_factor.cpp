@@ -365,6 +365,8 @@ static int32_t refactor_once(hipkkt_handle h, int32_t static_reg_enable, double 
         S->n_sweep_timeouts++;
         return refactor_once(h, static_reg_enable, eps_const, eps_prop, eps_used, n_dynamic_reg);
     }
+    S->last_npolish = S->h_flags[FL_NPOLISH];            // wide diagonal blocks whose solves take a refinement step (kernels.hip k_invert_diag_wide)
+    if (S->last_npolish > 0) S->n_accurate_factorisations++;
     const double maxdiag = slot_value(S, SC_MAXDIAG);
     S->last_eps = static_reg_enable ? eps_const + eps_prop * maxdiag : 0.0;
     S->last_nreg = S->h_flags[FL_NREG];

@@ -146,6 +146,10 @@ struct hipkkt_solver {
     };
     std::vector<NextBatch> next_batch;
     int64_t split_scratch_doubles = 0;   // split-K partial tiles behind the panels in Lx (cleared with them before every factorisation)
+    // refined block solves (kernels.hip k_invert_diag_wide): wide diagonal blocks whose explicit inverse has an entry above the threshold
+    double accurate_threshold = 64.0;    // HIPKKT_ACCURATE=<threshold> ("0" = never, "-1" = every wide block)
+    int last_npolish = 0;                // marked blocks of the last factorisation
+    int64_t n_accurate_factorisations = 0;   // factorisations with at least one
     bool fb_v2 = true;                   // front batches by front_block2.hip (tiles transposed in the accumulators, round 5); HIPKKT_FB_V2=0: front_block.hip
     bool force_twin = false;             // HIPKKT_FORCE_TWIN=1 at create (tests): see hipkkt_refactor
     bool fb_extra = true;                // the partial last round of a batch's far updates rides in the next k_front_block launch (HIPKKT_FB_EXTRA=0: off)

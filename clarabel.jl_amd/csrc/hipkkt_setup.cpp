@@ -69,6 +69,9 @@ void init_runtime(hipkkt_solver *S) {
         S->fb_streamed = !(fs && fs[0] == '0');
         const char *f2 = getenv("HIPKKT_FB_V2");     // 0: the first form of the front-batch kernel (front_block.hip; A/B timing, comparison test)
         S->fb_v2 = !(f2 && f2[0] == '0') && S->fb_streamed;   // (HIPKKT_FB_STREAM=0 asks for the round-3 chain, which only the first form has)
+        const char *ac = getenv("HIPKKT_ACCURATE");   // threshold on the largest |entry| of a wide block's explicit inverse above which its solves take a
+        if (ac && ac[0] == '0' && ac[1] == 0) S->accurate_threshold = 1e300;   // refinement step (default 64): "0" = never, "-1" = every wide block
+        else if (ac) S->accurate_threshold = atof(ac);
         const char *ft = getenv("HIPKKT_FORCE_TWIN"); // 1 (tests): every successful factorisation in the cheap order counts as broken down (hipkkt_refactor)
         S->force_twin = ft && ft[0] == '1';
     }
@@ -434,6 +437,9 @@ void setup_device(hipkkt_solver *S) {
         D.spin_limit = sl ? (unsigned)strtoul(sl, nullptr, 10) : (1u << 20);
         const char *df = getenv("HIPKKT_DEBUG_FLAGS");    // timing experiments only: results are WRONG when set (device_plan.h DevPlan::dbg)
         D.dbg = df ? atoi(df) : 0;
+        D.sn_polish = S->dalloc<int>((size_t)std::max(P.nsuper, 1));
+        fill_async(S->stream, D.sn_polish, 0, (size_t)std::max(P.nsuper, 1) * sizeof(int));
+        D.polish_tau = S->accurate_threshold;
     }
     {
         const size_t nsync = seg_sync_ints(S->nseg, P.nsuper);

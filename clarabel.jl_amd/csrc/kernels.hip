@@ -487,10 +487,32 @@ k_invert_diag_wide(DevPlan P, int list_begin) {
     __syncthreads();
     double *li = P.Linv + P.sn_diag[s];
     double *lit = P.LinvT + P.sn_diag[s];
+    double mx = 0.0;
     for (int idx = tid; idx < w * w; idx += 256) {
         const int i = idx % w, j = idx / w;
         li[idx] = Xs[i * 65 + j];      // Linv[i][j], column-major
         lit[idx] = Xs[j * 65 + i];     // LinvT: element (i,j) of Linv at [j + i*w]
+        mx = fmax(mx, fabs(Xs[i * 65 + j]));
+    }
+    // REFINED BLOCK SOLVES.  The solve kernels multiply by this explicit inverse; where it has large entries the product is several
+    // times less accurate than the reference's substitution (forward error ~ eps |Linv| |b| against ~ eps |L^-1| |L| |y|) -- on
+    // batch seed 324 enough to flip the stop-ratio branch of the iterative refinement and to end the IPM one iteration apart, 1.3e-5
+    // off in the objective (round 4).  Established on the CPU with the host interpreter of the plan
+    // (tools/seed324_inverse_vs_substitution.py): the first-solve residual is 5.5e-5 with the inverses against substitution's
+    // 1.46e-5; one step  y += Linv (b - L y)  on the WIDE blocks (> 16 columns: 16 of that problem's 1361 supernodes) restores
+    // 1.46e-5 exactly, on the narrow ones it changes nothing.  So a wide block whose inverse has an entry above DevPlan::polish_tau
+    // is marked, and the kernels that solve with regular supernodes take that step on it (k_fwd_level / k_fwd_seg / k_bwd_final /
+    // k_bwd_seg).  The fronts' sweeps do not (their panels come in chains whose super-block inverses are a different construction).
+    {
+        __shared__ double wmx[4];
+        mx = wave_max(mx);
+        if ((tid & 63) == 0) wmx[tid >> 6] = mx;
+        __syncthreads();
+        if (tid == 0) {
+            const double m = fmax(fmax(wmx[0], wmx[1]), fmax(wmx[2], wmx[3]));
+            P.sn_polish[s] = (w > 16 && !(m <= P.polish_tau)) ? 1 : 0;
+            if (w > 16 && !(m <= P.polish_tau)) atomicAdd(P.flags + FL_NPOLISH, 1);
+        }
     }
 }
 
@@ -747,6 +769,42 @@ k_permute_in(const double *__restrict__ b, const int *__restrict__ perm, double 
     if (k < n) y[k] = b[perm[k]];
 }
 
+// One refinement step of a marked block's forward solve against the factored block itself (k_invert_diag_wide explains):
+// yv += Linv (rhs - L yv); rhs, yv, scratch in LDS ([w] each), every thread of the workgroup calls it.
+__device__ __forceinline__ void polish_fwd(const DevPlan &P, int s, int w, const double *rhs, double *yv, double *scratch) {
+    const double *ldg = P.Ldiag + P.sn_diag[s], *li = P.Linv + P.sn_diag[s];
+    const int tid = threadIdx.x;
+    if (tid < w) {
+        double a = rhs[tid] - yv[tid];
+        for (int k2 = 0; k2 < tid; k2++) a -= ldg[tid + k2 * w] * yv[k2];
+        scratch[tid] = a;
+    }
+    __syncthreads();
+    double c = 0.0;
+    if (tid < w)
+        for (int k2 = 0; k2 <= tid; k2++) c += li[tid + k2 * w] * scratch[k2];
+    __syncthreads();
+    if (tid < w) yv[tid] += c;
+    __syncthreads();
+}
+// the same for the backward solve: xv += Linv^T (tv - L^T xv)
+__device__ __forceinline__ void polish_bwd(const DevPlan &P, int s, int w, const double *tv, double *xv, double *scratch) {
+    const double *ldg = P.Ldiag + P.sn_diag[s], *lit = P.LinvT + P.sn_diag[s];
+    const int tid = threadIdx.x;
+    if (tid < w) {
+        double a = tv[tid] - xv[tid];
+        for (int i2 = tid + 1; i2 < w; i2++) a -= ldg[i2 + tid * w] * xv[i2];
+        scratch[tid] = a;
+    }
+    __syncthreads();
+    double c = 0.0;
+    if (tid < w)
+        for (int i2 = tid; i2 < w; i2++) c += lit[tid + i2 * w] * scratch[i2];
+    __syncthreads();
+    if (tid < w) xv[tid] += c;
+    __syncthreads();
+}
+
 // Latency model behind these kernels (measured on MI355X, tools/ubench.hip): a dependent f64 FMA
 // costs 32 cycles, an LDS round trip 60, an L2 hit ~220, HBM/MALL ~650, and one CU pulls only
 // ~10 B/clk from HBM.  Hence: every dot product runs on 4 independent accumulators, and a panel is
@@ -806,14 +864,14 @@ k_fwd_level(DevPlan P, int item_begin, double *__restrict__ y, double *__restric
     }
     __syncthreads();
     if (tid < w) {
-        const double v = ((part[0][tid] + part[1][tid]) + part[2][tid]) + part[3][tid];
-        yv[tid] = v;
-        if (it.blk == 0) z[f + tid] = v * P.Dinv[f + tid];   // y keeps the right-hand side: the other block items of
-                                                              // this supernode (same launch) may still have to read it
+        yv[tid] = ((part[0][tid] + part[1][tid]) + part[2][tid]) + part[3][tid];
     } else if (tid < kMaxSnWidth) {
         yv[tid] = 0.0;   // padded columns multiply prefetched zeros: keep them finite
     }
     __syncthreads();
+    if (P.sn_polish[s]) polish_fwd(P, s, w, rhs, yv, part[0]);           // (workgroup-uniform)
+    if (tid < w && it.blk == 0) z[f + tid] = yv[tid] * P.Dinv[f + tid];   // y keeps the right-hand side: the other block items of
+                                                                          // this supernode (same launch) may still have to read it
     // this panel's update vector = children's contributions passed through + L21 * y_J
     {
         double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
@@ -995,6 +1053,17 @@ k_bwd_final(DevPlan P, int sn_begin, const double *__restrict__ z, double *__res
         red[pq][k] = a0 + a1;
     }
     __syncthreads();
+    if (P.sn_polish[s]) {                                                 // (workgroup-uniform)
+        __shared__ double xv[kMaxSnWidth];
+        if (tid < w) xv[tid] = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
+        __syncthreads();
+        polish_bwd(P, s, w, tv, xv, red[0]);
+        if (tid < w) {
+            x[f + tid] = xv[tid];
+            xout[P.perm[f + tid]] = xv[tid];
+        }
+        return;
+    }
     if (tid < w) {
         const double v = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
         x[f + tid] = v;
@@ -1433,13 +1502,13 @@ k_fwd_seg(DevPlan P, int seg, int item_begin, int nitems, int nsuper, int first_
     }
     __syncthreads();
     if (tid < w) {
-        const double v = ((part[0][tid] + part[1][tid]) + part[2][tid]) + part[3][tid];
-        yv[tid] = v;
-        if (it.blk == 0) z[f + tid] = v * dinv_own;   // y is never overwritten (see k_fwd_level)
+        yv[tid] = ((part[0][tid] + part[1][tid]) + part[2][tid]) + part[3][tid];
     } else if (tid < kMaxSnWidth) {
         yv[tid] = 0.0;
     }
     __syncthreads();
+    if (P.sn_polish[s]) polish_fwd(P, s, w, rhs, yv, part[0]);   // (workgroup-uniform)
+    if (tid < w && it.blk == 0) z[f + tid] = yv[tid] * dinv_own;   // y is never overwritten (see k_fwd_level)
     {
         double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
 #pragma unroll
@@ -1598,6 +1667,18 @@ k_bwd_seg(DevPlan P, int seg, int item_begin, int nitems, int nsuper, int first_
         red[wave][lane] = s0 + s1;
     }
     __syncthreads();
+    if (P.sn_polish[s]) {                                                 // (workgroup-uniform; k_invert_diag_wide explains)
+        __shared__ double xv[kMaxSnWidth];
+        if (tid < w) xv[tid] = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
+        __syncthreads();
+        polish_bwd(P, s, w, tv, xv, red[0]);
+        if (tid < w) {
+            seg_slot_st(P.xseg + f + tid, xv[tid], key);
+            x[f + tid] = xv[tid];
+            xout[perm_own] = xv[tid];
+        }
+        return;
+    }
     if (tid < w) {   // publish: tagged slot for the descendants solved in this launch, plain copy for everybody else
         const double v = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
         seg_slot_st(P.xseg + f + tid, v, key);

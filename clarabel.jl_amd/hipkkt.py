@@ -256,7 +256,8 @@ class Handle:
         self.L.hipkkt_get_counters(self.h, o, len(o))
         return dict(sweep_timeouts=int(o[0]), persistent=bool(o[1]), twin_refactors=int(o[2]), twin_exists=bool(o[3]),
                     in_twin=bool(o[4]), ordering=int(o[5]), fronts=int(o[6]), segments=int(o[7]), front_batches=int(o[8]),
-                    front_block=bool(o[9]), plan_cache_hits=int(o[10]), plan_cache_misses=int(o[11]), streamed_chain=bool(o[12]))
+                    front_block=bool(o[9]), plan_cache_hits=int(o[10]), plan_cache_misses=int(o[11]), streamed_chain=bool(o[12]),
+                    accurate_factorisations=int(o[13]))
 
     def profile_launches(self):
         n = C.c_int64(0)
@@ -273,11 +274,12 @@ class Handle:
         return out[: ln.value]
 
     def profile(self):
-        o = np.zeros(10)
+        o = np.zeros(12)
         self.L.hipkkt_get_profile(self.h, o, len(o))
         return dict(update_ms=o[0], dense4_ms=o[1], dense4_flops=o[2], dense4_launches=int(o[3]), front_block_ms=o[4],
                     front_block_launches=int(o[5]), front_block_panels=int(o[6]), front_block_update_flops=o[7],
-                    front_block_extra_tiles=int(o[8]), front_block_extra_flops=o[9])
+                    front_block_extra_tiles=int(o[8]), front_block_extra_flops=o[9], refined_blocks=int(o[10]),
+                    factorisations_with_refined_blocks=int(o[11]))
 
     # ---- numeric
     def update_values(self, index, values):

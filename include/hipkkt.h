@@ -284,8 +284,11 @@ int32_t hipkkt_reset_timing(hipkkt_handle h);
  * number; out[4] = ms of the k_front_block launches (one per update batch of a front), out[5] = their number, out[6] = the panels
  * they factor, out[7] = the Schur-update flops of the stages they absorb (not part of out[0]'s kernels), out[8] / out[9] = dense update
  * tiles / their flops that rode in those launches as extra workgroups instead of in their stage's own launch (the partial last round
- * of a front batch's far updates; not part of out[0] .. out[2] either) */
-int32_t hipkkt_get_profile(hipkkt_handle h, double *out, int64_t cap);   /* writes min(cap, 10) values */
+ * of a front batch's far updates; not part of out[0] .. out[2] either); out[10] = the wide diagonal blocks (> 16 columns) of the last factorisation
+ * whose explicit inverse has an entry above 64 in magnitude: the solve kernels take one refinement step  y += Linv (b - L y)  on these
+ * (a product with such an inverse is several times less accurate than the reference's substitution; HIPKKT_ACCURATE=<threshold>,
+ * "0" = never, "-1" = every wide block), out[11] = factorisations so far with at least one */
+int32_t hipkkt_get_profile(hipkkt_handle h, double *out, int64_t cap);   /* writes min(cap, 12) values */
 /* the k_update_dense<4,4> launches of that refactorisation one by one: ms[i], algorithmic flops[i], target tiles[i]
  * (any array may be NULL; at most cap entries are written, *count receives the number of launches) */
 int32_t hipkkt_get_profile_launches(hipkkt_handle h, double *ms, double *flops, double *tiles, int64_t cap, int64_t *count);
@@ -302,7 +305,7 @@ int32_t hipkkt_set_profiling(hipkkt_handle h, int32_t enable);
  * enabled (0 after one of its hand-offs timed out: the handle then keeps one launch per panel), out[10] / out[11] = symbolic plans
  * taken from / not found in the process-wide plan cache (same KKT pattern and options => the analysis of an earlier handle is reused;
  * HIPKKT_PLAN_CACHE=0 disables it), out[12] = the pivot chain of the front batches is streamed block by block (front_block.hip; 0 with
- * HIPKKT_FB_STREAM=0), out[13] = reserved (0).  Writes min(cap, 14) values. */
+ * HIPKKT_FB_STREAM=0), out[13] = factorisations with refined block solves (hipkkt_get_profile out[11]).  Writes min(cap, 14) values. */
 int32_t hipkkt_get_counters(hipkkt_handle h, int64_t *out, int64_t cap);
 
 /* developer diagnostic, not part of the plugin contract: copies an internal vector of the last LDL solve (what = 0 the

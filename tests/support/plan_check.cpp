@@ -355,8 +355,11 @@ int plan_check_run(int64_t N, const int64_t *Ap, const int64_t *Ai, const double
     const bool xinv = xmode >= 1;
     const double xtau = getenv("PLANCHECK_INV_TAU") ? atof(getenv("PLANCHECK_INV_TAU")) : 0.0;
     int64_t nflag = 0;
+    const int xwmax = getenv("PLANCHECK_INV_WMAX") ? atoi(getenv("PLANCHECK_INV_WMAX")) : 1 << 30;   // refine only blocks up to this width
+    const int xwmin = getenv("PLANCHECK_INV_WMIN") ? atoi(getenv("PLANCHECK_INV_WMIN")) : 0;         // ... and from this width
     auto flagged = [&](int s_, int w_) {
         if (xmode < 2) return false;
+        if (w_ > xwmax || w_ < xwmin) return false;
         double mx = 0;
         const double *li = &sbe.Linv[P.sn_diag[s_]];
         for (int q = 0; q < w_ * w_; q++) mx = std::max(mx, std::fabs(li[q]));

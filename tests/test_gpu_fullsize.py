@@ -284,7 +284,7 @@ def test_batch_config_matches_oracle(seed, oracle_factory, capsys):
     (the 240 outside the original sample carry the `slow` marker: -m "gpu and not slow" skips them).
     Gate: status equal, iterations equal or +-1, objective and residuals to 1e-10.  Where the plain 1e-10 is not met
     the cause is measured, not assumed: the ORACLE is run on a second elimination order (SuperLU MMD) and what IT moves by between
-    the two orders (CPU vs CPU, the reference's own arithmetic) is added four-fold to the gate and logged -- these problems
+    the two orders (CPU vs CPU, the reference's own arithmetic) is added four-fold to the gate and logged; there is no third tier -- these problems
     carry column scalings of 10^U(-2,2), and the last IPM iterations of some are decided by digits no LDL^T reproduces across
     orderings.  When the iteration counts differ by one, the two runs are compared at their last COMMON iterate instead."""
     P, q, A, b, cones = problems.batch_problem(seed)
@@ -328,29 +328,13 @@ def test_batch_config_matches_oracle(seed, oracle_factory, capsys):
         if solg.iterations != solc.iterations:  # a termination / step-length test decided below 1e-10: the oracle must show it too
             assert abs(sol2.iterations - solc.iterations) <= 1
         return
-    # Still apart: the remaining legitimate cause is a BRANCH of the reference's iterative refinement (kktsolver_directldl.jl:437-444:
-    # stop when a step improves the residual by less than the stop ratio 5) taken differently on a system whose refinement stagnates
-    # -- max |K| reaches 1e15 ... 1e25 in the last iterations of these problems, the residuals sit at 1e-6 against abstol 1e-12, and
-    # whether the first step gains a factor 4.9 or 5.1 decides about a second one.  Establish it: the oracle drives the run, the HIP
-    # solver shadows it on identical inputs; every solve before the first one with different step counts must agree to 1e-6.
-    from clarabel_jl_amd.kktsolver import HipKKTSolver
-    from oracle.kkt_oracle import OracleKKTSolver
-    from tests.fixtures import ShadowKKT
-
-    sh = cl.Solver(P, q, A, b, cones, cl.Settings(), kktsolver_factory=lambda *a: ShadowKKT(HipKKTSolver, OracleKKTSolver, *a))
-    sh.solve()
-    log = sh.kktsystem.kktsolver.log
-    first = next((k for k, r in enumerate(log) if r[2] != r[3]), None)
-    with capsys.disabled():
-        print(f"[batch-parity seed {seed}] not explained by the ordering spread; shadow run: first solve with different refinement step counts = "
-              f"{None if first is None else log[first]} (iteration, rel_dx, steps hip, steps oracle, hip (||e|| before its last step, ||b||, ||e|| after it), "
-              f"oracle ||e|| before / after every step); max rel_dx before it "
-              f"{max([r[1] for r in log[:first]] or [0.0]):.2e}")
-    assert first is not None, "trajectories part without a refinement-branch difference"
-    assert max([r[1] for r in log[:first]] or [0.0]) <= 1e-6      # (identical inputs, |K| up to 1e15: the two factorisations agree this far)
-    assert log[first][0] <= itc                 # ... and it happens no later than the iterate where the runs are compared
-    assert abs(solg.iterations - solc.iterations) <= 1
-    assert dobj <= 1e-4 and dres <= 1e-8        # both runs end SOLVED at the IPM's own tolerances; this is how far apart that leaves them
+    # Nothing is waved through beyond that.  (Rounds 3 - 4 had a third tier here, |dobj| <= 1e-4, for seed 324: a stop-ratio branch of the
+    # iterative refinement taken differently because the HIP path's first, unrefined solve was 1.6x less accurate than the oracle's.  Cause
+    # found in round 5 -- the solve kernels multiply by explicit inverses of the diagonal blocks, tools/seed324_inverse_vs_substitution.py
+    # -- and removed: wide blocks whose inverse has large entries take one refinement step against the factored block, kernels.hip
+    # k_invert_diag_wide.  Seed 324 now meets the plain 1e-10 with equal iteration counts.)
+    raise AssertionError(f"seed {seed}: |dobj| {dobj:.3e}, |dres| {dres:.3e}, iterations hip/oracle/oracle(mmd) {solg.iterations}/{solc.iterations}/{sol2.iterations} "
+                         f"-- outside 1e-10 and outside the oracle's own spread between two elimination orders (obj {spread_obj:.3e}, res {spread_res:.3e})")
 
 
 @pytest.mark.parametrize("name", ["cfg2a", "cfg3", "cfg5"])

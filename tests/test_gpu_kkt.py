@@ -148,6 +148,7 @@ def test_plan_variants_agree(policy, maxw, oracle_factory):
     {"HIPKKT_NO_FRONT": "1"},
     {"HIPKKT_FB_STREAM": "0", "HIPKKT_FRONT_BLOCK_MIN_ROWS": "0"},
     {"HIPKKT_FB_V2": "0", "HIPKKT_FRONT_BLOCK_MIN_ROWS": "0"},
+    {"HIPKKT_ACCURATE": "-1"},       # every factorisation's solves in the accurate mode (per-level kernels + refined block solves)
     {"HIPKKT_FRONT_BLOCK_MIN_ROWS": "0"},
     {"HIPKKT_ORDERING": "amd"},
     {"HIPKKT_FRONT_BLOCK": "0"},

@@ -60,9 +60,12 @@ def main(seed, want):
         Ku = sp.csc_matrix((nz_unreg, k.rowval, k.colptr), shape=(k.N, k.N))
         Ks = Ku + sp.triu(Ku, 1).T
         out = []
-        for mode, tau in (("0", 0), ("1", 0), ("2", 0), ("2", 8), ("2", 64), ("2", 1024), ("2", 1e6)):
+        for mode, tau, wmin, wmax in (("0", 0, 0, 99), ("1", 0, 0, 99), ("2", 0, 0, 99), ("2", 8, 0, 99), ("2", 64, 0, 99), ("2", 1024, 0, 99), ("2", 1e6, 0, 99),
+                                      ("2", 0, 0, 4), ("2", 0, 0, 8), ("2", 0, 0, 16), ("2", 0, 9, 99), ("2", 0, 17, 99)):
             os.environ["PLANCHECK_EXPLICIT_INV"] = mode
             os.environ["PLANCHECK_INV_TAU"] = repr(float(tau))
+            os.environ["PLANCHECK_INV_WMIN"] = str(wmin)
+            os.environ["PLANCHECK_INV_WMAX"] = str(wmax)
             rc, x, _, stt = ps.run(k.N, k.colptr, k.rowval, nz_reg, ds, b=c["b"])
             assert rc == 0
             out.append((float(np.max(np.abs(c["b"] - Ks @ x))), int(stt["max_group_tasks"]) if mode == "2" else 0))
@@ -70,7 +73,8 @@ def main(seed, want):
               f"first-solve ||b - K x||_inf of the supernodal plan: diagonal blocks by SUBSTITUTION {out[0][0]:.4e}; by EXPLICIT INVERSES {out[1][0]:.4e}; "
               f"inverses + one block-level refinement step on every block {out[2][0]:.4e} ({out[2][1]} block solves); only where max|Linv| > 8: "
               f"{out[3][0]:.4e} ({out[3][1]}); > 64: {out[4][0]:.4e} ({out[4][1]}); > 1024: {out[5][0]:.4e} ({out[5][1]}); > 1e6: {out[6][0]:.4e} ({out[6][1]}); "
-              f"eps {c['eps']:.3e}, max|K| {np.max(np.abs(nz_unreg)):.2e}")
+              f"eps {c['eps']:.3e}, max|K| {np.max(np.abs(nz_unreg)):.2e}; refinement only on blocks of width <= 4: {out[7][0]:.4e} ({out[7][1]}), <= 8: {out[8][0]:.4e} ({out[8][1]}), "
+              f"<= 16: {out[9][0]:.4e} ({out[9][1]}), >= 9: {out[10][0]:.4e} ({out[10][1]}), >= 17: {out[11][0]:.4e} ({out[11][1]})")
 
 
 if __name__ == "__main__":
