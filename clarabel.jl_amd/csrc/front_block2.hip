@@ -134,7 +134,8 @@ k_front_block2(DevPlan P, FrontBatch B, int *sync_all, double *scratch_all, doub
     auto body = [&](auto diag_tag) {
     constexpr bool diag = decltype(diag_tag)::value;
     const int ncb = diag ? i + 1 : nb;                    // column blocks held here
-    const int nsteps = diag ? 0 : nb;                     // regular steps (with the published inverses): the workgroups below the diagonal;
+    const int nsteps = diag ? 0 : nb - 1;                 // regular steps (with the published inverses): the workgroups below the diagonal,
+                                                          // all panels but the batch's last (taken from the stream: the launch ends sooner);
                                                           // a diagonal workgroup takes every panel left of its tile from the stream
     const int nr = min(64, B.r0 - 64 * i);
     const int n = 16 * wv + l15;                          // this lane's row of the block
@@ -396,8 +397,34 @@ k_front_block2(DevPlan P, FrontBatch B, int *sync_all, double *scratch_all, doub
         }
     }
     F2_T(2);
-    if constexpr (!diag) return;
-    else {
+    if constexpr (!diag) {
+        // the batch's last panel: behind its pivot blocks instead of behind its inverse (published 4 - 5 us after the last pivot, then a
+        // staged product): every workgroup below the diagonal ends ~6 us earlier, and with it the launch
+        v4f64 x[4];
+#pragma unroll
+        for (int sub = 0; sub < 4; sub++) {
+            x[sub] = (v4f64){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int k = 0; k < kFbMax; k++)
+                if (k == nb - 1) x[sub] = acc[k][sub];
+        }
+        double dj[4][4];
+        if (!consume(std::false_type{}, nb - 1, x, dj)) return;
+        f2_settle();
+        if (rowok) {
+            const FrontPanel pj = fp[nb - 1];
+            double *dst = P.Lx + pj.panel_off + 64 * (i - (nb - 1)) + n;
+            double *lt2 = P.LT + pj.lt_off + (int64_t)(64 * (i - (nb - 1)) - 64 + n) * 64;
+#pragma unroll
+            for (int sub = 0; sub < 4; sub++)
+#pragma unroll
+                for (int reg = 0; reg < 4; reg++) {
+                    dst[(int64_t)(16 * sub + lk + 4 * reg) * pj.r] = x[sub][reg];
+                    lt2[16 * sub + lk + 4 * reg] = x[sub][reg];
+                }
+        }
+        return;
+    } else {
 
     // ---- a diagonal workgroup's panels j2 < i - 1 from the stream (a later reader of tile j2's records, behind the workgroups i' < i):
     //      no step waits for the inverse of a tile, which is published 4 - 5 us after its pivots.  Then the step's hand-off and
@@ -517,7 +544,7 @@ k_front_block2(DevPlan P, FrontBatch B, int *sync_all, double *scratch_all, doub
     const unsigned long long spos = __ballot(sgn_l > 0);
     const double dyn_delta_inv = 1.0 / dyn_delta;
     int nreg = 0;
-    const bool pub = i + 1 < nb;
+    const bool pub = i + 1 < nb || B.nblk > nb;          // (the last tile's records are read by the workgroups below the diagonal)
     auto publish = [&](int Bp) {                          // waves 1 - 3: record of block Bp for the next diagonal workgroup
         const double *cP = (Bp & 1) ? cCb : cCa;
         double *rec = stream + ((int64_t)i * 8 + Bp) * kFbRec;
@@ -622,6 +649,31 @@ k_front_block2(DevPlan P, FrontBatch B, int *sync_all, double *scratch_all, doub
         tr[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(cC[lk * CS + 16 * q + l15], b0, tr[q], 0, 0, 0);
         tr[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(cC[(4 + lk) * CS + 16 * q + l15], b1, tr[q], 0, 0, 0);
     };
+    // this wave's rows of the panels left of the tile (kept in the tiles' registers since their steps): the panels (column-major) and
+    // their row-major copies for the backward solves, after the pivots (stores during the second pivot block by the idle waves were
+    // measured: they arrive late at the block's barrier, 11.6 -> 15.8 us per tile).
+    auto store_panels = [&]() {
+        if (!rowok) return;
+#pragma unroll
+        for (int k = 0; k < kFbMax - 1; k++) {
+            if (k < i) {
+                // uniform base + 32-bit lane offset per store (no 64-bit address arithmetic on the vector side: these 32 stores per
+                // tile are the tail of the launch for the batch's last diagonal workgroup)
+                const FrontPanel pk = fp[k];
+                double *dst = P.Lx + pk.panel_off + 64 * (i - k);
+                double *lt2 = P.LT + pk.lt_off + (int64_t)(64 * (i - k) - 64) * 64;
+                const unsigned o1 = 8u * (unsigned)(n + lk * pk.r), o2 = 8u * (unsigned)(n * 64 + lk);
+#pragma unroll
+                for (int sub = 0; sub < 4; sub++)
+#pragma unroll
+                    for (int reg = 0; reg < 4; reg++) {
+                        const double v = k == i - 1 ? xr[sub][reg] : acc[k][sub][reg];
+                        st_off(dst + (int64_t)(16 * sub + 4 * reg) * pk.r, o1, v);
+                        st_off(lt2, o2 + 8u * (unsigned)(16 * sub + 4 * reg), v);
+                    }
+            }
+        }
+    };
     f2_bar();                                             // the l d buffers of the streamed step are free
     F2_T(5);
 #pragma unroll
@@ -673,6 +725,10 @@ k_front_block2(DevPlan P, FrontBatch B, int *sync_all, double *scratch_all, doub
     double dkeep = 0.0;
     if (tid < 64) { dkeep = dsave[tid]; Sd[tid] = 1.0 / dkeep; }
     __syncthreads();
+    // the inverse is read by the workgroups below the diagonal in their steps with the published inverses -- all panels but the
+    // batch's last (their last step, like every step of a diagonal workgroup, follows the stream)
+    const bool need_minv = i + 1 < nb && B.nblk > nb;
+    if (need_minv) {
     for (int idx = tid; idx < 64 * LDT; idx += 256) Sa[idx] = 0.0;
     __syncthreads();
     if (tid < 64) {   // thread = column j of diagonal block bq
@@ -731,6 +787,7 @@ k_front_block2(DevPlan P, FrontBatch B, int *sync_all, double *scratch_all, doub
         __syncthreads();
         if (tid == 0) __hip_atomic_store(fl_minv + i, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    }   // need_minv
     F2_T(7);
     // ---- off the critical path: the factored block for the solves' explicit inverses, D and 1/D (exact division)
     {
@@ -746,26 +803,7 @@ k_front_block2(DevPlan P, FrontBatch B, int *sync_all, double *scratch_all, doub
         }
         if (lane == 0 && nreg) atomicAdd(P.flags + FL_NREG, nreg);
     }
-    if (rowok) {
-        // this workgroup's rows of the panels left of its tile (kept in the tiles' registers since their steps): the panels
-        // (column-major) and their row-major copies for the backward solves
-#pragma unroll
-        for (int k = 0; k < kFbMax - 1; k++) {
-            if (k < i) {
-                const FrontPanel pk = fp[k];
-                double *dst = P.Lx + pk.panel_off + 64 * (i - k) + n;
-                double *lt2 = P.LT + pk.lt_off + (int64_t)(64 * (i - k) - 64 + n) * 64;
-#pragma unroll
-                for (int sub = 0; sub < 4; sub++)
-#pragma unroll
-                    for (int reg = 0; reg < 4; reg++) {
-                        const double v = k == i - 1 ? xr[sub][reg] : acc[k][sub][reg];
-                        dst[(int64_t)(16 * sub + lk + 4 * reg) * pk.r] = v;
-                        lt2[16 * sub + lk + 4 * reg] = v;
-                    }
-            }
-        }
-    }
+    store_panels();
     F2_T(8);
     }
     };   // body
