@@ -7,8 +7,8 @@ mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 if [ "$mode" != "notests" ]; then
 sel="gpu"; [ "$mode" = "quick" ] && sel="gpu and not slow"
-# (6 worker processes: the slow part of the suite is the oracle's scalar CPU factorisations, the GPU box has 256 cores)
-(timeout 2400 python -m pytest tests -m "$sel" -q -s -n 6 > gpurun_out/pytest_gpu_$tag.log 2>&1; echo "pytest rc=$?" >> gpurun_out/pytest_gpu_$tag.log); tail -3 gpurun_out/pytest_gpu_$tag.log
+# THE DRIVER'S COMMAND, one process, file order (round 4's red suite was a leak between two tests that six xdist workers hid):
+(timeout 2400 python -m pytest tests -x -q -m "$sel" > gpurun_out/pytest_gpu_$tag.log 2>&1; echo "pytest rc=$?" >> gpurun_out/pytest_gpu_$tag.log); tail -3 gpurun_out/pytest_gpu_$tag.log
 grep -h "batch-parity\|order-parity\|full-size-ipm\|twin-parity" gpurun_out/pytest_gpu_$tag.log > gpurun_out/parity_causes_$tag.txt
 fi
 [ "$mode" = "testsonly" ] && exit 0
@@ -44,6 +44,8 @@ for c in 2a 2b 3 5; do
   python tools/prof_summary.py $(ls gpurun_out/prof_${c}_$tag/*results.db | head -1) > gpurun_out/prof_summary_${c}_$tag.txt 2>&1
   grep "^AB" gpurun_out/prof_${c}_$tag.log >> gpurun_out/prof_summary_${c}_$tag.txt
 done
-timeout 300 python tools/fb_trace.py > gpurun_out/fbtrace_$tag.txt 2>&1
+timeout 300 python tools/fb2_trace.py > gpurun_out/fbtrace_$tag.txt 2>&1
+python -c "import clarabel_jl_amd; from clarabel_jl_amd import hipkkt; print(hipkkt.box_probe(0))" > gpurun_out/box_probe_$tag.txt 2>&1
+rocm-smi --showclocks --showperflevel --showcomputepartition --showmemorypartition >> gpurun_out/box_probe_$tag.txt 2>&1
 head -8 gpurun_out/pmc_summary_2a_$tag.txt
 find gpurun_out -name "*.db" -delete      # (only the summaries travel back: gpurun merges at most 64 MiB)
