@@ -189,24 +189,19 @@ k_front_block2(DevPlan P, FrontBatch B, int *sync_all, double *scratch_all, doub
     //      the sentinel and polls).  Fully unrolled: the strip / register of a block's columns is static.  The loop is instruction-
     //      issue bound (one wavefront issues every ~5 cycles): uniform base + lane offset addressing, one negation per record (the B
     //      operand), the freshness test by unsigned maxima, the panel stores elsewhere.
-    double rc[3][4][2], rt[3][2], rd[3][2];               // the ring (one set of registers for every reader of the stream)
+    auto consume = [&](auto with_tr_tag, int jt, v4f64 (&t)[4], double (&dcol)[4][4]) -> bool {
+        constexpr bool WITH_TR = decltype(with_tr_tag)::value;
+        const double *rec0 = stream + (int64_t)jt * 8 * kFbRec;
+        double *ldx = S0 + 4096;                          // [2 buffers][4 waves][2][64 lanes]
+        double rc[3][4][2], rt[3][2], rd[3][2];
+        double pn0 = 0.0, pn1 = 0.0;                      // -l of the record before (WITH_TR: its diagonal-tile update trails by one record)
 #define F2_REQUEST(slot, Bq) do { \
             const double *rq_ = rec0 + (int64_t)(Bq) * kFbRec; \
             _Pragma("unroll") for (int q = (Bq) >> 1; q < 4; q++) { \
                 rc[slot][q][0] = f2_ldo(rq_, lane8 + (q * 2) * 512); rc[slot][q][1] = f2_ldo(rq_, lane8 + (q * 2 + 1) * 512); } \
             rt[slot][0] = f2_ldo(rq_ + 512, lane8); rt[slot][1] = f2_ldo(rq_ + 512, lane8 + 512); \
             rd[slot][0] = f2_ldo(rq_ + 512, lane8 + 1024); rd[slot][1] = f2_ldo(rq_ + 512, lane8 + 1536); } while (0)
-    // the first three records of tile jt requested ahead of their consumption (the request takes ~1.6 us under load)
-    auto prefetch = [&](int jt) {
-        const double *rec0 = stream + (int64_t)jt * 8 * kFbRec;
         F2_REQUEST(0, 0); F2_REQUEST(1, 1); F2_REQUEST(2, 2);
-    };
-    auto consume = [&](auto with_tr_tag, int jt, v4f64 (&t)[4], double (&dcol)[4][4], bool prefetched) -> bool {
-        constexpr bool WITH_TR = decltype(with_tr_tag)::value;
-        const double *rec0 = stream + (int64_t)jt * 8 * kFbRec;
-        double *ldx = S0 + 4096;                          // [2 buffers][4 waves][2][64 lanes]
-        double pn0 = 0.0, pn1 = 0.0;                      // -l of the record before (WITH_TR: its diagonal-tile update trails by one record)
-        if (!prefetched) { F2_REQUEST(0, 0); F2_REQUEST(1, 1); F2_REQUEST(2, 2); }
 #pragma unroll
         for (int Bk = 0; Bk < 8; Bk++) {
             const int sb = Bk >> 1, par = Bk & 1, sl = Bk % 3;
@@ -290,6 +285,7 @@ k_front_block2(DevPlan P, FrontBatch B, int *sync_all, double *scratch_all, doub
                 tr[so] = __builtin_amdgcn_mfma_f64_16x16x4f64(la[so][1], pn1, tr[so], 0, 0, 0);
             }
         }
+#undef F2_REQUEST
         return true;
     };
 
@@ -413,7 +409,7 @@ k_front_block2(DevPlan P, FrontBatch B, int *sync_all, double *scratch_all, doub
                 if (k == nb - 1) x[sub] = acc[k][sub];
         }
         double dj[4][4];
-        if (!consume(std::false_type{}, nb - 1, x, dj, false)) return;
+        if (!consume(std::false_type{}, nb - 1, x, dj)) return;
         f2_settle();
         if (rowok) {
             const FrontPanel pj = fp[nb - 1];
@@ -444,7 +440,7 @@ k_front_block2(DevPlan P, FrontBatch B, int *sync_all, double *scratch_all, doub
                 if (k == j2) x[sub] = acc[k][sub];
         }
         double dj[4][4];
-        if (!consume(std::false_type{}, j2, x, dj, false)) return;
+        if (!consume(std::false_type{}, j2, x, dj)) return;
         if (j2 == i - 2) F2_T(9);
         {
             double *lt = ltiles + (int64_t)(i * (i - 1) / 2 + j2) * 4096 + (wv * 16) * 64;
@@ -459,9 +455,6 @@ k_front_block2(DevPlan P, FrontBatch B, int *sync_all, double *scratch_all, doub
                 }
 #pragma unroll
             for (int so = 0; so < 4; so++) x[so] = -x[so];
-            // last of these steps: the first records of the panel next to the own tile are requested now -- they arrive while the
-            // diagonal tile and the tile of that panel are updated below
-            if (j2 == i - 2) prefetch(i - 1);
             f2_bar();
 #pragma unroll
             for (int so = 0; so < 4; so++) {
@@ -525,7 +518,7 @@ k_front_block2(DevPlan P, FrontBatch B, int *sync_all, double *scratch_all, doub
     if (i > 0) {
         double dl[4][4];
         f2_bar();                                         // the X D buffers of the steps before are free
-        if (!consume(std::true_type{}, i - 1, xr, dl, i > 1)) return;
+        if (!consume(std::true_type{}, i - 1, xr, dl)) return;
         // L(i, i-1) D for the workgroups below (operand order); the flag follows during the first pivot block
         double *lt = ltiles + (int64_t)(i * (i - 1) / 2 + i - 1) * 4096 + (wv * 16) * 64;
 #pragma unroll
@@ -813,7 +806,6 @@ k_front_block2(DevPlan P, FrontBatch B, int *sync_all, double *scratch_all, doub
     store_panels();
     F2_T(8);
     }
-#undef F2_REQUEST
     };   // body
     if (i < nb) body(std::true_type{});
     else body(std::false_type{});
