@@ -565,7 +565,8 @@ k_front_block(DevPlan P, FrontBatch B, int *sync_all, double *scratch_all, doubl
                         tacc[sub] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, cC[4 * ks + lk][16 * sub + l15], tacc[sub], 0, 0, 0);
             }
         }
-        FB_TB(3);
+        fb_mfma_settle();                                 // the stamp below is an exec-masked block between the matrix-core instructions above and the
+        FB_TB(3);                                         // next iteration's reads of their accumulators (this form is not the default any more)
         // Pc / colL are rewritten after the next iteration's first barrier / by wave 0 after it: every wave is past its reads
     }
     if (pub) publish(7);
