@@ -337,6 +337,41 @@ def test_batch_config_matches_oracle(seed, oracle_factory, capsys):
                          f"-- outside 1e-10 and outside the oracle's own spread between two elimination orders (obj {spread_obj:.3e}, res {spread_res:.3e})")
 
 
+@pytest.mark.parametrize("refined", [True, False])
+def test_refined_block_solves_keep_the_refinement_branches_of_the_reference(refined, monkeypatch, capsys):
+    """Batch seed 324 with the ORACLE driving the IPM and the HIP solver shadowing it on identical inputs (same elimination order): with
+    the refined block solves (kernels.hip k_invert_diag_wide: wide diagonal blocks whose explicit inverse has large entries take one
+    refinement step in the solve kernels) EVERY solve of the run takes the same number of iterative-refinement steps on both paths --
+    the branch of kktsolver_directldl.jl:437-444 that rounds 3 - 4 saw flip at iteration 19 does not.  With them switched off
+    (HIPKKT_ACCURATE=0) the flip is back: that is the cause, shown on the device (the CPU side of the evidence is
+    tests/test_block_refinement.py)."""
+    from clarabel_jl_amd.kktsolver import HipKKTSolver
+    from oracle.kkt_oracle import OracleKKTSolver
+    from tests.fixtures import ShadowKKT
+
+    monkeypatch.setenv("HIPKKT_PLAN_CACHE", "0")
+    if not refined:
+        monkeypatch.setenv("HIPKKT_ACCURATE", "0")
+    P, q, A, b, cones = problems.batch_problem(324)
+    sh = cl.Solver(P, q, A, b, cones, cl.Settings(), kktsolver_factory=lambda *a: ShadowKKT(HipKKTSolver, OracleKKTSolver, *a))
+    sol = sh.solve()
+    kk = sh.kktsystem.kktsolver
+    log = kk.log
+    first = next((k for k, r in enumerate(log) if r[2] != r[3]), None)
+    marked = kk.g.h.counters()["accurate_factorisations"]
+    with capsys.disabled():
+        print(f"\n[refined-block-solves seed 324, refined={refined}] oracle-driven run {sol.status} in {sol.iterations} iterations, {len(log)} solves; factorisations with "
+              f"marked blocks: {marked}; first solve with different refinement step counts: {None if first is None else log[first][:4]}")
+    assert sol.status == "SOLVED" and sol.iterations == 23
+    if refined:
+        assert marked > 0, "no block was marked: the mechanism under test did not run"
+        assert first is None, log[first]
+        assert max(r[1] for r in log) <= 1e-6          # identical inputs, |K| up to 1e15: the refined solutions agree this far at every solve
+    else:
+        assert marked == 0
+        assert first is not None and log[first][0] >= 15, "the flip of rounds 3 - 4 did not reproduce with the refinement off"
+
+
 @pytest.mark.parametrize("name", ["cfg2a", "cfg3", "cfg5"])
 def test_streamed_pivot_chain_equals_whole_tile_handoff(name, monkeypatch):
     """front_block.hip, round 4: the diagonal workgroups of a front batch hand their tile over block by block (8 pivots at a time, the
