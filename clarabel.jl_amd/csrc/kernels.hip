@@ -14,6 +14,7 @@
 //   residuals (N4)    k_residuals + k_residuals_finish;  k_block_products
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "device_plan.h"
 #include "kernels.h"
@@ -256,6 +257,15 @@ __device__ __forceinline__ double pivot_rcp(double d) {
     return r;
 }
 
+// r (1 + e + e^2), e = 1 - d r: three dependent operations after the hardware reciprocal instead of the four of two Newton steps
+// (error ~ e^3 + one rounding: 1.9 units of 2^-53 measured over 6.7e7 values, tools/ubench_pivot.hip)
+__device__ __forceinline__ double pivot_rcp3(double d) {
+    const double r = __builtin_amdgcn_rcp(d);
+    const double e = fma(-d, r, 1.0);
+    const double e2 = fma(e, e, e);
+    return fma(r, e2, r);
+}
+
 // Blocked by 8 pivots: wave v of a group owns the column blocks {v, v+4} (8 columns each).  The owner of block B
 // eliminates its 8 columns WITHOUT leaving the wavefront (pivot and the entries a_jk come from the lanes that hold
 // them: v_readlane), publishes the block's L columns / raw columns / 1/d through LDS, and after ONE barrier every
@@ -300,26 +310,74 @@ k_factor_panel(DevPlan P, int item_begin, double dyn_eps, double dyn_delta) {
     for (int B = 0; B <= 8; B++) {
         if (B <= nB) {                                    // workgroup-uniform
             if (grp == 0 && B < 8 && B < nB && v == (B & 3)) {   // diagonal rows, block B: 8 pivots in-wave
+                // Round 5: the lean chain of the front-batch kernels (front_block.hip, front_block2.hip) here as well --
+                //   d_k = a_kk - c_{k,k-1}^2 / d_{k-1}  ->  1 / d_k   is one fma, the hardware reciprocal and three more fma;
+                //   a_kk and c_{k,k-1} are fetched from the lanes that hold them one pivot EARLIER;
+                //   the pivot rule is only TESTED, at the end of the block from the eight pivots (no compare / select / branch on the
+                //   chain); a block that needs a substituted pivot is repeated from its saved input with the rule applied;
+                //   the pivots / reciprocals are published once per block.
                 const int rb = 8 * (B >> 2), pb = B & 1, p3 = B % 3;
+                double a_in[8];
 #pragma unroll
-                for (int kk = 0; kk < 8; kk++) {
-                    const int k = 8 * B + kk;
-                    const double reg = a[rb + kk];
-                    double d = readlane_f64(reg, k);
-                    const double sg = ((spos >> k) & 1ull) ? 1.0 : -1.0;
-                    if (k < w && d * sg < dyn_eps) { d = dyn_delta * sg; nreg++; }
-                    const double dinv = k < w ? pivot_rcp(d) : 0.0;
-                    const double li = reg * dinv;
-                    colL[pb][kk][lane] = li;
-                    colC[p3][kk][lane] = k < w ? reg : 0.0;
-                    myY[k] = li;
-                    if (lane == k) dsave[k] = d;
-                    if (lane == 0) dinvs[p3][kk] = dinv;
+                for (int q = 0; q < 8; q++) a_in[q] = a[rb + q];
+                auto eliminate = [&](auto rule_tag) -> bool {
+                    constexpr bool RULE = decltype(rule_tag)::value;
+                    double dk[8], dik[8];
+                    int nr_ = 0;
+                    double akk = readlane_f64(a[rb], 8 * B), csq = 0.0, dinv_prev = 0.0;
 #pragma unroll
-                    for (int jj = kk + 1; jj < 8; jj++) {
-                        const double cj = readlane_f64(reg, 8 * B + jj);
-                        a[rb + jj] = fma(-li, cj, a[rb + jj]);
+                    for (int kk = 0; kk < 8; kk++) {
+                        const int k = 8 * B + kk;
+                        double d = fma(-csq, dinv_prev, akk);
+                        double dinv = pivot_rcp3(d);
+                        if (RULE) {
+                            const double sg = ((spos >> k) & 1ull) ? 1.0 : -1.0;
+                            const bool bad = k < w && d * sg < dyn_eps;
+                            d = bad ? dyn_delta * sg : d;
+                            dinv = bad ? sg / dyn_delta : dinv;
+                            nr_ += bad ? 1 : 0;
+                        }
+                        dinv = k < w ? dinv : 0.0;          // (columns past the panel's width: padding)
+                        dk[kk] = d;
+                        dik[kk] = dinv;
+                        const double reg = a[rb + kk];
+                        if (kk < 7) {
+                            akk = readlane_f64(a[rb + kk + 1], k + 1);
+                            const double cn = readlane_f64(reg, k + 1);
+                            csq = cn * cn;
+                        }
+                        dinv_prev = dinv;
+                        const double li = reg * dinv;
+                        colL[pb][kk][lane] = li;
+                        colC[p3][kk][lane] = k < w ? reg : 0.0;
+                        myY[k] = li;
+#pragma unroll
+                        for (int jj = kk + 1; jj < 8; jj++) {
+                            const double cj = readlane_f64(reg, 8 * B + jj);
+                            a[rb + jj] = fma(-li, cj, a[rb + jj]);
+                        }
                     }
+                    if (!RULE) {
+                        bool anybad = false;
+#pragma unroll
+                        for (int kk = 0; kk < 8; kk++) {
+                            const int k = 8 * B + kk;
+                            const double sg = ((spos >> k) & 1ull) ? 1.0 : -1.0;
+                            anybad = anybad || (k < w && dk[kk] * sg < dyn_eps);
+                        }
+                        if (__builtin_amdgcn_readfirstlane((int)anybad)) return false;
+                    }
+                    nreg += nr_;
+                    if (lane == 0) {
+#pragma unroll
+                        for (int kk = 0; kk < 8; kk++) { dsave[8 * B + kk] = dk[kk]; dinvs[p3][kk] = dik[kk]; }
+                    }
+                    return true;
+                };
+                if (!eliminate(std::false_type{})) {
+#pragma unroll
+                    for (int q = 0; q < 8; q++) a[rb + q] = a_in[q];
+                    eliminate(std::true_type{});
                 }
             }
             if (grp == 1 && B >= 1 && v == ((B - 1) & 3)) {       // chunk rows, block B-1: published operands
