@@ -6,15 +6,21 @@
 // With D[m][n] += A[m][k] B[k][n], lane (l15, lk): A[l15][lk], B[lk][l15], D[lk + 4 reg][l15], a product  C^T = S^T R^T  takes its
 // B operand -- the workgroup's own rows R -- STRAIGHT FROM THE ACCUMULATOR REGISTERS (k-step kk <-> sub = kk / 4, reg = kk % 4) and
 // its A operand -- data shared by all rows: the inverse of a diagonal block, the rows of a diagonal workgroup above, a streamed block
-// of pivots -- from global memory in "operand order" (one coalesced 512-byte load per k-step and 16-row strip).  Consequences:
-//   * no LDS staging and no workgroup barrier anywhere in the steps left of the diagonal: the four wavefronts of a workgroup run
-//     independently; tiles are loaded from / stored to the panels directly from the accumulator layout;
-//   * the consumer of the streamed pivot chain is 2 + <= 8 + 8 matrix-core instructions per block of 8 pivots, all operands in
-//     registers or prefetched: l = p T with T = L_bb^-T D_b^-1 of the block's 8 x 8 diagonal part (formed by an idle wavefront of the
-//     producer), then the rank-8 updates.  It keeps up with the producer however late it starts, so the chain advances by
-//     8 pivot blocks + one hand-off per panel (round 4: + a lead of 8 us and a consumer no faster than the producer);
-// LDS carries only what crosses wavefronts: the diagonal tile's update (X D of all 64 rows), the pivot loop (block columns -> wave 0,
-// its l / raw columns -> everybody) and the blocked inverse of L11.
+// of pivots -- in "operand order" (one coalesced 512-byte load per k-step and 16-row strip).  Consequences:
+//   * a workgroup's own tiles are never transposed through LDS: they are loaded from / stored to the panels directly in the
+//     accumulator layout.  The workgroups BELOW the diagonal stage only the shared operand of a step through LDS (all 256 threads
+//     fetch 16 values each in one round trip -- per-wave loads straight into registers were four times the traffic and, as relaxed
+//     atomic loads next to their use, a memory round trip per k-step);
+//   * the DIAGONAL workgroups take EVERY panel left of their tile from the stream of 8-pivot records (the later readers trail the
+//     first): per record 2 + <= 8 (+ 8 for the panel next to the own tile) matrix-core instructions, all operands in registers or
+//     prefetched: l = p T with T = L_bb^-T D_b^-1 of the block's 8 x 8 diagonal part (formed by an idle wavefront of the producer),
+//     then the rank-8 updates.  No step of the chain waits for an explicit 64 x 64 inverse (round 4: the chain waited 4 - 5 us for
+//     it, then 14 us for the step with it); the successor finishes its last record 3 - 6 us behind the producer's last pivot block;
+//   * no global store inside the record loops (one in-order memory counter on gfx9: a store there made every record wait for a
+//     write-through acknowledgement), finished rows stay in the tiles' registers until the end.
+// LDS carries only what crosses wavefronts: the shared operand of a regular step, the diagonal tile's update (X D / l d of all 64
+// rows), the pivot loop (block columns -> wave 0, its l / raw columns -> everybody) and the blocked inverse of L11.
+// Measured: 121 -> 94 us per launch of 5 panels, chain of diagonal tiles 20.4 -> 15.9 us per panel.
 //
 // Scratch layouts of a batch (private to this kernel; same sizes as the first form):
 //   operand order of a 64 x 64 tile M, value M(mu, kappa):  offset (16 (mu / 16) + kappa / 4) * 64 + 16 (kappa % 4) + mu % 16
@@ -129,8 +135,8 @@ k_front_block2(DevPlan P, FrontBatch B, int *sync_all, double *scratch_all, doub
     F2_T(0);
     const FrontPanel *fp = P.front_panels + B.fp_off;
     const int nb = B.nb;
-    // the two kinds of workgroup are compiled separately (diagonal: at most kFbMax - 3 regular steps, then the streamed steps and the
-    // pivots; below the diagonal: kFbMax regular steps and nothing else) -- one body with run-time flags spills registers
+    // the two kinds of workgroup are compiled separately (diagonal: streamed steps, then the pivots; below the diagonal: nb - 1 steps
+    // with the published inverses, the last panel from the stream, nothing else) -- one body with run-time flags spills registers
     auto body = [&](auto diag_tag) {
     constexpr bool diag = decltype(diag_tag)::value;
     const int ncb = diag ? i + 1 : nb;                    // column blocks held here
@@ -181,7 +187,7 @@ k_front_block2(DevPlan P, FrontBatch B, int *sync_all, double *scratch_all, doub
     // ---- consumer of the streamed pivot chain: the eight records of tile jt turn this workgroup's tile t of panel jt into its rows of
     //      L (l = p T per block of 8 columns, then the rank-8 update of the columns right of it), wave by wave, everything in
     //      registers.  WITH_TR (the panel next to the own tile, jt = i - 1): every record also updates the diagonal tile (l d of all
-    //      64 rows through LDS, one barrier per record) and goes out as L(i, jt) D for the workgroups below.  Without (jt = i - 2):
+    //      64 rows through LDS, one barrier per record) and goes out as L(i, jt) D for the workgroups below.  Without (every other reader):
     //      no LDS, no barrier; the pivots of the lane's columns are returned in dcol for the step that follows.
     //      Ring of three records in registers: while record Bk is processed, records Bk + 1 and Bk + 2 are in flight (a fourth
     //      slot changed nothing: the loop is bound by its 18 FP64 matrix-core instructions of 64 cycles each per record) (a consumer that
@@ -303,7 +309,7 @@ k_front_block2(DevPlan P, FrontBatch B, int *sync_all, double *scratch_all, doub
     };
 #pragma unroll
     for (int j = 0; j < (diag ? 0 : kFbMax); j++) {
-        if (j < nsteps) {                                 // workgroup-uniform (diagonal workgroups: j < i - 2, the last two panels are streamed)
+        if (j < nsteps) {                                 // workgroup-uniform (only the workgroups below the diagonal run these steps)
             const FrontPanel pj = fp[j];
             const double *mv = scratch + (int64_t)j * 4160;
             v4f64 x[4];
