@@ -48,7 +48,7 @@ def kernel_sources_hash():
     import hashlib
 
     h = hashlib.sha1()
-    for f in ("kernels.hip", "dense_tile.h", "front_block.hip", "front_sweep.hip", "device_plan.h", "symbolic.cpp"):
+    for f in ("kernels.hip", "dense_tile.h", "front_block.hip", "front_block2.hip", "front_sweep.hip", "device_plan.h", "symbolic.cpp"):
         with open(os.path.join(ROOT, "clarabel.jl_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:12]
