@@ -254,6 +254,18 @@ def bench_batch(args, cl, torch, dist, rank, world, local):
                   "note": "HIP path vs the oracle on the SAME elimination order, whole IPM solves of the same problems in the same run; "
                           "every problem outside 1e-10 is listed with its measured cause"}
     if rank == 0:
+        # measured HBM traffic (separate rocprofv3 --pmc passes of a ONE-process sample of this workload, tools/latency_counters.sh):
+        # bytes of every kernel in the trace per refactorisation ~ per IPM iteration, beside the algorithmic bytes per IPM iteration
+        ctr4, why4 = pmc_counters("4")
+        wt4 = (ctr4 or {}).get("whole_trace")
+        alg_it = total_bytes / max(1, total_iters)
+        traffic4 = None if not wt4 else dict(
+            bytes_per_refactor=wt4["bytes_per_refactor"], read_x2_MB=wt4["read_x2_MB"], write_MB=wt4["write_MB"],
+            dispatches_per_refactor=wt4.get("dispatches_per_refactor"), refactorisations_in_trace=wt4.get("refactorisations_in_trace"),
+            algorithmic_bytes_per_ipm_iteration=round(alg_it), ratio_to_algorithmic=round(wt4["bytes_per_refactor"] / alg_it, 2) if alg_it else None,
+            source=ctr4["source"], sample=wt4.get("command"),
+            note="FETCH_SIZE x2 + WRITE_SIZE of EVERY kernel of the sample's trace / its refactorisations (one per IPM iteration + each problem's "
+                 "set-up); the algorithmic figure is this run's mean over all 256 problems")
         print(json.dumps({
             "metric": "IPM iterations/sec + KKT factor+solve ms, 10k-var sparse QP, 1/2/4/8 GPU",
             "value": round(total_iters / elapsed, 3), "unit": "IPM-iterations/s (whole solves incl. set-up, batch of independent problems)",
@@ -267,7 +279,9 @@ def bench_batch(args, cl, torch, dist, rank, world, local):
                        "parallelism": f"{world} rank(s), {len(mine)} problems on rank 0"},
             "problems_per_s": round(total_probs / elapsed, 3),
             "roofline": {"bound": "hbm", "achieved": round(total_bytes / elapsed / 1e9, 3), "peak": 8000.0 * world, "unit": "GB/s",
-                         "frac": round(total_bytes / elapsed / 1e9 / (8000.0 * world), 6), "traffic": None,
+                         "frac": round(total_bytes / elapsed / 1e9 / (8000.0 * world), 6),
+                         "traffic": None if traffic4 is None else traffic4["bytes_per_refactor"], "traffic_of": "one refactorisation ~ one IPM iteration, all kernels",
+                         "traffic_detail": traffic4, "traffic_unavailable": why4,
                          "note": "algorithmic bytes of all solved problems (B_factor + 6 (B_solve + B_spmv) per IPM iteration, from each "
                                  "problem's symbolic factor) / wall time: a batch of small problems is bound by host work and launch / "
                                  "dependency latency, not by HBM -- the fraction says how far, it is not a kernel-quality figure"},
@@ -526,6 +540,18 @@ def main():
                        ratio_to_algorithmic=None if not alg_bytes else round(ctr["bytes_per_launch"] / alg_bytes, 2),
                        note="fabric-side bytes (L2 misses; Infinity-Cache hits are counted): FETCH_SIZE x2 (calibrated on this access shape, "
                             "profiles/r03_a_traffic_calibration.txt) + WRITE_SIZE per launch")
+    # the refactorisation as a whole, from the same counter passes: what a latency-regime workload (cfg 1 / 2b: the big dense-update
+    # launches never run, `launches_in_trace` 0) quotes as `traffic` -- against B_factor of SURVEY section 8(d)
+    whole_traffic = None
+    if ctr is not None and ctr.get("whole_refactor"):
+        wr_ = ctr["whole_refactor"]
+        whole_traffic = dict(bytes_per_refactor=wr_["bytes_per_refactor"], read_x2_MB=wr_["read_x2_MB"], write_MB=wr_["write_MB"],
+                             dispatches_per_refactor=wr_.get("dispatches_per_refactor"), algorithmic_bytes_per_refactor=round(cm["bytes_factor"]),
+                             ratio_to_algorithmic=round(wr_["bytes_per_refactor"] / cm["bytes_factor"], 2) if cm["bytes_factor"] else None,
+                             source=ctr["source"], note=wr_.get("note"))
+    big_launches = ctr is not None and ctr.get("launches_in_trace", 0) > 0
+    if ctr is not None and not big_launches:
+        traffic = None
     cm_f = cm["flops_factor"]
     whole = cm_f / (factor_ms * 1e-3) / 1e12
     # per-kernel table underneath the headline: the dense-update family (throughput-bound), the front-batch kernel (latency-bound; its
@@ -572,8 +598,11 @@ def main():
                     what="SURVEY section 8(d): F_factor / t_factor with F_factor = sum_j (c_j^2 + 3 c_j) from the symbolic factor in use and t_factor = the "
                          "mean HIP-event time of hipkkt_refactor over the timed steps",
                     flops=cm_f, ms=round(factor_ms, 4),
-                    traffic=None if traffic is None else traffic["bytes_per_launch"], traffic_of="kernels.dense_update (per launch of the dominant throughput kernel)",
-                    traffic_unavailable=why,
+                    traffic=(traffic["bytes_per_launch"] if traffic is not None else
+                             (whole_traffic["bytes_per_refactor"] if (whole_traffic is not None and not big_launches) else None)),
+                    traffic_of=("kernels.dense_update (per launch of the dominant throughput kernel)" if (traffic is not None or whole_traffic is None) else
+                                "whole_refactor (every kernel of one refactorisation: this workload never reaches the big dense-update launches)"),
+                    traffic_unavailable=why, whole_refactor=whole_traffic,
                     kernels=dict(dense_update=dense_k, front_block=fbk,
                                  all_update_kernels=dict(achieved=round(agg, 3), frac=round(agg / F64_MFMA_PEAK_TFLOPS, 4), ms_per_refactor=round(upd, 4),
                                                          flops_per_refactor=flops_upd_kernels)),

@@ -14,9 +14,13 @@ fi
 [ "$mode" = "testsonly" ] && exit 0
 # ---- counter passes first: bench.py then finds counter files stamped with the current kernel sources
 if [ "$ctrs" = "counters" ]; then
-for c in 2a 3 5; do
-  # cfg 2a: the bench command itself; cfg 3 / 5: refactor + refined-solve loops without the end-to-end runs (tools/ab_variant.py)
+for c in ${PMC_CONFIGS:-2a 3 5 2b 1 4}; do
+  # cfg 2a / 2b / 1: the bench command itself; cfg 3 / 5: refactor + refined-solve loops without the end-to-end runs (tools/ab_variant.py);
+  # cfg 4: a ONE-process sample of the batch (24 problems; rocprofv3 follows one process)
   cmd="python tools/ab_variant.py $c pmc 3"; [ $c = 2a ] && cmd="python bench.py --steps 2 --warmup 1 --no-cpu-baseline"
+  [ $c = 2b -o $c = 1 ] && cmd="python bench.py --config $c --steps 2 --warmup 1 --no-cpu-baseline"
+  [ $c = 4 ] && cmd="python bench.py --config 4 --workers 1 --steps 24 --warmup 2 --no-cpu-baseline"
+  export PMC_COMMAND="$cmd"
   pass() { rm -rf gpurun_out/$1_${c}_$tag; timeout 600 rocprofv3 --pmc $2 --kernel-trace -d gpurun_out/$1_${c}_$tag -o p -- $cmd > gpurun_out/$1_${c}_$tag.log 2>&1; }
   pass pmcf FETCH_SIZE
   pass pmcw WRITE_SIZE

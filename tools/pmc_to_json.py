@@ -66,6 +66,26 @@ def main(cfg, out, fetch_db, write_db, sq_db, grbm_db):
                             mfma_busy_pct=round(100.0 * (fb_busy / max(1, nfS)) / ((fb_active / max(1, nfG)) * 1024.0), 2) if fb_active else None)
     all_mops = sum(r[0] for kn, v in S.get("SQ_INSTS_VALU_MFMA_MOPS_F64", {}).items() for r in v)
     d["hw_flops_per_refactor_all_kernels"] = round(all_mops * 512.0 / nref) if all_mops else None
+    # the factorisation as a whole (what the latency-regime workloads -- cfg 1 / 2b: no big dense-update launch ever runs -- quote):
+    # the kernels that run between one k_init_panels and the end of that refactorisation, i.e. everything in FACTOR below
+    FACTOR = ("k_scatter_values", "k_soc_batch", "k_maxabs_gather", "k_init_panels", "k_fb_reset", "k_front_block", "k_update_dense",
+              "k_update_gather", "k_factor_panel", "k_factor_level", "k_split_reduce", "k_invert_diag", "k_invert_super")
+    nrefF = max(1, len(family(F, "FETCH_SIZE", ("k_init_panels",))))
+    nrefW = max(1, len(family(W, "WRITE_SIZE", ("k_init_panels",))))
+    f_rd = 2.0 * sum(r[0] for r in family(F, "FETCH_SIZE", FACTOR)) * 1024 / nrefF
+    f_wr = sum(r[0] for r in family(W, "WRITE_SIZE", FACTOR)) * 1024 / nrefW
+    d["whole_refactor"] = dict(bytes_per_refactor=round(f_rd + f_wr), read_x2_MB=round(f_rd / 1e6, 3), write_MB=round(f_wr / 1e6, 3),
+                               refactorisations_in_trace=nrefF, dispatches_per_refactor=round(len(family(F, "FETCH_SIZE", FACTOR)) / nrefF, 1),
+                               kernels=sorted({kn.split("(")[0][:48] for kn in F.get("FETCH_SIZE", {}) if any(f in kn for f in FACTOR)}),
+                               note="FETCH_SIZE x2 + WRITE_SIZE summed over every kernel of a refactorisation (update of the values, "
+                                    "regularisation, panels, updates, block inverses) / refactorisations in the trace")
+    # every kernel of the trace (solves, refinement, assembly, copies included) per refactorisation: what a batch of small problems
+    # (cfg 4) moves per IPM iteration, roughly -- one refactorisation per iteration plus the few of each problem's set-up
+    t_rd = 2.0 * sum(r[0] for v in F.get("FETCH_SIZE", {}).values() for r in v) * 1024 / nrefF
+    t_wr = sum(r[0] for v in W.get("WRITE_SIZE", {}).values() for r in v) * 1024 / nrefW
+    d["whole_trace"] = dict(bytes_per_refactor=round(t_rd + t_wr), read_x2_MB=round(t_rd / 1e6, 3), write_MB=round(t_wr / 1e6, 3),
+                            refactorisations_in_trace=nrefF, dispatches_per_refactor=round(sum(len(v) for v in F.get("FETCH_SIZE", {}).values()) / nrefF, 1),
+                            command=os.environ.get("PMC_COMMAND"))
     with open(out, "w") as f:
         json.dump(d, f, indent=1)
     print(json.dumps(d))
