@@ -27,14 +27,42 @@ class PSDTriangleConeT:
     dim: int  # matrix side dimension
 
 
+@dataclass(frozen=True)
+class ExponentialConeT:
+    """cone_api.jl:47-49: no fields, always three rows"""
+
+
+@dataclass(frozen=True)
+class PowerConeT:
+    """cone_api.jl:33-36: three rows, exponent alpha"""
+    alpha: float
+
+
+@dataclass(frozen=True)
+class GenPowerConeT:
+    """cone_api.jl:38-46: exponents alpha (all > 0, summing to one) for the first len(alpha) rows, then dim2 rows"""
+    alpha: tuple
+    dim2: int
+
+    def __post_init__(self):
+        a = tuple(float(v) for v in self.alpha)
+        object.__setattr__(self, "alpha", a)
+        if not all(v > 0.0 for v in a) or abs(sum(a) - 1.0) > 2.220446049250313e-16 * len(a) / 2:
+            raise ValueError("GenPowerConeT: the exponents must be positive and sum to one")
+
+
 def triangular_number(k: int) -> int:
     return (k * (k + 1)) >> 1
 
 
 def nvars(spec) -> int:
-    """cone_api.jl: number of rows a cone spec occupies."""
+    """cone_api.jl:56-69: number of rows a cone spec occupies."""
     if isinstance(spec, PSDTriangleConeT):
         return triangular_number(spec.dim)
+    if isinstance(spec, (ExponentialConeT, PowerConeT)):
+        return 3
+    if isinstance(spec, GenPowerConeT):
+        return len(spec.alpha) + spec.dim2
     return spec.dim
 
 

@@ -5,8 +5,9 @@
     {"settings": {...}, "P": CSC, "q": [...], "A": CSC, "b": [...], "cones": [{"NonnegativeConeT": 3}, ...]}
     CSC = {"m": rows, "n": cols, "colptr": [...], "rowval": [...], "nzval": [...]}     (0-based indices)
 
-so that problems can be exchanged with a Julia / Rust Clarabel.  Only the symmetric cones of this package are
-accepted (Zero, Nonnegative, SecondOrder, PSDTriangle); the reference writes the data it solves (after presolve and
+so that problems can be exchanged with a Julia / Rust Clarabel.  All seven cone types of the reference are carried
+(Zero, Nonnegative, SecondOrder, PSDTriangle: {type: dim}; PowerConeT: {type: alpha}; ExponentialConeT: {type: []};
+GenPowerConeT: {type: [alpha, dim2]}); the reference writes the data it solves (after presolve and
 chordal decomposition, unscaled), and so does this writer: it stores exactly what it is given."""
 import dataclasses
 import json
@@ -16,13 +17,13 @@ import sys
 import numpy as np
 import scipy.sparse as sp
 
-from .cone_api import NonnegativeConeT, PSDTriangleConeT, SecondOrderConeT, ZeroConeT
+from .cone_api import (ExponentialConeT, GenPowerConeT, NonnegativeConeT, PowerConeT, PSDTriangleConeT, SecondOrderConeT,
+                       ZeroConeT)
 from .settings import Settings
 
 _FLOATMAX = sys.float_info.max
 _CONES = {"ZeroConeT": ZeroConeT, "NonnegativeConeT": NonnegativeConeT, "SecondOrderConeT": SecondOrderConeT,
           "PSDTriangleConeT": PSDTriangleConeT}
-_UNSUPPORTED = ("ExponentialConeT", "PowerConeT", "GenPowerConeT")
 
 
 def _lower_csc(M):  # json.jl:131-139
@@ -37,7 +38,13 @@ def _parse_csc(d):  # json.jl:161-170
                           np.asarray(d["colptr"], dtype=np.int64)), shape=(int(d["m"]), int(d["n"])))
 
 
-def _lower_cone(c):  # json.jl:142-158: {type name: its single scalar field}
+def _lower_cone(c):  # json.jl:142-158: {type name: its single field}; PowerConeT: alpha; ExponentialConeT: (); GenPowerConeT: [alpha, dim2]
+    if isinstance(c, PowerConeT):
+        return {"PowerConeT": float(c.alpha)}
+    if isinstance(c, ExponentialConeT):
+        return {"ExponentialConeT": []}
+    if isinstance(c, GenPowerConeT):
+        return {"GenPowerConeT": [[float(v) for v in c.alpha], int(c.dim2)]}
     for name, typ in _CONES.items():
         if isinstance(c, typ):
             return {name: int(c.dim)}
@@ -46,8 +53,12 @@ def _lower_cone(c):  # json.jl:142-158: {type name: its single scalar field}
 
 def _parse_cone(d):  # json.jl:190-213
     (key, val), = d.items()
-    if key in _UNSUPPORTED:
-        raise NotImplementedError(f"{key}: non-symmetric cones are outside this package's scope (DESIGN.md section 9)")
+    if key == "GenPowerConeT":
+        return GenPowerConeT(tuple(float(v) for v in val[0]), int(val[1]))
+    if key == "ExponentialConeT":
+        return ExponentialConeT()
+    if key == "PowerConeT":
+        return PowerConeT(float(val))
     if key not in _CONES:
         raise ValueError(f"unknown cone type {key!r}")
     return _CONES[key](int(val))

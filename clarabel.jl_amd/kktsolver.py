@@ -31,7 +31,10 @@ class HipKKTSolver:
             dynamic_reg_delta=settings.dynamic_regularization_delta, **optkw)
         self.p = self.h.p
         self.Hsblocks = np.zeros(self.h.nHs)          # ref: _allocate_kkt_Hsblocks
-        self._soc = [c for c in cones if c.is_sparse_expandable]
+        # sparse-expandable cones in sparse-map order: SOC (rank-2 expansion, batched upload) and GenPow (rank-3 expansion)
+        sparse = [c for c in cones if c.is_sparse_expandable]
+        self._soc = [c for c in sparse if getattr(c, "sparse_kind", 1) == 1]
+        self._genpow = [(i, c) for i, c in enumerate(sparse) if getattr(c, "sparse_kind", 1) == 2]
         self._soc_total = sum(c.dim for c in self._soc)
         self._u = np.zeros(self._soc_total)
         self._v = np.zeros(self._soc_total)
@@ -43,9 +46,11 @@ class HipKKTSolver:
         self._psd_dim = np.array([c.n for c, _ in self._psd], dtype=np.int64)
         self._psd_cones = tuple(c for c, _ in self._psd)
         # N1: cone types for the on-device update_scaling! / get_Hs! (hipkkt_set_cone_types); optional in the cones object
-        self._has_cone_kinds = hasattr(cones, "kkt_cone_kinds")
+        # (the on-device scaling knows the symmetric cones only: include/hipkkt.h hipkkt_set_cone_types)
+        kinds = cones.kkt_cone_kinds() if hasattr(cones, "kkt_cone_kinds") else None
+        self._has_cone_kinds = kinds is not None and bool(np.all(np.asarray(kinds) >= 0))
         if self._has_cone_kinds:
-            self.h.set_cone_types(cones.kkt_cone_kinds())
+            self.h.set_cone_types(kinds)
         self.scaling_w = self.scaling_lambda = self.scaling_soc_eta = None
         self.diagonal_regularizer = 0.0
         self.last_ir_steps = 0
@@ -71,6 +76,8 @@ class HipKKTSolver:
                 self._eta2[i] = c.eta * c.eta
                 off += c.dim
             self.h.set_soc_batch(self._eta2, self._u, self._v)
+        for i, c in self._genpow:                      # _csc_update_sparsecone(::GenPowerCone), directldl_datamaps.jl:146-167
+            self.h.set_genpow(i, float(np.sqrt(c.mu)), c.p, c.q, c.r)
         return self._refactor()
 
     def _refactor(self) -> bool:

@@ -7,7 +7,8 @@ from __future__ import annotations
 import numpy as np
 import scipy.sparse as sp
 
-from .cone_api import NonnegativeConeT, PSDTriangleConeT, SecondOrderConeT, ZeroConeT, triangular_number
+from .cone_api import (ExponentialConeT, GenPowerConeT, NonnegativeConeT, PowerConeT, PSDTriangleConeT, SecondOrderConeT, ZeroConeT,
+                       triangular_number)
 
 
 def _sparse_rows(rng, nrows, ncols, k, window=None, centers=None):
@@ -112,4 +113,45 @@ def batch_problem(seed):
     b = A @ x0 + s0
     q = rng.standard_normal(n)
     cones = ([ZeroConeT(nzero)] if nzero else []) + [NonnegativeConeT(m - nzero)]
+    return P, q, A, b, cones
+
+
+def nonsymmetric_mix(n=300, nexp=60, npow=40, ngenpow=10, nn=100, nzero=10, socdim=8, seed=7, kA=4):
+    """The non-symmetric cones of the reference next to the symmetric ones (no benchmark config uses them; this is the parity case
+    for the 3 x 3 dense Hs blocks of the Exponential / Power cone and the rank-3 expansion of the Generalized Power cone):
+    Zero(nzero), NN(nn), nexp x Exp, npow x Pow(alpha ~ U(0.1, 0.9)), ngenpow x GenPow(len(alpha) in 2..4, dim2 in 1..3), SOC(socdim).
+    Strictly feasible by construction (s0 on a positive multiple of each cone's central ray), P positive definite."""
+    rng = np.random.default_rng(seed)
+    cones, s0 = [], []
+    if nzero:
+        cones.append(ZeroConeT(nzero))
+        s0.append(np.zeros(nzero))
+    if nn:
+        cones.append(NonnegativeConeT(nn))
+        s0.append(rng.uniform(0.1, 1.0, nn))
+    for _ in range(nexp):          # (-1.0514, 0.5564, 1.2590): the point the reference starts this cone from (coneops_expcone.jl:42-44)
+        cones.append(ExponentialConeT())
+        s0.append(rng.uniform(0.5, 2.0) * np.array([-1.051383945322714, 0.556409619469370, 1.258967884768947]))
+    for _ in range(npow):
+        a = float(rng.uniform(0.1, 0.9))
+        cones.append(PowerConeT(a))
+        s0.append(rng.uniform(0.5, 2.0) * np.array([np.sqrt(1.0 + a), np.sqrt(2.0 - a), 0.0]))
+    for _ in range(ngenpow):
+        d1, d2 = int(rng.integers(2, 5)), int(rng.integers(1, 4))
+        a = rng.uniform(0.2, 1.0, d1)
+        a = a / a.sum()
+        a[-1] = 1.0 - a[:-1].sum()
+        cones.append(GenPowerConeT(tuple(float(v) for v in a), d2))
+        s0.append(rng.uniform(0.5, 2.0) * np.concatenate([np.sqrt(1.0 + a), np.zeros(d2)]))
+    if socdim:
+        cones.append(SecondOrderConeT(socdim))
+        v = rng.standard_normal(socdim - 1)
+        s0.append(np.concatenate([[1.0 + np.linalg.norm(v)], v]))
+    s0 = np.concatenate(s0)
+    m = s0.size
+    A = _sparse_rows(rng, m, n, kA)
+    P = _psd_P(rng, n, 2)
+    x0 = rng.standard_normal(n)
+    b = A @ x0 + s0
+    q = rng.standard_normal(n)
     return P, q, A, b, cones

@@ -31,7 +31,9 @@ class Settings:
     equilibrate_max_iter: int = 10
     equilibrate_min_scaling: float = 1e-4
     equilibrate_max_scaling: float = 1e4
-    min_terminate_step_length: float = 1e-4     # :106
+    linesearch_backtrack_step: float = 0.8      # :104-106 (line search of the non-symmetric cones)
+    min_switch_step_length: float = 1e-1
+    min_terminate_step_length: float = 1e-4
     max_threads: int = 0                        # :110
     direct_solve_method: str = "hip"            # :114 (reference default :auto)
     static_regularization_enable: bool = True   # :117-119

@@ -21,8 +21,15 @@ FLOATMAX = float(np.finfo(np.float64).max)
 SOC_NO_EXPANSION_MAX_SIZE = 4  # cone_types.jl:101
 
 
-from clarabel_jl_amd.cone_api import (NonnegativeConeT, PSDTriangleConeT, SecondOrderConeT, ZeroConeT,  # noqa: F401
-                                       cones_new_collapsed, nvars, triangular_number)
+def _logsafe(v):  # mathutils.jl:12-18
+    if v < 0:
+        return -FLOATMAX
+    return math.log(v) if v > 0 else -math.inf
+
+
+from clarabel_jl_amd.cone_api import (ExponentialConeT, GenPowerConeT, NonnegativeConeT, PowerConeT, PSDTriangleConeT,  # noqa: F401
+                                       SecondOrderConeT, ZeroConeT, cones_new_collapsed, nvars, triangular_number)
+from .cones_nonsym import ExponentialCone, GenPowerCone, PowerCone  # noqa: E402
 
 
 # ------------------------------------------------------------------ concrete cones
@@ -73,6 +80,13 @@ class ZeroCone:
 
     def step_length(self, dz, ds, z, s, alpha_max):
         return alpha_max, alpha_max
+
+    def unit_initialization(self, z, s):  # coneops_zerocone.jl unit_initialization!
+        s[:] = 0.0
+        z[:] = 0.0
+
+    def compute_barrier(self, z, s, dz, ds, alpha):
+        return 0.0
 
 
 class NonnegativeCone:
@@ -144,6 +158,16 @@ class NonnegativeCone:
         if neg.any():
             as_ = min(as_, float((-s[neg] / ds[neg]).min()))
         return az, as_
+
+    def unit_initialization(self, z, s):  # coneops_nncone.jl unit_initialization!
+        s[:] = 1.0
+        z[:] = 1.0
+
+    def compute_barrier(self, z, s, dz, ds, alpha):  # coneops_nncone.jl compute_barrier: -sum log(s_i z_i) at the shifted point
+        barrier = 0.0
+        for i in range(self.dim):
+            barrier -= _logsafe((s[i] + alpha * ds[i]) * (z[i] + alpha * dz[i]))
+        return barrier
 
 
 def _soc_residual(z):  # coneops_socone.jl:395-399
@@ -304,6 +328,19 @@ class SecondOrderCone:
     def step_length(self, dz, ds, z, s, alpha_max):  # :270-286
         return (_step_length_soc_component(z, dz, alpha_max),
                 _step_length_soc_component(s, ds, alpha_max))
+
+    def unit_initialization(self, z, s):  # coneops_socone.jl unit_initialization!
+        s[:] = 0.0
+        z[:] = 0.0
+        self.scaled_unit_shift(s, 1.0, "primal")
+        self.scaled_unit_shift(z, 1.0, "dual")
+
+    def compute_barrier(self, z, s, dz, ds, alpha):  # :288-305
+        res_s = _soc_residual(s + alpha * ds)
+        res_z = _soc_residual(z + alpha * dz)
+        if res_s > 0 and res_z > 0:
+            return -_logsafe(res_s * res_z) / 2
+        return math.inf
 
 
 def _step_length_soc_component(x, y, alpha_max):  # coneops_socone.jl:443-512
@@ -488,6 +525,25 @@ class PSDTriangleCone:
         as_ = self._step_component(d, alpha_max)
         return az, as_
 
+    def unit_initialization(self, z, s):  # coneops_psdtrianglecone.jl unit_initialization!
+        s[:] = 0.0
+        z[:] = 0.0
+        self.scaled_unit_shift(s, 1.0, "primal")
+        self.scaled_unit_shift(z, 1.0, "dual")
+
+    def _logdet_barrier(self, x, dx, alpha):  # :272-290: log det by Cholesky; +Inf when the shifted point is not positive definite
+        try:
+            L = np.linalg.cholesky(self.svec_to_mat(x + alpha * dx))
+        except np.linalg.LinAlgError:
+            return math.inf
+        return 2.0 * float(np.sum(np.log(np.diag(L))))
+
+    def compute_barrier(self, z, s, dz, ds, alpha):  # :256-270
+        barrier = 0.0
+        barrier -= self._logdet_barrier(z, dz, alpha)
+        barrier -= self._logdet_barrier(s, ds, alpha)
+        return barrier
+
 
 def _combined_ds_shift_symmetric(K, shift, step_z, step_s, sigma_mu):
     """coneops_symmetric_common.jl:1-36: shift = W^-1 ds o W dz - sigma*mu*e (step_z/step_s overwritten)."""
@@ -514,11 +570,17 @@ def make_cone(spec):
         return SecondOrderCone(spec.dim)
     if isinstance(spec, PSDTriangleConeT):
         return PSDTriangleCone(spec.dim)
-    raise TypeError(f"unsupported cone spec {spec!r} (Exp/Pow/GenPow are outside the benchmark configs)")
+    if isinstance(spec, ExponentialConeT):
+        return ExponentialCone()
+    if isinstance(spec, PowerConeT):
+        return PowerCone(spec.alpha)
+    if isinstance(spec, GenPowerConeT):
+        return GenPowerCone(spec.alpha, spec.dim2)
+    raise TypeError(f"unsupported cone spec {spec!r}")
 
 
 class CompositeCone:
-    """compositecone_type.jl:28-66 + coneops_compositecone.jl (symmetric cones only)."""
+    """compositecone_type.jl:28-66 + coneops_compositecone.jl."""
 
     def __init__(self, specs):
         self.cones = [make_cone(s) for s in specs]
@@ -535,7 +597,8 @@ class CompositeCone:
             self.rng_blocks.append(slice(b, b + nb))
             b += nb
         self.nnz_Hs = b
-        self._is_symmetric = True
+        self._is_symmetric = all(getattr(c, "is_symmetric", True) for c in self.cones)      # compositecone_type.jl:54-60
+        self._settings = None      # line-search constants of the non-symmetric cones (Solver passes its Settings)
 
     def __iter__(self):
         return iter(self.cones)
@@ -545,6 +608,22 @@ class CompositeCone:
 
     def is_symmetric(self):
         return self._is_symmetric
+
+    def allows_primal_dual_scaling(self):  # coneops_compositecone.jl:23-25
+        return all(getattr(c, "allows_primal_dual_scaling", True) for c in self.cones)
+
+    def use_settings(self, settings):
+        self._settings = settings
+
+    def unit_initialization(self, z, s):  # :78-89
+        for c, r in zip(self.cones, self.rng_cones):
+            c.unit_initialization(z[r], s[r])
+
+    def compute_barrier(self, z, s, dz, ds, alpha):  # :254-266
+        barrier = 0.0
+        for c, r in zip(self.cones, self.rng_cones):
+            barrier += c.compute_barrier(z[r], s[r], dz[r], ds[r], alpha)
+        return barrier
 
     def rectify_equilibration(self, delta, e):  # :26-45
         any_changed = False
@@ -569,9 +648,13 @@ class CompositeCone:
         for c in self.cones:
             c.set_identity_scaling()
 
-    def update_scaling(self, s, z, mu):
+    def update_scaling(self, s, z, mu, strategy="primal_dual"):  # :103-120
         for c, r in zip(self.cones, self.rng_cones):
-            if not c.update_scaling(s[r], z[r], mu):
+            if getattr(c, "is_symmetric", True):
+                ok = c.update_scaling(s[r], z[r], mu)
+            else:
+                ok = c.update_scaling(s[r], z[r], mu, strategy)
+            if not ok:
                 return False
         return True
 
@@ -596,11 +679,18 @@ class CompositeCone:
         for c, r in zip(self.cones, self.rng_cones):
             c.ds_from_dz_offset(out[r], ds[r], work[r], z[r])
 
-    def step_length(self, dz, ds, z, s, alpha_max):  # :216-252
-        alpha = alpha_max
+    def step_length(self, dz, ds, z, s, alpha_max):  # :216-252: the symmetric cones first, then (from a step slightly short
+        alpha = alpha_max                                # of 1, so that the logarithms stay finite) the non-symmetric ones
         for c, r in zip(self.cones, self.rng_cones):
-            az, as_ = c.step_length(dz[r], ds[r], z[r], s[r], alpha)
-            alpha = min(alpha, az, as_)
+            if getattr(c, "is_symmetric", True):
+                az, as_ = c.step_length(dz[r], ds[r], z[r], s[r], alpha)
+                alpha = min(alpha, az, as_)
+        if not self._is_symmetric:
+            alpha = min(alpha, 1.0 - math.sqrt(float(np.finfo(np.float64).eps)))
+            for c, r in zip(self.cones, self.rng_cones):
+                if not getattr(c, "is_symmetric", True):
+                    az, as_ = c.step_length(dz[r], ds[r], z[r], s[r], alpha, self._settings)
+                    alpha = min(alpha, az, as_)
         return alpha, alpha
 
     # ---- what the KKT structure needs to know (directldl_kkt_assembly.jl:66-86)
@@ -608,8 +698,8 @@ class CompositeCone:
         """Per cone (numel, hs_dense, sparse_kind, dim1) for the C ABI / the oracle."""
         numel = np.array([c.numel for c in self.cones], dtype=np.int64)
         hs_dense = np.array([0 if c.hs_is_diagonal else 1 for c in self.cones], dtype=np.int32)
-        sparse_kind = np.array([1 if c.is_sparse_expandable else 0 for c in self.cones], dtype=np.int32)
-        dim1 = np.zeros(len(self.cones), dtype=np.int64)
+        sparse_kind = np.array([getattr(c, "sparse_kind", 1) if c.is_sparse_expandable else 0 for c in self.cones], dtype=np.int32)
+        dim1 = np.array([getattr(c, "dim1", 0) if getattr(c, "sparse_kind", 1) == 2 else 0 for c in self.cones], dtype=np.int64)
         return numel, hs_dense, sparse_kind, dim1
 
     def kkt_cone_kinds(self):

@@ -24,7 +24,7 @@ from dataclasses import dataclass, field
 import numpy as np
 import scipy.sparse as sp
 
-from .cones import CompositeCone, cones_new_collapsed
+from .cones import CompositeCone, _logsafe, cones_new_collapsed
 from clarabel_jl_amd.settings import Settings
 
 INFINITY = 1e20  # Clarabel.jl:15
@@ -372,6 +372,7 @@ class Solver:
         self.cones = CompositeCone(data.cone_specs)
         if self.cones.numel != data.m:
             raise ValueError("cone dimensions do not match the rows of A")
+        self.cones.use_settings(st)
         data.equilibrate(self.cones, st)
         m, n = data.m, data.n
         self.variables = Variables.zeros(n, m)
@@ -531,6 +532,32 @@ class Solver:
             alpha *= self.settings.max_step_fraction
         return alpha
 
+    def _get_step_length(self, steptype, scaling):  # solver.jl:408-424
+        alpha = self._calc_step_length(steptype)
+        if not self.cones.is_symmetric() and steptype == "combined" and scaling == "dual":
+            alpha = self._backtrack_step_to_barrier(alpha)
+        return alpha
+
+    def _backtrack_step_to_barrier(self, alpha_init):  # solver.jl:427-445: distance to the boundary of the non-symmetric cones
+        step = self.settings.linesearch_backtrack_step
+        alpha = alpha_init
+        for _ in range(50):
+            if self._variables_barrier(alpha) < 1.0:
+                return alpha
+            alpha = step * alpha
+        return alpha
+
+    def _variables_barrier(self, alpha):  # variables.jl:46-74
+        v, step, cones = self.variables, self.step_lhs, self.cones
+        central_coef = cones.degree + 1
+        cur_tau = v.tau + alpha * step.tau
+        cur_kappa = v.kappa + alpha * step.kappa
+        sz = float(np.dot(v.z + alpha * step.z, v.s + alpha * step.s))        # dot_shifted, mathutils.jl:23-43
+        mu = (sz + cur_tau * cur_kappa) / central_coef
+        barrier = central_coef * _logsafe(mu) - _logsafe(cur_tau) - _logsafe(cur_kappa)
+        barrier += cones.compute_barrier(v.z, v.s, step.z, step.s, alpha)
+        return barrier
+
     def _shift_to_cone_interior(self, z, pd):  # :181-208
         cones = self.cones
         min_margin, pos_margin = cones.margins(z, pd)
@@ -543,7 +570,15 @@ class Solver:
         else:
             cones.scaled_unit_shift(z, 0.0, pd)
 
-    def _default_start(self):  # solver.jl:383-405 (symmetric branch)
+    def _default_start(self):  # solver.jl:383-405
+        if not self.cones.is_symmetric():
+            # variables_unit_initialization!, variables.jl:211-225: unit (z, s) along the central rays, x = 0
+            v = self.variables
+            self.cones.unit_initialization(v.z, v.s)
+            v.x[:] = 0.0
+            v.tau = 1.0
+            v.kappa = 1.0
+            return
         self.cones.set_identity_scaling()
         self.kktsystem.kkt_update(self.data, self.cones)
         self.kktsystem.kkt_solve_initial_point(self.variables, self.data)
@@ -580,6 +615,8 @@ class Solver:
         self._default_start()
         tm["default start"] = time.perf_counter() - t0
         t_loop = time.perf_counter()
+        nonsym = not cones.is_symmetric()
+        scaling = "primal_dual" if cones.allows_primal_dual_scaling() else "dual"      # solver.jl:222
         while True:
             self._residuals_update()
             mu = (r.dot_sz + v.tau * v.kappa) / (cones.degree + 1)  # variables.jl:2-11
@@ -594,12 +631,16 @@ class Solver:
                                        cost_dual=info.cost_dual, res_primal=info.res_primal,
                                        res_dual=info.res_dual, ktratio=info.ktratio))
             if self._check_termination(it):
-                # _strategy_checkpoint_insufficient_progress (:453-473), symmetric cones: Fail
+                # _strategy_checkpoint_insufficient_progress (:453-473)
                 if info.status == INSUFFICIENT_PROGRESS:
                     self._reset_to_prev_iterate()
+                    if nonsym and scaling == "primal_dual":      # continue with the dual-only scaling
+                        info.status = UNSOLVED
+                        scaling = "dual"
+                        continue
                 break
             t0 = time.perf_counter()
-            ok_scaling = cones.update_scaling(v.s, v.z, mu)
+            ok_scaling = cones.update_scaling(v.s, v.z, mu, scaling) if nonsym else cones.update_scaling(v.s, v.z, mu)
             tm["scale cones"] += time.perf_counter() - t0
             if not ok_scaling:
                 info.status = NUMERICAL_ERROR
@@ -618,7 +659,7 @@ class Solver:
             ok = ok and self.kktsystem.kkt_solve(lhs, rhs, data, v, cones, "affine")
             tm["kkt solve"] += time.perf_counter() - t0
             if ok:
-                alpha = self._calc_step_length("affine")
+                alpha = self._get_step_length("affine", scaling)
                 sigma = (1.0 - alpha) ** 3  # :446-449
                 mcorr = 1.0 if it > 1 else alpha
                 # variables_combined_step_rhs!, variables.jl:124-162
@@ -634,12 +675,20 @@ class Solver:
                 t0 = time.perf_counter()
                 ok = self.kktsystem.kkt_solve(lhs, rhs, data, v, cones, "combined")
                 tm["kkt solve"] += time.perf_counter() - t0
-            if not ok:  # _strategy_checkpoint_numerical_error (:476-490), symmetric: Fail
-                info.status = NUMERICAL_ERROR
+            if not ok:  # _strategy_checkpoint_numerical_error (:476-490)
                 alpha = 0.0
+                if nonsym and scaling == "primal_dual":
+                    scaling = "dual"
+                    continue
+                info.status = NUMERICAL_ERROR
                 break
-            alpha = self._calc_step_length("combined")
-            if alpha <= max(0.0, st.min_terminate_step_length):  # :493-506
+            alpha = self._get_step_length("combined", scaling)
+            # _strategy_checkpoint_small_step (:493-506)
+            if nonsym and scaling == "primal_dual" and alpha < st.min_switch_step_length:
+                scaling = "dual"
+                alpha = 0.0
+                continue
+            if alpha <= max(0.0, st.min_terminate_step_length):
                 info.status = INSUFFICIENT_PROGRESS
                 alpha = 0.0
                 break

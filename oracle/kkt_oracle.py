@@ -214,8 +214,12 @@ class OracleKKTSolver:
         si = 0
         for cone in cones:
             if cone.is_sparse_expandable:
-                L.oracle_kkt_update_soc(h, si, cone.eta * cone.eta, np.ascontiguousarray(cone.u),
-                                        np.ascontiguousarray(cone.v))
+                if getattr(cone, "sparse_kind", 1) == 2:      # directldl_datamaps.jl:146-167
+                    L.oracle_kkt_update_genpow(h, si, float(np.sqrt(cone.mu)), np.ascontiguousarray(cone.p),
+                                               np.ascontiguousarray(cone.q), np.ascontiguousarray(cone.r))
+                else:
+                    L.oracle_kkt_update_soc(h, si, cone.eta * cone.eta, np.ascontiguousarray(cone.u),
+                                            np.ascontiguousarray(cone.v))
                 si += 1
         st = self.settings
         eps = C.c_double(0.0)

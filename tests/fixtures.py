@@ -72,6 +72,41 @@ def basic_sdp():  # basic_sdp.jl:6-20
     return P, c, A, b, [cl.PSDTriangleConeT(3)]
 
 
+def basic_exp():  # basic_exp.jl:6-37
+    A1 = np.hstack([np.ones((1, 3)), np.zeros((1, 4))])                      # ZeroCone
+    A2 = np.hstack([np.zeros((3, 2)), -np.eye(3), np.zeros((3, 2))])         # NNCone
+    A3 = np.zeros((3, 7))                                                    # expcone
+    A3[0, 0] = -1.0
+    A3[1, 2] = -1.0
+    A3[2, 4] = -1.0
+    c = np.array([1.0, 0.5, -2.0, -0.1, 1.0, 3.0, 0.0])
+    P = sp.identity(7, format="csc") * 1e-1
+    A = sp.csc_matrix(np.vstack([A1, A2, A3]))
+    b = np.concatenate([[10.0], np.zeros(3), np.zeros(3)])
+    return P, c, A, b, [cl.ZeroConeT(1), cl.NonnegativeConeT(3), cl.ExponentialConeT()]
+
+
+def basic_pow():  # basic_pow.jl:6-39: x = (x1, y, z1, x2, y2, z2), (x1, y, z1) in K_pow(0.6), (x2, y2, z2) in K_pow(0.1)
+    P = sp.csc_matrix((6, 6))
+    q = np.zeros(6)
+    q[2] = q[5] = -1.0
+    A1 = np.eye(6)
+    A2 = np.array([[1.0, 2.0, 0.0, 3.0, 0.0, 0.0]])      # x1 + 2 y + 3 x2 == 3
+    A3 = np.array([[0.0, 0.0, 0.0, 0.0, 1.0, 0.0]])      # y2 == 1
+    A = -sp.csc_matrix(np.vstack([A1, A2, A3]))
+    b = np.concatenate([np.zeros(6), [-3.0], [-1.0]])
+    return P, q, A, b, [cl.PowerConeT(0.6), cl.PowerConeT(0.1), cl.ZeroConeT(1), cl.ZeroConeT(1)]
+
+
+def basic_genpow():  # basic_genpow.jl:7-33: the same problem with the two power cones written as generalized power cones
+    P = sp.csc_matrix((6, 6))
+    q = np.zeros(6)
+    q[2] = q[5] = -1.0
+    A = sp.csc_matrix(np.vstack([-np.eye(6), [[1.0, 2.0, 0.0, 3.0, 0.0, 0.0]], [[0.0, 0.0, 0.0, 0.0, 1.0, 0.0]]]))
+    b = np.array([0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 3.0, 1.0])
+    return P, q, A, b, [cl.GenPowerConeT([0.6, 0.4], 1), cl.GenPowerConeT([0.1, 0.9], 1), cl.ZeroConeT(2)]
+
+
 def updating_data():  # data_updating.jl:6-21
     P = sp.csc_matrix(np.array([[4.0, 1.0], [1.0, 2.0]]))
     q = np.array([1.0, 1.0])
@@ -129,6 +164,41 @@ def scale_cones(cones, rng):
             z[r] = rng.random(c.numel) + 0.2
     assert cones.update_scaling(s, z, 1.0)
     return s, z
+
+
+def scale_cones_nonsymmetric(cones, rng, strategy="primal_dual"):
+    """scale_cones for a cone set with Exponential / Power / Generalized Power members: (s, z) = a positive multiple of each such
+    cone's central ray plus a perturbation that keeps both strictly inside (checked with the cone's own feasibility tests), the
+    symmetric members as in scale_cones; update_scaling! with mu = <s, z> / (degree + 1) and the given scaling strategy."""
+    m = cones.numel
+    s, z = np.zeros(m), np.zeros(m)
+    for c, r in zip(cones.cones, cones.rng_cones):
+        if getattr(c, "is_symmetric", True):
+            if isinstance(c, cl.cones.SecondOrderCone):
+                for v in (s, z):
+                    t = rng.standard_normal(c.dim)
+                    t[0] = np.linalg.norm(t[1:]) + 0.5 + rng.random()
+                    v[r] = t
+            elif isinstance(c, cl.cones.ZeroCone):
+                pass
+            else:
+                assert isinstance(c, cl.cones.NonnegativeCone)
+                s[r] = rng.random(c.numel) + 0.2
+                z[r] = rng.random(c.numel) + 0.2
+            continue
+        z0, s0 = np.zeros(c.numel), np.zeros(c.numel)
+        c.unit_initialization(z0, s0)
+        for v, inside in ((s, c.is_primal_feasible), (z, c.is_dual_feasible)):
+            for _ in range(200):
+                t = s0 * rng.uniform(0.5, 2.0) + 0.2 * rng.standard_normal(c.numel)
+                if inside(t) and inside(s0 + 0.5 * (t - s0)):
+                    break
+            else:
+                raise AssertionError("no interior point")
+            v[r] = t
+    mu = float(s @ z) / (cones.degree + 1)
+    assert mu > 0 and cones.update_scaling(s, z, mu, strategy)
+    return s, z, mu
 
 
 def scale_cones_late(cones, rng, mu=1e-9, span=6.0):

@@ -44,6 +44,12 @@ REFERENCE = [
     ("sdp", fx.basic_sdp, "SOLVED", [-3.0729833267361095, 0.3696004167288786, -0.022226685581313674,
                                      0.31441213129613066, -0.026739700851545107, -0.016084530571308823],
      4.840076866013861, 1e-3, "test/OptTests/basic_sdp.jl:6-20,31-48; linear_solvers.jl:47-67"),
+    # the non-symmetric cones: 3 x 3 dense Hs blocks (Exponential, Power) and the rank-3 expansion (Generalized Power)
+    ("exp", fx.basic_exp, "SOLVED", [-9.425995201329599, 4.828561507482018, 14.59743362204262, 1.0000012112102774,
+                                     7.65314081561849, -29.99999978458479, -0.0],
+     -54.41243965302268, 1e-3, "test/OptTests/basic_exp.jl:6-37,54-71"),
+    ("pow", fx.basic_pow, "SOLVED", None, -1.8458, 1e-3, "test/OptTests/basic_pow.jl:6-39,56-62"),
+    ("genpow", fx.basic_genpow, "SOLVED", None, -1.8458, 1e-3, "test/OptTests/basic_genpow.jl:7-33,50-56"),
 ]
 
 # SURVEY.md Appendix B (1-based, exactly as Julia would hold them)
@@ -64,7 +70,19 @@ def dump_problem(prob):
                 P=dict(colptr=P.indptr.tolist(), rowval=P.indices.tolist(), nzval=P.data.tolist()),
                 A=dict(colptr=A.indptr.tolist(), rowval=A.indices.tolist(), nzval=A.data.tolist()),
                 q=np.asarray(q, float).tolist(), b=np.asarray(b, float).tolist(),
-                cones=[[type(c).__name__, int(c.dim)] for c in cones])
+                cones=[dump_cone(c) for c in cones])
+
+
+def dump_cone(c):
+    """[type name, field] with the field the reference's JSON form carries (json.jl:142-158): dim; alpha; (); [alpha, dim2]"""
+    name = type(c).__name__
+    if name == "ExponentialConeT":
+        return [name, []]
+    if name == "PowerConeT":
+        return [name, float(c.alpha)]
+    if name == "GenPowerConeT":
+        return [name, [list(c.alpha), int(c.dim2)]]
+    return [name, int(c.dim)]
 
 
 def build():
@@ -75,10 +93,14 @@ def build():
         s = cl.Solver(P, q, A, b, cones, cl.Settings(),
                       kktsolver_factory=lambda *a: OracleKKTSolver(*a, ordering="natural"))
         sol = s.solve()
+        # cross_order_tol: how far a run on ANOTHER elimination order may sit from this one.  1e-8 = the IPM's stopping tolerance for the
+        # symmetric fixtures; the non-symmetric ones move by up to 3e-9 (objective, relative) between orders in the oracle itself
+        # (tests/test_nonsymmetric_cones.py::test_spread_of_the_reference_arithmetic_between_elimination_orders holds it under 2.5e-8)
         out["oracle"].append(dict(name=name, ordering="natural", status=sol.status, iterations=int(sol.iterations),
                                   x=np.asarray(sol.x).tolist(),
                                   obj=None if np.isnan(sol.obj_val) else float(sol.obj_val),
-                                  r_prim=float(sol.r_prim), r_dual=float(sol.r_dual)))
+                                  r_prim=float(sol.r_prim), r_dual=float(sol.r_dual),
+                                  cross_order_tol=2.5e-8 if name in ("exp", "pow", "genpow") else 1e-8))
     return out
 
 

@@ -18,7 +18,9 @@ with open(os.path.join(HERE, "golden", "reference_known_answers.json")) as f:
     GOLD = json.load(f)
 
 CONE_TYPES = {"ZeroConeT": cl.ZeroConeT, "NonnegativeConeT": cl.NonnegativeConeT,
-              "SecondOrderConeT": cl.SecondOrderConeT, "PSDTriangleConeT": cl.PSDTriangleConeT}
+              "SecondOrderConeT": cl.SecondOrderConeT, "PSDTriangleConeT": cl.PSDTriangleConeT,
+              "ExponentialConeT": lambda _: cl.ExponentialConeT(), "PowerConeT": cl.PowerConeT,
+              "GenPowerConeT": lambda v: cl.GenPowerConeT(v[0], v[1])}
 
 
 def load_problem(p):
@@ -88,9 +90,10 @@ def test_hip_path_meets_golden_file(e):
     # (1e-10, enforced in tests/test_gpu_kkt.py where the oracle is handed the product's permutation).
     o = next(r for r in GOLD["oracle"] if r["name"] == e["name"])
     assert sol.iterations == o["iterations"]
+    tol = o.get("cross_order_tol", 1e-8)          # (the non-symmetric fixtures: the oracle's own measured spread between orders, see make_golden.py)
     if o["obj"] is not None:
-        assert abs(sol.obj_val - o["obj"]) <= 1e-8 * max(1.0, abs(o["obj"]))
-        assert abs(sol.r_prim - o["r_prim"]) <= 1e-8 and abs(sol.r_dual - o["r_dual"]) <= 1e-8
+        assert abs(sol.obj_val - o["obj"]) <= tol * max(1.0, abs(o["obj"]))
+        assert abs(sol.r_prim - o["r_prim"]) <= tol and abs(sol.r_dual - o["r_dual"]) <= tol
 
 
 @pytest.mark.gpu

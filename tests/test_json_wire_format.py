@@ -75,7 +75,10 @@ def test_foreign_file(tmp_path):
     P, q, A, b, cones, st = jsonio.load_from_file(f)
     assert st.max_iter == 50 and st.extra == {"direct_kkt_solver": True} and st.time_limit == float("inf")
     assert cones == [cl.NonnegativeConeT(1)] and P[0, 0] == 2.0
-    d["cones"] = [{"ExponentialConeT": []}]
+    d["cones"] = [{"ExponentialConeT": []}]                      # json.jl:201-202 (non-symmetric cones: tests/test_nonsymmetric_cones.py)
     json.dump(d, open(f, "w"))
-    with pytest.raises(NotImplementedError):
+    assert jsonio.load_from_file(f)[4] == [cl.ExponentialConeT()]
+    d["cones"] = [{"HyperbolicConeT": 3}]
+    json.dump(d, open(f, "w"))
+    with pytest.raises(ValueError):
         jsonio.load_from_file(f)
