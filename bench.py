@@ -512,10 +512,9 @@ def main():
             kernel="k_front_block", bound="dependency latency (pivot chain)", launches_per_refactor=p4["front_block_launches"],
             panels=p4["front_block_panels"], ms_per_refactor=round(p4["front_block_ms"], 4),
             us_per_panel=round(1e3 * p4["front_block_ms"] / max(1, p4["front_block_panels"]), 2),
-            floor_note="wall-clock stamps (tools/fb_trace.py, profiles/r04_*_cfg2a_front_block_stamps.txt): from one diagonal workgroup's pivot start to the "
-                       "next one's ~22 us = 8.7 us until the next workgroup has its tile L(i,i-1) of the panel before (flag after 2 pivot blocks, "
-                       "hand-off 2.5, tile load 1.3, 64^3 product 2) + 8 streamed blocks of 8 pivots at 1.7 us each on the consumer side (the "
-                       "producer's own pivots take 11.6 us: the consumer, not the producer, paces the chain)",
+            floor_note="one diagonal workgroup's 64 pivots + the next one finishing the last streamed record behind them; the per-phase "
+                       "stamps of the committed code are under profiles/ (<round>_*_cfg2a_front_block_stamps.txt, tools/fb2_trace.py) and in "
+                       "DESIGN.md section 7 -- this line carries no numbers of its own",
             extra_update_tiles=p4.get("front_block_extra_tiles", 0), extra_update_flops=p4.get("front_block_extra_flops", 0.0),
             extra_note="dense update tiles of the partial last rounds of the far stages, executed by extra workgroups of these launches on compute "
                        "units the panel chain leaves idle; their flops are NOT in roofline.achieved / all_update_kernels (those time the update "

@@ -664,17 +664,4 @@ void launch_front_block(hipStream_t st, const DevPlan &P, const FrontBatch &B, i
     else hipLaunchKernelGGL(k_front_block<false>, grid, dim3(256), 0, st, P, B, sync_all, scratch_all, stream_all, dyn_eps, dyn_delta, trace);
 }
 
-// before every factorisation: the sync words of all front batches to zero, the stream records to "not written yet"
-__global__ void k_fb_reset(int *sync_all, int nsync, unsigned long long *stream_all, long long nstream) {
-    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x, step = (long long)gridDim.x * blockDim.x;
-    for (long long q = t; q < nsync; q += step) sync_all[q] = 0;
-    for (long long q = t; q < nstream; q += step) stream_all[q] = kFbSentinel;
-}
-void launch_fb_reset(hipStream_t st, int *sync_all, int nsync, double *stream_all, int64_t nstream) {
-    const long long n = std::max<long long>(nsync, nstream);
-    if (n <= 0) return;
-    const int blocks = (int)std::min<long long>((n + 255) / 256, 1024);
-    hipLaunchKernelGGL(k_fb_reset, dim3(blocks), dim3(256), 0, st, sync_all, nsync, (unsigned long long *)stream_all, (long long)nstream);
-}
-
 }  // namespace hipkkt

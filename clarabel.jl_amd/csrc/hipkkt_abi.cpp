@@ -8,6 +8,8 @@ using namespace hipkkt_host;
 
 namespace hipkkt_host {
 thread_local std::string g_create_error;
+DebugOpts &debug_opts() { static DebugOpts o; return o; }
+bool verbose() { static const bool v = getenv("HIPKKT_VERBOSE") != nullptr; return v; }   // (the one place that reads it)
 }
 
 extern "C" {
@@ -106,11 +108,10 @@ int32_t hipkkt_create_from_parts(int32_t device_id, int64_t n, int64_t m, const 
             S->cone_hs_dense.assign(cone_hs_dense, cone_hs_dense + ncones);
             S->cone_sparse_kind.assign(cone_sparse_kind, cone_sparse_kind + ncones);
         }
-        // the image is assembled by count -> scan -> fill kernels on the device (assemble_dev.hip); HIPKKT_HOST_ASSEMBLY=1
-        // selects the host twin (assemble.cpp), which the GPU tests compare the device image with
-        const char *ha = getenv("HIPKKT_HOST_ASSEMBLY");
+        // the image is assembled by count -> scan -> fill kernels on the device (assemble_dev.hip); the debug switch HOST_ASSEMBLY
+        // (testing build only) selects the host twin (assemble.cpp), which the GPU tests compare the device image with
         std::string err;
-        if (ha && ha[0] == '1') {
+        if (debug_opts().host_assembly) {
             err = assemble_kkt(n, m, Pp.data(), Pi.data(), Pnzval, Ap.data(), Ai.data(), Anzval, ncones, cone_numel, cone_hs_dense,
                                cone_sparse_kind, dim1.data(), S->img);
         } else {
@@ -136,7 +137,7 @@ int32_t hipkkt_create_from_parts(int32_t device_id, int64_t n, int64_t m, const 
 }
 
 void hipkkt_destroy(hipkkt_handle h) {
-    if (h && getenv("HIPKKT_VERBOSE")) {
+    if (h && verbose()) {
         const auto t0 = std::chrono::steady_clock::now();
         delete h;
         fprintf(stderr, "hipkkt: destroy %.2f ms\n", 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
@@ -733,6 +734,76 @@ int32_t hipkkt_selftest_mfma(int32_t device_id, double *max_err) {
     for (int i = 0; i < 256; i++) me = std::max(me, std::fabs(Dd[i] - Dh[i]));
     if (max_err) *max_err = me;
     return me < 1e-12 ? HIPKKT_OK : HIPKKT_NUMERICAL_FAILURE;
+}
+
+int32_t hipkkt_debug_is_testing_build(void) {
+#ifdef HIPKKT_TESTING
+    return 1;
+#else
+    return 0;
+#endif
+}
+
+// the switches of struct DebugOpts (hipkkt_internal.h), by name; value NULL = default
+int32_t hipkkt_debug_set(const char *key, const char *value) {
+    DebugOpts &o = debug_opts();
+    const DebugOpts def;
+    if (!key) { o = def; return HIPKKT_OK; }
+#ifndef HIPKKT_TESTING
+    (void)value;
+    g_create_error = "hipkkt_debug_set: this is the production library (no -DHIPKKT_TESTING): switches keep their defaults";
+    return HIPKKT_ERR_ARGUMENT;
+#else
+    const std::string k(key);
+    auto is0 = [&] { return value && value[0] == '0'; };
+    auto is1 = [&] { return value && value[0] == '1'; };
+    // a number, checked to its end (atof turned "0.0" and any non-numeric text into threshold 0)
+    auto num = [&](double *out) {
+        char *end = nullptr;
+        const double v = strtod(value, &end);
+        while (end && (*end == ' ' || *end == '\t')) end++;
+        if (!end || end == value || *end != 0 || !(v == v)) return false;
+        *out = v;
+        return true;
+    };
+    double v = 0;
+    if (k == "PLAN_CACHE") o.plan_cache = !is0();
+    else if (k == "FB_EXTRA") o.fb_extra = !is0();
+    else if (k == "FB_STREAM") o.fb_stream = !is0();
+    else if (k == "FB_V2") o.fb_v2 = !is0();
+    else if (k == "FORCE_TWIN") o.force_twin = is1();
+    else if (k == "NO_GRAPH") o.no_graph = is1();
+    else if (k == "NO_PERSIST") o.no_persist = is1();
+    else if (k == "FULL_TILES") o.full_tiles = !is0();
+    else if (k == "FRONT_BLOCK") o.front_block = !is0();
+    else if (k == "SPLIT_K") o.split_k = !is0();
+    else if (k == "DENSE_TRI") o.dense_tri = !is0();
+    else if (k == "ORDERING") o.ordering_amd = value && value[0] == 'a';
+    else if (k == "NO_FRONT") o.no_front = is1();
+    else if (k == "HOST_ASSEMBLY") o.host_assembly = is1();
+    else if (k == "FRONT_BLOCK_MIN_ROWS") { if (!value) o.front_block_min_rows = def.front_block_min_rows; else if (num(&v)) o.front_block_min_rows = (int)v; else return HIPKKT_ERR_ARGUMENT; }
+    else if (k == "SUPERHOP") { if (!value) o.superhop = def.superhop; else if (num(&v)) o.superhop = (int)v; else return HIPKKT_ERR_ARGUMENT; }
+    else if (k == "DEBUG_FLAGS") { if (!value) o.debug_flags = 0; else if (num(&v)) o.debug_flags = (int)v; else return HIPKKT_ERR_ARGUMENT; }
+    else if (k == "SPIN_LIMIT") { if (!value) o.spin_limit = def.spin_limit; else if (num(&v) && v >= 0) o.spin_limit = (long long)v; else return HIPKKT_ERR_ARGUMENT; }
+    else if (k == "PERSIST_RETRY") { if (!value) o.persist_retry = def.persist_retry; else if (num(&v) && v >= 0) o.persist_retry = (long long)v; else return HIPKKT_ERR_ARGUMENT; }
+    else if (k == "ACCURATE") {
+        // threshold on the largest |entry| of a wide block's explicit inverse: any value equal to 0 = never, negative = every block
+        if (!value) o.accurate = def.accurate;
+        else if (!num(&v)) return HIPKKT_ERR_ARGUMENT;
+        else o.accurate = v == 0.0 ? 1e300 : v;
+    } else if (k == "FB_EXTRA_PW") {
+        o.fb_extra_pw = def.fb_extra_pw; o.fb_pen1 = def.fb_pen1; o.fb_pen2 = def.fb_pen2;
+        if (value) {
+            int m = o.fb_extra_pw; double a = o.fb_pen1, b = o.fb_pen2;
+            if (sscanf(value, "%d,%lf,%lf", &m, &a, &b) < 1) return HIPKKT_ERR_ARGUMENT;
+            o.fb_extra_pw = std::max(1, std::min(m, 2)); o.fb_pen1 = a; o.fb_pen2 = b;
+        }
+    } else {
+        g_create_error = "hipkkt_debug_set: unknown switch " + k;
+        return HIPKKT_ERR_ARGUMENT;
+    }
+    return HIPKKT_OK;
+#endif
 }
 
 const char *hipkkt_last_error(hipkkt_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }

@@ -20,6 +20,19 @@ void enqueue_factor_level(hipkkt_solver *S, int l) {
         launch_factor_panel(S->stream, S->dp, P.fac_lvl_ptr[l], n, S->opts.dynamic_reg_eps, S->opts.dynamic_reg_delta);
 }
 
+// one update batch of a front (front_block2.hip; the first form of the kernel, front_block.hip, exists in the testing build only)
+static void enqueue_front_batch(hipkkt_solver *S, const FrontBatch &B) {
+#ifdef HIPKKT_TESTING
+    if (!S->fb_v2) {
+        launch_front_block(S->stream, S->dp, B, S->d_fb_sync, S->d_fb_scratch, S->d_fb_stream, S->opts.dynamic_reg_eps,
+                           S->opts.dynamic_reg_delta, S->fb_streamed, S->d_fb_trace);
+        return;
+    }
+#endif
+    launch_front_block2(S->stream, S->dp, B, S->d_fb_sync, S->d_fb_scratch, S->d_fb_stream, S->opts.dynamic_reg_eps,
+                        S->opts.dynamic_reg_delta, S->d_fb_trace);
+}
+
 // split-K part of a stage's dense updates (hipkkt_setup.cpp plan_split_k): the chunk tiles, then their fixed-order reduction
 void enqueue_split_k(hipkkt_solver *S, int l) {
     if (S->split_group_count[l] <= 0) return;
@@ -63,12 +76,11 @@ static double dense_stage_cost_us(int m) {
 }
 int fb_extra_tiles_of_stage(int nd, int ncrit, int next_blk, int *per_wave_out) {
     constexpr int cus = 254, rmin = 64;
-    // what the panel launch gains in duration (us) with one / two tiles per wavefront; experiments: HIPKKT_FB_EXTRA_PW=<max tiles per
-    // wavefront>,<penalty 1>,<penalty 2>
-    static const struct Tun { int pw_max; double pen[3]; Tun() : pw_max(1), pen{0.0, 10.0, 28.0} {   // (round 5: one tile per wavefront since the panel chain got shorter than two tile times)
-        if (const char *e = getenv("HIPKKT_FB_EXTRA_PW")) { double a = pen[1], b = pen[2]; int m = pw_max; if (sscanf(e, "%d,%lf,%lf", &m, &a, &b) >= 1) { pw_max = std::max(1, std::min(m, 2)); pen[1] = a; pen[2] = b; } } } } tun;
-    const int pw_max = tun.pw_max;
-    const double *pen = tun.pen;
+    // what the panel launch gains in duration (us) with one / two tiles per wavefront (round 5: one tile per wavefront since the
+    // panel chain got shorter than two tile times); experiments: debug switch FB_EXTRA_PW=<max tiles per wavefront>,<penalty 1>,<penalty 2>
+    const DebugOpts &dbo = debug_opts();
+    const int pw_max = dbo.fb_extra_pw;
+    const double pen[3] = {0.0, dbo.fb_pen1, dbo.fb_pen2};
     double best = dense_stage_cost_us(nd);
     int best_r = 0, best_pw = 1;
     for (int pw = 1; pw <= pw_max; pw++) {
@@ -112,10 +124,7 @@ void enqueue_factor(hipkkt_solver *S, int static_enable, double eps_const, doubl
                 FrontBatch B = S->fbatches[(size_t)cur_bi];
                 B.x_begin = extra_begin; B.x_count = extra_count; B.pad = extra_pw;     // far tiles of the stage before (fb_extra_tiles_of_stage)
                 extra_begin = extra_count = 0;
-                if (S->fb_v2) launch_front_block2(st, S->dp, B, S->d_fb_sync, S->d_fb_scratch, S->d_fb_stream, S->opts.dynamic_reg_eps,
-                                                  S->opts.dynamic_reg_delta, S->d_fb_trace);
-                else launch_front_block(st, S->dp, B, S->d_fb_sync, S->d_fb_scratch, S->d_fb_stream, S->opts.dynamic_reg_eps,
-                                        S->opts.dynamic_reg_delta, S->fb_streamed, S->d_fb_trace);
+                enqueue_front_batch(S, B);
             }
             const bool last = l + 1 >= P.nlevels || S->lvl_fb[l + 1] != -2;
             if (!last) continue;                          // the stages inside the batch are applied by the kernel itself
@@ -200,7 +209,7 @@ int32_t hipkkt_refactor(hipkkt_handle h, int32_t static_reg_enable, double eps_c
             const auto t_b = std::chrono::steady_clock::now();
             init_runtime(T.get());
             setup_device(T.get());
-            if (getenv("HIPKKT_VERBOSE"))
+            if (verbose())
                 fprintf(stderr, "hipkkt: robust-order twin (minimum degree on K): N %d nnzL %lld levels %d: waited %.2f ms for its symbolic analysis (%s), device set-up %.2f ms\n",
                         T->plan.N, (long long)T->plan.nnzL, T->plan.nlevels, 1e3 * std::chrono::duration<double>(t_b - t_a).count(),
                         T->plan.timing_note.c_str(), 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t_b).count());
@@ -266,10 +275,7 @@ static int32_t refactor_once(hipkkt_handle h, int32_t static_reg_enable, double 
                     FrontBatch B = S->fbatches[(size_t)cur_bi];
                     B.x_begin = extra_begin; B.x_count = extra_count; B.pad = extra_pw;
                     extra_begin = extra_count = 0;
-                    if (S->fb_v2) launch_front_block2(st, S->dp, B, S->d_fb_sync, S->d_fb_scratch, S->d_fb_stream, S->opts.dynamic_reg_eps,
-                                                      S->opts.dynamic_reg_delta, S->d_fb_trace);
-                    else launch_front_block(st, S->dp, B, S->d_fb_sync, S->d_fb_scratch, S->d_fb_stream, S->opts.dynamic_reg_eps,
-                                            S->opts.dynamic_reg_delta, S->fb_streamed, S->d_fb_trace);
+                    enqueue_front_batch(S, B);
                     HK_CHECK(hipEventRecord(b, st));
                     evf.push_back(a);
                     evf.push_back(b);

@@ -58,6 +58,39 @@ inline void fill_async(hipStream_t st, void *dst, int value, size_t bytes) {
     if (bytes) HK_CHECK(hipMemsetAsync(dst, value, bytes, st));
 }
 
+// Test / experiment switches (hipkkt_debug_set, include/hipkkt.h).  The library reads NO environment variable for them: a production
+// build (libclarabel_hipkkt.so, what the Julia glue and bench.py load) keeps these defaults for ever -- hipkkt_debug_set refuses -- and
+// does not even contain the code some of them select (the first form of the front-batch kernel, the debug flags of the sweeps).
+// The -DHIPKKT_TESTING build (libclarabel_hipkkt_testing.so, what tests/ load) accepts them; a handle reads them when it is created.
+// (Until round 5 every one of them was an environment read inside the product: a HIPKKT_* variable left over in a caller's environment
+// silently changed the arithmetic order, or -- DEBUG_FLAGS -- the results.)
+struct DebugOpts {
+    bool plan_cache = true;        // PLAN_CACHE=0: no process-wide plan cache
+    bool fb_extra = true;          // FB_EXTRA=0: every far stage applies all of its tiles in its own launch
+    bool fb_stream = true;         // FB_STREAM=0: the round-3 pivot chain (whole-tile hand-off; first form of the kernel only)
+    bool fb_v2 = true;             // FB_V2=0: the first form of the front-batch kernel (front_block.hip)
+    bool force_twin = false;       // FORCE_TWIN=1: every successful factorisation in the cheap order counts as broken down
+    bool no_graph = false;         // NO_GRAPH=1: eager launches
+    bool no_persist = false;       // NO_PERSIST=1: per-level solve kernels only
+    bool full_tiles = true;        // FULL_TILES=0: the general core for every dense tile
+    bool front_block = true;       // FRONT_BLOCK=0: one launch per panel
+    bool split_k = true;           // SPLIT_K=0
+    bool dense_tri = true;         // DENSE_TRI=0: dense Hs triangles stay in the symmetric view
+    bool ordering_amd = false;     // ORDERING=amd: minimum degree on K only
+    bool no_front = false;         // NO_FRONT=1: no persistent front kernels
+    bool host_assembly = false;    // HOST_ASSEMBLY=1: the host twin of the assembly kernels
+    int front_block_min_rows = -1; // FRONT_BLOCK_MIN_ROWS=<n> (-1: the plan's default)
+    int superhop = -1;             // SUPERHOP=<n> (-1: the plan's default)
+    int debug_flags = 0;           // DEBUG_FLAGS=<bits>: timing experiments, results are WRONG when set
+    long long spin_limit = -1;     // SPIN_LIMIT=<n> (-1: 2^20)
+    long long persist_retry = -1;  // PERSIST_RETRY=<n> (-1: 64)
+    double accurate = 64.0;        // ACCURATE=<tau>: 0 = never, negative = every wide block
+    int fb_extra_pw = 1;           // FB_EXTRA_PW=<tiles per wavefront>,<penalty 1>,<penalty 2>
+    double fb_pen1 = 10.0, fb_pen2 = 28.0;
+};
+DebugOpts &debug_opts();
+bool verbose();                    // HIPKKT_VERBOSE in the environment: diagnostic lines on stderr (changes no result)
+
 struct GraphSlot {
     hipGraphExec_t exec = nullptr;
     bool valid = false;

@@ -8,7 +8,7 @@ namespace hipkkt_host {
 
 // Process-wide cache of symbolic plans keyed by the KKT pattern + the plan options: a batch of problems with
 // IDENTICAL structure (the same model re-solved with new data, MPC, parameter sweeps) pays the ordering + symbolic analysis once.
-// Patterns are compared exactly (hash first); a hit deep-copies the plan into the handle.  HIPKKT_PLAN_CACHE=0 disables it.
+// Patterns are compared exactly (hash first); a hit deep-copies the plan into the handle.  (Debug switch PLAN_CACHE=0 disables it.)
 namespace {
 struct PlanCache {
     struct Entry {
@@ -23,7 +23,7 @@ struct PlanCache {
     static constexpr size_t kMaxEntries = 8;
     static constexpr int64_t kMaxNnzL = 40000000;      // bigger plans (hundreds of MB of work lists) are not kept
     static PlanCache &get() { static PlanCache c; return c; }
-    static bool enabled() { const char *e = getenv("HIPKKT_PLAN_CACHE"); return !(e && e[0] == '0'); }   // (read ONCE per create call below)
+    static bool enabled() { return debug_opts().plan_cache; }   // (read ONCE per create call below)
     static uint64_t fnv(uint64_t h, const void *p, size_t n) {
         const unsigned char *b = (const unsigned char *)p;
         for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 1099511628211ull; }
@@ -63,17 +63,16 @@ void init_runtime(hipkkt_solver *S) {
     // the stream count is kept where the measurement put it (it was the "side" stream of rounds 1-3, dropped once and missed).
     S->idle_stream = (hipStream_t)need(rp.stream_get(S->device, 1));
     {
-        const char *fx = getenv("HIPKKT_FB_EXTRA");   // 0: every far stage applies all of its tiles in its own launch (A/B timing, bit-identity test)
-        S->fb_extra = !(fx && fx[0] == '0');
-        const char *fs = getenv("HIPKKT_FB_STREAM");  // 0: the pivot chain of k_front_block hands over L11^-T D^-1 after all 64 pivots (round-3 form)
-        S->fb_streamed = !(fs && fs[0] == '0');
-        const char *f2 = getenv("HIPKKT_FB_V2");     // 0: the first form of the front-batch kernel (front_block.hip; A/B timing, comparison test)
-        S->fb_v2 = !(f2 && f2[0] == '0') && S->fb_streamed;   // (HIPKKT_FB_STREAM=0 asks for the round-3 chain, which only the first form has)
-        const char *ac = getenv("HIPKKT_ACCURATE");   // threshold on the largest |entry| of a wide block's explicit inverse above which its solves take a
-        if (ac && ac[0] == '0' && ac[1] == 0) S->accurate_threshold = 1e300;   // refinement step (default 64): "0" = never, "-1" = every wide block
-        else if (ac) S->accurate_threshold = atof(ac);
-        const char *ft = getenv("HIPKKT_FORCE_TWIN"); // 1 (tests): every successful factorisation in the cheap order counts as broken down (hipkkt_refactor)
-        S->force_twin = ft && ft[0] == '1';
+        // test / experiment switches (hipkkt_debug_set; the production library keeps the defaults), latched per handle
+        const DebugOpts &o = debug_opts();
+        S->fb_extra = o.fb_extra;            // false: every far stage applies all of its tiles in its own launch (A/B timing, bit-identity test)
+        S->fb_streamed = o.fb_stream;        // false: the pivot chain of k_front_block hands over L11^-T D^-1 after all 64 pivots (round-3 form)
+        S->fb_v2 = o.fb_v2 && S->fb_streamed;   // false: the first form of the front-batch kernel (front_block.hip; the round-3 chain exists only there)
+#ifndef HIPKKT_TESTING
+        S->fb_streamed = S->fb_v2 = true;    // (the production library does not contain the first form)
+#endif
+        S->accurate_threshold = o.accurate;  // largest |entry| of a wide block's explicit inverse above which its solves take a refinement step
+        S->force_twin = o.force_twin;        // tests: every successful factorisation in the cheap order counts as broken down (hipkkt_refactor)
     }
     static_assert(SC_COUNT * sizeof(double) <= RuntimePool::kPinned && sizeof(RefineState) <= RuntimePool::kPinned, "pinned chunk too small");
     for (hipEvent_t *e : {&S->ev0, &S->ev1, &S->ev2, &S->ev3}) *e = (hipEvent_t)need(rp.event_get(S->device));
@@ -83,8 +82,7 @@ void init_runtime(hipkkt_solver *S) {
     static_assert((16 + 10) * sizeof(double) <= RuntimePool::kPinned, "pinned chunk too small for the reduced-solve scalars");
     memset(S->h_scal, 0, SC_COUNT * sizeof(double));
     memset(S->h_flags, 0, FL_COUNT * sizeof(int));
-    const char *ng = getenv("HIPKKT_NO_GRAPH");
-    if (ng && ng[0] == '1') S->use_graph = false;
+    if (debug_opts().no_graph) S->use_graph = false;
     for (int c = 0; c < kNumCtx; c++) {
         SolveCtx &C = S->ctx[c];
         if (c == 0) C.stream = S->stream;
@@ -117,8 +115,7 @@ void setup_device(hipkkt_solver *S) {
     S->slab_left = 0;
     S->slv_items.clear(); S->bwd_items.clear(); S->reg_lvl_sn.clear(); S->pbwd_items.clear();
     {
-        const char *np_ = getenv("HIPKKT_NO_PERSIST");
-        S->use_persist = !(np_ && np_[0] == '1');
+        S->use_persist = !debug_opts().no_persist;
         S->persist_allowed = S->use_persist;
         S->persist_retry_at = -1;
     }
@@ -348,7 +345,7 @@ void setup_device(hipkkt_solver *S) {
     D.upd_groups = S->upload(P.upd_groups);
     std::vector<DenseGroup> dg(P.upd_groups.size());       // uploaded after the front batches are known (plan_split_k appends to it)
     {
-        const bool no_full_tiles = [] { const char *e = getenv("HIPKKT_FULL_TILES"); return e && e[0] == '0'; }();   // bit-identity test of the full-tile core
+        const bool no_full_tiles = !debug_opts().full_tiles;   // bit-identity test of the full-tile core
         for (size_t q = 0; q < dg.size(); q++) {
             const UpdGroup &G = P.upd_groups[q];
             const int t = G.tgt;
@@ -433,10 +430,13 @@ void setup_device(hipkkt_solver *S) {
     D.nseg = S->nseg;
     {
         D.seg_ticket = 3;                                  // bit 0: forward sweep, bit 1: backward sweep take their items by atomic ticket
-        const char *sl = getenv("HIPKKT_SPIN_LIMIT");      // tests force a sweep time-out with a tiny bound
-        D.spin_limit = sl ? (unsigned)strtoul(sl, nullptr, 10) : (1u << 20);
-        const char *df = getenv("HIPKKT_DEBUG_FLAGS");    // timing experiments only: results are WRONG when set (device_plan.h DevPlan::dbg)
-        D.dbg = df ? atoi(df) : 0;
+        D.spin_limit = debug_opts().spin_limit >= 0 ? (unsigned)debug_opts().spin_limit : (1u << 20);   // tests force a sweep time-out with a tiny bound
+#ifdef HIPKKT_TESTING
+        D.dbg = debug_opts().debug_flags;                  // timing experiments only: results are WRONG when set (device_plan.h DevPlan::dbg)
+        if (D.dbg) fprintf(stderr, "hipkkt: DEBUG_FLAGS = %d: timing experiment, the results of this handle are WRONG\n", D.dbg);
+#else
+        D.dbg = 0;
+#endif
         D.sn_polish = S->dalloc<int>((size_t)std::max(P.nsuper, 1));
         fill_async(S->stream, D.sn_polish, 0, (size_t)std::max(P.nsuper, 1) * sizeof(int));
         D.polish_tau = S->accurate_threshold;
@@ -569,10 +569,7 @@ static void order_far_stages(hipkkt_solver *S) {
     const auto hb = front_batches(P, S->plan_opts.update_policy, kFbMax);
     const size_t nbh = hb.size();
     S->next_batch.assign(nbh, hipkkt_solver::NextBatch());
-    {
-        const char *e = getenv("HIPKKT_FRONT_BLOCK");
-        if (!S->fb_extra || (e && e[0] == '0')) return;
-    }
+    if (!S->fb_extra || !debug_opts().front_block) return;
     std::vector<std::vector<int>> panel_batch(P.fronts.size());
     for (size_t fi = 0; fi < P.fronts.size(); fi++) panel_batch[fi].assign((size_t)P.fronts[fi].np, -1);
     for (size_t q = 0; q < nbh; q++)
@@ -607,10 +604,7 @@ static int64_t plan_split_k(hipkkt_solver *S, std::vector<DenseGroup> &dg) {
     S->split_rec_ptr.assign(P.nlevels + 1, 0);
     std::vector<SplitRec> recs;
     int64_t scratch_max = 0;
-    {
-        const char *e = getenv("HIPKKT_SPLIT_K");         // 0: never (A/B timing, comparison test)
-        if (e && e[0] == '0') { S->d_split_recs = S->upload(recs); return 0; }
-    }
+    if (!debug_opts().split_k) { S->d_split_recs = S->upload(recs); return 0; }   // (A/B timing, comparison test)
     for (int l = 0; l < P.nlevels; l++) {
         S->split_rec_ptr[l + 1] = S->split_rec_ptr[l];
         const int g0 = P.upd_stage_ptr[l], nd = P.upd_stage_ndense[l];
@@ -644,7 +638,7 @@ static int64_t plan_split_k(hipkkt_solver *S, std::vector<DenseGroup> &dg) {
         scratch_max = std::max(scratch_max, scratch);
     }
     S->d_split_recs = S->upload(recs);
-    if (getenv("HIPKKT_VERBOSE") && !recs.empty())
+    if (verbose() && !recs.empty())
         fprintf(stderr, "hipkkt: split-K: %zu target tiles cut into %zu chunks, %.1f MB of partial tiles\n", recs.size(), dg.size() - P.upd_groups.size(), scratch_max * 8e-6);
     return scratch_max;
 }
@@ -654,8 +648,7 @@ static void build_front_batches(hipkkt_solver *S) {
     const HostPlan &P = S->plan;
     S->fbatches.clear(); S->fb_last_level.clear();
     S->lvl_fb.assign(std::max(P.nlevels, 1), -1);
-    const char *e = getenv("HIPKKT_FRONT_BLOCK");
-    if (e && e[0] == '0') S->use_front_block = false;
+    if (!debug_opts().front_block) S->use_front_block = false;
     if (S->use_front_block)
         for (const FrontBatchHost &H : front_batches(P, S->plan_opts.update_policy, kFbMax)) {
             const FrontDesc &F = P.fronts[H.front];
@@ -673,7 +666,7 @@ static void build_front_batches(hipkkt_solver *S) {
             S->fbatches.push_back(B);
             S->fb_last_level.push_back(H.level_last);
         }
-    if (getenv("HIPKKT_VERBOSE")) fprintf(stderr, "hipkkt: %zu front batch(es) factored by one launch each (fronts %zu, update batch %d)\n", S->fbatches.size(), P.fronts.size(), P.update_batch_used);
+    if (verbose()) fprintf(stderr, "hipkkt: %zu front batch(es) factored by one launch each (fronts %zu, update batch %d)\n", S->fbatches.size(), P.fronts.size(), P.update_batch_used);
     const size_t nb_ = std::max<size_t>(S->fbatches.size(), 1);
     S->d_fb_sync = S->dalloc<int>(128 * nb_);
     S->d_fb_scratch = S->dalloc<double>((size_t)kFbScratch * nb_);
@@ -696,22 +689,18 @@ int32_t finish_create(hipkkt_solver *S, const hipkkt_opts *opts, hipkkt_handle *
     po.front_min_panels = opts->front_min_panels == 0 ? 4 : std::max(0, opts->front_min_panels);
     po.n_hold = S->l1 ? (int)S->img.n : 0;
     {
-        const char *dt = getenv("HIPKKT_DENSE_TRI");   // 0: dense Hs triangles stay in the symmetric view (A/B timing, parity test of k_spmv_dense_tri)
-        po.dense_tri_first_col = (S->l1 && !(dt && dt[0] == '0')) ? (int)S->img.n : -1;
+        // debug switch DENSE_TRI=0: dense Hs triangles stay in the symmetric view (A/B timing, parity test of k_spmv_dense_tri)
+        po.dense_tri_first_col = (S->l1 && debug_opts().dense_tri) ? (int)S->img.n : -1;
     }
     {
-        const char *mr = getenv("HIPKKT_FRONT_BLOCK_MIN_ROWS");   // tests: 0, so that small fronts take the front-batch kernel too
-        if (mr) po.front_block_min_width = atoi(mr);
-        const char *sh = getenv("HIPKKT_SUPERHOP");    // 0: one hop per panel in the front sweeps; N: fronts of >= N panels go super-block by super-block
-        if (sh) po.superhop = atoi(sh);
+        if (debug_opts().front_block_min_rows >= 0) po.front_block_min_width = debug_opts().front_block_min_rows;   // tests: 0, so that small fronts take the front-batch kernel too
+        if (debug_opts().superhop >= 0) po.superhop = debug_opts().superhop;   // 0: one hop per panel in the front sweeps; N: fronts of >= N panels go super-block by super-block
     }
     {
-        const char *nh = getenv("HIPKKT_ORDERING");   // "amd": minimum degree on K only
-        if (nh && nh[0] == 'a') po.n_hold = 0;
+        if (debug_opts().ordering_amd) po.n_hold = 0;   // minimum degree on K only
     }
     {
-        const char *nf = getenv("HIPKKT_NO_FRONT");
-        if (nf && nf[0] == '1') po.front_min_panels = 0;
+        if (debug_opts().no_front) po.front_min_panels = 0;
     }
     std::vector<int64_t> up;
     const int64_t *uperm = nullptr;
@@ -782,7 +771,7 @@ int32_t finish_create(hipkkt_solver *S, const hipkkt_opts *opts, hipkkt_handle *
         if (!S->runtime_ready) init_runtime(S);
         S->runtime_ready = true;
         setup_device(S);
-        if (getenv("HIPKKT_VERBOSE"))
+        if (verbose())
             fprintf(stderr, "hipkkt: N %d nnzL %lld levels %d ordering %d: symbolic %.2f ms (%s), device set-up %.2f ms, runtime objects %.2f ms\n", S->plan.N, (long long)S->plan.nnzL,
                     S->plan.nlevels, S->plan.ordering_used, 1e3 * std::chrono::duration<double>(t_b - t_a).count(), S->plan.timing_note.c_str(),
                     1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t_b).count(), 1e3 * S->t_init_runtime);

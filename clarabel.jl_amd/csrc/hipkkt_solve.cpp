@@ -87,7 +87,7 @@ static inline bool sweep_failed(const SolveCtx &C) {
 // A persistent sweep kernel gave up (bounded spin expired: the workgroups were not dispatched in the order the
 // hardware was shared with something that starved a hand-off).  Re-arm every hand-off word, drop to the per-level
 // kernels and tell the caller to repeat the solve.  The downgrade is temporary: after 64 further LDL solves (doubling
-// with every time-out; HIPKKT_PERSIST_RETRY=<n> sets the first interval, 0 = never) the persistent kernels are tried
+// with every time-out; debug switch PERSIST_RETRY=<n>: the first interval, 0 = never) the persistent kernels are tried
 // again.  Returns false when there is nothing left to fall back to.
 bool recover_from_sweep_failure(hipkkt_solver *S) {
     if (!S->use_persist) return false;
@@ -95,8 +95,7 @@ bool recover_from_sweep_failure(hipkkt_solver *S) {
     for (SolveCtx &C : S->ctx) HK_CHECK(hipStreamSynchronize(C.stream));
     S->n_sweep_timeouts++;
     {
-        const char *rt = getenv("HIPKKT_PERSIST_RETRY");
-        const int64_t first = rt ? atoll(rt) : 64;
+        const int64_t first = debug_opts().persist_retry >= 0 ? debug_opts().persist_retry : 64;
         S->persist_backoff = S->persist_backoff > 0 ? 2 * S->persist_backoff : first;
         S->persist_retry_at = first > 0 ? S->n_ldlsolves + S->persist_backoff : -1;
     }

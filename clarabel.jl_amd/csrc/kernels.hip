@@ -568,8 +568,12 @@ k_invert_diag_wide(DevPlan P, int list_begin) {
         __syncthreads();
         if (tid == 0) {
             const double m = fmax(fmax(wmx[0], wmx[1]), fmax(wmx[2], wmx[3]));
-            P.sn_polish[s] = (w > 16 && !(m <= P.polish_tau)) ? 1 : 0;
-            if (w > 16 && !(m <= P.polish_tau)) atomicAdd(P.flags + FL_NPOLISH, 1);
+            // every wide block is marked (after a sweep time-out the per-level kernels solve the fronts' panels too, and refine them);
+            // COUNTED are the blocks the regular kernels solve (sn_nitems > 0: not a panel of a front) -- the front sweeps never
+            // refine, so counting their 64-column panels overstated what is refined (review of round 5)
+            const bool big = w > 16 && !(m <= P.polish_tau);
+            P.sn_polish[s] = big ? 1 : 0;
+            if (big && P.sn_nitems[s] > 0) atomicAdd(P.flags + FL_NPOLISH, 1);
         }
     }
 }
@@ -755,21 +759,48 @@ k_update_dense_tail(DevPlan P, int group_begin, int nfull, int ngroups) {
 // TARGET ENTRY sums its (source, row i, row j) pairs  sum_k L_s[i,k] d_k L_s[j,k]  in the fixed order
 // of the plan's gather list and subtracts once: no atomics, deterministic, fully parallel.
 // ------------------------------------------------------------------------------------------
+// sum_k L_s[i,k] d_k L_s[j,k] of one pair, added to acc in k order.  The 24 operands of eight k's are requested TOGETHER and the
+// dependent fma chain runs afterwards (a plain loop waits for the memory round trip of every k).  Same products, same order of
+// accumulation as the plain loop.  [Round 6, measured: this does NOT shorten cfg 2a's big gather launch (355 us for 4.0e6 entries,
+// 5.5e6 pairs): that launch is bound by the number of scattered memory requests -- adjacent target entries take their operands from
+// different small source panels -- not by the dependent chain of its longest thread.]
+__device__ __forceinline__ double gath_pair_sum(const DevPlan &P, const GathPair &G, double acc) {
+    const double *li = P.Lx + G.src;
+    const double *lj = li + G.dj;
+    const double *dv = P.D + G.dfirst;
+    const int64_t r = G.r;
+    const int K = G.K;
+    for (int k0 = 0; k0 < K; k0 += 8) {
+        double a[8], b[8], d[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const int kk = k0 + q < K ? k0 + q : K - 1;      // clamped: loads past the end repeat the last column and are not used
+            a[q] = li[kk * r];
+            b[q] = lj[kk * r];
+            d[q] = dv[kk];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; q++)
+            if (k0 + q < K) acc = fma(a[q] * d[q], b[q], acc);
+    }
+    return acc;
+}
 __global__ void __launch_bounds__(256)
 k_update_gather(DevPlan P, int64_t ebegin, int64_t n) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n) return;
     const int64_t p0 = P.gath_pptr[ebegin + e], p1 = P.gath_pptr[ebegin + e + 1];
-    if (p1 - p0 > kGathHeavy) return;          // k_update_gather_heavy
+    if (p1 - p0 > kGathHeavy || p1 <= p0) return;          // k_update_gather_heavy
+    double *tp = P.Lx + P.gath_tgt[ebegin + e];
+    const double t0 = *tp;                                 // (requested next to the first record)
     double acc = 0.0;
+    GathPair G = P.gath_pairs[p0];
     for (int64_t p = p0; p < p1; p++) {
-        const GathPair G = P.gath_pairs[p];
-        const double *li = P.Lx + G.src;
-        const double *lj = li + G.dj;
-        const double *dv = P.D + G.dfirst;
-        for (int k = 0; k < G.K; k++) acc = fma(li[(int64_t)k * G.r] * dv[k], lj[(int64_t)k * G.r], acc);
+        const GathPair Gn = P.gath_pairs[p + 1 < p1 ? p + 1 : p];   // the next record is on its way while this pair is summed
+        acc = gath_pair_sum(P, G, acc);
+        G = Gn;
     }
-    P.Lx[P.gath_tgt[ebegin + e]] -= acc;
+    *tp = t0 - acc;
 }
 // target entries with long pair lists (a dense row / column of the root that every leaf touches: 1189 pairs on cfg 3) kept
 // ONE thread busy for a millisecond while the rest of the launch had finished: one wavefront each, lane l takes the
@@ -784,10 +815,7 @@ k_update_gather_heavy(DevPlan P, int64_t hbegin, int64_t n) {
     double acc = 0.0;
     for (int64_t p = p0 + lane; p < p1; p += 64) {
         const GathPair G = P.gath_pairs[p];
-        const double *li = P.Lx + G.src;
-        const double *lj = li + G.dj;
-        const double *dv = P.D + G.dfirst;
-        for (int k = 0; k < G.K; k++) acc = fma(li[(int64_t)k * G.r] * dv[k], lj[(int64_t)k * G.r], acc);
+        acc = gath_pair_sum(P, G, acc);
     }
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
     if (lane == 0) P.Lx[P.gath_tgt[e]] -= acc;

@@ -97,33 +97,48 @@ __global__ void k_probe_handoff(int *ctl, long long *out, int rounds) {
 // out: [0] effective shader GHz of one busy wavefront, [1] flag round trip same XCD (ns), [2] other XCD (ns), [3] XCDs seen,
 //      [4] hipDeviceProp clockRate (MHz), [5] memoryClockRate (MHz), [6] compute units, [7] constant-clock ticks per microsecond assumed (100)
 int box_probe(int device, double *out) {
+    // the caller's current device is restored, the work runs on a private stream (no device-wide synchronisation: other
+    // streams of the process keep running), the buffers are released on every path
+    int prev = -1;
+    (void)hipGetDevice(&prev);
     if (hipSetDevice(device) != hipSuccess) return 1;
-    hipDeviceProp_t pr;
-    if (hipGetDeviceProperties(&pr, device) != hipSuccess) return 1;
     int *ctl = nullptr; long long *o = nullptr; double *sink = nullptr;
-    if (hipMalloc(&ctl, 4096 * sizeof(int)) != hipSuccess || hipMalloc(&o, 64) != hipSuccess || hipMalloc(&sink, 64 * sizeof(double)) != hipSuccess) return 1;
-    long long h[4] = {0, 0, 0, 0};
+    hipStream_t st = nullptr;
+    int rc = 1;
+    hipDeviceProp_t pr;
     double ghz = 0.0, same = -1.0, other = -1.0, nx = 0.0;
-    for (int rep = 0; rep < 3; rep++) {            // the last repetition counts (clocks ramp up)
-        hipLaunchKernelGGL(k_probe_clock, dim3(1), dim3(64), 0, 0, o, sink, 20000);
-        if (hipDeviceSynchronize() != hipSuccess) return 1;
-        (void)hipMemcpy(h, o, 16, hipMemcpyDeviceToHost);
-        if (h[1] > 0) ghz = (double)h[0] / ((double)h[1] * 10.0);
-    }
-    const int rounds = 1000;
-    for (int rep = 0; rep < 2; rep++) {
-        (void)hipMemset(ctl, 0, 4096 * sizeof(int));
-        hipLaunchKernelGGL(k_probe_handoff, dim3(256), dim3(64), 0, 0, ctl, o, rounds);
-        if (hipDeviceSynchronize() != hipSuccess) return 1;
-        (void)hipMemcpy(h, o, 24, hipMemcpyDeviceToHost);
-        same = h[0] > 0 ? h[0] * 10.0 / rounds : -1.0;
-        other = h[1] > 0 ? h[1] * 10.0 / rounds : -1.0;
-        nx = (double)h[2];
-    }
-    (void)hipFree(ctl); (void)hipFree(o); (void)hipFree(sink);
-    out[0] = ghz; out[1] = same; out[2] = other; out[3] = nx;
-    out[4] = pr.clockRate / 1000.0; out[5] = pr.memoryClockRate / 1000.0; out[6] = pr.multiProcessorCount; out[7] = 100.0;
-    return 0;
+    long long h[4] = {0, 0, 0, 0};
+    do {
+        if (hipGetDeviceProperties(&pr, device) != hipSuccess) break;
+        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { st = nullptr; break; }
+        if (hipMalloc(&ctl, 4096 * sizeof(int)) != hipSuccess || hipMalloc(&o, 64) != hipSuccess || hipMalloc(&sink, 64 * sizeof(double)) != hipSuccess) break;
+        bool ok = true;
+        for (int rep = 0; rep < 3 && ok; rep++) {        // the last repetition counts (clocks ramp up)
+            hipLaunchKernelGGL(k_probe_clock, dim3(1), dim3(64), 0, st, o, sink, 20000);
+            ok = hipMemcpyAsync(h, o, 16, hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
+            if (ok && h[1] > 0) ghz = (double)h[0] / ((double)h[1] * 10.0);
+        }
+        const int rounds = 1000;
+        for (int rep = 0; rep < 2 && ok; rep++) {
+            ok = hipMemsetAsync(ctl, 0, 4096 * sizeof(int), st) == hipSuccess;
+            hipLaunchKernelGGL(k_probe_handoff, dim3(256), dim3(64), 0, st, ctl, o, rounds);
+            ok = ok && hipMemcpyAsync(h, o, 24, hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
+            if (!ok) break;
+            same = h[0] > 0 ? h[0] * 10.0 / rounds : -1.0;
+            other = h[1] > 0 ? h[1] * 10.0 / rounds : -1.0;
+            nx = (double)h[2];
+        }
+        if (!ok) break;
+        out[0] = ghz; out[1] = same; out[2] = other; out[3] = nx;
+        out[4] = pr.clockRate / 1000.0; out[5] = pr.memoryClockRate / 1000.0; out[6] = pr.multiProcessorCount; out[7] = 100.0;
+        rc = 0;
+    } while (0);
+    if (ctl) (void)hipFree(ctl);
+    if (o) (void)hipFree(o);
+    if (sink) (void)hipFree(sink);
+    if (st) (void)hipStreamDestroy(st);
+    if (prev >= 0 && prev != device) (void)hipSetDevice(prev);
+    return rc;
 }
 
 }  // namespace hipkkt

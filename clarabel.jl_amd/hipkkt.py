@@ -10,7 +10,17 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("CLARABEL_HIPKKT_LIB", os.path.join(_HERE, "libclarabel_hipkkt.so"))
+# The PRODUCT is libclarabel_hipkkt.so.  CLARABEL_HIPKKT_TESTING=1 (set by tests/conftest.py and by the developer tools that compare a
+# mechanism with its off state) selects the testing build of the same sources, the only one whose hipkkt_debug_set accepts switches.
+_TESTING = os.environ.get("CLARABEL_HIPKKT_TESTING", "0") == "1"
+LIB_PATH = os.environ.get("CLARABEL_HIPKKT_LIB", os.path.join(_HERE, "libclarabel_hipkkt_testing.so" if _TESTING else "libclarabel_hipkkt.so"))
+
+# switches of hipkkt_debug_set (struct DebugOpts, csrc/hipkkt_internal.h).  The C library reads no environment variable for them; this
+# binding forwards HIPKKT_<KEY> from os.environ to the testing build whenever a handle is created (tests use monkeypatch.setenv) and
+# refuses to create a handle on the production library while one of them is set.
+DEBUG_KEYS = ["PLAN_CACHE", "FB_EXTRA", "FB_STREAM", "FB_V2", "FORCE_TWIN", "NO_GRAPH", "NO_PERSIST", "FULL_TILES", "FRONT_BLOCK", "SPLIT_K",
+              "DENSE_TRI", "ORDERING", "NO_FRONT", "HOST_ASSEMBLY", "FRONT_BLOCK_MIN_ROWS", "SUPERHOP", "DEBUG_FLAGS", "SPIN_LIMIT",
+              "PERSIST_RETRY", "ACCURATE", "FB_EXTRA_PW"]
 
 _i64p = np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
 _i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
@@ -26,7 +36,7 @@ SYMBOLS = [
     "hipkkt_set_hs", "hipkkt_set_hs_dev", "hipkkt_set_hs_psd", "hipkkt_set_cone_types", "hipkkt_update_scaling", "hipkkt_update_scaling_dev", "hipkkt_block_products", "hipkkt_set_soc", "hipkkt_set_soc_batch", "hipkkt_set_genpow",
     "hipkkt_update_P", "hipkkt_update_A", "hipkkt_refactor", "hipkkt_setrhs", "hipkkt_setrhs_dev", "hipkkt_solve",
     "hipkkt_solve_dev", "hipkkt_solve_multi", "hipkkt_solve_multi_dev", "hipkkt_kkt_solve_reduced", "hipkkt_kkt_solve_reduced_dev", "hipkkt_ldl_solve", "hipkkt_get_timing", "hipkkt_reset_timing", "hipkkt_get_profile", "hipkkt_get_profile_launches", "hipkkt_set_profiling",
-    "hipkkt_get_counters", "hipkkt_debug_dump", "hipkkt_debug_extra_tiles", "hipkkt_set_qb", "hipkkt_residuals", "hipkkt_residuals_dev",
+    "hipkkt_get_counters", "hipkkt_debug_dump", "hipkkt_debug_extra_tiles", "hipkkt_debug_set", "hipkkt_debug_is_testing_build", "hipkkt_set_qb", "hipkkt_residuals", "hipkkt_residuals_dev",
     "hipkkt_selftest_mfma", "hipkkt_box_probe", "hipkkt_last_error",
 ]
 
@@ -114,6 +124,9 @@ def lib():
     L.hipkkt_debug_dump.argtypes = [vp, i32, vp, i64, C.POINTER(i64)]
     L.hipkkt_debug_extra_tiles.argtypes = [i32, i32, i32, C.POINTER(i32)]
     L.hipkkt_debug_extra_tiles.restype = i32
+    L.hipkkt_debug_set.argtypes = [C.c_char_p, C.c_char_p]
+    L.hipkkt_debug_set.restype = i32
+    L.hipkkt_debug_is_testing_build.restype = i32
     L.hipkkt_selftest_mfma.argtypes = [i32, C.POINTER(f64)]
     L.hipkkt_box_probe.argtypes = [i32, vp, i64]
     L.hipkkt_last_error.argtypes = [vp]
@@ -124,6 +137,22 @@ def lib():
             f.restype = i32
     _lib = L
     return L
+
+
+def sync_debug_switches():
+    """Forward the HIPKKT_<KEY> variables of os.environ to hipkkt_debug_set (testing build); called before every create."""
+    L = lib()
+    wanted = {k: os.environ.get("HIPKKT_" + k) for k in DEBUG_KEYS}
+    if not L.hipkkt_debug_is_testing_build():
+        bad = [k for k, v in wanted.items() if v is not None]
+        if bad:
+            raise HipKKTError(f"HIPKKT_{bad[0]} is set but {LIB_PATH} is the production library, which has no switches: "
+                              "set CLARABEL_HIPKKT_TESTING=1 to load libclarabel_hipkkt_testing.so")
+        return
+    for k, v in wanted.items():
+        rc = L.hipkkt_debug_set(k.encode(), None if v is None else v.encode())
+        if rc != 0:
+            raise HipKKTError(f"hipkkt_debug_set({k}, {v!r}) failed ({rc})")
 
 
 def default_opts(**kw):
@@ -153,6 +182,7 @@ class Handle:
     @classmethod
     def from_kkt(cls, colptr, rowval, nzval, dsigns, device=0, **optkw):
         L = lib()
+        sync_debug_switches()
         o, keep = default_opts(**optkw)
         out = C.c_void_p()
         N = len(colptr) - 1
@@ -166,6 +196,7 @@ class Handle:
     @classmethod
     def from_parts(cls, P, A, numel, hs_dense, sparse_kind, dim1, device=0, **optkw):
         L = lib()
+        sync_debug_switches()
         o, keep = default_opts(**optkw)
         out = C.c_void_p()
         n, m = P.shape[0], A.shape[0]

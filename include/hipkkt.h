@@ -285,9 +285,10 @@ int32_t hipkkt_reset_timing(hipkkt_handle h);
  * they factor, out[7] = the Schur-update flops of the stages they absorb (not part of out[0]'s kernels), out[8] / out[9] = dense update
  * tiles / their flops that rode in those launches as extra workgroups instead of in their stage's own launch (the partial last round
  * of a front batch's far updates; not part of out[0] .. out[2] either); out[10] = the wide diagonal blocks (> 16 columns) of the last factorisation
- * whose explicit inverse has an entry above 64 in magnitude: the solve kernels take one refinement step  y += Linv (b - L y)  on these
- * (a product with such an inverse is several times less accurate than the reference's substitution; HIPKKT_ACCURATE=<threshold>,
- * "0" = never, "-1" = every wide block), out[11] = factorisations so far with at least one */
+ * OUTSIDE the fronts whose explicit inverse has an entry above 64 in magnitude: the solve kernels take one refinement step
+ * y += Linv (b - L y)  on these (a product with such an inverse is several times less accurate than the reference's substitution; the
+ * 64-column panels of a front are solved by the front sweeps, which never refine, and are not counted; testing build: switch
+ * ACCURATE=<threshold>, 0 = never, negative = every wide block), out[11] = factorisations so far with at least one */
 int32_t hipkkt_get_profile(hipkkt_handle h, double *out, int64_t cap);   /* writes min(cap, 12) values */
 /* the k_update_dense<4,4> launches of that refactorisation one by one: ms[i], algorithmic flops[i], target tiles[i]
  * (any array may be NULL; at most cap entries are written, *count receives the number of launches) */
@@ -304,8 +305,8 @@ int32_t hipkkt_set_profiling(hipkkt_handle h, int32_t enable);
  * out[7] = #segments, out[8] = update batches of fronts factored by one launch each (front_block.hip), out[9] = that path is
  * enabled (0 after one of its hand-offs timed out: the handle then keeps one launch per panel), out[10] / out[11] = symbolic plans
  * taken from / not found in the process-wide plan cache (same KKT pattern and options => the analysis of an earlier handle is reused;
- * HIPKKT_PLAN_CACHE=0 disables it), out[12] = the pivot chain of the front batches is streamed block by block (front_block.hip; 0 with
- * HIPKKT_FB_STREAM=0), out[13] = factorisations with refined block solves (hipkkt_get_profile out[11]).  Writes min(cap, 14) values. */
+ * testing build: switch PLAN_CACHE=0 disables it), out[12] = the pivot chain of the front batches is streamed block by block (front_block2.hip; 0 only in the testing build with
+ * the switch FB_STREAM=0), out[13] = factorisations with refined block solves (hipkkt_get_profile out[11]).  Writes min(cap, 14) values. */
 int32_t hipkkt_get_counters(hipkkt_handle h, int64_t *out, int64_t cap);
 
 /* developer diagnostic, not part of the plugin contract: copies an internal vector of the last LDL solve (what = 0 the
@@ -319,6 +320,16 @@ int32_t hipkkt_debug_dump(hipkkt_handle h, int32_t what, double *out, int64_t ca
  * first `ncrit` of them belong to the next batch's columns -- ride in the next k_front_block launch, which has `next_blk` workgroups
  * of its own; *per_wave receives the tiles per wavefront there (hipkkt_factor.cpp fb_extra_tiles_of_stage) */
 int32_t hipkkt_debug_extra_tiles(int32_t nd, int32_t ncrit, int32_t next_blk, int32_t *per_wave);
+/* test / experiment switches -- NOT part of the plugin contract, the Julia glue never calls it.  key = the switch's name ("FB_V2",
+ * "SPLIT_K", "ACCURATE", "SPIN_LIMIT", ...: struct DebugOpts in csrc/hipkkt_internal.h lists them), value = its setting as text, NULL =
+ * back to the default; key == NULL resets every switch.  A handle reads the switches when it is created.  Only the TESTING build of
+ * the library (libclarabel_hipkkt_testing.so, compiled with -DHIPKKT_TESTING; what tests/ load) accepts a setting: the production
+ * library returns HIPKKT_ERR_ARGUMENT for every key, contains neither the first form of the front-batch kernel nor the debug flags
+ * of the sweeps, and reads no environment variable for any switch (HIPKKT_VERBOSE and HIPKKT_FB_TRACE, which change no result, are
+ * the only two it reads).  Process-wide, not thread-safe against concurrent creates. */
+int32_t hipkkt_debug_set(const char *key, const char *value);
+/* 1 in the testing build, 0 in the production library */
+int32_t hipkkt_debug_is_testing_build(void);
 
 /* diagnostic: checks the FP64 matrix-core operand/result lane maps used by the update kernel
  * against a host product with an asymmetric B (returns 0 when they agree to 1e-12) */

@@ -598,7 +598,8 @@ class CompositeCone:
             b += nb
         self.nnz_Hs = b
         self._is_symmetric = all(getattr(c, "is_symmetric", True) for c in self.cones)      # compositecone_type.jl:54-60
-        self._settings = None      # line-search constants of the non-symmetric cones (Solver passes its Settings)
+        from clarabel_jl_amd.settings import Settings   # line-search constants of the non-symmetric cones: the defaults until Solver passes its own
+        self._settings = Settings()
 
     def __iter__(self):
         return iter(self.cones)

@@ -23,6 +23,44 @@ def test_header_symbols_are_bound_and_exported():
     assert sorted(hipkkt.SYMBOLS) == decl
 
 
+def test_both_builds_export_the_same_interface_and_only_the_testing_build_takes_switches():
+    """libclarabel_hipkkt.so is the product: it exports everything the header declares, and hipkkt_debug_set refuses every switch
+    there (the library reads no HIPKKT_* variable for them: a caller's environment cannot change its arithmetic).  The testing build
+    accepts them, checks numbers to their end, and does contain the first form of the front-batch kernel."""
+    import ctypes as C
+    import subprocess
+
+    pkg = os.path.join(ROOT, "clarabel.jl_amd")
+    prod, test = (C.CDLL(os.path.join(pkg, n)) for n in ("libclarabel_hipkkt.so", "libclarabel_hipkkt_testing.so"))
+    for L in (prod, test):
+        for s in _declared_symbols():
+            assert hasattr(L, s), s
+        L.hipkkt_debug_set.argtypes = [C.c_char_p, C.c_char_p]
+    assert prod.hipkkt_debug_is_testing_build() == 0 and test.hipkkt_debug_is_testing_build() == 1
+    for k in hipkkt.DEBUG_KEYS:
+        assert prod.hipkkt_debug_set(k.encode(), b"0") != 0, k          # refused
+        assert test.hipkkt_debug_set(k.encode(), b"0") == 0, k
+        assert test.hipkkt_debug_set(k.encode(), None) == 0, k          # back to the default
+    assert prod.hipkkt_debug_set(None, None) == 0                        # "reset everything" is a no-op there
+    assert test.hipkkt_debug_set(b"NO_SUCH_SWITCH", b"1") != 0
+    for bad in (b"abc", b"1x", b""):                                     # numbers are parsed to their end
+        assert test.hipkkt_debug_set(b"ACCURATE", bad) != 0 and test.hipkkt_debug_set(b"SPIN_LIMIT", bad) != 0
+    for ok in (b"0", b"0.0", b"00", b"0 ", b"-1", b"64"):
+        assert test.hipkkt_debug_set(b"ACCURATE", ok) == 0
+    assert test.hipkkt_debug_set(None, None) == 0
+    # no environment reads for switches in the product's host sources: VERBOSE and FB_TRACE only
+    n = 0
+    for f in os.listdir(os.path.join(pkg, "csrc")):
+        if f.endswith((".cpp", ".hip", ".h")):
+            n += len(re.findall(r"\bgetenv\s*\(", open(os.path.join(pkg, "csrc", f)).read()))
+    assert n == 2, n
+    # the first form of the front-batch kernel is in the testing build only
+    syms = {lib: subprocess.run(["strings", "-a", os.path.join(pkg, lib)], capture_output=True, text=True).stdout
+            for lib in ("libclarabel_hipkkt.so", "libclarabel_hipkkt_testing.so")}
+    assert "k_front_block2" in syms["libclarabel_hipkkt.so"] and "13k_front_blockI" not in syms["libclarabel_hipkkt.so"]
+    assert "13k_front_blockI" in syms["libclarabel_hipkkt_testing.so"]
+
+
 def test_is_available_never_fails():
     assert hipkkt.lib().hipkkt_is_available() >= 0
 

@@ -3,6 +3,8 @@
 process was started with (HIPKKT_* switches are read at handle creation).  Prints ONE line.
 usage: [HIPKKT_...=..] ab_variant.py <cfg> <label> [reps]"""
 import os, sys
+if any(k.startswith("HIPKKT_") and k not in ("HIPKKT_VERBOSE", "HIPKKT_FB_TRACE") for k in os.environ) or __file__.endswith("chk_stream.py"):
+    os.environ.setdefault("CLARABEL_HIPKKT_TESTING", "1")   # switches exist in the testing build of the library only
 import numpy as np, scipy.sparse as sp
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench

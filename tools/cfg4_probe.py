@@ -3,6 +3,8 @@
 (each its own HIP context, like bench.py's workers) and prints wall ms of construct / solve next to the handle's own device clocks.
 usage: [HIPKKT_...=..] cfg4_probe.py <label> <procs> [nseeds]"""
 import os, sys, time
+if any(k.startswith("HIPKKT_") and k not in ("HIPKKT_VERBOSE", "HIPKKT_FB_TRACE") for k in os.environ) or __file__.endswith("chk_stream.py"):
+    os.environ.setdefault("CLARABEL_HIPKKT_TESTING", "1")   # switches exist in the testing build of the library only
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 

@@ -2,6 +2,8 @@
 """developer tool: unrefined LDL solve of the streamed pivot chain against the whole-tile hand-off (HIPKKT_FB_STREAM=0) on a bench config,
 over several factorisations with DIFFERENT values.   usage: chk_stream.py <cfg> <label>"""
 import os, sys
+if any(k.startswith("HIPKKT_") and k not in ("HIPKKT_VERBOSE", "HIPKKT_FB_TRACE") for k in os.environ) or __file__.endswith("chk_stream.py"):
+    os.environ.setdefault("CLARABEL_HIPKKT_TESTING", "1")   # switches exist in the testing build of the library only
 import numpy as np, scipy.sparse as sp
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
