@@ -630,14 +630,17 @@ int32_t hipkkt_get_profile_launches(hipkkt_handle h, double *ms, double *flops, 
 
 int32_t hipkkt_get_counters(hipkkt_handle h, int64_t *out, int64_t cap) {
     if (!h || !out || cap < 0) return HIPKKT_ERR_ARGUMENT;
-    int64_t o[14];
+    int64_t o[15];
     o[0] = h->n_sweep_timeouts; o[1] = h->use_persist ? 1 : 0; o[2] = h->n_twin_refactors; o[3] = h->fallback ? 1 : 0;
     o[4] = h->using_fallback ? 1 : 0; o[5] = h->plan.ordering_used; o[6] = (int64_t)h->plan.fronts.size(); o[7] = h->nseg;
     o[8] = (int64_t)h->fbatches.size(); o[9] = h->use_front_block ? 1 : 0;
     plan_cache_counts(&o[10], &o[11]);   // process-wide: symbolic plans taken from / not found in the plan cache
     o[12] = h->fb_streamed ? 1 : 0;
     o[13] = h->n_accurate_factorisations;
-    for (int64_t i = 0; i < cap && i < 14; i++) out[i] = o[i];
+    o[14] = 0;                                                            // gather entries that run on the side stream (split_gather_stages)
+    for (int l = 0; l < h->plan.nlevels && l < (int)h->gath_split.size(); l++)
+        if (h->gath_split[l] >= 0) o[14] += h->plan.gath_stage_ptr[l + 1] - h->plan.gath_stage_ptr[l] - h->gath_split[l];
+    for (int64_t i = 0; i < cap && i < 15; i++) out[i] = o[i];
     return HIPKKT_OK;
 }
 
@@ -777,6 +780,9 @@ int32_t hipkkt_debug_set(const char *key, const char *value) {
     else if (k == "FULL_TILES") o.full_tiles = !is0();
     else if (k == "FRONT_BLOCK") o.front_block = !is0();
     else if (k == "SPLIT_K") o.split_k = !is0();
+    else if (k == "GATHER_OVERLAP") o.gather_overlap = !is0();
+    else if (k == "GATHER_SORT") o.gather_sort = !is0();
+    else if (k == "GATHER_SIDE_BLOCKS") { if (!value) o.gather_side_blocks = def.gather_side_blocks; else if (num(&v) && v >= 0) o.gather_side_blocks = (int)v; else return HIPKKT_ERR_ARGUMENT; }
     else if (k == "DENSE_TRI") o.dense_tri = !is0();
     else if (k == "ORDERING") o.ordering_amd = value && value[0] == 'a';
     else if (k == "NO_FRONT") o.no_front = is1();

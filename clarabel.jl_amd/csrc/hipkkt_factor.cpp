@@ -40,6 +40,27 @@ void enqueue_split_k(hipkkt_solver *S, int l) {
     launch_split_reduce(S->stream, S->dp, S->d_split_recs + S->split_rec_ptr[l], S->split_rec_ptr[l + 1] - S->split_rec_ptr[l]);
 }
 
+// The stage's per-entry gather lists; a split stage (hipkkt_setup.cpp split_gather_stages) runs its deferred part on the side stream
+void enqueue_gather(hipkkt_solver *S, int l) {
+    const HostPlan &P = S->plan;
+    const int64_t e0 = P.gath_stage_ptr[l], n = P.gath_stage_ptr[l + 1] - e0, h0 = S->gath_heavy_ptr[l], nh = S->gath_heavy_ptr[l + 1] - h0;
+    const int64_t head = S->gath_split[l];
+    if (head < 0 || S->side_join_level >= 0) { launch_update_gather(S->stream, S->dp, e0, n, h0, nh); return; }
+    const int64_t hh = S->gath_heavy_split[l];
+    launch_update_gather(S->stream, S->dp, e0, head, h0, hh);
+    HK_CHECK(hipEventRecord(S->ev_fork, S->stream));
+    HK_CHECK(hipStreamWaitEvent(S->idle_stream, S->ev_fork, 0));
+    launch_update_gather(S->idle_stream, S->dp, e0 + head, n - head, h0 + hh, nh - hh, debug_opts().gather_side_blocks);
+    HK_CHECK(hipEventRecord(S->ev_join, S->idle_stream));
+    S->side_join_level = l + P.update_batch_used;
+}
+// ... which everything from the far stage of the next batch on must wait for
+void join_side(hipkkt_solver *S, int l) {
+    if (S->side_join_level < 0 || l < S->side_join_level) return;
+    HK_CHECK(hipStreamWaitEvent(S->stream, S->ev_join, 0));
+    S->side_join_level = -1;
+}
+
 // Schur-complement updates applied after level l is factored: dense register tiles (matrix cores),
 // per-entry gather lists (tiny scattered contributions), relative-index scatter (whatever is left).
 // The three kinds own disjoint target tiles, so their order inside a stage is immaterial.
@@ -48,10 +69,10 @@ void enqueue_updates(hipkkt_solver *S, int l, int dense_skip_tail = 0) {
     const HostPlan &P = S->plan;
     hipStream_t st = S->stream;
     const int g0 = P.upd_stage_ptr[l], nd = P.upd_stage_ndense[l], ng = P.upd_stage_ngather[l];
+    join_side(S, l);
     launch_update_dense(st, S->dp, g0, nd - dense_skip_tail, nd > 0 && P.upd_stage_flops_dense[l] >= 1.5e6 * nd);
     enqueue_split_k(S, l);
-    launch_update_gather(st, S->dp, P.gath_stage_ptr[l], P.gath_stage_ptr[l + 1] - P.gath_stage_ptr[l], S->gath_heavy_ptr[l],
-                         S->gath_heavy_ptr[l + 1] - S->gath_heavy_ptr[l]);
+    enqueue_gather(S, l);
     launch_update_stage(st, S->dp, g0 + nd + ng, P.upd_stage_ptr[l + 1] - g0 - nd - ng);
 }
 
@@ -107,6 +128,7 @@ int fb_extra_tiles_of_stage(int nd, int ncrit, int next_blk, int *per_wave_out) 
 void enqueue_factor(hipkkt_solver *S, int static_enable, double eps_const, double eps_prop) {
     const HostPlan &P = S->plan;
     hipStream_t st = S->stream;
+    S->side_join_level = -1;
     launch_zero_words(st, S->dp.scal, 2);                 // SC_MAXDIAG  (kernels.hip: why not hipMemsetAsync)
     launch_zero_words(st, S->dp.flags, FL_COUNT);
     launch_maxabs_gather(st, S->dp.kval, S->d_diag_full, S->N, (unsigned long long *)S->dp.scal + SC_MAXDIAG);
@@ -121,6 +143,7 @@ void enqueue_factor(hipkkt_solver *S, int static_enable, double eps_const, doubl
             // a front's update batch: one launch for its panels and their just-in-time updates, then the batch's far stage
             if (S->lvl_fb[l] >= 0) {
                 cur_bi = S->lvl_fb[l];
+                join_side(S, S->fb_last_level[(size_t)cur_bi]);       // (a batch that reaches beyond the join level touches deferred targets)
                 FrontBatch B = S->fbatches[(size_t)cur_bi];
                 B.x_begin = extra_begin; B.x_count = extra_count; B.pad = extra_pw;     // far tiles of the stage before (fb_extra_tiles_of_stage)
                 extra_begin = extra_count = 0;
@@ -147,6 +170,7 @@ void enqueue_factor(hipkkt_solver *S, int static_enable, double eps_const, doubl
         }
         enqueue_updates(S, l, skip);
     }
+    join_side(S, P.nlevels);
     launch_invert_diag(st, S->dp, S->inv_nsmall, S->inv_wsmall, S->inv_nwide);
     for (const FrontDesc &F : P.fronts) launch_invert_super(st, S->dp, F);   // super-block inverses for the front sweeps
 }
@@ -239,6 +263,7 @@ static int32_t refactor_once(hipkkt_handle h, int32_t static_reg_enable, double 
         // eager, with the dense-update launches timed separately (adds event overhead)
         const HostPlan &P = S->plan;
         hipStream_t st = S->stream;
+        S->side_join_level = -1;
         launch_zero_words(st, S->dp.scal, 2);
         launch_zero_words(st, S->dp.flags, FL_COUNT);
         launch_maxabs_gather(st, S->dp.kval, S->d_diag_full, S->N, (unsigned long long *)S->dp.scal + SC_MAXDIAG);
@@ -272,6 +297,7 @@ static int32_t refactor_once(hipkkt_handle h, int32_t static_reg_enable, double 
                     HK_CHECK(hipEventCreate(&b));
                     HK_CHECK(hipEventRecord(a, st));
                     cur_bi = S->lvl_fb[l];
+                    join_side(S, S->fb_last_level[(size_t)cur_bi]);
                     FrontBatch B = S->fbatches[(size_t)cur_bi];
                     B.x_begin = extra_begin; B.x_count = extra_count; B.pad = extra_pw;
                     extra_begin = extra_count = 0;
@@ -291,6 +317,7 @@ static int32_t refactor_once(hipkkt_handle h, int32_t static_reg_enable, double 
                 HK_CHECK(hipEventCreate(&b));
                 HK_CHECK(hipEventRecord(a, st));
                 const int g0 = P.upd_stage_ptr[l], nd = P.upd_stage_ndense[l], ng = P.upd_stage_ngather[l];
+                join_side(S, l);
                 int skip = 0;                                              // (the same rule as enqueue_factor)
                 if (fb && S->fb_extra && !S->profiling_no_extra && cur_bi >= 0 && S->lvl_fb[l] != -1 && S->next_batch[(size_t)cur_bi].has_next &&
                     P.upd_stage_flops_dense[l] >= 1.5e6 * nd) {
@@ -310,14 +337,14 @@ static int32_t refactor_once(hipkkt_handle h, int32_t static_reg_enable, double 
                     evd_flops.push_back(P.upd_stage_flops_dense[l] - xf);
                     evd_tiles.push_back(nd - skip);
                 }
-                launch_update_gather(st, S->dp, P.gath_stage_ptr[l], P.gath_stage_ptr[l + 1] - P.gath_stage_ptr[l], S->gath_heavy_ptr[l],
-                         S->gath_heavy_ptr[l + 1] - S->gath_heavy_ptr[l]);
+                enqueue_gather(S, l);
                 launch_update_stage(st, S->dp, g0 + nd + ng, P.upd_stage_ptr[l + 1] - g0 - nd - ng);
                 HK_CHECK(hipEventRecord(b, st));
                 evs.push_back(a);
                 evs.push_back(b);
             }
         }
+        join_side(S, P.nlevels);
         launch_invert_diag(st, S->dp, S->inv_nsmall, S->inv_wsmall, S->inv_nwide);
         for (const FrontDesc &F : P.fronts) launch_invert_super(st, S->dp, F);   // super-block inverses for the front sweeps
         HK_CHECK(hipStreamSynchronize(st));

@@ -75,6 +75,9 @@ struct DebugOpts {
     bool full_tiles = true;        // FULL_TILES=0: the general core for every dense tile
     bool front_block = true;       // FRONT_BLOCK=0: one launch per panel
     bool split_k = true;           // SPLIT_K=0
+    bool gather_overlap = true;    // GATHER_OVERLAP=0: big gather stages run whole, in line (no side stream)
+    bool gather_sort = true;       // GATHER_SORT=0: the entries of a gather stage stay in target order
+    int gather_side_blocks = 512;  // GATHER_SIDE_BLOCKS=<n>: grid bound of the side-stream gather (2 workgroups per compute unit; 0 = unbounded)
     bool dense_tri = true;         // DENSE_TRI=0: dense Hs triangles stay in the symmetric view
     bool ordering_amd = false;     // ORDERING=amd: minimum degree on K only
     bool no_front = false;         // NO_FRONT=1: no persistent front kernels
@@ -206,6 +209,13 @@ struct hipkkt_solver {
     std::vector<int> split_group_begin, split_group_count, split_rec_ptr;
     SplitRec *d_split_recs = nullptr;
     std::vector<int64_t> gath_heavy_ptr;   // [nlevels+1] into the list of heavy gather entries (kernels.hip k_update_gather_heavy)
+    // Deferred part of a big gather stage (hipkkt_setup.cpp split_gather_stages): the entries of stage l are ordered [targets the next
+    // update batch factors or updates | targets beyond it]; the second part runs on the side stream NEXT TO the levels of the next
+    // batch and is joined before that batch's far stage (hipkkt_factor.cpp enqueue_gather / join_side).  gath_split[l] = entries of
+    // the first part (-1: the stage is not split), gath_heavy_split[l] = how many of the stage's heavy entries belong to it.
+    std::vector<int64_t> gath_split, gath_heavy_split;
+    int side_join_level = -1;              // >= 0 while a side-stream gather is in flight: the first level whose update stage must wait for it
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 
     // device index arrays for value updates
     int64_t *d_mapHs = nullptr, *d_mapP = nullptr, *d_mapA = nullptr, *d_diag_full = nullptr;
@@ -328,7 +338,7 @@ struct hipkkt_solver {
         for (auto &a : allocs) rp.dev_free(device, a.first, a.second);
         rp.pinned_free(device, h_scal);
         rp.pinned_free(device, h_flags);
-        for (hipEvent_t e : {ev0, ev1, ev2, ev3}) rp.event_put(device, e);
+        for (hipEvent_t e : {ev0, ev1, ev2, ev3, ev_fork, ev_join}) rp.event_put(device, e);
         rp.stream_put(device, 0, stream);
         rp.stream_put(device, 1, idle_stream);
     }

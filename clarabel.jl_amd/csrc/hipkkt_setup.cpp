@@ -75,7 +75,7 @@ void init_runtime(hipkkt_solver *S) {
         S->force_twin = o.force_twin;        // tests: every successful factorisation in the cheap order counts as broken down (hipkkt_refactor)
     }
     static_assert(SC_COUNT * sizeof(double) <= RuntimePool::kPinned && sizeof(RefineState) <= RuntimePool::kPinned, "pinned chunk too small");
-    for (hipEvent_t *e : {&S->ev0, &S->ev1, &S->ev2, &S->ev3}) *e = (hipEvent_t)need(rp.event_get(S->device));
+    for (hipEvent_t *e : {&S->ev0, &S->ev1, &S->ev2, &S->ev3, &S->ev_fork, &S->ev_join}) *e = (hipEvent_t)need(rp.event_get(S->device));
     S->h_scal = (double *)need(rp.pinned_alloc(S->device));
     S->h_flags = (int *)need(rp.pinned_alloc(S->device));
     S->h_scal_red = S->h_scal + 16;     // second half of the same pinned chunk (10 doubles; RuntimePool::kPinned = 256 bytes)
@@ -100,6 +100,7 @@ void init_runtime(hipkkt_solver *S) {
 // (re)builds every device-resident structure from S->plan and S->img (values included)
 static void build_front_batches(hipkkt_solver *S);
 static void order_far_stages(hipkkt_solver *S);
+static void split_gather_stages(hipkkt_solver *S);
 static int64_t plan_split_k(hipkkt_solver *S, std::vector<DenseGroup> &dg);
 void setup_device(hipkkt_solver *S) {
     HK_CHECK(hipSetDevice(S->device));
@@ -128,6 +129,7 @@ void setup_device(hipkkt_solver *S) {
     S->red_have_const = false;
 
     order_far_stages(S);
+    split_gather_stages(S);
     HostPlan &P = S->plan;
     const int N = P.N;
     S->N = N;
@@ -383,9 +385,14 @@ void setup_device(hipkkt_solver *S) {
         D.gath_pairs = S->upload(gp);
         std::vector<int64_t> heavy;
         S->gath_heavy_ptr.assign(P.nlevels + 1, 0);
+        S->gath_heavy_split.assign(std::max(P.nlevels, 1), 0);
         for (int l = 0; l < P.nlevels; l++) {
+            const int64_t e_split = S->gath_split[l] >= 0 ? P.gath_stage_ptr[l] + S->gath_split[l] : P.gath_stage_ptr[l + 1];
             for (int64_t e = P.gath_stage_ptr[l]; e < P.gath_stage_ptr[l + 1]; e++)
-                if (P.gath_pptr[e + 1] - P.gath_pptr[e] > kGathHeavy) heavy.push_back(e);
+                if (P.gath_pptr[e + 1] - P.gath_pptr[e] > kGathHeavy) {
+                    heavy.push_back(e);
+                    if (e < e_split) S->gath_heavy_split[l]++;
+                }
             S->gath_heavy_ptr[l + 1] = (int64_t)heavy.size();
         }
         D.gath_heavy = S->upload(heavy);
@@ -587,6 +594,72 @@ static void order_far_stages(hipkkt_solver *S) {
         A.ncrit = (int)(std::stable_partition(gb, ge, near) - gb);
         A.has_next = next;
         A.next_blk = next ? (P.front_panels[P.fronts[(size_t)hb[b + 1].front].fp_off + hb[b + 1].p0].r + 63) / 64 : 0;
+    }
+}
+
+// The per-entry gather of the bottom update batch is one long launch (cfg 2a: 4.0e6 target entries, 355 us) in front of a string of
+// small, dependency-bound launches (the levels of the next batch: 13 launches, ~200 us, a few hundred workgroups each) -- and 97 % of
+// its entries land in panels that nothing reads or writes before that next batch's FAR stage.  A batch-end stage with at least
+// kGatherSplitMin such entries is reordered [targets up to the next batch's last level | targets beyond]; the second part runs on the
+// side stream next to the next batch's levels and is joined before its far stage (hipkkt_factor.cpp).  Why that is safe: with the
+// batched schedule (symbolic.cpp, stage = min(level(t) - 1, batch end of the source)) every stage s strictly inside the next batch
+// holds only targets of level s + 1, and a level's panel kernels touch their own panels only.  Entries keep their pair lists and
+// their order inside each part: same arithmetic, bit for bit.
+constexpr int64_t kGatherSplitMin = 200000;
+// ORDER OF THE ENTRIES (round 6).  The plan lists a stage's entries in target order (tile, column, row): consecutive threads own
+// consecutive rows of a target column -- and take their operands from whatever small source panel put something there: every lane of
+// a wavefront reads another cache line (cfg 2a: 4.0e6 entries x 28 operand loads, 355 us, bound by the rate at which the L1 looks up
+// divergent lines).  The kernel does not care in which order it meets the entries (each owns its target), so a stage of at least
+// kGatherSortMin entries is re-sorted by the SOURCE of each entry's first pair (stable counting sort: within a source the target
+// order remains, i.e. column by column with the source's rows ascending): the lanes of a wavefront then read consecutive rows of one
+// source column, the column operand and the pivot are one address for all of them, and only the single read-modify-write of the
+// target scatters.  Same pair lists, same arithmetic per entry: bit-identical results.
+constexpr int64_t kGatherSortMin = 50000;
+static void split_gather_stages(hipkkt_solver *S) {
+    HostPlan &P = S->plan;
+    S->gath_split.assign(std::max(P.nlevels, 1), -1);
+    const int B = P.update_batch_used;
+    const bool may_split = S->plan_opts.update_policy == 2 && B >= 2 && debug_opts().gather_overlap;
+    for (int l = 0; l < P.nlevels; l++) {
+        const int64_t e0 = P.gath_stage_ptr[l], e1 = P.gath_stage_ptr[l + 1], ne = e1 - e0;
+        if (ne < kGatherSortMin || !debug_opts().gather_sort) continue;
+        // part of every entry: 1 = deferred to the side stream
+        std::vector<char> far((size_t)ne, 0);
+        int64_t nfar = 0;
+        if (may_split && ne >= kGatherSplitMin && l % B == B - 1 && l + B < P.nlevels) {
+            for (int64_t e = e0; e < e1; e++) {
+                const int t = (int)(std::upper_bound(P.sn_panel.begin(), P.sn_panel.begin() + P.nsuper, P.gath_tgt[e]) - P.sn_panel.begin()) - 1;
+                far[(size_t)(e - e0)] = P.sn_level[t] > l + B;
+                nfar += far[(size_t)(e - e0)];
+            }
+            if (nfar < kGatherSplitMin) { std::fill(far.begin(), far.end(), 0); nfar = 0; }
+        }
+        // stable counting sort by (part, source of the first pair).  [Measured and rejected, round 6: keys that also keep the
+        // entries of a target slab (2^12 .. 2^24 doubles) or of a 64-byte target line together: 1 - 2 % slower on cfg 2a.]
+        const size_t nkeys = (size_t)2 * (size_t)P.nsuper;
+        std::vector<int64_t> cnt(nkeys + 1, 0);
+        auto key = [&](int64_t e) { return (size_t)far[(size_t)(e - e0)] * (size_t)P.nsuper + (size_t)P.gath_sn[P.gath_pptr[e]]; };
+        for (int64_t e = e0; e < e1; e++) cnt[key(e) + 1]++;
+        for (size_t k = 0; k < nkeys; k++) cnt[k + 1] += cnt[k];
+        std::vector<int64_t> ord((size_t)ne);
+        for (int64_t e = e0; e < e1; e++) ord[(size_t)cnt[key(e)]++] = e;
+        const int64_t p0 = P.gath_pptr[e0], p1 = P.gath_pptr[e1];
+        std::vector<int64_t> tgt((size_t)ne), pptr((size_t)ne), src((size_t)(p1 - p0));
+        std::vector<int32_t> dj((size_t)(p1 - p0)), sn((size_t)(p1 - p0));
+        int64_t w = 0;
+        for (int64_t q = 0; q < ne; q++) {
+            const int64_t e = ord[(size_t)q];
+            tgt[(size_t)q] = P.gath_tgt[e];
+            for (int64_t pq = P.gath_pptr[e]; pq < P.gath_pptr[e + 1]; pq++, w++) { src[(size_t)w] = P.gath_src[pq]; dj[(size_t)w] = P.gath_dj[pq]; sn[(size_t)w] = P.gath_sn[pq]; }
+            pptr[(size_t)q] = p0 + w;
+        }
+        std::copy(tgt.begin(), tgt.end(), P.gath_tgt.begin() + e0);
+        std::copy(pptr.begin(), pptr.end(), P.gath_pptr.begin() + e0 + 1);
+        std::copy(src.begin(), src.end(), P.gath_src.begin() + p0);
+        std::copy(dj.begin(), dj.end(), P.gath_dj.begin() + p0);
+        std::copy(sn.begin(), sn.end(), P.gath_sn.begin() + p0);
+        if (nfar > 0) S->gath_split[l] = ne - nfar;
+        if (verbose()) fprintf(stderr, "hipkkt: gather stage %d: %lld entries sorted by source, %lld of them deferred to the side stream (targets beyond level %d)\n", l, (long long)ne, (long long)nfar, l + B);
     }
 }
 

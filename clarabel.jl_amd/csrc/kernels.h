@@ -43,7 +43,7 @@ void launch_psd_rrt(hipStream_t st, const double *R, double *W, int n);
 void launch_block_products(hipStream_t st, const DevPlan &P, const double *x, const double *z, double *Px, double *ATz,
                            double *Ax, int n, int m);
 void launch_zero_words(hipStream_t st, void *p, int nwords);
-void launch_update_gather(hipStream_t st, const DevPlan &P, int64_t ebegin, int64_t n, int64_t hbegin, int64_t nheavy);
+void launch_update_gather(hipStream_t st, const DevPlan &P, int64_t ebegin, int64_t n, int64_t hbegin, int64_t nheavy, int max_blocks = 0);
 void launch_invert_diag(hipStream_t st, const DevPlan &P, int n_small, int wmax_small, int n_wide);
 void launch_mfma_probe(hipStream_t st, const double *A, const double *B, double *out);
 void launch_permute_in(hipStream_t st, const double *b, const int *perm, double *y, int n, int *epoch, int *ticks, int nticks);

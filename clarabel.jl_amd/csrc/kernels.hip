@@ -759,7 +759,7 @@ k_update_dense_tail(DevPlan P, int group_begin, int nfull, int ngroups) {
 // TARGET ENTRY sums its (source, row i, row j) pairs  sum_k L_s[i,k] d_k L_s[j,k]  in the fixed order
 // of the plan's gather list and subtracts once: no atomics, deterministic, fully parallel.
 // ------------------------------------------------------------------------------------------
-// sum_k L_s[i,k] d_k L_s[j,k] of one pair, added to acc in k order.  The 24 operands of eight k's are requested TOGETHER and the
+// sum_k L_s[i,k] d_k L_s[j,k] of one pair, added to acc in k order.  The 12 operands of four k's are requested TOGETHER and the
 // dependent fma chain runs afterwards (a plain loop waits for the memory round trip of every k).  Same products, same order of
 // accumulation as the plain loop.  [Round 6, measured: this does NOT shorten cfg 2a's big gather launch (355 us for 4.0e6 entries,
 // 5.5e6 pairs): that launch is bound by the number of scattered memory requests -- adjacent target entries take their operands from
@@ -770,37 +770,39 @@ __device__ __forceinline__ double gath_pair_sum(const DevPlan &P, const GathPair
     const double *dv = P.D + G.dfirst;
     const int64_t r = G.r;
     const int K = G.K;
-    for (int k0 = 0; k0 < K; k0 += 8) {
-        double a[8], b[8], d[8];
+    for (int k0 = 0; k0 < K; k0 += 4) {
+        double a[4], b[4], d[4];
 #pragma unroll
-        for (int q = 0; q < 8; q++) {
+        for (int q = 0; q < 4; q++) {
             const int kk = k0 + q < K ? k0 + q : K - 1;      // clamped: loads past the end repeat the last column and are not used
             a[q] = li[kk * r];
             b[q] = lj[kk * r];
             d[q] = dv[kk];
         }
 #pragma unroll
-        for (int q = 0; q < 8; q++)
+        for (int q = 0; q < 4; q++)
             if (k0 + q < K) acc = fma(a[q] * d[q], b[q], acc);
     }
     return acc;
 }
 __global__ void __launch_bounds__(256)
 k_update_gather(DevPlan P, int64_t ebegin, int64_t n) {
-    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n) return;
-    const int64_t p0 = P.gath_pptr[ebegin + e], p1 = P.gath_pptr[ebegin + e + 1];
-    if (p1 - p0 > kGathHeavy || p1 <= p0) return;          // k_update_gather_heavy
-    double *tp = P.Lx + P.gath_tgt[ebegin + e];
-    const double t0 = *tp;                                 // (requested next to the first record)
-    double acc = 0.0;
-    GathPair G = P.gath_pairs[p0];
-    for (int64_t p = p0; p < p1; p++) {
-        const GathPair Gn = P.gath_pairs[p + 1 < p1 ? p + 1 : p];   // the next record is on its way while this pair is summed
-        acc = gath_pair_sum(P, G, acc);
-        G = Gn;
+    // grid-stride: a launch on the side stream (hipkkt_factor.cpp enqueue_gather) is given a bounded grid so that it leaves wavefront
+    // slots and registers on every compute unit to the small kernels of the main stream it runs next to
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p0 = P.gath_pptr[ebegin + e], p1 = P.gath_pptr[ebegin + e + 1];
+        if (p1 - p0 > kGathHeavy || p1 <= p0) continue;        // k_update_gather_heavy
+        double *tp = P.Lx + P.gath_tgt[ebegin + e];
+        const double t0 = *tp;                                 // (requested next to the first record)
+        double acc = 0.0;
+        GathPair G = P.gath_pairs[p0];
+        for (int64_t p = p0; p < p1; p++) {
+            const GathPair Gn = P.gath_pairs[p + 1 < p1 ? p + 1 : p];   // the next record is on its way while this pair is summed
+            acc = gath_pair_sum(P, G, acc);
+            G = Gn;
+        }
+        *tp = t0 - acc;
     }
-    *tp = t0 - acc;
 }
 // target entries with long pair lists (a dense row / column of the root that every leaf touches: 1189 pairs on cfg 3) kept
 // ONE thread busy for a millisecond while the rest of the launch had finished: one wavefront each, lane l takes the
@@ -2326,8 +2328,8 @@ void launch_psd_hs(hipStream_t st, double *kval, const int64_t *map_hs, int64_t 
 void launch_zero_words(hipStream_t st, void *p, int nwords) {
     if (nwords > 0) hipLaunchKernelGGL(k_zero_words, dim3(nblk(nwords, 64)), dim3(64), 0, st, (int *)p, nwords);
 }
-void launch_update_gather(hipStream_t st, const DevPlan &P, int64_t ebegin, int64_t n, int64_t hbegin, int64_t nheavy) {
-    if (n > 0) hipLaunchKernelGGL(k_update_gather, dim3(nblk(n)), dim3(256), 0, st, P, ebegin, n);
+void launch_update_gather(hipStream_t st, const DevPlan &P, int64_t ebegin, int64_t n, int64_t hbegin, int64_t nheavy, int max_blocks) {
+    if (n > 0) hipLaunchKernelGGL(k_update_gather, dim3(max_blocks > 0 ? std::min<unsigned>(nblk(n), (unsigned)max_blocks) : nblk(n)), dim3(256), 0, st, P, ebegin, n);
     if (nheavy > 0) hipLaunchKernelGGL(k_update_gather_heavy, dim3(nblk(nheavy, 4)), dim3(256), 0, st, P, hbegin, nheavy);
 }
 // inv_list = [n_small supernodes of width <= wmax_small | n_wide supernodes of width in (16, 64]]

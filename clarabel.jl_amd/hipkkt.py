@@ -20,7 +20,7 @@ LIB_PATH = os.environ.get("CLARABEL_HIPKKT_LIB", os.path.join(_HERE, "libclarabe
 # refuses to create a handle on the production library while one of them is set.
 DEBUG_KEYS = ["PLAN_CACHE", "FB_EXTRA", "FB_STREAM", "FB_V2", "FORCE_TWIN", "NO_GRAPH", "NO_PERSIST", "FULL_TILES", "FRONT_BLOCK", "SPLIT_K",
               "DENSE_TRI", "ORDERING", "NO_FRONT", "HOST_ASSEMBLY", "FRONT_BLOCK_MIN_ROWS", "SUPERHOP", "DEBUG_FLAGS", "SPIN_LIMIT",
-              "PERSIST_RETRY", "ACCURATE", "FB_EXTRA_PW"]
+              "PERSIST_RETRY", "ACCURATE", "FB_EXTRA_PW", "GATHER_OVERLAP", "GATHER_SIDE_BLOCKS", "GATHER_SORT"]
 
 _i64p = np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
 _i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
@@ -283,12 +283,12 @@ class Handle:
                     n_solve_calls=int(o[5]), n_ldl_solves=int(o[6]), last_update_ms=o[7])
 
     def counters(self):
-        o = np.zeros(14, dtype=np.int64)
+        o = np.zeros(15, dtype=np.int64)
         self.L.hipkkt_get_counters(self.h, o, len(o))
         return dict(sweep_timeouts=int(o[0]), persistent=bool(o[1]), twin_refactors=int(o[2]), twin_exists=bool(o[3]),
                     in_twin=bool(o[4]), ordering=int(o[5]), fronts=int(o[6]), segments=int(o[7]), front_batches=int(o[8]),
                     front_block=bool(o[9]), plan_cache_hits=int(o[10]), plan_cache_misses=int(o[11]), streamed_chain=bool(o[12]),
-                    accurate_factorisations=int(o[13]))
+                    accurate_factorisations=int(o[13]), deferred_gather_entries=int(o[14]))
 
     def profile_launches(self):
         n = C.c_int64(0)

@@ -306,7 +306,8 @@ int32_t hipkkt_set_profiling(hipkkt_handle h, int32_t enable);
  * enabled (0 after one of its hand-offs timed out: the handle then keeps one launch per panel), out[10] / out[11] = symbolic plans
  * taken from / not found in the process-wide plan cache (same KKT pattern and options => the analysis of an earlier handle is reused;
  * testing build: switch PLAN_CACHE=0 disables it), out[12] = the pivot chain of the front batches is streamed block by block (front_block2.hip; 0 only in the testing build with
- * the switch FB_STREAM=0), out[13] = factorisations with refined block solves (hipkkt_get_profile out[11]).  Writes min(cap, 14) values. */
+ * the switch FB_STREAM=0), out[13] = factorisations with refined block solves (hipkkt_get_profile out[11]), out[14] = target entries of the per-entry gather lists
+ * that every factorisation applies on a side stream next to the levels of the following update batch (round 6).  Writes min(cap, 15) values. */
 int32_t hipkkt_get_counters(hipkkt_handle h, int64_t *out, int64_t cap);
 
 /* developer diagnostic, not part of the plugin contract: copies an internal vector of the last LDL solve (what = 0 the

@@ -589,3 +589,34 @@ def test_extra_tiles_in_front_block_launches_are_bit_identical(name, monkeypatch
     assert p1["front_block_extra_tiles"] > 0 and p0["front_block_extra_tiles"] == 0
     assert abs((p1["dense4_flops"] + p1["front_block_extra_flops"]) - p0["dense4_flops"]) <= 1e-9 * p0["dense4_flops"] or p1["dense4_launches"] != p0["dense4_launches"]
     assert np.array_equal(d1, d0) and np.array_equal(x1, x0)
+
+
+@pytest.mark.parametrize("name", ["cfg2a", "cfg3"])
+def test_deferred_gather_on_the_side_stream_is_bit_identical(name, monkeypatch):
+    """hipkkt_setup.cpp split_gather_stages / hipkkt_factor.cpp enqueue_gather (round 6): the entries of the bottom batch's big
+    per-entry gather that land beyond the next update batch run on the side stream next to that batch's levels and are joined
+    before its far stage.  Every entry keeps its pair list: the factor (D) and the solve are bit-identical to the whole gather in
+    line (switch GATHER_OVERLAP=0), in the graph path and in the eager profiled path, and the split really happened on cfg 2a."""
+    rng = np.random.default_rng(43)
+    Pt, A, cones = _prep(FULL[name]())
+    m, n = A.shape
+    scale_cones(cones, rng)
+    monkeypatch.setenv("HIPKKT_PLAN_CACHE", "0")
+    out = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("HIPKKT_GATHER_OVERLAP", flag)
+        hk = HipKKTSolver(Pt, A, cones, m, n, cl.Settings())
+        for _ in range(2):                                   # graph capture, then its replay
+            assert hk.kktsolver_update(cones)
+        b = np.random.default_rng(44).standard_normal(hk.h.N)
+        x = hk.h.ldl_solve(b)
+        d = hk.h.debug_dump(5)
+        hk.h.set_profiling(True)
+        assert hk.kktsolver_update(cones)
+        assert np.array_equal(hk.h.ldl_solve(b), x) and np.array_equal(hk.h.debug_dump(5), d)
+        hk.h.set_profiling(False)
+        out.append((x, d, hk.h.counters()))
+    (x1, d1, c1), (x0, d0, c0) = out
+    assert np.array_equal(d1, d0) and np.array_equal(x1, x0)
+    if name == "cfg2a":
+        assert c1["deferred_gather_entries"] > 3_000_000 and c0["deferred_gather_entries"] == 0

@@ -1,12 +1,16 @@
 #!/bin/bash
 # Round-6 developer loop on the GPU box: parity of the factorisation path, bench line of cfg 2a, per-launch timeline of one
 # refactorisation.   usage (via gpurun): bash tools/r6_quick.sh <tag> [tests: kkt|none|full] [configs for extra bench lines]
-tag=${1:-r6}; tests=${2:-kkt}; cfgs=${3:-}
+tag=${1:-r6}; tests=${2:-kkt}; cfgs=${3:-}; kexpr=${4:-}
 mkdir -p gpurun_out; cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 if [ "$tests" = "kkt" ]; then
 (timeout 900 python -m pytest tests/test_gpu_kkt.py -x -q -m gpu > gpurun_out/${tag}_pytest_kkt.txt 2>&1; echo "pytest rc=$?" >> gpurun_out/${tag}_pytest_kkt.txt); tail -2 gpurun_out/${tag}_pytest_kkt.txt
 (timeout 600 python -m pytest tests/test_gpu_fullsize.py -x -q -m gpu -k "full_size_matches_oracle or full_size_solve_properties or second_form" > gpurun_out/${tag}_pytest_fs.txt 2>&1; echo "pytest rc=$?" >> gpurun_out/${tag}_pytest_fs.txt); tail -2 gpurun_out/${tag}_pytest_fs.txt
-elif [ "$tests" = "full" ]; then
+if [ -n "$kexpr" ]; then
+(timeout 900 python -m pytest tests -x -q -m gpu -k "$kexpr" > gpurun_out/${tag}_pytest_k.txt 2>&1; echo "pytest rc=$?" >> gpurun_out/${tag}_pytest_k.txt); tail -4 gpurun_out/${tag}_pytest_k.txt
+fi
+fi
+if [ "$tests" = "full" ]; then
 (timeout 2400 python -m pytest tests -x -q -m "gpu and not slow" > gpurun_out/${tag}_pytest_gpu.txt 2>&1; echo "pytest rc=$?" >> gpurun_out/${tag}_pytest_gpu.txt); tail -3 gpurun_out/${tag}_pytest_gpu.txt
 fi
 timeout 400 python bench.py --no-cpu-baseline > gpurun_out/${tag}_bench_2a.json 2> gpurun_out/${tag}_bench_2a.err; python - <<PY
