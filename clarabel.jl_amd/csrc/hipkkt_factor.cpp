@@ -212,10 +212,17 @@ int32_t hipkkt_refactor(hipkkt_handle h, int32_t static_reg_enable, double eps_c
             // streams / device pointers behind -- the next failing factorisation then simply tries again
             std::unique_ptr<hipkkt_solver> T;
             const auto t_a = std::chrono::steady_clock::now();
-            if (S->twin_future.valid()) {               // analysed ahead on a host thread (finish_create): wait for it
+            if (S->twin_future.valid()) {               // analysed (and made device-resident) ahead on a host thread (finish_create): wait for it
                 const std::string err = S->twin_future.get();
                 T = std::move(S->twin_pending);
-                if (!err.empty()) T.reset();
+                if (!err.empty() && err.rfind("twin device set-up", 0) == 0) {
+                    // the analysis is fine, only its residency failed on the thread: release what it got and repeat that part here
+                    std::unique_ptr<hipkkt_solver> T2(new hipkkt_solver());
+                    T2->device = T->device; T2->opts = T->opts; T2->l1 = T->l1; T2->img = std::move(T->img); T2->plan = std::move(T->plan);
+                    T2->plan_opts = T->plan_opts;
+                    T = std::move(T2);
+                    T->plan_opts.cancel = nullptr;
+                } else if (!err.empty()) T.reset();
                 else T->plan_opts.cancel = nullptr;
             }
             if (!T) {
@@ -231,8 +238,10 @@ int32_t hipkkt_refactor(hipkkt_handle h, int32_t static_reg_enable, double eps_c
                 T->plan_opts = po;
             }
             const auto t_b = std::chrono::steady_clock::now();
-            init_runtime(T.get());
-            setup_device(T.get());
+            if (!T->device_ready) {
+                init_runtime(T.get());
+                setup_device(T.get());
+            }
             if (verbose())
                 fprintf(stderr, "hipkkt: robust-order twin (minimum degree on K): N %d nnzL %lld levels %d: waited %.2f ms for its symbolic analysis (%s), device set-up %.2f ms\n",
                         T->plan.N, (long long)T->plan.nnzL, T->plan.nlevels, 1e3 * std::chrono::duration<double>(t_b - t_a).count(),

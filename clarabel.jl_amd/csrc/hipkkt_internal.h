@@ -261,6 +261,7 @@ struct hipkkt_solver {
     // "variables last" order; every later factorisation still tries the fast order first
     hipkkt_solver *fallback = nullptr;
     // the twin's symbolic analysis runs on a host thread from the moment the cheap order is chosen (finish_create)
+    bool device_ready = false;      // (a twin:) init_runtime + setup_device already ran on the speculation thread
     std::unique_ptr<hipkkt_solver> twin_pending;
     std::future<std::string> twin_future;
     std::shared_ptr<std::atomic<bool>> twin_cancel;   // set when the twin turns out not to be needed

@@ -806,7 +806,23 @@ int32_t finish_create(hipkkt_solver *S, const hipkkt_opts *opts, hipkkt_handle *
                 std::vector<int64_t> pv(perm_md.begin(), perm_md.end());
                 S->twin_pending = std::move(T);
                 S->twin_future = std::async(std::launch::async, [Tp, pv, po2]() {
-                    return build_plan((int)Tp->img.N, Tp->img.colptr.data(), Tp->img.rowval.data(), pv.data(), po2, Tp->plan);
+                    std::string err = build_plan((int)Tp->img.N, Tp->img.colptr.data(), Tp->img.rowval.data(), pv.data(), po2, Tp->plan);
+                    if (!err.empty()) return err;
+                    // Round 6: the twin's device residency too (its work lists are hundreds of MB on the problems that take this path:
+                    // 0.32 - 0.40 s of set-up on cfg 5, paid until now by the FIRST factorisation that breaks down -- half of that
+                    // problem's whole IPM time).  Here it overlaps the owner's own analysis and set-up; a cancelled speculation
+                    // (the cheap order was not chosen after all) never gets here.
+                    if (po2.cancel && po2.cancel->load(std::memory_order_relaxed)) return std::string("cancelled");
+                    try {
+                        init_runtime(Tp);
+                        setup_device(Tp);
+                        Tp->device_ready = true;
+                    } catch (const DeviceError &e) {
+                        return std::string("twin device set-up: ") + e.msg;       // (the failing factorisation will try again, synchronously)
+                    } catch (const std::bad_alloc &) {
+                        return std::string("twin device set-up: out of memory");
+                    }
+                    return err;
                 });
             };
     }
