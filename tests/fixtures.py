@@ -228,7 +228,7 @@ def scale_cones_late(cones, rng, mu=1e-9, span=6.0):
 class ShadowKKT:
     """Test infrastructure: the ORACLE drives an IPM run while the HIP solver is handed the very same inputs at every KKT call
     (same elimination order); per solve the two solutions and refinement-step counts are recorded in `log` as
-    (iteration, rel_dx, ir_hip, ir_oracle).  Used to establish the CAUSE when two IPM trajectories part."""
+    (iteration, rel_dx, ir_hip, ir_oracle, HIP's residual norms, the oracle's, max|D| / min|D| of the factorisation).  Used to establish the CAUSE when two IPM trajectories part."""
     batch_constant_rhs = False
 
     def __init__(self, hip_cls, oracle_cls, *a):
@@ -245,6 +245,11 @@ class ShadowKKT:
         self.it += 1
         okc = self.c.kktsolver_update(cones_)
         self.g.kktsolver_update(cones_)
+        try:
+            d = self.np.abs(self.g.h.debug_dump(5))                 # the pivots of this factorisation: max / min = a lower estimate of cond(K)
+            self.kappa = float(d.max() / max(d.min(), 1e-300))
+        except Exception:
+            self.kappa = float("nan")
         return okc
 
     def kktsolver_setrhs(self, rx, rz):
@@ -264,7 +269,7 @@ class ShadowKKT:
         except Exception:
             gn = ()
         self.log.append((self.it, float(np.max(np.abs(xg - xc)) / max(1.0, np.max(np.abs(xc)))), int(self.g.last_ir_steps), int(self.c.last_ir_steps),
-                         gn, tuple(float(v) for v in getattr(self.c, "last_norms", ()))))
+                         gn, tuple(float(v) for v in getattr(self.c, "last_norms", ())), getattr(self, "kappa", float("nan"))))
         return okc
 
     def __getattr__(self, k):

@@ -117,9 +117,9 @@ def _compare_trajectories(name, prob, oracle_factory, capsys):
     (factors of 0.8, coneops_nonsymmetric_common.jl:5-33) and a centrality test, i.e. by DISCRETE decisions: the oracle itself takes
     different last steps -- and one or two iterations more or less -- on different elimination orders (measured on the CPU:
     tests/test_nonsymmetric_cones.py::test_spread...).  So: along the COMMON part of the trajectories (until the first step length
-    that differs in any of the runs HIP / oracle / oracle on a second and a third order) the iterates agree to 1e-10 + 4 x the oracle's own
-    spread there; that part is most of the run; all runs end SOLVED at objectives within the solver's tolerance of each other, after
-    iteration counts that differ no more than the oracle's own do between its orders."""
+    that differs in any of the runs HIP / oracle / oracle on a second and a third order) the iterates agree to 1e-10 + the oracle's own
+    spread there (1 x); that part is most of the run; all runs end SOLVED at objectives within the solver's tolerance of each other, and
+    the HIP run's iteration count lies inside the range of the oracle's own counts over eight elimination orders (no widening)."""
     P, q, A, b, cones = prob
     sg = cl.Solver(P, q, A, b, cones, cl.Settings())
     assert isinstance(sg.kktsystem.kktsolver, HipKKTSolver)
@@ -135,25 +135,32 @@ def _compare_trajectories(name, prob, oracle_factory, capsys):
     s3 = cl.Solver(P, q, A, b, cones, cl.Settings(), kktsolver_factory=lambda *a: oracle_factory(*a, ordering=perm[::-1].copy()))
     s3.trace = []
     sol3 = s3.solve()                # (a third order: the spread of two runs is a noisy estimate of its own scale)
+    # five more elimination orders for the oracle's own RANGE of iteration counts (random symmetric permutations of the HIP order:
+    # more fill, same mathematics)
+    more = []
+    for sd in range(5):
+        pr = np.random.default_rng(1000 + sd).permutation(perm)
+        sx = cl.Solver(P, q, A, b, cones, cl.Settings(), kktsolver_factory=lambda *a, pr=pr: oracle_factory(*a, ordering=pr))
+        more.append(sx.solve())
     cut = min(_first_step_difference(sg.trace, sc.trace), _first_step_difference(s2.trace, sc.trace), _first_step_difference(s3.trace, sc.trace))
     d_obj, d_res = _trace_spread(sg.trace, sc.trace, cut)
     sp_obj, sp_res = (max(v) for v in zip(_trace_spread(s2.trace, sc.trace, cut), _trace_spread(s3.trace, sc.trace, cut),
                                          _trace_spread(s3.trace, s2.trace, cut)))          # all pairs of the three oracle runs
+    its = [solc.iterations, sol2.iterations, sol3.iterations] + [m_.iterations for m_ in more]
     with capsys.disabled():
-        print(f"\n[nonsymmetric-parity {name}] iterations hip/oracle/oracle(mmd)/oracle(reversed) = {solg.iterations}/{solc.iterations}/{sol2.iterations}/{sol3.iterations} "
+        print(f"\n[nonsymmetric-parity {name}] iterations hip {solg.iterations}, oracle on 8 elimination orders {its} "
               f"({solg.status}/{solc.status}/{sol2.status}/{sol3.status}); common trajectory: {cut} iterates; on it |dobj| {d_obj:.2e}, |dres| {d_res:.2e}; "
               f"the oracle's own spread between two elimination orders there: obj {sp_obj:.2e}, res {sp_res:.2e}; final objectives "
               f"{solg.obj_val:.12e} / {solc.obj_val:.12e} / {sol2.obj_val:.12e}")
-    assert solg.status == solc.status == sol2.status == sol3.status
+    assert solg.status == solc.status == sol2.status == sol3.status and all(m_.status == solg.status for m_ in more)
     assert solg.status in ("SOLVED", "ALMOST_SOLVED")
     assert cut >= (3 * len(sc.trace)) // 5, "the trajectories part early: not a last-digits effect"
-    assert d_obj <= 1e-10 + 4.0 * sp_obj and d_res <= 1e-10 + 4.0 * sp_res
-    # iteration counts: decided by convergence / step tests at the 1e-8 level on iterates that differ at the 1e-10 level.  The oracle's
-    # own counts on its three orders span [lo, hi]; the HIP run may sit as far outside that range as the range is wide (at least 1).
-    its = [solc.iterations, sol2.iterations, sol3.iterations]
+    # along the common part: 1e-10 (north_star) on top of what the ORACLE moves by between two of its own elimination orders there
+    # (1 x, measured in this run; the per-solve statement without any such allowance is test_oracle_driven_run_shadowed_by_the_hip_solver)
+    assert d_obj <= 1e-10 + sp_obj and d_res <= 1e-10 + sp_res
+    # iteration counts: inside the oracle's own range over its eight elimination orders, no widening
     lo, hi = min(its), max(its)
-    w = max(1, hi - lo)
-    assert lo - w <= solg.iterations <= hi + w, (solg.iterations, its)
+    assert lo <= solg.iterations <= hi, (solg.iterations, its)
     tol = 1e-7 if solg.status == "SOLVED" else 1e-4                 # tol_gap_rel 1e-8 / reduced_tol_gap_rel 5e-5 of the settings
     assert abs(solg.obj_val - solc.obj_val) <= tol * max(1.0, abs(solc.obj_val))
     return solg
@@ -173,3 +180,55 @@ def test_reference_known_answers_with_non_symmetric_cones(name, mk, xref, obj, o
 @pytest.mark.parametrize("name", ["mix_60", "mix_300"])
 def test_ipm_trajectories_with_non_symmetric_cones(name, oracle_factory, capsys):
     _compare_trajectories(name, PROBLEMS[name](), oracle_factory, capsys)
+
+
+@pytest.mark.parametrize("name", ["mix_60", "mix_300"])
+def test_oracle_driven_run_shadowed_by_the_hip_solver(name, capsys):
+    """The strict form of the trajectory comparison (review of round 5): the ORACLE drives the IPM, the HIP solver is handed the very
+    same inputs at every KKT call (same elimination order), so no discrete decision of the caller (line search by factors of 0.8,
+    centrality test) can separate the two: EVERY solve of the run leaves the same residual to 1e-10, gives the same solution to 1e-10
+    (+ cond(K) x round-off on the last, ill-conditioned iterates) and takes the same number of iterative-refinement steps
+    (kktsolver_directldl.jl:389-449) except where a residual sits on the stopping threshold itself."""
+    from oracle.kkt_oracle import OracleKKTSolver
+
+    P, q, A, b, cones = PROBLEMS[name]()
+    sh = cl.Solver(P, q, A, b, cones, cl.Settings(), kktsolver_factory=lambda *a: fx.ShadowKKT(HipKKTSolver, OracleKKTSolver, *a))
+    sol = sh.solve()
+    log = sh.kktsystem.kktsolver.log
+    worst = max(log, key=lambda r: r[1])
+    first = next((r for r in log if r[2] != r[3]), None)
+    with capsys.disabled():
+        print(f"\n[nonsymmetric-shadow {name}] oracle-driven run {sol.status} in {sol.iterations} iterations, {len(log)} solves; worst |x_hip - x_oracle| / max(1, |x|) = "
+              f"{worst[1]:.2e} at iteration {worst[0]}; first solve with different refinement-step counts: {None if first is None else first[:4]}")
+        for r in log:
+            if r[1] > 1e-11 or r[2] != r[3]:
+                print(f"    iteration {r[0]}: rel_dx {r[1]:.2e} ir hip/oracle {r[2]}/{r[3]} max|D|/min|D| {r[6]:.1e} norms hip {tuple(f'{v:.2e}' for v in r[4])} oracle {tuple(f'{v:.2e}' for v in r[5])}")
+    assert sol.status == "SOLVED"
+    # Every solve, three statements.  tol = the reference's stopping threshold abstol + reltol ||b|| (kktsolver_directldl.jl:421-424);
+    # "converged" = both paths end below 10 tol (the first ~70 % of these runs); afterwards the systems are so ill-conditioned
+    # (max|D| / min|D| 1e19 .. 1e25) that the refinement of BOTH paths stalls at a residual floor far above tol.
+    st = cl.Settings()
+    nconv = 0
+    border = []
+    for r in log:
+        normb, e_hip, e_or = r[4][1], r[4][2], r[5][-1]
+        tol = st.iterative_refinement_abstol + st.iterative_refinement_reltol * normb
+        converged = e_hip <= 10.0 * tol and e_or <= 10.0 * tol
+        nconv += converged
+        # (a) accuracy class: what HIP leaves of b - K x (the same unregularised K, bit for bit) is never more than 4 x what the
+        #     oracle leaves (or the threshold itself)
+        assert e_hip <= max(tol, 4.0 * e_or), ("residual", r)
+        # (b) where the reference's own stopping rule is met, the two solutions agree to 1e-10
+        if converged:
+            assert r[1] <= 1e-10, ("solution", r)
+        # (c) refinement-step counts are equal, except where a residual of either path sits at the threshold itself (within a
+        #     factor of 3: last digits of a residual of 1e-12 on ||b|| ~ 10), the refinement has stalled above it, or the iterate is
+        #     one of the last, ill-conditioned ones (max|D| / min|D| >= 1e19: the first step of one path reaches the threshold from
+        #     1e-4, the other path's needs a second); then by one step
+        if r[2] != r[3]:
+            resid = [v for v in list(r[5]) + [r[4][0], r[4][2]] if v > 0]
+            at_threshold = any(tol / 3.0 <= v <= 3.0 * tol for v in resid)
+            assert (at_threshold or not converged or r[6] >= 1e19) and abs(r[2] - r[3]) == 1, ("refinement steps", r)
+            border.append(r[0])
+    assert nconv >= (3 * len(log)) // 5, nconv
+    assert len(border) <= len(log) // 10, border
