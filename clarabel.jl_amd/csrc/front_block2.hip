@@ -107,6 +107,9 @@ __device__ __forceinline__ void f2_extra_tiles(const DevPlan &P, int begin, int 
 #define F2_T(slot) do { if (TRACE) { if (trace && tid == 0 && i < 5) trace[(B.sync_off / 128 * 8 + i) * 16 + (slot)] = (long long)wall_clock64(); } } while (0)
 #define F2_TB(ph) do { if (TRACE) { if (trace && tid == 0 && i == 0) trace[(B.sync_off / 128 * 8 + 5) * 16 + 4 * Bk + (ph)] = (long long)clock64(); } } while (0)
 
+#ifndef FB_EARLY_STORE
+#define FB_EARLY_STORE 1
+#endif
 template <bool TRACE>
 __global__ void __launch_bounds__(256)
 k_front_block2(DevPlan P, FrontBatch B, int *sync_all, double *scratch_all, double *stream_all, double dyn_eps, double dyn_delta,
@@ -435,6 +438,7 @@ k_front_block2(DevPlan P, FrontBatch B, int *sync_all, double *scratch_all, doub
     // ---- a diagonal workgroup's panels j2 < i - 1 from the stream (a later reader of tile j2's records, behind the workgroups i' < i):
     //      no step waits for the inverse of a tile, which is published 4 - 5 us after its pivots.  Then the step's hand-off and
     //      updates as in the regular steps.  One copy of the code, rolled over j2; the tiles are selected by run-time index.
+    const bool early_store = FB_EARLY_STORE && i == nb - 1 && B.nblk > nb;
 #pragma unroll 1
     for (int j2 = 0; j2 < i - 1; j2++) {
         v4f64 x[4];
@@ -511,6 +515,23 @@ k_front_block2(DevPlan P, FrontBatch B, int *sync_all, double *scratch_all, doub
 #pragma unroll
             for (int kk = 0; kk < kFbMax; kk++)
                 if (kk == j2) acc[kk][sub] = -x[sub];
+        // ... except in the batch's LAST diagonal workgroup (round 6): the launch ends with ITS panel stores (four tiles, ~10 us after
+        // its last pivot), and it spends most of the launch waiting for the workgroups before it -- its stores of a finished panel
+        // wait in front of flag polls that are not due yet
+        if (early_store && rowok) {
+            const FrontPanel pk = fp[j2];
+            double *dst = P.Lx + pk.panel_off + 64 * (i - j2);
+            double *lt2 = P.LT + pk.lt_off + (int64_t)(64 * (i - j2) - 64) * 64;
+            const unsigned o1 = 8u * (unsigned)(n + lk * pk.r), o2 = 8u * (unsigned)(n * 64 + lk);
+#pragma unroll
+            for (int sub = 0; sub < 4; sub++)
+#pragma unroll
+                for (int reg = 0; reg < 4; reg++) {
+                    const double v = -x[sub][reg];
+                    st_off(dst + (int64_t)(16 * sub + 4 * reg) * pk.r, o1, v);
+                    st_off(lt2, o2 + 8u * (unsigned)(16 * sub + 4 * reg), v);
+                }
+        }
     }
     v4f64 xr[4];                                          // the tile of panel i - 1, L(i, i-1) after the streamed step
 #pragma unroll
@@ -662,7 +683,7 @@ k_front_block2(DevPlan P, FrontBatch B, int *sync_all, double *scratch_all, doub
         if (!rowok) return;
 #pragma unroll
         for (int k = 0; k < kFbMax - 1; k++) {
-            if (k < i) {
+            if (k < i && !(early_store && k < i - 1)) {
                 // uniform base + 32-bit lane offset per store (no 64-bit address arithmetic on the vector side: these 32 stores per
                 // tile are the tail of the launch for the batch's last diagonal workgroup)
                 const FrontPanel pk = fp[k];
