@@ -606,7 +606,12 @@ def main():
                                  all_update_kernels=dict(achieved=round(agg, 3), frac=round(agg / F64_MFMA_PEAK_TFLOPS, 4), ms_per_refactor=round(upd, 4),
                                                          flops_per_refactor=flops_upd_kernels)),
                     solves=hbm_solve,
-                    peak_source="MI355X datasheet FP64 matrix; tools/ubench.hip measures 72-77 TFLOP/s on the box")
+                    peak_source="MI355X datasheet FP64 matrix (the figure every frac here is priced against)",
+                    sustained_matrix_rate=dict(tflops=50.3, frac_of_peak=round(50.3 / F64_MFMA_PEAK_TFLOPS, 3),
+                                               source="profiles/r06_a_ubench_macro_tile_and_mfma_mix.txt (tools/ubench_mfma_mix.hip)",
+                                               note="what the chip sustains when all 1024 SIMDs issue v_mfma_f64_16x16x4_f64 back to back and do nothing else "
+                                                    "(~55 us kernels, measured in round 6): the ceiling a Schur-update kernel can approach; the dense update's own "
+                                                    "launches (kernels.dense_update, 39 - 44 TFLOP/s on whole rounds) sit at ~80 % of it"))
 
     result = {
         "metric": "IPM iterations/sec + KKT factor+solve ms, 10k-var sparse QP, 1/2/4/8 GPU",
