@@ -21,6 +21,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "assemble.h"
@@ -265,6 +266,7 @@ struct hipkkt_solver {
     std::unique_ptr<hipkkt_solver> twin_pending;
     std::future<std::string> twin_future;
     std::shared_ptr<std::atomic<bool>> twin_cancel;   // set when the twin turns out not to be needed
+    std::shared_ptr<std::atomic<int>> twin_go;        // 0: the owner has not chosen its order yet, 1: cheap order chosen (the twin may take device memory), 2: not needed
     bool using_fallback = false;
     bool profiling = false;
     bool profiling_no_extra = false;     // hipkkt_set_profiling(h, 2): the profiled refactorisations keep every far tile in its stage's own launch
@@ -318,6 +320,7 @@ struct hipkkt_solver {
     }
     ~hipkkt_solver() {
         if (twin_cancel) twin_cancel->store(true);
+        if (twin_go && twin_go->load() == 0) twin_go->store(2);
         if (twin_future.valid()) twin_future.wait();     // the thread reads twin_pending's image (a cancelled one ends at its next phase)
         twin_pending.reset();
         delete fallback;

@@ -805,14 +805,19 @@ int32_t finish_create(hipkkt_solver *S, const hipkkt_opts *opts, hipkkt_handle *
                 hipkkt_solver *Tp = T.get();
                 std::vector<int64_t> pv(perm_md.begin(), perm_md.end());
                 S->twin_pending = std::move(T);
-                S->twin_future = std::async(std::launch::async, [Tp, pv, po2]() {
+                S->twin_go = std::make_shared<std::atomic<int>>(0);
+                std::shared_ptr<std::atomic<int>> go = S->twin_go;
+                S->twin_future = std::async(std::launch::async, [Tp, pv, po2, go]() {
                     std::string err = build_plan((int)Tp->img.N, Tp->img.colptr.data(), Tp->img.rowval.data(), pv.data(), po2, Tp->plan);
                     if (!err.empty()) return err;
                     // Round 6: the twin's device residency too (its work lists are hundreds of MB on the problems that take this path:
                     // 0.32 - 0.40 s of set-up on cfg 5, paid until now by the FIRST factorisation that breaks down -- half of that
                     // problem's whole IPM time).  Here it overlaps the owner's own analysis and set-up; a cancelled speculation
                     // (the cheap order was not chosen after all) never gets here.
-                    if (po2.cancel && po2.cancel->load(std::memory_order_relaxed)) return std::string("cancelled");
+                    // ... but only once the owner has settled on the cheap order (small problems finish this analysis before the
+                    // owner has compared the two orders: without the wait every batch problem of cfg 4 set up a twin it never used)
+                    while (go->load(std::memory_order_acquire) == 0) std::this_thread::sleep_for(std::chrono::microseconds(200));
+                    if (go->load(std::memory_order_acquire) != 1 || (po2.cancel && po2.cancel->load(std::memory_order_relaxed))) return std::string("cancelled");
                     try {
                         init_runtime(Tp);
                         setup_device(Tp);
@@ -854,6 +859,7 @@ int32_t finish_create(hipkkt_solver *S, const hipkkt_opts *opts, hipkkt_handle *
     po.on_alternative_order = nullptr;
     if (!err.empty()) { g_create_error = err; delete S; return HIPKKT_ERR_ARGUMENT; }
     if (S->plan.ordering_used != 1 && S->twin_cancel) S->twin_cancel->store(true);   // speculative twin not needed: the thread stops at its next phase
+    if (S->twin_go) S->twin_go->store((S->plan.ordering_used == 1 && err.empty()) ? 1 : 2, std::memory_order_release);   // ... or goes on to its device set-up
     S->plan_opts = po;
     const auto t_b = std::chrono::steady_clock::now();
     try {
