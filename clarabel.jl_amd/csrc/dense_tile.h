@@ -31,11 +31,6 @@ __device__ __forceinline__ void st_off(double *base, unsigned byte_off, double v
     *(HK_GLOBAL double *)((HK_GLOBAL char *)base + byte_off) = v;
 }
 
-#ifndef HIPKKT_DENSE_STREAM
-#define HIPKKT_DENSE_STREAM 1
-#endif
-constexpr bool kDenseStream = HIPKKT_DENSE_STREAM != 0;   // the general tile as one stream over its tasks (dense_tile_core_stream)
-
 // NT 16-column strips x NR 16-row blocks of a tile per wavefront
 template <int NT, int NR>
 struct DenseRaw {
@@ -202,117 +197,10 @@ __device__ __forceinline__ void dense_tile_core(const DevPlan &P, double *tp, in
         }
 }
 
-// The general tile (any geometry, tile maps) as ONE stream over all its tasks (round 6).  dense_tile_core restarts per task: record ->
-// tile map -> lane offsets -> first operands are three dependent memory round trips in front of the few k-steps of a NARROW source
-// (the stage that carries the sparse part of the tree into a front: 20 sources of ~13 columns per tile on cfg 2a, i.e. four k-steps
-// of matrix-core work each; 11 TFLOP/s).  Here the NEXT task is set up while the current one is being multiplied: its record was
-// requested two tasks earlier, its tile map one task earlier, its lane offsets are formed and its first operands requested in the
-// place where the current task's double buffer would fetch past its end.  Same products in the same order: bit-identical.
-__device__ __forceinline__ void dense_tile_core_stream(const DevPlan &P, double *tp, int rt, int nrt, int wt, int task_begin, int task_end, int lane) {
-    const int l15 = lane & 15, lk = lane >> 4;
-    v4f64 acc[4][4];
-#pragma unroll
-    for (int tj = 0; tj < 4; tj++)
-#pragma unroll
-        for (int reg = 0; reg < 4; reg++) {
-            const int jj = tj * 16 + lk + 4 * reg;
-#pragma unroll
-            for (int ti = 0; ti < 4; ti++) {
-                const int ii = ti * 16 + l15;
-                const bool ok = ii < nrt && jj < wt;
-                const double v = ld_off(tp, ok ? (unsigned)(ii + jj * rt) * 8u : 0u);
-                acc[tj][ti][reg] = ok ? v : 0.0;
-            }
-        }
-    // per-task state of the task being multiplied (c) and of the one after it (n)
-    struct Uni { const double *sp, *dv; unsigned r8; int K; };
-    auto uni = [&](const DenseTask &T) { return Uni{rfl_ptr(P.Lx + T.panel_off), rfl_ptr(P.D + T.dfirst), (unsigned)rfl(T.r8), rfl(T.K)}; };
-    // raw tile-map entries (or -2: not mapped, offsets come from the geometry) of a task: 8 values per lane
-    auto request_map = [&](const DenseTask &T, int (&mr)[4], int (&mc)[4]) {
-        const int geom = rfl(T.geom);
-        if (geom & (1 << 17)) {                                    // wave-uniform
-            const int16_t *tm = P.upd_tmap + (int64_t)rfl(T.map) * 128;
-#pragma unroll
-            for (int x = 0; x < 4; x++) { mr[x] = tm[x * 16 + l15]; mc[x] = tm[64 + x * 16 + l15]; }
-        } else {
-            const int c_r = geom & 255, c_c = (geom >> 8) & 255, nrows = rfl(T.nrows), ncols = rfl(T.ncols);
-#pragma unroll
-            for (int x = 0; x < 4; x++) {
-                const int ii = x * 16 + l15 - c_r, jj = x * 16 + l15 - c_c;
-                mr[x] = (ii >= 0 && ii < nrows) ? ii : -1;
-                mc[x] = (jj >= 0 && jj < ncols) ? jj : -1;
-            }
-        }
-    };
-    auto offsets = [&](const DenseTask &T, const int (&mr)[4], const int (&mc)[4], unsigned (&roff)[4], unsigned (&coff)[4], unsigned &mbits) {
-        const int row_lo = rfl(T.row_lo), col_lo = rfl(T.col_lo);
-        mbits = 0;
-#pragma unroll
-        for (int x = 0; x < 4; x++) {
-            roff[x] = (unsigned)(row_lo + (mr[x] >= 0 ? mr[x] : 0)) * 8u;
-            coff[x] = (unsigned)(col_lo + (mc[x] >= 0 ? mc[x] : 0)) * 8u;
-            mbits |= (mr[x] >= 0 ? 16u << x : 0u) | (mc[x] >= 0 ? 1u << x : 0u);
-        }
-    };
-    DenseTask Tc = P.dtasks[task_begin];
-    DenseTask Tn = P.dtasks[task_begin + 1 < task_end ? task_begin + 1 : task_begin];
-    int mr[4], mc[4];
-    unsigned roff[4], coff[4], mbits;
-    request_map(Tc, mr, mc);
-    offsets(Tc, mr, mc, roff, coff, mbits);
-    Uni U = uni(Tc);
-    DenseRaw<4, 4> fa, fb;
-    dense_load<4, 4>(fa, U.sp, U.dv, coff, roff, U.r8, U.K, 0, lk);
-    for (int q = task_begin; q < task_end; q++) {
-        const bool more = q + 1 < task_end;                        // wave-uniform
-        // the next task: its record is here (requested a task ago); request its tile map now and the record after it
-        const DenseTask Tx = Tn;
-        int nmr[4], nmc[4];
-        if (more) {
-            request_map(Tx, nmr, nmc);
-            Tn = P.dtasks[q + 2 < task_end ? q + 2 : q + 1];
-        }
-        const int K = U.K;
-        for (int k0 = 0; k0 < K; k0 += 8) {
-            const bool last = k0 + 8 >= K;
-            if (k0 + 4 < K) dense_load<4, 4>(fb, U.sp, U.dv, coff, roff, U.r8, K, k0 + 4, lk);
-            __builtin_amdgcn_sched_barrier(0);
-            dense_mma<4, 4>(fa, acc, mbits, K, k0, lk);
-            __builtin_amdgcn_sched_barrier(0);
-            unsigned nroff[4], ncoff[4], nmbits = 0;
-            Uni Un = U;
-            if (!last) {
-                dense_load<4, 4>(fa, U.sp, U.dv, coff, roff, U.r8, K, k0 + 8, lk);
-            } else if (more) {
-                // where the double buffer would fetch past this task's end: the first operands of the next task
-                offsets(Tx, nmr, nmc, nroff, ncoff, nmbits);
-                Un = uni(Tx);
-                dense_load<4, 4>(fa, Un.sp, Un.dv, ncoff, nroff, Un.r8, Un.K, 0, lk);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if (k0 + 4 < K) dense_mma<4, 4>(fb, acc, mbits, K, k0 + 4, lk);
-            __builtin_amdgcn_sched_barrier(0);
-            if (last && more) {
-#pragma unroll
-                for (int x = 0; x < 4; x++) { roff[x] = nroff[x]; coff[x] = ncoff[x]; }
-                mbits = nmbits;
-                U = Un;
-            }
-        }
-    }
-#pragma unroll
-    for (int tj = 0; tj < 4; tj++)
-#pragma unroll
-        for (int reg = 0; reg < 4; reg++) {
-            const int jj = tj * 16 + lk + 4 * reg;
-#pragma unroll
-            for (int ti = 0; ti < 4; ti++) {
-                const int ii = ti * 16 + l15;
-                if (ii < nrt && jj < wt) st_off(tp, (unsigned)(ii + jj * rt) * 8u, acc[tj][ti][reg]);
-            }
-        }
-}
-
+// [Round 6, measured and removed: the general tile as ONE stream over all its tasks -- the next task's record / tile map / lane offsets
+// prepared and its first operands requested while the current task is multiplied, instead of three dependent round trips per task.
+// Bit-identical, 26 more registers spilled, and SLOWER: cfg 2a's factorisation 3.66 -> 3.77 ms, cfg 5's 4.55 -> 4.96 ms.  With two
+// wavefronts per SIMD the other wavefront already covers those round trips.]
 // FULL tiles (DenseGroup::pad & 1, set when the plan is uploaded: a 64 x 64 tile whose every task covers all 64 rows and columns
 // contiguously with K a multiple of 8 -- all but the edge tiles of a front's big launches): nothing to mask, the lane offsets are
 // loop-invariant, and the k-steps advance the UNIFORM base pointers in scalar registers: 9 loads + 4 multiplies per 16 matrix-core
@@ -424,10 +312,6 @@ __device__ __forceinline__ void dense_tile(const DevPlan &P, const DenseGroup *G
     if (ti0 * 16 >= nrt) return;
     if (NT == 4 && NR == 4 && (rfl(G.pad) & 1)) {       // wave-uniform
         dense_tile_core_full(P, tp, rt, task_begin, task_end, lane);
-        return;
-    }
-    if (NT == 4 && NR == 4 && !DEEP && kDenseStream) {
-        dense_tile_core_stream(P, tp, rt, nrt, wt, task_begin, task_end, lane);
         return;
     }
     dense_tile_core<NT, NR, DEEP>(P, tp, rt, nrt, wt, task_begin, task_end, lane, tj0, ti0);

@@ -816,6 +816,11 @@ int32_t finish_create(hipkkt_solver *S, const hipkkt_opts *opts, hipkkt_handle *
                     // (the cheap order was not chosen after all) never gets here.
                     // ... but only once the owner has settled on the cheap order (small problems finish this analysis before the
                     // owner has compared the two orders: without the wait every batch problem of cfg 4 set up a twin it never used)
+                    // ... and only for a twin whose set-up is worth hiding (>= 2e7 entries of L: tenths of a second).  A small twin is set
+                    // up in milliseconds when it is needed, and until then costs its process three more HIP streams -- which is what
+                    // a batch of small problems is most sensitive to (cfg 4 fell from 1070 to 890 IPM iterations/s
+                    // when every batch problem in the cheap order kept a resident twin).
+                    if (Tp->plan.nnzL < 20000000) return err;
                     while (go->load(std::memory_order_acquire) == 0) std::this_thread::sleep_for(std::chrono::microseconds(200));
                     if (go->load(std::memory_order_acquire) != 1 || (po2.cancel && po2.cancel->load(std::memory_order_relaxed))) return std::string("cancelled");
                     try {
