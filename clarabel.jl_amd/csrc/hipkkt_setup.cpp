@@ -600,12 +600,14 @@ static void order_far_stages(hipkkt_solver *S) {
 // The per-entry gather of the bottom update batch is one long launch (cfg 2a: 4.0e6 target entries, 355 us) in front of a string of
 // small, dependency-bound launches (the levels of the next batch: 13 launches, ~200 us, a few hundred workgroups each) -- and 97 % of
 // its entries land in panels that nothing reads or writes before that next batch's FAR stage.  A batch-end stage with at least
-// kGatherSplitMin such entries is reordered [targets up to the next batch's last level | targets beyond]; the second part runs on the
+// kGatherSplitMin (10^6) such entries is reordered [targets up to the next batch's last level | targets beyond]; the second part runs on the
 // side stream next to the next batch's levels and is joined before its far stage (hipkkt_factor.cpp).  Why that is safe: with the
 // batched schedule (symbolic.cpp, stage = min(level(t) - 1, batch end of the source)) every stage s strictly inside the next batch
 // holds only targets of level s + 1, and a level's panel kernels touch their own panels only.  Entries keep their pair lists and
 // their order inside each part: same arithmetic, bit for bit.
-constexpr int64_t kGatherSplitMin = 200000;
+constexpr int64_t kGatherSplitMin = 1000000;   // (200 000 at first: a batch of small problems, six processes per GPU, lost 20 % of its rate
+                                               // to the parallel branch in the factorisation graphs of the problems that qualified -- cfg 4,
+                                               // 1070 -> 860 IPM iterations/s; a launch of a few hundred microseconds is what is worth hiding)
 // ORDER OF THE ENTRIES (round 6).  The plan lists a stage's entries in target order (tile, column, row): consecutive threads own
 // consecutive rows of a target column -- and take their operands from whatever small source panel put something there: every lane of
 // a wavefront reads another cache line (cfg 2a: 4.0e6 entries x 28 operand loads, 355 us, bound by the rate at which the L1 looks up
