@@ -15,6 +15,8 @@ Tolerances (Float64, stated by north_star: residuals/objective to 1e-10):
 X_TOL = 1e-6
 import zlib
 
+import os
+
 import numpy as np
 import pytest
 import scipy.sparse as sp
@@ -33,7 +35,8 @@ pytestmark = pytest.mark.gpu
 def _front_batches_on_small_fronts(monkeypatch):
     """the problems of this file are small: let their fronts take the one-launch-per-update-batch factorisation (front_block.hip)
     that the product reserves for fronts of >= 1024 rows, so that it is covered here against the oracle as well"""
-    monkeypatch.setenv("HIPKKT_FRONT_BLOCK_MIN_ROWS", "0")
+    if os.environ.get("HIPKKT_TEST_PRODUCTION", "0") != "1":   # (the production library has no switches: its own threshold applies)
+        monkeypatch.setenv("HIPKKT_FRONT_BLOCK_MIN_ROWS", "0")
 
 EPS2 = float(np.finfo(np.float64).eps) ** 2
 

@@ -8,6 +8,8 @@ produce, the reference's three known answers for them (basic_exp.jl, basic_pow.j
 stand-in IPM, and the IPM trajectories of HIP-driven and oracle-driven runs side by side."""
 import zlib
 
+import os
+
 import numpy as np
 import pytest
 import scipy.sparse as sp
@@ -23,7 +25,8 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(autouse=True)
 def _front_batches_on_small_fronts(monkeypatch):
-    monkeypatch.setenv("HIPKKT_FRONT_BLOCK_MIN_ROWS", "0")      # as in tests/test_gpu_kkt.py
+    if os.environ.get("HIPKKT_TEST_PRODUCTION", "0") != "1":   # (the production library has no switches: its own threshold applies)
+        monkeypatch.setenv("HIPKKT_FRONT_BLOCK_MIN_ROWS", "0")      # as in tests/test_gpu_kkt.py
 
 
 PROBLEMS = {
