@@ -272,7 +272,12 @@ int32_t hipkkt_set_hs_dev(hipkkt_handle h, const double *hs_dev, int64_t nHs) {
     HK_ENTER(h)
     if (!S->l1 || nHs != S->img.nHs || (nHs && !hs_dev)) { S->err = "set_hs: wrong length / not an L1 handle"; return HIPKKT_ERR_ARGUMENT; }
     launch_scatter_values(S->stream, S->dp.kval, S->d_mapHs, hs_dev, nHs, -1.0);
-    HK_CHECK(hipStreamSynchronize(S->stream));
+    // no host synchronisation (round 6: a device-resident input needs none; it cost a round trip + a cold start of the next launch
+    // per IPM iteration).  The factorisation that follows runs on the same stream; the second solve context's stream is made to
+    // wait for this event the next time it is used (hipkkt_solve.cpp solve_begin).  hs_dev must stay valid until the next call that
+    // synchronises (hipkkt_refactor, any solve) has returned.
+    HK_CHECK(hipEventRecord(S->ev3, S->stream));
+    S->kval_event_pending = true;
     return HIPKKT_OK;
     HK_LEAVE
 }

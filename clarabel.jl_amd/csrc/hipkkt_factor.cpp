@@ -394,6 +394,7 @@ static int32_t refactor_once(hipkkt_handle h, int32_t static_reg_enable, double 
     HK_CHECK(hipEventRecord(S->ev1, S->stream));
     HK_CHECK(hipMemcpyAsync(S->h_flags, S->dp.flags, FL_COUNT * sizeof(int), hipMemcpyDeviceToHost, S->stream));
     read_scalars(S);
+    S->kval_event_pending = false;       // (the main stream has been synchronised: every value update before it is complete)
     float ms = 0;
     HK_CHECK(hipEventElapsedTime(&ms, S->ev0, S->ev1));
     S->t_last_factor = ms;

@@ -271,6 +271,7 @@ struct hipkkt_solver {
     bool profiling = false;
     bool profiling_no_extra = false;     // hipkkt_set_profiling(h, 2): the profiled refactorisations keep every far tile in its stage's own launch
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
+    bool kval_event_pending = false;     // ev3 marks an asynchronous value update of the resident K on the main stream (hipkkt_set_hs_dev)
     double t_last_factor = 0, t_last_solve = 0, t_acc_factor = 0, t_acc_solve = 0, t_last_update = 0;
     int64_t n_factor = 0, n_solvecalls = 0, n_ldlsolves = 0, n_rhs_solved = 0;
     double last_eps = 0;

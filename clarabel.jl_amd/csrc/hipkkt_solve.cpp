@@ -119,6 +119,7 @@ bool recover_from_sweep_failure(hipkkt_solver *S) {
 // the read-back of the state -- no synchronisation: several contexts can be started before any is finished.
 void solve_begin(hipkkt_solver *S, SolveCtx &C, int ir_enable, double reltol, double abstol, int64_t max_iter, double stop_ratio) {
     hipStream_t st = C.stream;
+    if (S->kval_event_pending && st != S->stream) HK_CHECK(hipStreamWaitEvent(st, S->ev3, 0));   // an asynchronous hipkkt_set_hs_dev on the main stream
     HK_CHECK(hipEventRecord(C.ev_a, st));
     C.ir_used = ir_enable != 0;
     if (ir_enable) {
@@ -245,7 +246,7 @@ int32_t hipkkt_setrhs_dev(hipkkt_handle h, const double *rhs_dev) {
     HK_ENTER(h)
     if (!S->l1 || !rhs_dev) return HIPKKT_ERR_ARGUMENT;
     launch_set_rhs(S->stream, S->d_b, rhs_dev, (int)(S->img.n + S->img.m), S->N);
-    HK_CHECK(hipStreamSynchronize(S->stream));
+    // (no host synchronisation: the solve that reads d_b runs on the same stream; rhs_dev must stay valid until that solve has returned)
     return HIPKKT_OK;
     HK_LEAVE
 }

@@ -142,6 +142,8 @@ int32_t hipkkt_scale_values(hipkkt_handle h, const int64_t *index, int64_t k, do
 /* ref: kktsolver_update! first half, kktsolver_directldl.jl:223-228: Hs as produced by
  * get_Hs!(cones,Hsblocks); negated and scattered through map.Hsblocks on the device. */
 int32_t hipkkt_set_hs(hipkkt_handle h, const double *hs, int64_t nHs);
+/* the _dev form does not synchronise with the host: hs_dev must stay valid until the next synchronising call on this handle
+ * (hipkkt_refactor, any solve) has returned */
 int32_t hipkkt_set_hs_dev(hipkkt_handle h, const double *hs_dev, int64_t nHs);
 
 /* SURVEY section 8(f) row N1 (first step): the Hs block of PSD triangle cones formed ON THE DEVICE.
@@ -208,7 +210,7 @@ int32_t hipkkt_refactor(hipkkt_handle h, int32_t static_reg_enable, double eps_c
 
 /* ref: kktsolver_setrhs!, kktsolver_directldl.jl:313-327: b = [rhsx; rhsz; 0_p] */
 int32_t hipkkt_setrhs(hipkkt_handle h, const double *rhsx, const double *rhsz);
-int32_t hipkkt_setrhs_dev(hipkkt_handle h, const double *rhs_dev /* n+m contiguous */);
+int32_t hipkkt_setrhs_dev(hipkkt_handle h, const double *rhs_dev /* n+m contiguous; not synchronised with the host: valid until the solve has returned */);
 /* ref: kktsolver_solve!, kktsolver_directldl.jl:346-371 incl. _iterative_refinement :389-449 and
  * kktsolver_getlhs! :330-343.  lhsx / lhsz may be NULL (Julia `nothing`).  ir_steps may be NULL. */
 int32_t hipkkt_solve(hipkkt_handle h, double *lhsx, double *lhsz, int32_t ir_enable, double reltol,
