@@ -273,13 +273,20 @@ __device__ __forceinline__ double pivot_rcp3(double d) {
 // values and a second barrier.  16 barriers per 64-column panel instead of 64, and only the 8x8 triangle of the
 // current block sits on the pivot-to-pivot critical path.
 
-__global__ void __launch_bounds__(512)
+// Round 6: TWO workgroups per compute unit (62 KB of LDS instead of 96, <= 128 registers).  A level of many panels -- the 20 cone
+// chains of an SDP: 400 items per level on cfg 5 -- ran in two rounds of one workgroup per compute unit, 31 us per level against the
+// 15 us one round takes.  What went: the staging tile of the factored diagonal block (its columns now go from the published L columns
+// in LDS straight to Ldiag, by a wavefront that is not on the pivot chain, inside the loop -- whose barrier therefore no longer waits
+// for global memory).
+__device__ __forceinline__ void fp_bar() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }   // LDS-only workgroup barrier
+
+__global__ void __launch_bounds__(512, 4)                 // (HIP: the second figure is wavefronts per SIMD: 4 = two of these workgroups per compute unit)
 k_factor_panel(DevPlan P, int item_begin, double dyn_eps, double dyn_delta) {
     __shared__ double colL[2][8][64];     // l_ik of the diagonal-block rows of block B          (parity B & 1)
     __shared__ double colC[3][8][64];     // raw a_ik = d_k l_ik of the diagonal-block rows        (B % 3: read for two iterations)
     __shared__ double colLO[2][8][64];    // l_ik of the chunk rows                                (parity B & 1)
     __shared__ double dinvs[3][8];
-    __shared__ double Yt[2][64 * 65];     // [group][row * 65 + k]: L11 (group D) and L21 (group O), staged
+    __shared__ double Yt[64 * 65];        // [row * 65 + k]: L21 of the chunk rows (group O), staged for the panel and its row-major copy
     __shared__ double dsave[64];
     // one self-contained record per item: the panel kernels are the critical path of the factorisation, and the
     // chain  item -> supernode tables -> panel  cost two extra dependent memory round trips per launch
@@ -299,7 +306,7 @@ k_factor_panel(DevPlan P, int item_begin, double dyn_eps, double dyn_delta) {
         a[c] = (rvalid && j < w) ? pan[prow + (int64_t)j * r] : 0.0;
     }
     const unsigned long long spos = __ballot(lane < w && P.sgn_perm[f + (lane < w ? lane : 0)] > 0);
-    double *myY = &Yt[grp][lane * 65];
+    double *myY = &Yt[lane * 65];                        // (group O only)
     int nreg = 0;
     const int nB = (w + 7) >> 3;
     // Software pipeline with ONE barrier per block: in iteration B the diagonal-row owner eliminates block B while
@@ -350,7 +357,6 @@ k_factor_panel(DevPlan P, int item_begin, double dyn_eps, double dyn_delta) {
                         const double li = reg * dinv;
                         colL[pb][kk][lane] = li;
                         colC[p3][kk][lane] = k < w ? reg : 0.0;
-                        myY[k] = li;
 #pragma unroll
                         for (int jj = kk + 1; jj < 8; jj++) {
                             const double cj = readlane_f64(reg, 8 * B + jj);
@@ -392,7 +398,17 @@ k_factor_panel(DevPlan P, int item_begin, double dyn_eps, double dyn_delta) {
                     for (int jj = kk + 1; jj < 8; jj++) a[rb + jj] = fma(-li, colC[p3][kk][8 * Bo + jj], a[rb + jj]);
                 }
             }
-            __syncthreads();
+            fp_bar();
+            // the factored diagonal block goes to Ldiag from the published columns, by the diagonal-row wavefront that eliminated two
+            // blocks ago (not the one that eliminates next); colL[B & 1] stays valid until block B + 2 is published
+            if (grp == 0 && it.blk == 0 && B < nB && B < 8 && v == ((B + 2) & 3) && lane < w) {
+                double *ld = P.Ldiag + it.diag_off;
+#pragma unroll
+                for (int kk = 0; kk < 8; kk++) {
+                    const int k = 8 * B + kk;
+                    if (k < w) ld[lane + k * w] = lane > k ? colL[B & 1][kk][lane] : (lane == k ? 1.0 : 0.0);
+                }
+            }
             const int Bu = grp == 0 ? B : B - 1;          // block this wave applies now
             if (Bu >= 0 && Bu < nB && Bu < 8) {
                 const double(*Lsrc)[64] = grp == 0 ? colL[Bu & 1] : colLO[Bu & 1];
@@ -415,11 +431,6 @@ k_factor_panel(DevPlan P, int item_begin, double dyn_eps, double dyn_delta) {
     }
     __syncthreads();
     if (it.blk == 0) {
-        double *ld = P.Ldiag + it.diag_off;
-        for (int idx = tid; idx < w * w; idx += 512) {
-            const int i = idx % w, k = idx / w;
-            ld[idx] = i > k ? Yt[0][i * 65 + k] : (i == k ? 1.0 : 0.0);
-        }
         if (tid < w) {
             const double d = dsave[tid], dinv = 1.0 / d;
             P.D[f + tid] = d;
@@ -431,13 +442,13 @@ k_factor_panel(DevPlan P, int item_begin, double dyn_eps, double dyn_delta) {
     if (nr > 0) {
         for (int idx = tid; idx < nr * w; idx += 512) {   // column-major panel rows
             const int row = idx % nr, k = idx / nr;
-            pan[(lo + row) + (int64_t)k * r] = Yt[1][row * 65 + k];
+            pan[(lo + row) + (int64_t)k * r] = Yt[row * 65 + k];
         }
         // row-major copy (w contiguous doubles per row) for the backward solve's L21^T x
         double *lt = P.LT + it.lt_off + (int64_t)(lo - w) * w;
         for (int idx = tid; idx < nr * w; idx += 512) {
             const int k = idx % w, row = idx / w;
-            lt[idx] = Yt[1][row * 65 + k];
+            lt[idx] = Yt[row * 65 + k];
         }
     }
 }
