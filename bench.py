@@ -203,21 +203,34 @@ def bench_batch(args, cl, torch, dist, rank, world, local):
         # all-cores CPU baseline: the same problems, one per core, oracle KKT solver, bounded sample
         import multiprocessing as mp
 
-        ncores = min(os.cpu_count() or 1, 64)
+        # Round 6 (review of round 5): ALL cores of the box, not 64 -- and scheduled the way a CPU batch would be: every problem of
+        # the batch, one at a time per worker, the big ones first (with 64 workers and static chunks the longest pair of problems set
+        # the wall time: 25 % parallel efficiency, which flattered the GPU side)
+        ncores = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), args.cpu_cores or 256)
         by_seed = {r[0]: r for r in res}
-        seeds = [r[0] for r in res][: max(ncores, min(len(res), 2 * ncores))]
+        seeds = sorted((r[0] for r in res), key=lambda sd: -by_seed[sd][4])          # (descending algorithmic bytes: a size proxy)
         jobs = [(sd, by_seed[sd][5]) for sd in seeds]
         t0 = time.perf_counter()
+        # one BLAS / OpenMP thread per worker, like the GPU side's workers (inherited by the spawned processes): 256 workers with a
+        # thread pool each oversubscribe the box four times over (measured: 8 instead of 31 iterations/s per core)
+        saved_env = {k: os.environ.get(k) for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS", "NUMEXPR_NUM_THREADS")}
+        for k in saved_env:
+            os.environ[k] = "1"
         with mp.get_context("spawn").Pool(ncores) as pool:
+            for k, v in saved_env.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
             t_spawn = time.perf_counter() - t0
-            pool.map(_cpu_batch_worker, jobs[: min(len(jobs), ncores)])          # warm the workers (imports, oracle build)
+            pool.map(_cpu_batch_worker, jobs[-ncores:], chunksize=1)               # warm the workers (imports, oracle build) on the small ones
             t1 = time.perf_counter()
-            out = pool.map(_cpu_batch_worker, jobs)
+            out = list(pool.imap(_cpu_batch_worker, jobs, chunksize=1))
             t_cpu = time.perf_counter() - t1
         cpu_baseline = {"value": round(sum(o[0] for o in out) / t_cpu, 2), "unit": "IPM-iterations/s (whole solves incl. set-up)",
                         "cores": ncores, "kind": "port",
-                        "sample": f"{len(seeds)} of the same problems, one per core on {ncores} worker processes, oracle/ C restatement "
-                                  "of the :qdldl path inside the same numpy caller, on the HIP path's elimination order", "problems": len(seeds),
+                        "sample": f"all {len(seeds)} problems of the batch on {ncores} worker processes (one problem at a time per worker, big ones first), "
+                                  "oracle/ C restatement of the :qdldl path inside the same numpy caller, on the HIP path's elimination order", "problems": len(seeds),
                         "wall_s": round(t_cpu, 3), "sum_of_per_problem_s": round(sum(o[2] for o in out), 3),
                         "one_core_iterations_per_s": round(sum(o[0] for o in out) / sum(o[2] for o in out), 2),
                         "host_cores_available": os.cpu_count(), "pool_start_s": round(t_spawn, 2)}
@@ -285,7 +298,14 @@ def bench_batch(args, cl, torch, dist, rank, world, local):
                          "note": "algorithmic bytes of all solved problems (B_factor + 6 (B_solve + B_spmv) per IPM iteration, from each "
                                  "problem's symbolic factor) / wall time: a batch of small problems is bound by host work and launch / "
                                  "dependency latency, not by HBM -- the fraction says how far, it is not a kernel-quality figure"},
-            "cpu_baseline": cpu_baseline, "parity": parity}))
+            "cpu_baseline": cpu_baseline,
+            "gpu_vs_cpu_batch": None if not cpu_baseline else {
+                "one_gpu_over_all_host_cores": round(total_iters / elapsed / cpu_baseline["value"], 3),
+                "winner": "the host's CPU cores" if cpu_baseline["value"] > total_iters / elapsed else "the GPU",
+                "note": f"one MI355X with {max(1, args.workers)} host processes against the CPU restatement on {cpu_baseline['cores']} cores of the same box, "
+                        "both inside the same numpy stand-in of the caller (whose Python costs ~0.8 ms per IPM iteration and 10 - 30 ms per Solver "
+                        "construction on either side: tools/cfg4_breakdown.py)"},
+            "parity": parity}))
     if dist is not None:
         dist.destroy_process_group()
 
@@ -297,6 +317,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="2a")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-cores", type=int, default=0, help="cfg 4: worker processes of the CPU batch baseline (0 = every core of the box, at most 256)")
     ap.add_argument("--cpu-budget", type=float, default=80.0,
                     help="seconds of CPU-oracle work allowed for cpu_baseline / parity (default: three KKT iteration units of the headline "
                          "config, 23 s each on one host core: SURVEY section 8d asks for >= 3)")
