@@ -18,6 +18,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "kernels.h"
 #include "sweep_common.h"
 
@@ -74,6 +76,23 @@ __device__ __forceinline__ void sb_fetch(const SbTileSrc &T, double (&v)[4], int
         v[q] = in ? (T.coherent ? front_ld(p) : *p) : 0.0;
     }
 }
+// the same in two halves for operands requested several products ahead: the loads are UNCONDITIONAL (addresses clamped into the
+// tile: a load under a per-lane condition sits in a branch, and the register copies at the join of that branch wait for every
+// load in flight), the zero padding is applied when the values go to LDS
+__device__ __forceinline__ void sb_fetch_raw(const SbTileSrc &T, double (&v)[4], int tid) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int idx = tid + kInvThreads * q, i = min(idx & 63, T.ni - 1), k = min(idx >> 6, T.nk - 1);
+        v[q] = T.base[i * T.si + k * T.sk];
+    }
+}
+__device__ __forceinline__ void sb_put_masked(double *S, const double (&v)[4], int tid, int ni, int nk, bool lower) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int idx = tid + kInvThreads * q, i = idx & 63, k = idx >> 6;
+        S[i * SLD + k] = (i < ni && k < nk && (!lower || k <= i)) ? v[q] : 0.0;
+    }
+}
 __device__ __forceinline__ void sb_put(double *S, const double (&v)[4], int tid) {      // S[row * SLD + col]
 #pragma unroll
     for (int q = 0; q < 4; q++) {
@@ -88,11 +107,22 @@ __device__ __forceinline__ void sb_mm16(const double *A, const double *Bm, v4f64
         c = __builtin_amdgcn_mfma_f64_16x16x4f64(A[(16 * ti + l15) * SLD + 4 * kk + lk], Bm[(4 * kk + lk) * SLD + 16 * tj + l15], c, 0, 0, 0);
 }
 
-// The chain of a super-block's first column is 28 + 7 dependent 64 x 64 x 64 products.  What a product costs on it: the A operand
-// L[bl,kl] (fetched one product ahead, into registers), two LDS stores, two barriers and 16 matrix-core instructions per wavefront.
-// The B operands Inv[kl,cl] are the workgroup's own earlier results: they stay in registers (7 tiles x 4 values per thread) instead of
-// being read back from memory past the L1 -- that round trip was half of the 3.7 us per product of the first version (129 us per
-// launch on cfg 2a; prefetching both operands of the next product WITHOUT keeping the results: 148 us).
+// The chain of a super-block's first column is 28 + 7 dependent 64 x 64 x 64 products.  What a product costs on it: two LDS stores,
+// two barriers and 16 matrix-core instructions per wavefront -- and NOT a memory round trip:
+//   * the B operands Inv[kl,cl] are the workgroup's own earlier results: they stay in registers (7 tiles x 4 values per thread)
+//     instead of being read back from memory past the L1 (round 3: that round trip was half of the 3.7 us per product of the first
+//     version, 129 us per launch on cfg 2a);
+//   * the A operands L[bl,kl] / Linv_bl come through a ring of FOUR register sets, requested three products ahead, and the barriers
+//     wait for LDS only (round 6: `__syncthreads()` also waits for every global load in flight, i.e. each product paid the full
+//     latency of the operand requested one product earlier: 3.0 us per product, 105 us per launch on cfg 2a).
+// The products, their operands and the order of accumulation are unchanged: bit-identical results.
+__device__ __forceinline__ void sb_bar() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+constexpr int kInvRing = 4;
+// row jb of operand m in the list "for jb = 1 .. : jb tiles of L, then Linv": first(jb) = (jb - 1)(jb + 2) / 2
+__host__ __device__ constexpr int sb_op_row(int m) {
+    return m < 2 ? 1 : m < 5 ? 2 : m < 9 ? 3 : m < 14 ? 4 : m < 20 ? 5 : m < 27 ? 6 : m < 35 ? 7 : 8;
+}
+static_assert(kSbG == 8 && sb_op_row(1) == 1 && sb_op_row(2) == 2 && sb_op_row(34) == 7 && sb_op_row(35) == 8, "operand list of k_invert_super");
 __global__ void __launch_bounds__(kInvThreads)
 k_invert_super(DevPlan P, FrontDesc F) {
     __shared__ double SA[64 * SLD], SB[64 * SLD];
@@ -115,38 +145,55 @@ k_invert_super(DevPlan P, FrontDesc F) {
     auto linv_src = [&](int b) { return SbTileSrc{P.Linv + s_diag[b], 1, s_w[b], s_w[b], s_w[b], true, false}; };
     double inv[kSbG - 1][4];              // Inv[cl + j, cl] in the thread layout of sb_put (value (i, k) at idx = tid + 1024 q: i = idx & 63, k = idx >> 6)
     sb_fetch(linv_src(cl), inv[0], tid);
+    // the A operands in the order of their use: for jb = 1 .. 7: L[cl + jb, cl + jk] (jk = 0 .. jb - 1), then Linv_{cl + jb}: operand
+    // m = first(jb) + jk with first(jb) = (jb - 1)(jb + 2) / 2.  The requests run kInvRing - 1 products ahead; every index below is a
+    // compile-time constant after unrolling .
+    double ring[kInvRing][4];
+    auto fetch_op = [&](int m) {          // m: compile-time
+        const int fjb = sb_op_row(m), fjk = m - ((fjb - 1) * (fjb + 2)) / 2;
+        if (fjb < kSbG && cl + fjb < nbB) {                  // workgroup-uniform; past the end of the super-block nothing is requested
+            if (fjk < fjb) sb_fetch_raw(a_src(cl + fjb, cl + fjk), ring[m % kInvRing], tid);
+            else sb_fetch_raw(linv_src(cl + fjb), ring[m % kInvRing], tid);
+        }
+    };
+    auto put_op = [&](int m) {            // operand m -> SA, zero-padded
+        const int fjb = sb_op_row(m), fjk = m - ((fjb - 1) * (fjb + 2)) / 2;
+        if (fjk < fjb) sb_put_masked(SA, ring[m % kInvRing], tid, s_w[cl + fjb], s_w[cl + fjk], false);
+        else sb_put_masked(SA, ring[m % kInvRing], tid, s_w[cl + fjb], s_w[cl + fjb], true);
+    };
 #pragma unroll
-    for (int jb = 1; jb < kSbG; jb++) {
+    for (int u = 0; u < kInvRing - 1; u++) fetch_op(u);
+    // one row of the inverse; jb is a template constant (seven instances: a `#pragma unroll` over the rows exceeded the unroller's
+    // size limit with the ring in the body, and everything fell back to scratch memory)
+    auto row = [&](auto jb_c) {
+        constexpr int jb = decltype(jb_c)::value;
         const int bl = cl + jb;
-        if (bl < nbB) {                  // workgroup-uniform
+        if (bl < nbB) {                   // workgroup-uniform
+            constexpr int n0 = ((jb - 1) * (jb + 2)) / 2;    // index of this row's first product
             v4f64 acc = {0.0, 0.0, 0.0, 0.0};
-            double va[4], vn[4];
-            sb_fetch(a_src(bl, cl), va, tid);
 #pragma unroll
-            for (int jk = 0; jk < kSbG - 1; jk++) {
-                if (jk < jb) {
-                    if (jk + 1 < jb) sb_fetch(a_src(bl, cl + jk + 1), vn, tid);      // the next product's A operand ...
-                    else sb_fetch(linv_src(bl), vn, tid);                            // ... or the panel inverse of the last step
-                    sb_put(SA, va, tid);
-                    sb_put(SB, inv[jk], tid);
-                    __syncthreads();
-                    sb_mm16(SA, SB, acc, ti, tj, l15, lk);
-                    __syncthreads();
-#pragma unroll
-                    for (int q = 0; q < 4; q++) va[q] = vn[q];
-                }
+            for (int jk = 0; jk < jb; jk++) {
+                const int n = n0 + jk;
+                fetch_op(n + kInvRing - 1);
+                put_op(n);
+                sb_put(SB, inv[jk], tid);
+                sb_bar();
+                sb_mm16(SA, SB, acc, ti, tj, l15, lk);
+                sb_bar();
             }
+            constexpr int n = n0 + jb;
             // Inv[bl,cl] = -Linv_bl * S
+            fetch_op(n + kInvRing - 1);
 #pragma unroll
             for (int reg = 0; reg < 4; reg++) SB[(16 * ti + lk + 4 * reg) * SLD + 16 * tj + l15] = acc[reg];
-            sb_put(SA, va, tid);
-            __syncthreads();
+            put_op(n);
+            sb_bar();
             v4f64 o = {0.0, 0.0, 0.0, 0.0};
             sb_mm16(SA, SB, o, ti, tj, l15, lk);
-            __syncthreads();
+            sb_bar();
 #pragma unroll
             for (int reg = 0; reg < 4; reg++) SA[(16 * ti + lk + 4 * reg) * SLD + 16 * tj + l15] = -o[reg];
-            __syncthreads();
+            sb_bar();
             double *t = P.SbInv + sb_tile(F, B, bl, cl);
 #pragma unroll
             for (int q = 0; q < 4; q++) {
@@ -154,11 +201,15 @@ k_invert_super(DevPlan P, FrontDesc F) {
                 const double v = SA[(idx & 63) * SLD + (idx >> 6)];
                 t[idx] = v;                                                      // column-major half [i + 64 k]
                 t[4096 + idx] = SA[(idx >> 6) * SLD + (idx & 63)];               // row-major half [64 i + k]
-                if (jb < kSbG - 1) inv[jb][q] = v;
+                if (jb < kSbG - 1) inv[jb < kSbG - 1 ? jb : 0][q] = v;
             }
-            __syncthreads();
+            sb_bar();
         }
-    }
+    };
+    row(std::integral_constant<int, 1>{}); row(std::integral_constant<int, 2>{}); row(std::integral_constant<int, 3>{});
+    row(std::integral_constant<int, 4>{}); row(std::integral_constant<int, 5>{}); row(std::integral_constant<int, 6>{});
+    row(std::integral_constant<int, 7>{});
+    static_assert(kSbG == 8, "seven rows below the diagonal");
 }
 
 // ------------------------------------------------------------------------------------------
@@ -249,27 +300,27 @@ k_front_fwd_sb(DevPlan P, FrontDesc F, double *__restrict__ y, double *__restric
             }
         }
     };
-    // the inverse tiles Inv[b, gB .. b] (own rows; zeros for the rows below the front)
-    auto load_inv = [&](double (&dst)[kSbG][NT]) {
+    // The inverse tiles Inv[b, gB .. b] of the own super-block (own rows only) do not depend on the sweep: they are requested NOW, into
+    // registers of their own, with unconditional loads (addresses clamped into the tiles; the zero pattern is applied where the values
+    // are used).  [Round 6: they used to be the prefetch of the LAST hop -- issued by the polling wavefronts after their poll had
+    // succeeded and awaited at that hop's barrier: one memory round trip on the critical path of every super-block.]
+    double inv[kSbG][NT];
 #pragma unroll
-        for (int p = 0; p < kSbG; p++) {
-            if (own && p < bl) {                 // (uniform) a full tile of the super-block inverse, column-major
-                const double *tl = P.SbInv + sb_tile(F, B, bl, p);
+    for (int p = 0; p < kSbG; p++) {
+        if (own && p < bl) {                     // (uniform) a full tile of the super-block inverse, column-major (rows past the panel's width are zero)
+            const double *tl = P.SbInv + sb_tile(F, B, bl, p);
 #pragma unroll
-                for (int t = 0; t < NT; t++) dst[p][t] = valid ? sb_ld(tl, (unsigned)(ir + 64 * (k0 + 32 * t)) * 8u) : 0.0;
-            } else if (own && p == bl) {         // the panel's own inverse (lower triangular, w x w column-major)
-                const double *li = P.Linv + me.diag_off;
+            for (int t = 0; t < NT; t++) inv[p][t] = sb_ld(tl, (unsigned)(ir + 64 * (k0 + 32 * t)) * 8u);
+        } else if (own && p == bl) {             // the panel's own inverse (lower triangular, w x w column-major)
+            const double *li = P.Linv + me.diag_off;
+            const int irc = min(ir, me.w - 1);
 #pragma unroll
-                for (int t = 0; t < NT; t++) {
-                    const int k = k0 + 32 * t;
-                    dst[p][t] = (valid && k <= ir) ? sb_ld(li, (unsigned)(ir + k * me.w) * 8u) : 0.0;
-                }
-            } else {
+            for (int t = 0; t < NT; t++) inv[p][t] = sb_ld(li, (unsigned)(irc + min(k0 + 32 * t, irc) * me.w) * 8u);
+        } else {
 #pragma unroll
-                for (int t = 0; t < NT; t++) dst[p][t] = 0.0;
-            }
+            for (int t = 0; t < NT; t++) inv[p][t] = 0.0;
         }
-    };
+    }
     double a0 = 0.0, a1 = 0.0;
     // wait for the y of super-block Q's panels while the next group is prefetched into `nxt`, accumulate `cur`, cur <- nxt;
     // false = give up.  The polling waves issue their share of the prefetch AFTER their poll has succeeded: a wave's loads return
@@ -293,19 +344,19 @@ k_front_fwd_sb(DevPlan P, FrontDesc F, double *__restrict__ y, double *__restric
             a0 = fma(cur[p][0], yb[p][k0], a0);
             a1 = fma(cur[p][1], yb[p][k0 + 32], a1);
         }
-#pragma unroll
-        for (int p = 0; p < kSbG; p++)
-#pragma unroll
-            for (int t = 0; t < NT; t++) cur[p][t] = nxt[p][t];
         return true;
     };
     bool ok = true;
     if (nQ > 0) {
         load_L(0, cur);
-        for (int Q = 0; Q + 1 < nQ && ok; Q++) ok = consume(Q, [&] { load_L(Q + 1, nxt); });
-        if (ok) ok = consume(nQ - 1, [&] { load_inv(nxt); });      // the last hop prefetches the inverse tiles instead
-    } else {
-        load_inv(cur);
+        for (int Q = 0; Q + 1 < nQ && ok; Q++) {
+            ok = consume(Q, [&] { load_L(Q + 1, nxt); });
+#pragma unroll
+            for (int p = 0; p < kSbG; p++)
+#pragma unroll
+                for (int t = 0; t < NT; t++) cur[p][t] = nxt[p][t];
+        }
+        if (ok) ok = consume(nQ - 1, [] {});                       // the last hop has nothing left to request
     }
     put_part(red, wv, lr, a0 + a1);
     __syncthreads();
@@ -337,8 +388,9 @@ k_front_fwd_sb(DevPlan P, FrontDesc F, double *__restrict__ y, double *__restric
         double s0 = 0.0, s1 = 0.0;
 #pragma unroll
         for (int p = 0; p < kSbG; p++) {
-            s0 = fma(cur[p][0], rbuf[p][k0], s0);
-            s1 = fma(cur[p][1], rbuf[p][k0 + 32], s1);
+            const bool m0 = valid && (p < bl || k0 <= ir), m1 = valid && (p < bl || k0 + 32 <= ir);
+            s0 = fma(m0 ? inv[p][0] : 0.0, rbuf[p][k0], s0);
+            s1 = fma(m1 ? inv[p][1] : 0.0, rbuf[p][k0 + 32], s1);
         }
         put_part(red, wv, lr, s0 + s1);          // (the first reduction's reads finished before the barrier above)
     }
@@ -419,26 +471,25 @@ k_front_bwd_sb(DevPlan P, FrontDesc F, const double *__restrict__ z, double *__r
             }
         }
     };
-    auto load_inv = [&](double (&dst)[kSbG][NT]) {
+    // the inverse tiles Inv[p .. , p]^T of the own super-block: requested now, unconditionally, into registers of their own (see
+    // k_front_fwd_sb)
+    double inv[kSbG][NT];
 #pragma unroll
-        for (int cl = 0; cl < kSbG; cl++) {
-            if (cl > pl && cl < nbB) {           // (uniform) a full tile of the super-block inverse, row-major half
-                const double *tl = P.SbInv + sb_tile(F, B, cl, pl) + 4096;
+    for (int cl = 0; cl < kSbG; cl++) {
+        if (cl > pl && cl < nbB) {               // (uniform) a full tile of the super-block inverse, row-major half (columns past the width are zero)
+            const double *tl = P.SbInv + sb_tile(F, B, cl, pl) + 4096;
 #pragma unroll
-                for (int t = 0; t < NT; t++) dst[cl][t] = cvalid ? sb_ld(tl, (unsigned)((j0 + 32 * t) * 64 + kc) * 8u) : 0.0;
-            } else if (cl == pl) {               // the panel's own inverse, transposed copy: Linv[i][k] at [k + i w]
-                const double *lit = P.LinvT + me.diag_off;
+            for (int t = 0; t < NT; t++) inv[cl][t] = sb_ld(tl, (unsigned)((j0 + 32 * t) * 64 + kc) * 8u);
+        } else if (cl == pl) {                   // the panel's own inverse, transposed copy: Linv[i][k] at [k + i w]
+            const double *lit = P.LinvT + me.diag_off;
+            const int kcc = min(kc, w - 1);
 #pragma unroll
-                for (int t = 0; t < NT; t++) {
-                    const int i2 = j0 + 32 * t;
-                    dst[cl][t] = (cvalid && i2 >= kc && i2 < w) ? sb_ld(lit, (unsigned)(kc + i2 * w) * 8u) : 0.0;
-                }
-            } else {
+            for (int t = 0; t < NT; t++) inv[cl][t] = sb_ld(lit, (unsigned)(kcc + min(max(j0 + 32 * t, kcc), w - 1) * w) * 8u);
+        } else {
 #pragma unroll
-                for (int t = 0; t < NT; t++) dst[cl][t] = 0.0;
-            }
+            for (int t = 0; t < NT; t++) inv[cl][t] = 0.0;
         }
-    };
+    }
     auto consume = [&](int G, auto &&prefetch) -> bool {        // see k_front_fwd_sb
         const int Q = F.nsb - 1 - G;
         double (*xb)[64] = xbuf[G & 1];
@@ -459,19 +510,19 @@ k_front_bwd_sb(DevPlan P, FrontDesc F, const double *__restrict__ z, double *__r
             a0 = fma(cur[pp][0], xb[pp][j0], a0);
             a1 = fma(cur[pp][1], xb[pp][j0 + 32], a1);
         }
-#pragma unroll
-        for (int pp = 0; pp < kSbG; pp++)
-#pragma unroll
-            for (int t = 0; t < NT; t++) cur[pp][t] = nxt[pp][t];
         return true;
     };
     bool ok = true;
     if (nG > 0) {
         load_L(0, cur);
-        for (int G = 0; G + 1 < nG && ok; G++) ok = consume(G, [&] { load_L(G + 1, nxt); });
-        if (ok) ok = consume(nG - 1, [&] { load_inv(nxt); });
-    } else {
-        load_inv(cur);
+        for (int G = 0; G + 1 < nG && ok; G++) {
+            ok = consume(G, [&] { load_L(G + 1, nxt); });
+#pragma unroll
+            for (int pp = 0; pp < kSbG; pp++)
+#pragma unroll
+                for (int t = 0; t < NT; t++) cur[pp][t] = nxt[pp][t];
+        }
+        if (ok) ok = consume(nG - 1, [] {});
     }
     put_part(red, wv, lane & 31, a0 + a1);
     __syncthreads();
@@ -498,8 +549,9 @@ k_front_bwd_sb(DevPlan P, FrontDesc F, const double *__restrict__ z, double *__r
         double s0 = 0.0, s1 = 0.0;
 #pragma unroll
         for (int cl = 0; cl < kSbG; cl++) {
-            s0 = fma(cur[cl][0], sbuf[cl][j0], s0);
-            s1 = fma(cur[cl][1], sbuf[cl][j0 + 32], s1);
+            const bool m0 = cvalid && (cl > pl || (j0 >= kc && j0 < w)), m1 = cvalid && (cl > pl || (j0 + 32 >= kc && j0 + 32 < w));
+            s0 = fma(m0 ? inv[cl][0] : 0.0, sbuf[cl][j0], s0);
+            s1 = fma(m1 ? inv[cl][1] : 0.0, sbuf[cl][j0 + 32], s1);
         }
         put_part(red, wv, lane & 31, s0 + s1);
     }

@@ -686,6 +686,28 @@ int32_t hipkkt_debug_dump(hipkkt_handle h, int32_t what, double *out, int64_t ca
         case 19: host(1, [&](int64_t) { return (double)P.dtri.size(); }); break;   // dense triangles of K outside the symmetric view
         case 15: dev(S->d_fb_stream, std::max<int64_t>(S->fb_stream_doubles, 1)); break;   // stream records of the front batches (raw)
         case 16: dev(S->d_fb_scratch, (int64_t)kFbScratch * (int64_t)std::max<size_t>(S->fbatches.size(), 1)); break;
+        case 20: {   // the dense tiles of the plan, 6 values each: stage, tasks, sum of source widths, tasks through a tile map, full-tile
+                     // flag, sum over tasks of rows x columns x width (development: what a stage's update launch is made of)
+            std::vector<double> v;
+            const int nl = (int)P.upd_stage_ndense.size();
+            for (int l = 0; l < nl; l++)
+                for (int g = P.upd_stage_ptr[l]; g < P.upd_stage_ptr[l] + P.upd_stage_ndense[l]; g++) {
+                    const UpdGroup &G = P.upd_groups[g];
+                    double sumK = 0, mapped = 0, vol = 0;
+                    bool full = true;
+                    for (int t = G.task_begin; t < G.task_end; t++) {
+                        const UpdTask &T = P.upd_tasks[t];
+                        const int K = P.sn_first[T.src + 1] - P.sn_first[T.src];
+                        sumK += K; vol += (double)T.nrows * T.ncols * K;
+                        if (T.geom & (1 << 17)) mapped += 1;
+                        if (!(T.geom & (1 << 16)) || T.nrows != 64 || T.ncols != 64 || (K & 7)) full = false;
+                    }
+                    const double rec[6] = {(double)l, (double)(G.task_end - G.task_begin), sumK, mapped, full ? 1.0 : 0.0, vol};
+                    v.insert(v.end(), rec, rec + 6);
+                }
+            host((int64_t)v.size(), [&](int64_t i) { return v[i]; });
+            break;
+        }
         case 7: dev(S->d_soc_u, S->soc_total); break;
         case 8: dev(S->d_soc_v, S->soc_total); break;
         case 10: host(P.nsuper + 1, [&](int64_t i) { return P.sn_first[i]; }); break;

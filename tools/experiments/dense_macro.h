@@ -50,14 +50,6 @@ __device__ __forceinline__ void dense_macro_tile(double *Lx, const double *D, co
     double *tp = rfl_ptr(Lx + (wave == 0 ? G.tile_off[0] : wave == 1 ? G.tile_off[1] : wave == 2 ? G.tile_off[2] : G.tile_off[3]));
     const int rt = rfl(wj ? G.rt[1] : G.rt[0]);
 
-    v4f64 acc[4][4];               // acc[tj][ti][reg]: column tj * 16 + lk + 4 reg, row ti * 16 + l15 (dense_tile.h)
-#pragma unroll
-    for (int tj = 0; tj < 4; tj++)
-#pragma unroll
-        for (int reg = 0; reg < 4; reg++)
-#pragma unroll
-            for (int ti = 0; ti < 4; ti++) acc[tj][ti][reg] = ld_off(tp, (unsigned)(ti * 16 + l15 + (tj * 16 + lk + 4 * reg) * rt) * 8u);
-
     // ---- the fetch side runs P k-steps ahead of the matrix-core side and crosses task boundaries on its own.  Everything that
     //      changes from step to step is wave-uniform and lives in scalar registers: the base of a row range is panel + first row +
     //      (k0 + wave) * rows, the lane offset (lane * 8) never changes.  The task records wait in LDS (a task switch must not touch
@@ -101,6 +93,18 @@ __device__ __forceinline__ void dense_macro_tile(double *Lx, const double *D, co
     };
 #pragma unroll
     for (int u = 0; u < P; u++) issue(g[u]);
+    // the accumulators are requested AFTER the first operands (loads return in order: the first k-step only waits for its own row
+    // ranges and for the first quarter of the tile, not for all 32 KB of it)
+    v4f64 acc[4][4];               // acc[tj][ti][reg]: column tj * 16 + lk + 4 reg, row ti * 16 + l15 (dense_tile.h)
+#pragma unroll
+    for (int tj = 0; tj < 4; tj++) {
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++)
+#pragma unroll
+            for (int ti = 0; ti < 4; ti++) acc[tj][ti][reg] = ld_off(tp, (unsigned)(ti * 16 + l15 + (tj * 16 + lk + 4 * reg) * rt) * 8u);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
     // Three stages behind the fetch: ring slot -> LDS (one k-step ahead of its use) -> operand registers (read back right after the
     // barrier, while the matrix core works on the step before) -> matrix core.  One barrier per k-step; a slot's LDS buffer is
     // static (P even), and nobody can still be reading the buffer that is written: its reads were waited for at the barrier before.
@@ -160,11 +164,13 @@ __device__ __forceinline__ void dense_macro_tile(double *Lx, const double *D, co
         }
     }
 #pragma unroll
-    for (int tj = 0; tj < 4; tj++)
+    for (int tj = 0; tj < 4; tj++) {
 #pragma unroll
         for (int reg = 0; reg < 4; reg++)
 #pragma unroll
             for (int ti = 0; ti < 4; ti++) st_off(tp, (unsigned)(ti * 16 + l15 + (tj * 16 + lk + 4 * reg) * rt) * 8u, acc[tj][ti][reg]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
 }
 
 }  // namespace hipkkt

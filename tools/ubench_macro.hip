@@ -70,6 +70,14 @@ __global__ void __launch_bounds__(256, 2) k_base(const double *Lx, const double 
             for (int ti = 0; ti < 4; ti++) st_off(tp, (unsigned)(ti * 16 + l15 + (tj * 16 + lk + 4 * reg) * rt) * 8u, acc[tj][ti][reg]);
 }
 
+// the product's full-tile core (dense_tile.h), one wavefront per tile
+__global__ void __launch_bounds__(256, 2) k_prod(DevPlan P, const DenseGroup *dg, int ntiles) {
+    const int t = blockIdx.x * 4 + rfl(threadIdx.x >> 6);
+    if (t >= ntiles) return;
+    const DenseGroup G = dg[t];
+    dense_tile_core_full(P, rfl_ptr(P.Lx + G.tile_off), rfl(G.rt), rfl(G.task_begin), rfl(G.task_end), threadIdx.x & 63);
+}
+
 template <int P, int OCC>
 __global__ void __launch_bounds__(256, OCC) k_macro(DevPlanLite Pl, const MacroGroup *mg, const MacroTask *mt, int nmacro) {
     if ((int)blockIdx.x < nmacro) dense_macro_tile<P>(Pl.Lx, Pl.D, mg + blockIdx.x, mt);
@@ -121,11 +129,38 @@ int main(int argc, char **argv) {
         (void)hipMemcpy(res.data(), dL + src_d, tgt_d * 8, hipMemcpyDeviceToHost);
         printf("%-28s %8.1f us  %6.2f TFLOP/s  (%d tiles, K = %d)\n", name, best * 1e3, flops / (best * 1e-3) / 1e12, nmacro * 4, nsrc);
     };
+    {   // the same work as records of the product kernel
+        std::vector<DenseGroup> pg((size_t)nmacro * 4);
+        std::vector<DenseTask> pt((size_t)nmacro * 4 * ntask);
+        for (int m = 0; m < nmacro; m++)
+            for (int w = 0; w < 4; w++) {
+                DenseGroup &G = pg[(size_t)m * 4 + w];
+                G.tile_off = mg[m].tile_off[w]; G.rt = 64; G.nrt = 64; G.wt = 64; G.pad = 1;
+                G.task_begin = (int)((size_t)(m * 4 + w) * ntask); G.task_end = G.task_begin + ntask;
+                for (int q = 0; q < ntask; q++) {
+                    const MacroTask &T = mt[(size_t)m * ntask + q];
+                    DenseTask &X = pt[(size_t)G.task_begin + q];
+                    X = DenseTask{};
+                    X.panel_off = T.panel_off; X.r8 = T.r8; X.K = T.K; X.dfirst = T.dfirst;
+                    X.row_lo = T.row_off[w >> 1]; X.nrows = 64; X.col_lo = T.row_off[2 + (w & 1)]; X.ncols = 64;
+                }
+            }
+        DenseGroup *dpg; DenseTask *dpt;
+        CK(hipMalloc(&dpg, pg.size() * sizeof(DenseGroup))); CK(hipMalloc(&dpt, pt.size() * sizeof(DenseTask)));
+        CK(hipMemcpy(dpg, pg.data(), pg.size() * sizeof(DenseGroup), hipMemcpyHostToDevice));
+        CK(hipMemcpy(dpt, pt.data(), pt.size() * sizeof(DenseTask), hipMemcpyHostToDevice));
+        DevPlan DP{};
+        DP.Lx = dL; DP.D = dD; DP.dtasks = dpt;
+        run("product core (wave per tile)", [&] { hipLaunchKernelGGL(k_prod, dim3(nmacro), dim3(256), 0, 0, DP, dpg, nmacro * 4); }, ref);
+    }
+    std::vector<double> prod = ref;
     run("base (wave per tile, occ 2)", [&] { hipLaunchKernelGGL(k_base, dim3(nmacro), dim3(256), 0, 0, dL, dD, dg, dt, nmacro); }, ref);
+    { double e = 0; for (size_t i = 0; i < tgt_d; i++) e = std::fmax(e, std::fabs(prod[i] - ref[i])); printf("    product vs base: max |diff| = %.3e\n", e); }
     auto cmp = [&](const char *name) {
         double e = 0; for (size_t i = 0; i < tgt_d; i++) e = std::fmax(e, std::fabs(out[i] - ref[i]));
         printf("    %s vs base: max |diff| = %.3e\n", name, e);
     };
+    run("macro P=2 occ 2", [&] { hipLaunchKernelGGL((k_macro<2, 2>), dim3(nmacro), dim3(256), 0, 0, Pl, dg, dt, nmacro); }, out); cmp("macro P=2");
     run("macro P=4 occ 2", [&] { hipLaunchKernelGGL((k_macro<4, 2>), dim3(nmacro), dim3(256), 0, 0, Pl, dg, dt, nmacro); }, out); cmp("macro P=4");
     run("macro P=8 occ 2", [&] { hipLaunchKernelGGL((k_macro<8, 2>), dim3(nmacro), dim3(256), 0, 0, Pl, dg, dt, nmacro); }, out); cmp("macro P=8");
     run("macro P=4 occ 1", [&] { hipLaunchKernelGGL((k_macro<4, 1>), dim3(nmacro), dim3(256), 0, 0, Pl, dg, dt, nmacro); }, out); cmp("macro P=4 occ1");

@@ -6,8 +6,8 @@
 #include <cstdio>
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void bar() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-template <int MODE>
-__global__ void __launch_bounds__(256, 1) k_mix(const double *src, double *out, int steps) {
+template <int MODE, int OCC>
+__global__ void __launch_bounds__(256, OCC) k_mix(const double *src, double *out, int steps) {
     __shared__ double sb[2][1280];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lk = lane >> 4;
     v4f64 acc[4][4];
@@ -43,16 +43,19 @@ __global__ void __launch_bounds__(256, 1) k_mix(const double *src, double *out, 
     out[(size_t)blockIdx.x * 256 + tid] = sacc;
 }
 int main() {
-    double *src, *out; hipMalloc(&src, (size_t)64 * 5 * 4096 * 8 + 256 * 64 * 8); hipMalloc(&out, 256 * 256 * 8);
-    hipMemset(src, 0, (size_t)64 * 5 * 4096 * 8 + 256 * 64 * 8);
+    double *src, *out; hipMalloc(&src, (size_t)64 * 5 * 4096 * 8 + 1024 * 64 * 8); hipMalloc(&out, 1024 * 256 * 8);
+    hipMemset(src, 0, (size_t)64 * 5 * 4096 * 8 + 1024 * 64 * 8);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const int steps = 80;
-    auto run = [&](const char *nm, auto k) {
+    auto run = [&](const char *nm, auto k, int wgs) {
         float best = 1e30f;
-        for (int rep = 0; rep < 5; rep++) { hipEventRecord(e0, 0); hipLaunchKernelGGL(k, dim3(256), dim3(256), 0, 0, src, out, steps); hipEventRecord(e1, 0); hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms, e0, e1); best = ms < best ? ms : best; }
-        printf("%-44s %7.1f us  = %5.1f cycles at 2.4 GHz per matrix-core instruction, %5.1f TFLOP/s\n", nm, best * 1e3, best * 1e-3 * 2.4e9 / (steps * 16), 1024.0 * steps * 16 * 2048 / (best * 1e-3) / 1e12);
+        for (int rep = 0; rep < 5; rep++) { hipEventRecord(e0, 0); hipLaunchKernelGGL(k, dim3(wgs), dim3(256), 0, 0, src, out, steps); hipEventRecord(e1, 0); hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms, e0, e1); best = ms < best ? ms : best; }
+        printf("%-58s %7.1f us  = %5.1f cycles at 2.4 GHz per instruction and SIMD, %5.1f TFLOP/s\n", nm, best * 1e3, best * 1e-3 * 2.4e9 / (steps * 16 * (wgs / 256.0)), 1024.0 * steps * 16 * 2.0 * wgs * 4 / (best * 1e-3) / 1e12);
     };
-    run("0 matrix core only", k_mix<0>); run("1 + 8 LDS reads per step", k_mix<1>); run("2 + LDS barrier per step", k_mix<2>);
-    run("3 + 4 LDS writes per step", k_mix<3>); run("4 + 5 global loads per step, 4 steps ahead", k_mix<4>); run("5 = 4, barrier in the middle", k_mix<5>);
+    run("0 matrix core only, 1 wavefront per SIMD", k_mix<0, 1>, 256); run("1 + 8 LDS reads per step", k_mix<1, 1>, 256); run("2 + LDS barrier per step", k_mix<2, 1>, 256);
+    run("3 + 4 LDS writes per step", k_mix<3, 1>, 256); run("4 + 5 global loads per step, 4 steps ahead", k_mix<4, 1>, 256); run("5 = 4, barrier in the middle", k_mix<5, 1>, 256);
+    run("0 matrix core only, 2 wavefronts per SIMD (512 workgroups)", k_mix<0, 2>, 512); run("4 with 2 wavefronts per SIMD", k_mix<4, 2>, 512);
+    run("0 matrix core only, 4 wavefronts per SIMD (1024 workgroups)", k_mix<0, 4>, 1024);
+    run("0 matrix core only, 1 wavefront per SIMD, 64 workgroups only", k_mix<0, 1>, 64);
     return 0;
 }
