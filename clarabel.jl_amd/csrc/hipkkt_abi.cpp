@@ -708,6 +708,21 @@ int32_t hipkkt_debug_dump(hipkkt_handle h, int32_t what, double *out, int64_t ca
             host((int64_t)v.size(), [&](int64_t i) { return v[i]; });
             break;
         }
+        case 21: {   // per supernode solved in a persistent segment sweep (dump 14): level, width, rows, longest and mean gather list
+                     // of its row slots (development: what a hop of k_fwd_seg waits for)
+            std::vector<double> v;
+            for (int s = 0; s < P.nsuper; s++) {
+                if (!(P.sn_front[s] < 0 && P.sn_level[s] >= S->seg_lstar[S->seg_of_level[P.sn_level[s]]])) continue;
+                const int64_t a = P.sn_rowptr[s], b = P.sn_rowptr[s + 1];
+                int64_t mx = 0;
+                for (int64_t q = a; q < b; q++) mx = std::max<int64_t>(mx, P.g_ptr[q + 1] - P.g_ptr[q]);
+                const double rec[5] = {(double)P.sn_level[s], (double)(P.sn_first[s + 1] - P.sn_first[s]), (double)(b - a), (double)mx,
+                                       (double)(P.g_ptr[b] - P.g_ptr[a]) / (double)std::max<int64_t>(b - a, 1)};
+                v.insert(v.end(), rec, rec + 5);
+            }
+            host((int64_t)v.size(), [&](int64_t i) { return v[i]; });
+            break;
+        }
         case 7: dev(S->d_soc_u, S->soc_total); break;
         case 8: dev(S->d_soc_v, S->soc_total); break;
         case 10: host(P.nsuper + 1, [&](int64_t i) { return P.sn_first[i]; }); break;

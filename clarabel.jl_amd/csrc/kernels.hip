@@ -1543,15 +1543,21 @@ k_fwd_seg(DevPlan P, int seg, int item_begin, int nitems, int nsuper, int first_
         liv[t2] = (i < w && k <= i) ? li[i + k * w] : 0.0;
         pv[t2] = (row < r && k < w) ? pan[row + (int64_t)k * r] : 0.0;
     }
+    // (kSegGath indices per slot: a row of a supernode high in the tree collects one entry per child that reaches it -- up to 12 on
+    // the random QPs of the benchmark -- and every entry past the prefetched ones costs two dependent round trips, index then value,
+    // on the critical path of the level)
+    constexpr int kSegGath = 12;
     int64_t ga0 = 0, ga1 = 0, gb0 = 0, gb1 = 0;
-    int ia[4] = {0, 0, 0, 0}, ib[4] = {0, 0, 0, 0};   // the first gather indices of this thread's slots
+    int ia[kSegGath], ib[kSegGath];                   // the first gather indices of this thread's slots
+#pragma unroll
+    for (int q = 0; q < kSegGath; q++) { ia[q] = 0; ib[q] = 0; }
     double yin = 0.0, dinv_own = 0.0;
     if (tid < w) {
         dinv_own = P.Dinv[f + tid];
         ga0 = P.g_ptr[slot0 + tid];
         ga1 = P.g_ptr[slot0 + tid + 1];
 #pragma unroll
-        for (int q = 0; q < 4; q++)
+        for (int q = 0; q < kSegGath; q++)
             if (ga0 + q < ga1) ia[q] = P.g_idx[ga0 + q];
         yin = y[f + tid];
     }
@@ -1559,7 +1565,7 @@ k_fwd_seg(DevPlan P, int seg, int item_begin, int nitems, int nsuper, int first_
         gb0 = P.g_ptr[slot0 + row];
         gb1 = P.g_ptr[slot0 + row + 1];
 #pragma unroll
-        for (int q = 0; q < 4; q++)
+        for (int q = 0; q < kSegGath; q++)
             if (gb0 + q < gb1) ib[q] = P.g_idx[gb0 + q];
     }
     // ---- dependencies: every block of every same-segment child has been published; the children count
@@ -1571,23 +1577,30 @@ k_fwd_seg(DevPlan P, int seg, int item_begin, int nitems, int nsuper, int first_
     }
     __syncthreads();
     if (!sb) return;
+    // the sums run left to right over the list (the first four always take part, absent entries as 0.0: the order of rounds 2 - 5)
     if (tid < w) {
-        double u4[4];
+        double u[kSegGath];
 #pragma unroll
-        for (int q = 0; q < 4; q++) u4[q] = ga0 + q < ga1 ? front_ld(P.ubuf + ia[q]) : 0.0;   // in flight together
-        double acc = ((u4[0] + u4[1]) + u4[2]) + u4[3];
-        for (int64_t g = ga0 + 4; g < ga1; g++) acc += front_ld(P.ubuf + P.g_idx[g]);
+        for (int q = 0; q < kSegGath; q++) u[q] = ga0 + q < ga1 ? front_ld(P.ubuf + ia[q]) : 0.0;   // in flight together
+        double acc = ((u[0] + u[1]) + u[2]) + u[3];
+#pragma unroll
+        for (int q = 4; q < kSegGath; q++)
+            if (ga0 + q < ga1) acc += u[q];
+        for (int64_t g = ga0 + kSegGath; g < ga1; g++) acc += front_ld(P.ubuf + P.g_idx[g]);
         rhs[tid] = yin - acc;
     } else if (tid < kMaxSnWidth) {
         rhs[tid] = 0.0;   // padded columns meet zero weights: keep them finite
     }
     double gsum = 0.0;
     if (pq == 0 && row < r) {
-        double u4[4];
+        double u[kSegGath];
 #pragma unroll
-        for (int q = 0; q < 4; q++) u4[q] = gb0 + q < gb1 ? front_ld(P.ubuf + ib[q]) : 0.0;
-        gsum = ((u4[0] + u4[1]) + u4[2]) + u4[3];
-        for (int64_t g = gb0 + 4; g < gb1; g++) gsum += front_ld(P.ubuf + P.g_idx[g]);
+        for (int q = 0; q < kSegGath; q++) u[q] = gb0 + q < gb1 ? front_ld(P.ubuf + ib[q]) : 0.0;
+        gsum = ((u[0] + u[1]) + u[2]) + u[3];
+#pragma unroll
+        for (int q = 4; q < kSegGath; q++)
+            if (gb0 + q < gb1) gsum += u[q];
+        for (int64_t g = gb0 + kSegGath; g < gb1; g++) gsum += front_ld(P.ubuf + P.g_idx[g]);
     }
     __syncthreads();
     {   // y_J = L11^-1 rhs (explicit inverse; thread (i, pq) owns the columns k = pq + 4t <= i)
@@ -1740,11 +1753,33 @@ k_bwd_seg(DevPlan P, int seg, int item_begin, int nitems, int nsuper, int first_
     if (nblk > 1) {
         double a = 0.0;
         if (lane < w) {
+            // kSegPoll slots per round trip (round 6: one dependent poll per block made the finaliser of a 4500-row panel wait
+            // 18 round trips after the last partial sum had arrived); the sum still runs over b2 = wave, wave + 4, ... in order
+            constexpr int kSegPoll = 8;
             const FrontSlot *pb = P.pseg + P.p_off[s] + lane;
-            for (int b2 = wave; b2 < nblk && ok; b2 += 4) {
-                double v = 0.0;
-                ok = seg_slot_poll(pb + (int64_t)b2 * w, key, v, Y.err, P.flags + FL_FRONTFAIL, P.spin_limit);
-                a += v;
+            for (int b0 = wave; b0 < nblk && ok; b0 += 4 * kSegPoll) {
+                double v[kSegPoll];
+                bool got[kSegPoll];
+#pragma unroll
+                for (int u = 0; u < kSegPoll; u++) { v[u] = 0.0; got[u] = b0 + 4 * u >= nblk; }
+                unsigned spins = 0;
+                while (true) {
+                    bool all = true;
+#pragma unroll
+                    for (int u = 0; u < kSegPoll; u++) {
+                        if (!got[u]) {
+                            const FrontSlot sl = front_slot_ld(pb + (int64_t)(b0 + 4 * u) * w);
+                            if (((unsigned long long)__double_as_longlong(sl.v) ^ sl.h) == key) { v[u] = sl.v; got[u] = true; }
+                            else all = false;
+                        }
+                    }
+                    if (all) break;
+                    ok = seg_spin_check(spins, Y.err, P.flags + FL_FRONTFAIL, P.spin_limit);
+                    if (!ok) break;
+                }
+#pragma unroll
+                for (int u = 0; u < kSegPoll; u++)
+                    if (b0 + 4 * u < nblk) a += v[u];
             }
         }
         if (!ok) { bad = 1; atomicOr(P.flags + FL_FRONTFAIL, 4); }   // bit 2: the backward segment sweep gave up

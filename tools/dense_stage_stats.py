@@ -28,6 +28,12 @@ def main():
         print("%6d %6d %5d  %8.1f %5d  %12.1f  %7.1f  %6.1f  %6.2f  %5.1f" % (
             l, len(s), s[:, 4].sum(), s[:, 1].mean(), s[:, 1].max(), s[:, 2].mean(), s[:, 2].sum() / nt, 100 * s[:, 3].sum() / nt,
             2 * s[:, 5].sum() / 1e9, 100 * s[:, 5].sum() / (4096 * s[:, 2].sum())))
+    g = h.debug_dump(21).reshape(-1, 5)
+    print("persistent segment sweeps:", len(g), "supernodes")
+    print(" level  supernodes  width(mean)  rows(mean max)  longest gather list (mean max)  entries per row slot")
+    for l in np.unique(g[:, 0]):
+        s = g[g[:, 0] == l]
+        print("%6d %8d %10.1f %10.1f %6d %14.1f %6d %14.2f" % (l, len(s), s[:, 1].mean(), s[:, 2].mean(), s[:, 2].max(), s[:, 3].mean(), s[:, 3].max(), s[:, 4].mean()))
 
 
 if __name__ == "__main__":
