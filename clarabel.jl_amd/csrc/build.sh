@@ -6,7 +6,7 @@
 set -e
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-result"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-result $HIPKKT_EXTRA_FLAGS"   # (development: e.g. -DHIPKKT_SWEEP_TRACE)
 mkdir -p ../../build/obj ../../build/obj_testing
 HOSTSRC="hipkkt_abi.cpp hipkkt_setup.cpp hipkkt_factor.cpp hipkkt_solve.cpp symbolic.cpp ordering.cpp assemble.cpp"
 # kernels are identical in both builds (nothing in a .hip file depends on HIPKKT_TESTING): compiled once

@@ -23,6 +23,13 @@
 #include "kernels.h"
 #include "sweep_common.h"
 
+#ifdef HIPKKT_SWEEP_TRACE
+__device__ long long g_sweep_trace[8 * 512];
+#define SWT(i) do { if (threadIdx.x == 0) g_sweep_trace[tk * 8 + (i)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+extern "C" int hipkkt_debug_sweep_trace(long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sweep_trace), sizeof(long long) * 8 * 512); }
+#else
+#define SWT(i) do { } while (0)
+#endif
 namespace hipkkt {
 
 typedef double v4f64 __attribute__((ext_vector_type(4)));
@@ -55,161 +62,159 @@ static_assert(NW == 16 && NT == 2, "the half-tile thread map assumes 16 wavefron
 
 // ------------------------------------------------------------------------------------------
 // Inverse of the super-blocks' diagonal blocks: Inv[b,c] = -Linv_b * sum_{c <= k < b} L[b,k] Inv[k,c]  (Inv[c,c] = Linv_c, the
-// per-panel inverse of k_invert_diag / k_invert_diag_wide).  One workgroup per (super-block, column c); the 64 x 64 x 64 products
-// run on the matrix core with both operands in LDS.  Tiles are padded to 64 x 64 with zeros (panels narrower than 64 columns).
+// per-panel inverse of k_invert_diag / k_invert_diag_wide); the 64 x 64 x 64 products run on the matrix core.  Tiles are padded to
+// 64 x 64 with zeros (panels narrower than 64 columns).
 // ------------------------------------------------------------------------------------------
-// 1024 threads = 16 wavefronts, wavefront v forms the 16 x 16 piece (v >> 2, v & 3) of every product; the two operand tiles of a
-// product are fetched together (4 + 4 values per thread in flight) before they go to LDS.
-constexpr int kInvThreads = 1024;
-struct SbTileSrc {            // where a 64 x 64 operand comes from: value(i, k) = (i < ni && k < nk && (!lower || k <= i)) ? base[i * si + k * sk] : 0
-    const double *base;
-    int64_t si, sk;
-    int ni, nk;
-    bool lower, coherent;     // coherent: written earlier by this workgroup (read past the CU's L1)
-};
-__device__ __forceinline__ void sb_fetch(const SbTileSrc &T, double (&v)[4], int tid) {
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const int idx = tid + kInvThreads * q, i = idx & 63, k = idx >> 6;
-        const bool in = i < T.ni && k < T.nk && (!T.lower || k <= i);
-        const double *p = T.base + i * T.si + k * T.sk;
-        v[q] = in ? (T.coherent ? front_ld(p) : *p) : 0.0;
-    }
-}
-// the same in two halves for operands requested several products ahead: the loads are UNCONDITIONAL (addresses clamped into the
-// tile: a load under a per-lane condition sits in a branch, and the register copies at the join of that branch wait for every
-// load in flight), the zero padding is applied when the values go to LDS
-__device__ __forceinline__ void sb_fetch_raw(const SbTileSrc &T, double (&v)[4], int tid) {
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const int idx = tid + kInvThreads * q, i = min(idx & 63, T.ni - 1), k = min(idx >> 6, T.nk - 1);
-        v[q] = T.base[i * T.si + k * T.sk];
-    }
-}
-__device__ __forceinline__ void sb_put_masked(double *S, const double (&v)[4], int tid, int ni, int nk, bool lower) {
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const int idx = tid + kInvThreads * q, i = idx & 63, k = idx >> 6;
-        S[i * SLD + k] = (i < ni && k < nk && (!lower || k <= i)) ? v[q] : 0.0;
-    }
-}
-__device__ __forceinline__ void sb_put(double *S, const double (&v)[4], int tid) {      // S[row * SLD + col]
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const int idx = tid + kInvThreads * q;
-        S[(idx & 63) * SLD + (idx >> 6)] = v[q];
-    }
-}
-// c += A(rows 16 ti ..) * B(:, 16 tj ..); output layout: column 16 tj + l15, rows 16 ti + lk + 4 reg
-__device__ __forceinline__ void sb_mm16(const double *A, const double *Bm, v4f64 &c, int ti, int tj, int l15, int lk) {
-#pragma unroll 4
-    for (int kk = 0; kk < 16; kk++)
-        c = __builtin_amdgcn_mfma_f64_16x16x4f64(A[(16 * ti + l15) * SLD + 4 * kk + lk], Bm[(4 * kk + lk) * SLD + 16 * tj + l15], c, 0, 0, 0);
-}
-
-// The chain of a super-block's first column is 28 + 7 dependent 64 x 64 x 64 products.  What a product costs on it: two LDS stores,
-// two barriers and 16 matrix-core instructions per wavefront -- and NOT a memory round trip:
-//   * the B operands Inv[kl,cl] are the workgroup's own earlier results: they stay in registers (7 tiles x 4 values per thread)
-//     instead of being read back from memory past the L1 (round 3: that round trip was half of the 3.7 us per product of the first
-//     version, 129 us per launch on cfg 2a);
-//   * the A operands L[bl,kl] / Linv_bl come through a ring of FOUR register sets, requested three products ahead, and the barriers
-//     wait for LDS only (round 6: `__syncthreads()` also waits for every global load in flight, i.e. each product paid the full
-//     latency of the operand requested one product earlier: 3.0 us per product, 105 us per launch on cfg 2a).
-// The products, their operands and the order of accumulation are unchanged: bit-identical results.
-__device__ __forceinline__ void sb_bar() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// The chain of a super-block's first column is 28 + 7 dependent 64 x 64 x 64 products -- 1.7 us of FP64 matrix work EACH on one
+// compute unit, whatever else is done well (rounds 3 - 5: one workgroup of 16 wavefronts per (super-block, column), ~3 us per
+// product, 105 us per launch on cfg 2a).  Round 6: the columns of an inverse are independent of each other (Inv[:,cl] = L^-1 applied
+// to a block of unit vectors, everything is a multiplication from the LEFT), so a column block is cut into kInvSlices slices of 16
+// columns, one workgroup of FOUR wavefronts each (wavefront v = the rows 16 v .. 16 v + 15 of every tile):
+//   * a product is 16 matrix-core instructions per wavefront, one wavefront per SIMD;
+//   * the A operand (16 rows x 64 of L[bl,kl] or Linv_bl) goes from memory straight into the wavefront's registers in operand layout,
+//     unconditionally (clamped addresses; the zero padding is applied at the use), through a ring of kInvRing sets requested
+//     kInvRing - 1 products ahead;
+//   * the B operands Inv[kl,cl][:, slice] are the workgroup's own earlier results: they stay in LDS for the whole kernel (7 x 8 KB),
+//     so there is NO barrier between the products of a row -- only two per row (the sum S is exchanged between the wavefronts before
+//     the closing product with Linv_bl, and the new tile is published to the other wavefronts).
+// Every element still sums the same products in the same order (k = 0 .. 63 inside a product, the products of a row in the order of
+// their columns): bit-identical to the earlier forms.
+constexpr int kInvThreads = 256;
+constexpr int kInvSlices = 4;
 constexpr int kInvRing = 4;
 // row jb of operand m in the list "for jb = 1 .. : jb tiles of L, then Linv": first(jb) = (jb - 1)(jb + 2) / 2
 __host__ __device__ constexpr int sb_op_row(int m) {
     return m < 2 ? 1 : m < 5 ? 2 : m < 9 ? 3 : m < 14 ? 4 : m < 20 ? 5 : m < 27 ? 6 : m < 35 ? 7 : 8;
 }
 static_assert(kSbG == 8 && sb_op_row(1) == 1 && sb_op_row(2) == 2 && sb_op_row(34) == 7 && sb_op_row(35) == 8, "operand list of k_invert_super");
+__device__ __forceinline__ void sb_bar() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <bool CW64>                     // the front's panels are 64 wide (all but its last one): FrontDesc::cw == 64
 __global__ void __launch_bounds__(kInvThreads)
 k_invert_super(DevPlan P, FrontDesc F) {
-    __shared__ double SA[64 * SLD], SB[64 * SLD];
+    __shared__ double Bs[kSbG - 1][64 * 16];      // Bs[j][k * 16 + c] = Inv[cl + j, cl](k, 16 slice + c)
+    __shared__ double Ss[64 * 16];
     __shared__ int64_t s_off[kSbG];
     __shared__ int s_r[kSbG], s_w[kSbG];
     __shared__ int64_t s_diag[kSbG];
-    const int B = blockIdx.x / (kSbG - 1), cl = blockIdx.x % (kSbG - 1);
+    // the long chains (cl = 0) first: blockIdx = (cl, super-block, slice)
+    const int per_cl = F.nsb * kInvSlices;
+    const int cl = blockIdx.x / per_cl, B = (blockIdx.x % per_cl) / kInvSlices, sl = blockIdx.x % kInvSlices;
     const int nbB = min(kSbG, F.np - kSbG * B);
     if (cl + 1 >= nbB) return;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, lk = lane >> 4, ti = wv >> 2, tj = wv & 3;
+    const int tid = threadIdx.x, lane = tid & 63, wv = sb_rfl(tid >> 6), l15 = lane & 15, lk = lane >> 4;
     const FrontPanel *fps = P.front_panels + F.fp_off;
     if (tid < nbB) {
         const FrontPanel q = fps[kSbG * B + tid];
         s_off[tid] = q.panel_off; s_r[tid] = q.r; s_w[tid] = q.w; s_diag[tid] = q.diag_off;
     }
     __syncthreads();
-    auto a_src = [&](int bl, int kl) {   // L[bl,kl]: rows of block bl inside panel kl (column-major, stride r)
-        return SbTileSrc{P.Lx + s_off[kl] + F.cw * (bl - kl), 1, s_r[kl], s_w[bl], s_w[kl], false, false};
-    };
-    auto linv_src = [&](int b) { return SbTileSrc{P.Linv + s_diag[b], 1, s_w[b], s_w[b], s_w[b], true, false}; };
-    double inv[kSbG - 1][4];              // Inv[cl + j, cl] in the thread layout of sb_put (value (i, k) at idx = tid + 1024 q: i = idx & 63, k = idx >> 6)
-    sb_fetch(linv_src(cl), inv[0], tid);
-    // the A operands in the order of their use: for jb = 1 .. 7: L[cl + jb, cl + jk] (jk = 0 .. jb - 1), then Linv_{cl + jb}: operand
-    // m = first(jb) + jk with first(jb) = (jb - 1)(jb + 2) / 2.  The requests run kInvRing - 1 products ahead; every index below is a
-    // compile-time constant after unrolling .
-    double ring[kInvRing][4];
-    auto fetch_op = [&](int m) {          // m: compile-time
+    const int wcl = s_w[cl];
+    {   // Inv[cl,cl] = Linv_cl: this slice's 16 columns, zero-padded lower triangle
+        const double *li = P.Linv + s_diag[cl];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int idx = tid + kInvThreads * q, k = idx >> 4, c = idx & 15, col = 16 * sl + c;
+            Bs[0][idx] = (k < wcl && col <= k) ? li[k + col * wcl] : 0.0;
+        }
+    }
+    // The A operands in the order of their use: for jb = 1 .. 7: L[cl + jb, cl + jk] (jk = 0 .. jb - 1), then Linv_{cl + jb}: operand
+    // m = first(jb) + jk.  This lane's part of an operand: row i = 16 wv + l15, columns k = 4 kk + lk (kk = 0 .. 15).
+    const int irow = 16 * wv + l15;
+    double ring[kInvRing][16];
+    auto fetch_op = [&](int m) {          // m: compile-time after unrolling
         const int fjb = sb_op_row(m), fjk = m - ((fjb - 1) * (fjb + 2)) / 2;
-        if (fjb < kSbG && cl + fjb < nbB) {                  // workgroup-uniform; past the end of the super-block nothing is requested
-            if (fjk < fjb) sb_fetch_raw(a_src(cl + fjb, cl + fjk), ring[m % kInvRing], tid);
-            else sb_fetch_raw(linv_src(cl + fjb), ring[m % kInvRing], tid);
+        if (fjb < kSbG) {                 // (compile-time)
+            // Past the end of a short super-block the request is repeated for its last row instead of being skipped: a load
+            // under a condition makes the compiler wait for ALL loads at the next use of an earlier one (it must be right on the
+            // path without the load).  cl + 1 < nbB holds for every workgroup that gets here.
+            const int bl = min(cl + fjb, nbB - 1), wb = s_w[bl];
+            const int ic = min(irow, wb - 1);
+            if (fjk < fjb) {
+                // rows past the block's width and columns past the source panel's width need no zeroing here: they meet zero rows of
+                // the B operand / zero columns of Linv_bl; the addresses only have to stay inside the panel
+                const int kl = min(cl + fjk, bl - 1), wk = sb_rfl(s_w[kl]), rk = sb_rfl(s_r[kl]);
+                const double *base = P.Lx + sb_rfl64(s_off[kl]) + F.cw * (bl - kl);
+                if (CW64) {               // uniform base per k-step + one lane offset, no vector arithmetic (kl is never the front's last panel)
+                    const unsigned lo = (unsigned)(ic + lk * rk) * 8u;
+#pragma unroll
+                    for (int kk = 0; kk < 16; kk++) ring[m % kInvRing][kk] = sb_ld(base + (int64_t)(4 * kk) * rk, lo);
+                } else {
+#pragma unroll
+                    for (int kk = 0; kk < 16; kk++) ring[m % kInvRing][kk] = base[ic + (int64_t)min(4 * kk + lk, wk - 1) * rk];
+                }
+            } else {
+                const double *base = P.Linv + s_diag[bl] + ic;
+#pragma unroll
+                for (int kk = 0; kk < 16; kk++) ring[m % kInvRing][kk] = base[min(4 * kk + lk, ic) * wb];
+            }
         }
     };
-    auto put_op = [&](int m) {            // operand m -> SA, zero-padded
+    // value of operand m at kk with its zero pattern
+    auto a_val = [&](int m, int kk) -> double {
         const int fjb = sb_op_row(m), fjk = m - ((fjb - 1) * (fjb + 2)) / 2;
-        if (fjk < fjb) sb_put_masked(SA, ring[m % kInvRing], tid, s_w[cl + fjb], s_w[cl + fjk], false);
-        else sb_put_masked(SA, ring[m % kInvRing], tid, s_w[cl + fjb], s_w[cl + fjb], true);
+        if (fjk < fjb) return ring[m % kInvRing][kk];
+        return (irow < s_w[cl + fjb] && 4 * kk + lk <= irow) ? ring[m % kInvRing][kk] : 0.0;   // Linv_bl: lower triangle of a w x w block
     };
 #pragma unroll
     for (int u = 0; u < kInvRing - 1; u++) fetch_op(u);
-    // one row of the inverse; jb is a template constant (seven instances: a `#pragma unroll` over the rows exceeded the unroller's
-    // size limit with the ring in the body, and everything fell back to scratch memory)
-    auto row = [&](auto jb_c) {
+    sb_bar();                             // Bs[0] is complete
+    // the rows are nested (row jb + 1 inside the branch of row jb), not a sequence of seven branches: see fetch_op
+    auto row = [&](auto &&self, auto jb_c) -> void {
         constexpr int jb = decltype(jb_c)::value;
         const int bl = cl + jb;
         if (bl < nbB) {                   // workgroup-uniform
             constexpr int n0 = ((jb - 1) * (jb + 2)) / 2;    // index of this row's first product
-            v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+            // four partial sums (k-steps kk = c mod 4), added at the end: a matrix-core instruction that takes the result of the one
+            // before it waits ~200 cycles, four independent chains issue back to back
+            v4f64 pa[4];
+#pragma unroll
+            for (int c = 0; c < 4; c++) pa[c] = v4f64{0.0, 0.0, 0.0, 0.0};
+            // the B operands of a product are read from LDS while the matrix core works on the product before it
+            double bv[2][16];
+#pragma unroll
+            for (int kk = 0; kk < 16; kk++) bv[0][kk] = Bs[0][(4 * kk + lk) * 16 + l15];
 #pragma unroll
             for (int jk = 0; jk < jb; jk++) {
                 const int n = n0 + jk;
                 fetch_op(n + kInvRing - 1);
-                put_op(n);
-                sb_put(SB, inv[jk], tid);
-                sb_bar();
-                sb_mm16(SA, SB, acc, ti, tj, l15, lk);
-                sb_bar();
+                if (jk + 1 < jb) {
+#pragma unroll
+                    for (int kk = 0; kk < 16; kk++) bv[(jk + 1) & 1][kk] = Bs[jk + 1 < kSbG - 1 ? jk + 1 : 0][(4 * kk + lk) * 16 + l15];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int kk = 0; kk < 16; kk++)
+                    pa[kk & 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_val(n, kk), bv[jk & 1][kk], pa[kk & 3], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
+            const v4f64 acc = (pa[0] + pa[1]) + (pa[2] + pa[3]);
             constexpr int n = n0 + jb;
-            // Inv[bl,cl] = -Linv_bl * S
+            // Inv[bl,cl] = -Linv_bl * S: S changes hands between the wavefronts (this one holds the rows 16 wv + lk + 4 reg)
             fetch_op(n + kInvRing - 1);
 #pragma unroll
-            for (int reg = 0; reg < 4; reg++) SB[(16 * ti + lk + 4 * reg) * SLD + 16 * tj + l15] = acc[reg];
-            put_op(n);
+            for (int reg = 0; reg < 4; reg++) Ss[(16 * wv + lk + 4 * reg) * 16 + l15] = acc[reg];
             sb_bar();
-            v4f64 o = {0.0, 0.0, 0.0, 0.0};
-            sb_mm16(SA, SB, o, ti, tj, l15, lk);
-            sb_bar();
+            v4f64 po[4];
 #pragma unroll
-            for (int reg = 0; reg < 4; reg++) SA[(16 * ti + lk + 4 * reg) * SLD + 16 * tj + l15] = -o[reg];
-            sb_bar();
+            for (int c = 0; c < 4; c++) po[c] = v4f64{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int kk = 0; kk < 16; kk++) po[kk & 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_val(n, kk), Ss[(4 * kk + lk) * 16 + l15], po[kk & 3], 0, 0, 0);
+            const v4f64 o = (po[0] + po[1]) + (po[2] + po[3]);
             double *t = P.SbInv + sb_tile(F, B, bl, cl);
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const int idx = tid + kInvThreads * q;
-                const double v = SA[(idx & 63) * SLD + (idx >> 6)];
-                t[idx] = v;                                                      // column-major half [i + 64 k]
-                t[4096 + idx] = SA[(idx >> 6) * SLD + (idx & 63)];               // row-major half [64 i + k]
-                if (jb < kSbG - 1) inv[jb < kSbG - 1 ? jb : 0][q] = v;
+            for (int reg = 0; reg < 4; reg++) {
+                const int i = 16 * wv + lk + 4 * reg, col = 16 * sl + l15;
+                const double v = -o[reg];
+                if (jb < kSbG - 1) Bs[jb < kSbG - 1 ? jb : 0][i * 16 + l15] = v;
+                t[i + 64 * col] = v;                                             // column-major half [i + 64 k]
+                t[4096 + 64 * i + col] = v;                                      // row-major half [64 i + k]
             }
-            sb_bar();
+            sb_bar();                     // the new tile is visible to every wavefront; Ss may be written again
+            if constexpr (jb + 1 < kSbG) self(self, std::integral_constant<int, jb + 1>{});
         }
     };
-    row(std::integral_constant<int, 1>{}); row(std::integral_constant<int, 2>{}); row(std::integral_constant<int, 3>{});
-    row(std::integral_constant<int, 4>{}); row(std::integral_constant<int, 5>{}); row(std::integral_constant<int, 6>{});
-    row(std::integral_constant<int, 7>{});
-    static_assert(kSbG == 8, "seven rows below the diagonal");
+    row(row, std::integral_constant<int, 1>{});
 }
 
 // ------------------------------------------------------------------------------------------
@@ -254,6 +259,7 @@ k_front_fwd_sb(DevPlan P, FrontDesc F, double *__restrict__ y, double *__restric
     const int tk = sb_rfl(sb);                  // wave-uniform for the compiler too: scalar branches, SGPR tile bases
     const int b = tk >> 1, h = tk & 1;
     if (b >= F.nb) return;
+    SWT(0);
     // re-arm the backward sweep's block (idle during this launch), every workgroup a share
     for (int q = tk * kSbThreads + threadIdx.x; q < F.sync_blk; q += 2 * F.nb * kSbThreads) sync[F.sync_blk + q] = 0;
     FrontSlot *yslots = front_slots(sync, F.np), *rslots = yslots + (int64_t)F.np * 64;
@@ -356,10 +362,13 @@ k_front_fwd_sb(DevPlan P, FrontDesc F, double *__restrict__ y, double *__restric
 #pragma unroll
                 for (int t = 0; t < NT; t++) cur[p][t] = nxt[p][t];
         }
+        SWT(1);
         if (ok) ok = consume(nQ - 1, [] {});                       // the last hop has nothing left to request
+        SWT(2);
     }
     put_part(red, wv, lr, a0 + a1);
     __syncthreads();
+    SWT(3);
     if (!own) {
         if (lead && valid && ok) P.ubuf[F.ubelow_off + (i - F.W)] = base + sum_parts(red, lr);
         return;
@@ -383,6 +392,7 @@ k_front_fwd_sb(DevPlan P, FrontDesc F, double *__restrict__ y, double *__restric
         rbuf[bl][lane & 31] = v;
     }
     __syncthreads();
+    SWT(4);
     if (!okflag) return;
     {   // y_b = sum_c Inv[b,c] r_c  (tiles of the panels after b in the super-block are zero)
         double s0 = 0.0, s1 = 0.0;
@@ -395,11 +405,13 @@ k_front_fwd_sb(DevPlan P, FrontDesc F, double *__restrict__ y, double *__restric
         put_part(red, wv, lr, s0 + s1);          // (the first reduction's reads finished before the barrier above)
     }
     __syncthreads();
+    SWT(5);
     if (lead) {
         const double v = valid ? sum_parts(red, lr) : 0.0;
         front_slot_st(yslots + b * 64 + ir, v);              // first: the next super-block is waiting for it
         if (valid) z[me.f + ir] = v * dinv_own;
     }
+    SWT(6);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -573,7 +585,9 @@ void launch_front_bwd_sb(hipStream_t st, const DevPlan &P, const FrontDesc &F, c
     hipLaunchKernelGGL(k_front_bwd_sb, dim3(2 * F.np), dim3(kSbThreads), 0, st, P, F, z, x, xout);
 }
 void launch_invert_super(hipStream_t st, const DevPlan &P, const FrontDesc &F) {
-    if (F.sb_g > 0 && F.nsb > 0) hipLaunchKernelGGL(k_invert_super, dim3(F.nsb * (kSbG - 1)), dim3(kInvThreads), 0, st, P, F);
+    if (F.sb_g <= 0 || F.nsb <= 0) return;
+    if (F.cw == 64) hipLaunchKernelGGL(k_invert_super<true>, dim3(F.nsb * (kSbG - 1) * kInvSlices), dim3(kInvThreads), 0, st, P, F);
+    else hipLaunchKernelGGL(k_invert_super<false>, dim3(F.nsb * (kSbG - 1) * kInvSlices), dim3(kInvThreads), 0, st, P, F);
 }
 
 }  // namespace hipkkt
