@@ -120,7 +120,7 @@ struct DevPlan {
     double polish_tau;           // threshold on the largest |entry| of a wide block's explicit inverse (64; HIPKKT_ACCURATE)
     int dbg;                     // timing experiments only (HIPKKT_DEBUG_FLAGS; results are WRONG when set): bit 0 = the super-block sweeps skip
                                  // their L tile loads (what remains is the hand-off chain)
-    int nseg;                    //   fdone[nsuper], bdone[nsuper], pdone[nsuper]; error word last   // per front: {ticket, error, flags[np]} (zeroed before every front kernel)
+    int nseg;                    //   fdone[8][nsuper] (kernels.hip kSegSub); error word last   // per front: {ticket, error, flags[np]} (zeroed before every front kernel)
     // numeric state
     double *kval;    // resident, UNREGULARISED triu KKT values (original nz order)
     double *Lx;      // supernodal panels

@@ -351,9 +351,9 @@ struct hipkkt_solver {
 
 namespace hipkkt_host {
 
-// seg_sync = [forward tickets | backward tickets] padded to whole 128-byte lines, then fdone / bdone / pdone [nsuper each],
+// seg_sync = [forward tickets | backward tickets] padded to whole 128-byte lines, then fdone [kSegSub = 8 arrays of nsuper],
 // then the error word (kernels.hip seg_sync())
-inline size_t seg_sync_ints(int nseg, int nsuper) { return (size_t)((2 * nseg + 31) & ~31) + 3 * (size_t)nsuper + 16; }
+inline size_t seg_sync_ints(int nseg, int nsuper) { return (size_t)((2 * nseg + 31) & ~31) + 8 * (size_t)nsuper + 16; }
 
 // hipkkt_setup.cpp
 void plan_cache_counts(int64_t *hits, int64_t *misses);   // process-wide cache of symbolic plans (same pattern + options)

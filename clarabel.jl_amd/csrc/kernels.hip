@@ -1429,18 +1429,44 @@ k_front_bwd(DevPlan P, FrontDesc F, const double *__restrict__ z, double *__rest
 // Deadlock freedom and bounded spins: as for the front kernels.  The forward launch re-arms the backward
 // counters and vice versa.
 // ------------------------------------------------------------------------------------------
+// fdone: kSegSub arrays of nsuper counters.  The items of a child count themselves into its parent's counters, block b into array
+// b mod kSegSub: the device serialises atomics on one word at ~11 ns each, and a supernode high in the tree of a random QP waits for
+// the ~300 blocks of its children (3 us per level on one word).  The waiting thread adds the kSegSub words up.  Only for supernodes
+// that wait for at least kSegSubMin blocks: eight polled words instead of one made the sweeps of the banded QP (2400 waiting
+// workgroups, a few blocks per child) 5 % slower.
+constexpr int kSegSub = 8;
+constexpr int kSegSubMin = 64;
 struct SegSync {
-    int *ftick, *btick, *fdone, *bdone, *pdone, *err;
+    int *ftick, *btick, *fdone, *err;
 };
 __device__ __forceinline__ SegSync seg_sync(const DevPlan &P, int nsuper) {
     SegSync s;
     s.ftick = P.seg_sync;                                 // ticket words: [0, 2 nseg), padded to whole 128-byte lines
     s.btick = P.seg_sync + P.nseg;
     s.fdone = P.seg_sync + ((2 * P.nseg + 31) & ~31);     // (mirrored by seg_sync_ints() in hipkkt_internal.h)
-    s.bdone = s.fdone + nsuper;
-    s.pdone = s.bdone + nsuper;
-    s.err = s.pdone + nsuper;
+    s.err = s.fdone + (int64_t)kSegSub * nsuper;
     return s;
+}
+// thread 0 waits until the kSegSub counters of supernode s add up to `want` (relaxed polls); false on time-out / foreign failure
+__device__ __forceinline__ bool seg_wait_sum(int *ctr, int stride, int want, int *err, int *failflag, unsigned lim) {
+    for (unsigned spins = 0;; spins++) {
+        int v[kSegSub];
+#pragma unroll
+        for (int k = 0; k < kSegSub; k++) v[k] = front_ld_flag(ctr + (int64_t)k * stride);
+        int sum = 0;
+#pragma unroll
+        for (int k = 0; k < kSegSub; k++) sum += v[k];
+        if (sum >= want) return true;
+        if ((spins & 127u) == 127u || lim < 128u) {
+            if (spins > lim) {
+                __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                atomicOr(failflag, 1);
+                return false;
+            }
+            if (front_ld_flag(err) != 0) return false;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
 }
 // thread 0 waits until *ctr >= want (relaxed polls); false on time-out / foreign failure
 __device__ __forceinline__ bool seg_wait(int *ctr, int want, int *err, int *failflag, unsigned lim) {
@@ -1521,9 +1547,6 @@ k_fwd_seg(DevPlan P, int seg, int item_begin, int nitems, int nsuper, int first_
     const int t = (P.seg_ticket & 1) ? sb : (int)blockIdx.x;
     if (P.seg_ticket & 1) __syncthreads();   // sb is reused below
     if (t >= nitems) return;
-    if (first_launch && t == 0) {   // re-arm the backward sweep's state (idle during the forward sweep)
-        for (int q = tid; q < 2 * nsuper; q += 256) Y.bdone[q] = 0;   // bdone and pdone are adjacent
-    }
     const FacItem it = P.slv_items[item_begin + t];
     const int s = it.sn;
     const int f = P.sn_first[s];
@@ -1571,8 +1594,10 @@ k_fwd_seg(DevPlan P, int seg, int item_begin, int nitems, int nsuper, int first_
     // ---- dependencies: every block of every same-segment child has been published; the children count
     //      themselves into THIS supernode's counter, so the wait is one poll loop on one word
     const int want = P.dep_total[s], fpar = P.sn_bparent[s];
+    const int fsub = (fpar >= 0 && P.dep_total[fpar] >= kSegSubMin) ? (it.blk & (kSegSub - 1)) : 0;   // (read before the wait)
     if (tid == 0) {
-        sb = (want == 0 || seg_wait(Y.fdone + s, want, Y.err, P.flags + FL_FRONTFAIL, P.spin_limit)) ? 1 : 0;
+        sb = (want == 0 || (want >= kSegSubMin ? seg_wait_sum(Y.fdone + s, nsuper, want, Y.err, P.flags + FL_FRONTFAIL, P.spin_limit)
+                                               : seg_wait(Y.fdone + s, want, Y.err, P.flags + FL_FRONTFAIL, P.spin_limit))) ? 1 : 0;
         asm volatile("" ::: "memory");
     }
     __syncthreads();
@@ -1638,7 +1663,7 @@ k_fwd_seg(DevPlan P, int seg, int item_begin, int nitems, int nsuper, int first_
         front_st(P.ubuf + P.u_off[s] + (row - w), gsum + (((part[0][i] + part[1][i]) + part[2][i]) + part[3][i]));
     // publish: the storing wave drains its stores, then one device-scope increment
     if (pq == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (tid == 0 && fpar >= 0) atomicAdd(Y.fdone + fpar, 1);
+    if (tid == 0 && fpar >= 0) atomicAdd(Y.fdone + (int64_t)fsub * nsuper + fpar, 1);
 }
 
 // backward: item.blk >= 0 = partial dot products of one 64-row block of a long panel, item.blk == -1 = the
@@ -1656,8 +1681,8 @@ k_bwd_seg(DevPlan P, int seg, int item_begin, int nitems, int nsuper, int first_
     __syncthreads();                // `bad` may be set by any wave from here on
     const int t = tick;
     if (t >= nitems) return;
-    if (first_launch && t == 0) {   // re-arm the forward sweep's counters for the next solve
-        for (int q = tid; q < nsuper; q += 256) Y.fdone[q] = 0;
+    if (first_launch) {             // re-arm the forward sweep's counters for the next solve, every workgroup a share
+        for (int q = t * 256 + tid; q < kSegSub * nsuper; q += nitems * 256) Y.fdone[q] = 0;
     }
     const unsigned long long key = seg_key(P);
     const FacItem it = P.pbwd_items[item_begin + t];
@@ -1753,8 +1778,8 @@ k_bwd_seg(DevPlan P, int seg, int item_begin, int nitems, int nsuper, int first_
     if (nblk > 1) {
         double a = 0.0;
         if (lane < w) {
-            // kSegPoll slots per round trip (round 6: one dependent poll per block made the finaliser of a 4500-row panel wait
-            // 18 round trips after the last partial sum had arrived); the sum still runs over b2 = wave, wave + 4, ... in order
+            // kSegPoll slots per wavefront and round trip (round 6: one dependent poll per block made the finaliser of a 4500-row
+            // panel wait 18 round trips after the last partial sum had arrived); the sum still runs over b2 = wave, wave + 4, ... in order
             constexpr int kSegPoll = 8;
             const FrontSlot *pb = P.pseg + P.p_off[s] + lane;
             for (int b0 = wave; b0 < nblk && ok; b0 += 4 * kSegPoll) {
