@@ -628,11 +628,13 @@ def main():
                                                          flops_per_refactor=flops_upd_kernels)),
                     solves=hbm_solve,
                     peak_source="MI355X datasheet FP64 matrix (the figure every frac here is priced against)",
-                    sustained_matrix_rate=dict(tflops=50.3, frac_of_peak=round(50.3 / F64_MFMA_PEAK_TFLOPS, 3),
-                                               source="profiles/r06_a_ubench_macro_tile_and_mfma_mix.txt (tools/ubench_mfma_mix.hip)",
-                                               note="what the chip sustains when all 1024 SIMDs issue v_mfma_f64_16x16x4_f64 back to back and do nothing else "
-                                                    "(~55 us kernels, measured in round 6): the ceiling a Schur-update kernel can approach; the dense update's own "
-                                                    "launches (kernels.dense_update, 39 - 44 TFLOP/s on whole rounds) sit at ~80 % of it"))
+                    sustained_matrix_rate=dict(two_wavefronts_per_simd_tflops=67.0, one_wavefront_per_simd_tflops=50.2,
+                                               frac_of_peak=round(67.0 / F64_MFMA_PEAK_TFLOPS, 3),
+                                               source="profiles/r06_b_ubench_mfma_occupancy_and_dense_tile_fit.txt (tools/ubench_mfma_mix.hip, tools/ubench_macro.hip)",
+                                               note="v_mfma_f64_16x16x4_f64 back to back on all 1024 SIMDs, measured in round 6: 67 TFLOP/s with two wavefronts "
+                                                    "per SIMD (what the dense update kernel runs), 50 with one (what the update tiles riding in a front-batch launch "
+                                                    "run).  The dense update's tile core: 1.22 us per k-step against 1.0 us of pure matrix work (82 %), plus ~35 us "
+                                                    "per launch in which every wavefront reads / writes its 32 KB tile at the same time"))
 
     result = {
         "metric": "IPM iterations/sec + KKT factor+solve ms, 10k-var sparse QP, 1/2/4/8 GPU",

@@ -50,12 +50,13 @@ int main() {
     auto run = [&](const char *nm, auto k, int wgs) {
         float best = 1e30f;
         for (int rep = 0; rep < 5; rep++) { hipEventRecord(e0, 0); hipLaunchKernelGGL(k, dim3(wgs), dim3(256), 0, 0, src, out, steps); hipEventRecord(e1, 0); hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms, e0, e1); best = ms < best ? ms : best; }
-        printf("%-58s %7.1f us  = %5.1f cycles at 2.4 GHz per instruction and SIMD, %5.1f TFLOP/s\n", nm, best * 1e3, best * 1e-3 * 2.4e9 / (steps * 16 * (wgs / 256.0)), 1024.0 * steps * 16 * 2.0 * wgs * 4 / (best * 1e-3) / 1e12);
+        printf("%-58s %7.1f us  = %5.1f cycles at 2.4 GHz per instruction and SIMD, %5.1f TFLOP/s\n", nm, best * 1e3, best * 1e-3 * 2.4e9 / (steps * 16 * (wgs < 256 ? 1.0 : wgs / 256.0)), 1024.0 * steps * 16 * 2.0 * wgs * 4 / (best * 1e-3) / 1e12);
     };
     run("0 matrix core only, 1 wavefront per SIMD", k_mix<0, 1>, 256); run("1 + 8 LDS reads per step", k_mix<1, 1>, 256); run("2 + LDS barrier per step", k_mix<2, 1>, 256);
     run("3 + 4 LDS writes per step", k_mix<3, 1>, 256); run("4 + 5 global loads per step, 4 steps ahead", k_mix<4, 1>, 256); run("5 = 4, barrier in the middle", k_mix<5, 1>, 256);
     run("0 matrix core only, 2 wavefronts per SIMD (512 workgroups)", k_mix<0, 2>, 512); run("4 with 2 wavefronts per SIMD", k_mix<4, 2>, 512);
-    run("0 matrix core only, 4 wavefronts per SIMD (1024 workgroups)", k_mix<0, 4>, 1024);
+    // (a quarter of the chip: the same time per wavefront as line 0 -- the 100 cycles are no power or clock effect; the cycles column of
+    // this line counts the busy SIMDs only)
     run("0 matrix core only, 1 wavefront per SIMD, 64 workgroups only", k_mix<0, 1>, 64);
     return 0;
 }
