@@ -527,21 +527,23 @@ def test_dense_triangle_spmv_matches_host_product(monkeypatch):
         assert np.max(np.abs(a_ - b_)) <= 1e-12 * max(1.0, np.max(np.abs(b_)))
 
 
-@pytest.mark.parametrize("name", ["cfg1", "cfg2a"])
+@pytest.mark.parametrize("name", ["cfg1", "cfg1w16", "cfg2a"])
 def test_super_block_sweeps_equal_panel_sweeps(name, monkeypatch):
     """front_sweep.hip (two hand-offs per super-block of 8 panels, explicit inverse of the super-block's diagonal block) against the
     panel-by-panel sweeps of round 2 (HIPKKT_SUPERHOP=0) on the same factorisation: cfg 1's 12-panel root (below the default threshold
-    of 16 panels, forced on with HIPKKT_SUPERHOP=1: partial second super-block) and cfg 2a's 88-panel root (default)."""
+    of 16 panels, forced on with HIPKKT_SUPERHOP=1: partial second super-block), the same root cut into panels of 16 columns
+    (supernode_max_width = 16: k_invert_super's path for panels narrower than its 64 x 64 tiles) and cfg 2a's 88-panel root (default)."""
     rng = np.random.default_rng(31)
-    prob = problems.random_sparse_qp(1000, 2000, 1, 4, 2) if name == "cfg1" else FULL[name]()
+    prob = problems.random_sparse_qp(1000, 2000, 1, 4, 2) if name.startswith("cfg1") else FULL[name]()
     Pt, A, cones = _prep(prob)
     m, n = A.shape
     scale_cones(cones, rng)
     monkeypatch.setenv("HIPKKT_PLAN_CACHE", "0")
+    kw = dict(supernode_max_width=16) if name == "cfg1w16" else {}
     sols = []
     for sh in ("1", "0"):
         monkeypatch.setenv("HIPKKT_SUPERHOP", sh)
-        hk = HipKKTSolver(Pt, A, cones, m, n, cl.Settings())
+        hk = HipKKTSolver(Pt, A, cones, m, n, cl.Settings(), **kw)
         assert hk.kktsolver_update(cones)
         b = np.random.default_rng(32).standard_normal(hk.h.N)
         x = hk.h.ldl_solve(b)
