@@ -363,7 +363,7 @@ int32_t finish_create(hipkkt_solver *S, const hipkkt_opts *opts, hipkkt_handle *
 // hipkkt_factor.cpp
 void enqueue_factor(hipkkt_solver *S, int static_enable, double eps_const, double eps_prop);
 // hipkkt_solve.cpp
-void enqueue_ldl_solve(hipkkt_solver *S, SolveCtx &C, const double *in, double *out);
+void enqueue_ldl_solve(hipkkt_solver *S, SolveCtx &C, const double *in, double *out, int *zero = nullptr, int nzero = 0);
 int32_t solve_many(hipkkt_solver *S, int nrhs, int ir_enable, double reltol, double abstol, int64_t max_iter, double stop_ratio,
                    int64_t *ir_steps, double *const *out_dev, int nm);
 hipkkt_solver *solve_target(hipkkt_solver *S);

@@ -8,11 +8,11 @@ using namespace hipkkt_host;
 namespace hipkkt_host {
 
 // in -> out (original ordering on both sides) on context C
-void enqueue_ldl_solve(hipkkt_solver *S, SolveCtx &C, const double *in, double *out) {
+void enqueue_ldl_solve(hipkkt_solver *S, SolveCtx &C, const double *in, double *out, int *zero, int nzero) {
     const HostPlan &P = S->plan;
     hipStream_t st = C.stream;
     const DevPlan &D = C.dp;
-    launch_permute_in(st, in, D.perm, C.d_y, S->N, D.seg_epoch, D.seg_sync, 2 * S->nseg);
+    launch_permute_in(st, in, D.perm, C.d_y, S->N, D.seg_epoch, D.seg_sync, 2 * S->nseg, zero, nzero);
     // one launch per level (wide bottom levels, and every level on the fallback path); the leaves of such a level
     // take the thread-per-supernode kernels
     const bool all = !S->use_persist;   // no persistent kernel at all: level lists over every supernode
@@ -65,9 +65,8 @@ void maybe_retry_persistent(hipkkt_solver *S) {
 // one refinement step on the device: correction solve, candidate = iterate + correction, its residual, the decision
 void enqueue_refine_step(hipkkt_solver *S, SolveCtx &C, double reltol, double abstol, int64_t max_iter, double stop_ratio) {
     hipStream_t st = C.stream;
-    enqueue_ldl_solve(S, C, C.d_e, C.d_corr);
+    enqueue_ldl_solve(S, C, C.d_e, C.d_corr, (int *)(C.dp.scal + SC_NORME), 2);   // (||e|| of the candidate starts from zero)
     launch_refine_add(st, C.d_rs, C.d_x0, C.d_x1, C.d_corr, S->N);
-    launch_zero_words(st, (char *)C.dp.scal + SC_NORME * sizeof(double), 2);
     launch_spmv_residual_cand(st, C.dp, C.d_b, C.d_rs, C.d_x0, C.d_x1, C.d_e, S->N, (unsigned long long *)C.dp.scal + SC_NORME);
     launch_refine_decide(st, C.d_rs, C.dp.scal, 1, reltol, abstol, (int)std::min<int64_t>(max_iter, 1 << 30), stop_ratio);
 }
@@ -125,8 +124,7 @@ void solve_begin(hipkkt_solver *S, SolveCtx &C, int ir_enable, double reltol, do
     if (ir_enable) {
         const bool same = C.g_reltol == reltol && C.g_abstol == abstol && C.g_maxit == max_iter && C.g_stop == stop_ratio;
         run_graphed(S, st, C.g_first, same, [&] {
-            enqueue_ldl_solve(S, C, C.d_b, C.d_x0);
-            launch_zero_words(st, (char *)C.dp.scal + SC_NORMB * sizeof(double), 4);
+            enqueue_ldl_solve(S, C, C.d_b, C.d_x0, (int *)(C.dp.scal + SC_NORMB), 4);       // (||b||, ||e|| start from zero)
             launch_norm_inf(st, C.d_b, S->N, (unsigned long long *)C.dp.scal + SC_NORMB);
             launch_spmv_residual(st, C.dp, C.d_b, C.d_x0, C.d_e, S->N, (unsigned long long *)C.dp.scal + SC_NORME);
             launch_refine_decide(st, C.d_rs, C.dp.scal, 0, reltol, abstol, (int)std::min<int64_t>(max_iter, 1 << 30), stop_ratio);

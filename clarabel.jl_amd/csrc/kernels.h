@@ -46,7 +46,8 @@ void launch_zero_words(hipStream_t st, void *p, int nwords);
 void launch_update_gather(hipStream_t st, const DevPlan &P, int64_t ebegin, int64_t n, int64_t hbegin, int64_t nheavy, int max_blocks = 0);
 void launch_invert_diag(hipStream_t st, const DevPlan &P, int n_small, int wmax_small, int n_wide);
 void launch_mfma_probe(hipStream_t st, const double *A, const double *B, double *out);
-void launch_permute_in(hipStream_t st, const double *b, const int *perm, double *y, int n, int *epoch, int *ticks, int nticks);
+void launch_permute_in(hipStream_t st, const double *b, const int *perm, double *y, int n, int *epoch, int *ticks, int nticks, int *zero = nullptr,
+                       int nzero = 0);   // zero[0 .. nzero): words cleared by the solve's first kernel for the kernels behind it
 void launch_fwd_level(hipStream_t st, const DevPlan &P, int item_begin, int nitems, double *y, double *z);
 void launch_bwd_partial(hipStream_t st, const DevPlan &P, int item_begin, int nitems, const double *x);
 void launch_bwd_final(hipStream_t st, const DevPlan &P, int sn_begin, int nsn, const double *z, double *x, double *xout);

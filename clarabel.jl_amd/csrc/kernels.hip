@@ -854,7 +854,7 @@ __global__ void k_mfma_probe(const double *__restrict__ A, const double *__restr
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 k_permute_in(const double *__restrict__ b, const int *__restrict__ perm, double *__restrict__ y, int n, int *epoch,
-             int *ticks, int nticks) {
+             int *ticks, int nticks, int *zero, int nzero) {
     // first kernel of every LDL solve: a new epoch invalidates the tagged hand-off values of the previous solve
     if (blockIdx.x == 0 && threadIdx.x == 0 && epoch) ((unsigned *)epoch)[0] += 1u;   // wraps after 2^32 solves: any
                                                                                         // two consecutive epochs differ
@@ -862,8 +862,11 @@ k_permute_in(const double *__restrict__ b, const int *__restrict__ perm, double 
     // no atomics, and live in cache lines of their own (seg_sync layout): a plain store next to a word that other
     // workgroups are incrementing atomically can lose increments when the writer's L2 writes the line back (seen on
     // MI355X: duplicate tickets => the last items of a launch silently never ran).
-    if (blockIdx.x == 0)
+    if (blockIdx.x == 0) {
         for (int q = threadIdx.x; q < nticks; q += blockDim.x) ticks[q] = 0;
+        // the norm words the refinement kernels BEHIND this solve accumulate into with atomicMax (a launch of their own until round 6)
+        for (int q = threadIdx.x; q < nzero; q += blockDim.x) zero[q] = 0;
+    }
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k < n) y[k] = b[perm[k]];
 }
@@ -2413,8 +2416,8 @@ void launch_invert_diag(hipStream_t st, const DevPlan &P, int n_small, int wmax_
 void launch_mfma_probe(hipStream_t st, const double *A, const double *B, double *out) {
     hipLaunchKernelGGL(k_mfma_probe, dim3(1), dim3(64), 0, st, A, B, out);
 }
-void launch_permute_in(hipStream_t st, const double *b, const int *perm, double *y, int n, int *epoch, int *ticks, int nticks) {
-    if (n > 0) hipLaunchKernelGGL(k_permute_in, dim3(nblk(n)), dim3(256), 0, st, b, perm, y, n, epoch, ticks, nticks);
+void launch_permute_in(hipStream_t st, const double *b, const int *perm, double *y, int n, int *epoch, int *ticks, int nticks, int *zero, int nzero) {
+    if (n > 0) hipLaunchKernelGGL(k_permute_in, dim3(nblk(n)), dim3(256), 0, st, b, perm, y, n, epoch, ticks, nticks, zero, nzero);
 }
 void launch_fwd_level(hipStream_t st, const DevPlan &P, int item_begin, int nitems, double *y, double *z) {
     if (nitems > 0) hipLaunchKernelGGL(k_fwd_level, dim3(nitems), dim3(256), 0, st, P, item_begin, y, z);

@@ -316,8 +316,10 @@ int32_t hipkkt_get_counters(hipkkt_handle h, int64_t *out, int64_t cap);
  * permuted right-hand side, 1 z = D^-1 L^-1 b, 2 x in permuted order, 3 the forward update vectors, 4 the unregularised KKT values in nz order, 5 D and 6 1/D of the last factorisation, 7 / 8 the u / v vectors of the sparse second-order cones) or a plan table converted to doubles (10 supernode first
  * columns, 11 levels, 12 rows per supernode, 13 parents, 14 membership in the persistent sweeps; 15 / 16 the stream records / scratch
  * tiles of the front batches, 17 the refinement state of the last refined solve: ||e|| before its last step, ||b||, ||e|| after it, steps; 18 the residual b - K x of
- * the last SpMV on solve context 0 (original ordering), 19 the number of dense triangles of K outside the symmetric view); *len receives the
- * length, nothing is copied when cap is too small */
+ * the last SpMV on solve context 0 (original ordering), 19 the number of dense triangles of K outside the symmetric view, 20 six values per
+ * dense update tile of the plan: stage, tasks, sum of source widths, tasks through a tile map, full-tile flag, sum of rows x columns x
+ * width; 21 five values per supernode of the persistent segment sweeps: level, width, rows, longest and mean gather list of its row
+ * slots -- tools/dense_stage_stats.py); *len receives the length, nothing is copied when cap is too small */
 int32_t hipkkt_debug_dump(hipkkt_handle h, int32_t what, double *out, int64_t cap, int64_t *len);
 /* developer diagnostic, host logic only (no device needed): how many of the `nd` dense tiles of a front batch's far stage -- the
  * first `ncrit` of them belong to the next batch's columns -- ride in the next k_front_block launch, which has `next_blk` workgroups
