@@ -643,6 +643,12 @@ std::string build_plan(int N, const int64_t *Ap, const int64_t *Ai, const int64_
             auto b = P.upd_groups.begin() + P.upd_stage_ptr[l], e = P.upd_groups.begin() + P.upd_stage_ptr[l + 1];
             auto mid = std::stable_partition(b, e, [](const UpdGroup &g) { return g.dense == 1; });
             auto mid2 = std::stable_partition(mid, e, [](const UpdGroup &g) { return g.dense == 2; });
+            // the dense tiles of a stage in descending order of their number of contributions (in classes of 4, target order inside a
+            // class): a launch ends with its longest tile, and the launch of the sparse tree into a front (cfg 2a: 3828 tiles of 1 - 29
+            // contributions on 2048 wavefront slots) otherwise starts long tiles in its last round
+            // (only launches of more than one round of wavefront slots: the small just-in-time launches lose more locality than they gain)
+            if (mid - b >= 2048)
+                std::stable_sort(b, mid, [](const UpdGroup &x, const UpdGroup &y) { return (x.task_end - x.task_begin) / 4 > (y.task_end - y.task_begin) / 4; });
             P.upd_stage_ndense[l] = (int)(mid - b);
             P.upd_stage_ngather[l] = (int)(mid2 - mid);
             for (auto it = b; it != mid; ++it)
