@@ -102,29 +102,48 @@ __device__ __forceinline__ void dense_tile_core(const DevPlan &P, double *tp, in
             }
         }
 
-    // task records are 48-byte packed structs; the NEXT record is requested at the top of an iteration and only
-    // made wave-uniform (readfirstlane = the wait) at its end, so its latency hides under this task's MFMAs
+    // Task records are 48-byte packed structs; the NEXT record is requested at the top of an iteration and only made wave-uniform
+    // (readfirstlane = the wait) at its end, so its latency hides under this task's MFMAs.  Round 6: the tile MAP of the next task
+    // (which rows / columns of the tile a source that does not land contiguously feeds: 84 % of the tasks of the sparse tree's launch
+    // into a front) is requested one task ahead as well -- its index comes from a two-word look-ahead (geom, map) two tasks ahead --
+    // so that a task starts with ONE dependent round trip (its operands) instead of two (map, then operands).  The map loads are
+    // unconditional (an unmapped task reads map 0, which always exists: hipkkt_setup.cpp) -- loads under a condition would make the
+    // compiler wait for everything in flight at the next use of an earlier load.
+    const int last = task_end - 1;
+    auto gm_of = [&](int q, int &g_, int &m_) { const DenseTask *t = P.dtasks + (q < last ? q : last); g_ = t->geom; m_ = t->map; };
+    auto req_maps = [&](int geom_u, int map_u, int (&mr_)[NR], int (&mc_)[NT]) {     // (geom_u, map_u: wave-uniform)
+        const int16_t *tm = P.upd_tmap + (int64_t)((geom_u & (1 << 17)) ? map_u : 0) * 128;
+#pragma unroll
+        for (int x = 0; x < NR; x++) mr_[x] = tm[(ti0 + x) * 16 + l15];
+#pragma unroll
+        for (int x = 0; x < NT; x++) mc_[x] = tm[64 + (tj0 + x) * 16 + l15];
+    };
     DenseTask Tc = P.dtasks[task_begin];
+    int mr[NR], mc[NT], g1, m1;
+    req_maps(rfl(Tc.geom), rfl(Tc.map), mr, mc);
+    gm_of(task_begin + 1, g1, m1);
     for (int q = task_begin; q < task_end; q++) {
         const DenseTask Tn = P.dtasks[q + 1 < task_end ? q + 1 : q];
+        int g2, m2, mrn[NR], mcn[NT];
+        gm_of(q + 2, g2, m2);
+        req_maps(rfl(g1), rfl(m1), mrn, mcn);
         const int row_lo = rfl(Tc.row_lo), nrows = rfl(Tc.nrows), col_lo = rfl(Tc.col_lo), ncols = rfl(Tc.ncols),
-                  geom = rfl(Tc.geom), K = rfl(Tc.K), tmap_idx = rfl(Tc.map);
+                  geom = rfl(Tc.geom), K = rfl(Tc.K);
         const unsigned r8 = (unsigned)rfl(Tc.r8);
         const double *sp = rfl_ptr(P.Lx + Tc.panel_off);
         const double *dv = rfl_ptr(P.D + Tc.dfirst);
         const int c_r = geom & 255, c_c = (geom >> 8) & 255;
         unsigned roff[NR], coff[NT], mbits = 0;
         if (geom & (1 << 17)) {      // wave-uniform: operands gathered through the task's tile maps
-            const int16_t *tm = P.upd_tmap + (int64_t)tmap_idx * 128;
 #pragma unroll
             for (int x = 0; x < NR; x++) {
-                const int m = tm[(ti0 + x) * 16 + l15];
+                const int m = mr[x];
                 roff[x] = (unsigned)(row_lo + (m >= 0 ? m : 0)) * 8u;
                 mbits |= m >= 0 ? 16u << x : 0u;
             }
 #pragma unroll
             for (int x = 0; x < NT; x++) {
-                const int m = tm[64 + (tj0 + x) * 16 + l15];
+                const int m = mc[x];
                 coff[x] = (unsigned)(col_lo + (m >= 0 ? m : 0)) * 8u;
                 mbits |= m >= 0 ? 1u << x : 0u;
             }
@@ -183,6 +202,11 @@ __device__ __forceinline__ void dense_tile_core(const DevPlan &P, double *tp, in
             }
         }
         Tc = Tn;
+        g1 = g2; m1 = m2;
+#pragma unroll
+        for (int x = 0; x < NR; x++) mr[x] = mrn[x];
+#pragma unroll
+        for (int x = 0; x < NT; x++) mc[x] = mcn[x];
     }
 #pragma unroll
     for (int tj = 0; tj < NT; tj++)

@@ -363,7 +363,8 @@ void setup_device(hipkkt_solver *S) {
                      G.task_begin, G.task_end, full ? 1 : 0};
         }
     }
-    D.upd_tmap = S->upload(P.upd_tmap);
+    // (never empty: the dense tile core requests "the next task's map" unconditionally and reads map 0 for tasks without one)
+    D.upd_tmap = P.upd_tmap.size() >= 128 ? S->upload(P.upd_tmap) : S->upload(std::vector<int16_t>(128, (int16_t)-1));
     {
         std::vector<DenseTask> dt(P.upd_tasks.size());
         for (size_t q = 0; q < dt.size(); q++) {
