@@ -224,7 +224,9 @@ __device__ __forceinline__ void dense_tile_core(const DevPlan &P, double *tp, in
 // [Round 6, measured and removed: the general tile as ONE stream over all its tasks -- the next task's record / tile map / lane offsets
 // prepared and its first operands requested while the current task is multiplied, instead of three dependent round trips per task.
 // Bit-identical, 26 more registers spilled, and SLOWER: cfg 2a's factorisation 3.66 -> 3.77 ms, cfg 5's 4.55 -> 4.96 ms.  With two
-// wavefronts per SIMD the other wavefront already covers those round trips.]
+// wavefronts per SIMD the other wavefront already covers those round trips.  A second attempt at the end of the round, on top of the
+// map look-ahead of dense_tile_core and WITHOUT a second set of operand registers (the next task's first operands in place of the
+// wasted load one step past the end): 14 more spills, 3.54 -> 3.68 ms / 4.20 -> 4.58 ms.  What did pay is the map look-ahead alone.]
 // FULL tiles (DenseGroup::pad & 1, set when the plan is uploaded: a 64 x 64 tile whose every task covers all 64 rows and columns
 // contiguously with K a multiple of 8 -- all but the edge tiles of a front's big launches): nothing to mask, the lane offsets are
 // loop-invariant, and the k-steps advance the UNIFORM base pointers in scalar registers: 9 loads + 4 multiplies per 16 matrix-core
