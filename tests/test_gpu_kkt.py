@@ -201,6 +201,31 @@ def test_block_products_match_scipy(name):
             assert np.max(np.abs(got - ref)) <= 1e-13 * max(1.0, np.max(np.abs(ref)))
 
 
+def test_plan_statistics_tables_are_consistent():
+    """hipkkt_debug_dump 20 / 21 (development tables behind tools/dense_stage_stats.py): six values per dense update tile, five per
+    supernode of the persistent segment sweeps; checked against the plan tables 10 - 14 of the same handle."""
+    Pt, A, cones = _prep(problems.random_sparse_qp(1000, 2000, 1, 4, 2))
+    m, n = A.shape
+    hk = HipKKTSolver(Pt, A, cones, m, n, cl.Settings())
+    tiles = hk.h.debug_dump(20)
+    assert tiles.size % 6 == 0 and tiles.size > 0
+    tiles = tiles.reshape(-1, 6)
+    levels = hk.h.debug_dump(11)
+    assert np.all(tiles[:, 0] >= 0) and np.all(tiles[:, 0] <= levels.max())          # stage = a level of the tree
+    assert np.all(tiles[:, 1] >= 1) and np.all(tiles[:, 2] >= tiles[:, 1])           # >= 1 contribution, each >= 1 column wide
+    assert np.all(tiles[:, 3] <= tiles[:, 1]) and np.all((tiles[:, 4] == 0) | (tiles[:, 4] == 1))
+    assert np.all(tiles[:, 5] <= 4096 * tiles[:, 2])                                 # rows x columns x width <= a full tile per column
+    seg = hk.h.debug_dump(21)
+    assert seg.size % 5 == 0
+    seg = seg.reshape(-1, 5)
+    member = hk.h.debug_dump(14)
+    assert len(seg) == int(member.sum())
+    first, rows = hk.h.debug_dump(10), hk.h.debug_dump(12)
+    idx = np.nonzero(member)[0]
+    assert np.array_equal(seg[:, 0], levels[idx]) and np.array_equal(seg[:, 1], np.diff(first)[idx]) and np.array_equal(seg[:, 2], rows[idx])
+    assert np.all(seg[:, 3] >= seg[:, 4] - 1e-12)                                    # longest list >= mean list
+
+
 def test_l0_seam_matches_oracle(oracle_factory):
     """AbstractDirectLDLSolver seam: create from an assembled KKT, update_values / scale_values /
     refactor / solve (directldl_qdldl.jl call pattern)."""
